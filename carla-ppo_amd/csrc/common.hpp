@@ -1,0 +1,72 @@
+// common.hpp — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the Carla-ppo hot path.
+// wave = 64 lanes everywhere; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+typedef unsigned short bf16_t;                                   // raw bfloat16 bits in HBM / LDS
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));       // MFMA operand type
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32 (round-to-nearest-even, same as torch) ----
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c; c.u = (uint32_t)v << 16; return c.f;
+}
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c; c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __host__ __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __host__ __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static __host__ __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    static __host__ __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// ---- division by a runtime-invariant divisor: q = (n * mul) >> 40 style, exact for 0 <= n < 2^31 ----
+// host computes mul = floor(2^(31+s) / d) + 1 with s = ceil(log2 d); n*mul < 2^63.
+struct FastDiv {
+    uint32_t mul; uint32_t shift; uint32_t d; uint32_t pad;
+    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        return (uint32_t)(((uint64_t)n * mul) >> shift);
+    }
+    __host__ __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+        q = div(n); r = n - q * d;
+    }
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f; f.d = d; f.pad = 0;
+    if (d <= 1) { f.mul = 1; f.shift = 0; f.d = 1; return f; }
+    uint32_t s = 0; while ((1ull << s) < d) ++s;
+    f.shift = 31 + s;
+    f.mul = (uint32_t)(((1ull << f.shift) / d) + 1);
+    return f;
+}
+
+// ---- wave / block reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace mi

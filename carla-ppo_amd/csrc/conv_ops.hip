@@ -1,0 +1,247 @@
+// conv_ops.hip — host launchers (C ABI) for the MFMA tile kernels in gemm_core.hpp.
+// Every conv on this path is NHWC, stride 2, VALID (reference vae/models.py:250-253,261-264).
+#include "gemm_core.hpp"
+#include "mi_internal.hpp"
+
+using namespace mi;
+
+namespace {
+
+template <typename T, typename TIn, int AMODE, int BMODE, int VA, int AALIGN>
+int launch_gemm_bn(hipStream_t st, const GemmParams& p, int M_for_grid, int gz) {
+    const int gx = (M_for_grid + GEMM_BM - 1) / GEMM_BM;
+    if (gx <= 0) return MI_OK;
+    if (p.N <= 32) {
+        dim3 g(gx, 1, gz);
+        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 32>), g, dim3(GEMM_NT), 0, st, p);
+    } else if (p.N <= 64) {
+        dim3 g(gx, 1, gz);
+        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 64>), g, dim3(GEMM_NT), 0, st, p);
+    } else {
+        dim3 g(gx, (p.N + 127) / 128, gz);
+        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 128>), g, dim3(GEMM_NT), 0, st, p);
+    }
+    return mi_check_launch("gemm_kernel");
+}
+
+void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride, bool merged) {
+    p.IH = IH; p.IW = IW; p.C = C; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride;
+    p.nbatch = B;
+    p.M = B * OH * OW;
+    p.K = KH * KW * C;
+    p.a_frame_stride = (long long)IH * IW * C;
+    p.div_ohw = make_fastdiv(OH * OW);
+    p.div_ow = make_fastdiv(OW);
+    p.merged = merged ? 1 : 0;
+    p.run = merged ? KW * C : C;
+    p.div_run = make_fastdiv(p.run);
+    p.div_kw = make_fastdiv(KW);
+}
+
+// A_CONV GEMM with dtype/vector dispatch. in_f32: the A tensor is fp32 in HBM even when T = bf16 (input frames).
+template <int BMODE>
+int conv_form_gemm(hipStream_t st, int dtype, int in_f32, GemmParams& p, int gz) {
+    const int C = p.C;
+    const bool a16 = (((uintptr_t)p.a) & 15) == 0;
+    if (dtype == MI_F32) {
+        if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<float, float, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
+        if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
+            return launch_gemm_bn<float, float, A_CONV, BMODE, 4, 8>(st, p, p.M, gz);
+        return mi_fail(MI_ERR_SHAPE, "conv-form gemm (f32): channel count / alignment not supported");
+    }
+    if (in_f32) {
+        if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<bf16_t, float, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
+        if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
+            return launch_gemm_bn<bf16_t, float, A_CONV, BMODE, 4, 8>(st, p, p.M, gz);
+        return mi_fail(MI_ERR_SHAPE, "conv-form gemm (bf16, fp32 input): channel count / alignment not supported");
+    }
+    if (!p.merged && C % 8 == 0 && a16) return launch_gemm_bn<bf16_t, bf16_t, A_CONV, BMODE, 8, 16>(st, p, p.M, gz);
+    if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
+        return launch_gemm_bn<bf16_t, bf16_t, A_CONV, BMODE, 4, 4>(st, p, p.M, gz);
+    return mi_fail(MI_ERR_SHAPE, "conv-form gemm (bf16): channel count / alignment not supported");
+}
+
+bool vec_ok(const void* ptr, long long ld, int dtype) {
+    const int vb = dtype == MI_F32 ? 4 : 8;
+    return ((((uintptr_t)ptr) & 15) == 0) && (ld % vb == 0);
+}
+
+int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, int IW, int C, int OH, int OW, int N, int KH, int KW) {
+    // gather-form stride-2 transposed conv; output may be larger than the natural (IH-1)*2+KH (extra rows/cols get bias only)
+    p.IH = IH; p.IW = IW; p.C = C; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = 2;
+    p.nbatch = B; p.N = N; p.M = 0; p.K = 0;
+    p.a_frame_stride = (long long)IH * IW * C;
+    p.a_frame_idx = nullptr;
+    p.ksplit_len = 0;
+    int maxM = 0;
+    for (int ph = 0; ph < 2; ++ph) {
+        p.OHc[ph] = (OH - ph + 1) / 2; p.Th[ph] = (KH - ph + 1) / 2;
+        p.OWc[ph] = (OW - ph + 1) / 2; p.Tw[ph] = (KW - ph + 1) / 2;
+        p.dc_tw[ph] = make_fastdiv(p.Tw[ph] > 0 ? p.Tw[ph] : 1);
+    }
+    for (int c = 0; c < 4; ++c) {
+        const int oh = p.OHc[c >> 1], ow = p.OWc[c & 1];
+        p.dc_ohw[c] = make_fastdiv(oh * ow > 0 ? oh * ow : 1);
+        p.dc_ow[c] = make_fastdiv(ow > 0 ? ow : 1);
+        if (B * oh * ow > maxM) maxM = B * oh * ow;
+    }
+    p.dc_c = make_fastdiv(C);
+    const int vb = dtype == MI_F32 ? 4 : 8;
+    if (C % vb != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15))
+        return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: input channels must be a multiple of the 16-byte vector and pointers 16-B aligned");
+    if (KH < 2 || KW < 2) return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: kernel must be >= 2");
+    if (dtype == MI_F32) return launch_gemm_bn<float, float, A_DECONV, B_DECONV, 4, 16>(st, p, maxM, 4);
+    return launch_gemm_bn<bf16_t, bf16_t, A_DECONV, B_DECONV, 8, 16>(st, p, maxM, 4);
+}
+
+int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks) {
+    const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : WgradCfg<bf16_t>::BP;
+    const int gx = (p.Kc + 63) / 64, gy = (p.N + 63) / 64;
+    int splits = target_blocks / (gx * gy);
+    if (splits < 1) splits = 1;
+    int mps = (p.M + splits - 1) / splits;
+    mps = ((mps + BP - 1) / BP) * BP;
+    if (mps < BP) mps = BP;
+    splits = (p.M + mps - 1) / mps;
+    p.m_per_split = mps;
+    dim3 g(gx, gy, splits);
+    const bool a16 = (((uintptr_t)p.big) & 15) == 0;
+    const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
+    if (dtype == MI_F32) {
+        if (!p.merged && p.C % 4 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<float, float, 4, 16>), g, dim3(GEMM_NT), 0, st, p);
+        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<float, float, 4, 8>), g, dim3(GEMM_NT), 0, st, p);
+        else return mi_fail(MI_ERR_SHAPE, "wgrad (f32): channel count / alignment not supported");
+    } else if (in_f32) {
+        if (!p.merged && p.C % 4 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, float, 4, 16>), g, dim3(GEMM_NT), 0, st, p);
+        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<bf16_t, float, 4, 8>), g, dim3(GEMM_NT), 0, st, p);
+        else return mi_fail(MI_ERR_SHAPE, "wgrad (bf16, fp32 input): channel count / alignment not supported");
+    } else {
+        if (!p.merged && p.C % 8 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, bf16_t, 8, 16>), g, dim3(GEMM_NT), 0, st, p);
+        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<bf16_t, bf16_t, 4, 4>), g, dim3(GEMM_NT), 0, st, p);
+        else return mi_fail(MI_ERR_SHAPE, "wgrad (bf16): channel count / alignment not supported");
+    }
+    return mi_check_launch("wgrad_kernel");
+}
+
+void fill_wgrad_geom(WgradParams& p, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride, bool merged) {
+    p.IH = IH; p.IW = IW; p.C = C; p.OH = OH; p.OW = OW; p.KH = KH; p.KW = KW; p.stride = stride;
+    p.M = B * OH * OW; p.Kc = KH * KW * C;
+    p.frame_stride = (long long)IH * IW * C;
+    p.div_ohw = make_fastdiv(OH * OW); p.div_ow = make_fastdiv(OW);
+    p.merged = merged ? 1 : 0; p.run = merged ? KW * C : C;
+    p.div_run = make_fastdiv(p.run); p.div_kw = make_fastdiv(KW);
+}
+
+inline bool needs_merge(int C, int dtype, int in_f32) {
+    const int v = (dtype == MI_F32 || in_f32) ? 4 : 8;
+    return C % v != 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// conv2d NHWC stride-2 VALID forward: out[B,OH,OW,Cout] = relu?(im2col(x) * W[kh,kw,ci,co] + bias)
+// replaces tf.layers.conv2d in ConvVAE.build_encoder (reference vae/models.py:250-253)
+int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
+                       int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout,
+                       int relu, void* out) {
+    const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    GemmParams p = {};
+    p.a = x; p.a_frame_idx = frame_idx;
+    fill_conv_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
+    p.N = Cout; p.b = w; p.ldb = Cout; p.b_vec = vec_ok(w, Cout, dtype);
+    p.out = out; p.bias = bias; p.mask = nullptr; p.relu = relu; p.out_f32 = 0; p.ksplit_len = 0;
+    return conv_form_gemm<B_KN>((hipStream_t)stream, dtype, x_is_f32, p, 1);
+}
+
+// conv2d input gradient: dx[B,IH,IW,Cin] = mask>0 ? deconv_gather(dy[B,OH,OW,Cout], W[kh,kw,ci,co]) : 0
+// (TF Conv2DBackpropInput; the HWIO conv kernel read as a [kh,kw,out=ci,in=co] transposed-conv kernel)
+int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                         const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx) {
+    GemmParams p = {};
+    p.a = dy; p.b = w; p.ldb = 0; p.b_vec = 1;
+    p.out = dx; p.bias = nullptr; p.mask = mask; p.relu = 0; p.out_f32 = 0;
+    return deconv_form_gemm((hipStream_t)stream, dtype, p, B, OH, OW, Cout, IH, IW, Cin, KH, KW);
+}
+
+// conv2d filter gradient: dw[kh,kw,ci,co] += im2col(x)^T * dy      (TF Conv2DBackpropFilter), fp32 accumulate
+int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
+                         int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw) {
+    const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    WgradParams p = {};
+    p.big = x; p.frame_idx = frame_idx;
+    fill_wgrad_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
+    p.N = Cout; p.small = dy; p.s_vec = vec_ok(dy, Cout, dtype); p.out = dw;
+    return launch_wgrad((hipStream_t)stream, dtype, x_is_f32, p, 1024);
+}
+
+// conv2d_transpose NHWC stride-2 VALID forward, kernel [kh,kw,co,ci] (reference vae/models.py:261-264)
+int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin,
+                         const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out) {
+    const int OH = (IH - 1) * 2 + KH, OW = (IW - 1) * 2 + KW;
+    GemmParams p = {};
+    p.a = x; p.b = w; p.ldb = 0; p.b_vec = 1;
+    p.out = out; p.bias = bias; p.mask = nullptr; p.relu = relu; p.out_f32 = 0;
+    return deconv_form_gemm((hipStream_t)stream, dtype, p, B, IH, IW, Cin, OH, OW, Cout, KH, KW);
+}
+
+// conv2d_transpose input gradient = plain stride-2 conv of dy with the same kernel read as HWIO [kh,kw,I=co,O=ci]
+int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                           const void* w, int KH, int KW, int Cin, const void* mask, void* dx) {
+    const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
+    GemmParams p = {};
+    p.a = dy; p.a_frame_idx = nullptr;
+    fill_conv_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));
+    p.N = Cin; p.b = w; p.ldb = Cin; p.b_vec = vec_ok(w, Cin, dtype);
+    p.out = dx; p.bias = nullptr; p.mask = mask; p.relu = 0; p.out_f32 = 0; p.ksplit_len = 0;
+    return conv_form_gemm<B_KN>((hipStream_t)stream, dtype, 0, p, 1);
+}
+
+// conv2d_transpose filter gradient: dw[kh,kw,co,ci] += im2col(dy)^T * x
+int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                           const void* x, int KH, int KW, int Cin, float* dw) {
+    const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
+    WgradParams p = {};
+    p.big = dy; p.frame_idx = nullptr;
+    fill_wgrad_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));
+    p.N = Cin; p.small = x; p.s_vec = vec_ok(x, Cin, dtype); p.out = dw;
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, 1024);
+}
+
+// Dense: out[M,N] = act(a[M,K] * W + bias).  w_layout 0: W[K,N] (tf dense kernel), 1: W[N,K] (used for x * W^T).
+// nsplit > 1: split-K, raw fp32 partial slabs out[nsplit][M][N] (bias/act/mask must be unset; consumer reduces).
+int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const void* w, int w_layout, int N,
+                     const float* bias, int relu, const void* mask, void* out, int out_f32, int nsplit) {
+    GemmParams p = {};
+    p.a = a; p.a_frame_idx = nullptr;
+    fill_conv_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
+    const int vb = dtype == MI_F32 ? 4 : 8;
+    if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_bias_act: K must be a multiple of the 16-byte vector (pad K)");
+    p.N = N; p.b = w; p.ldb = w_layout == 0 ? N : K; p.b_vec = vec_ok(w, p.ldb, dtype);
+    p.out = out; p.bias = bias; p.mask = mask; p.relu = relu; p.out_f32 = out_f32;
+    int gz = 1;
+    if (nsplit > 1) {
+        if (bias || relu || mask || !out_f32) return mi_fail(MI_ERR_ARG, "mi_gemm_bias_act: split-K writes raw fp32 slabs only");
+        const int bk = dtype == MI_F32 ? 16 : 32;
+        int len = (K + nsplit - 1) / nsplit;
+        len = ((len + bk - 1) / bk) * bk;
+        if ((long long)len * (nsplit - 1) >= K) return mi_fail(MI_ERR_ARG, "mi_gemm_bias_act: nsplit too large for K (empty slab)");
+        p.ksplit_len = len; gz = nsplit;
+    }
+    if (w_layout == 0) return conv_form_gemm<B_KN>((hipStream_t)stream, dtype, 0, p, gz);
+    return conv_form_gemm<B_NK>((hipStream_t)stream, dtype, 0, p, gz);
+}
+
+// Dense filter gradient: dw[K,N] += a[M,K]^T * dy[M,N]   (fp32 atomics)
+int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw) {
+    WgradParams p = {};
+    p.big = a; p.frame_idx = nullptr;
+    fill_wgrad_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
+    const int vb = dtype == MI_F32 ? 4 : 8;
+    if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
+    p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, 512);
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// elementwise.hip — wavefront-fused HBM-bound kernels of the VAE path (gfx950, wave64):
+//   reparameterise + KL (fwd, bwd), BCE-with-logits loss + dlogits + deterministic row reduction,
+//   TF-form Adam over the flat parameter buffer (+ bf16 shadow weights, + grad clear), column sums (bias grads),
+//   sigmoid, range check, loss finalisation / on-device epoch metric accumulators.
+#include "common.hpp"
+#include "mi_internal.hpp"
+
+using namespace mi;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// reparam + KL forward (reference vae/models.py:7-9,97-105,131-134). One wave per batch row.
+//   heads : [nsplit][B][2Z] fp32 split-K partial sums of flat*[W_mean | W_logvar]
+//   mean/logvar = sum_s heads + bias ; z = mean + exp(.5 logvar) * eps (sample) or mean ; kl_b = -.5 sum(1+lv-mu^2-e^lv)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int nsplit, const float* __restrict__ bias_mean,
+                                      const float* __restrict__ bias_lv, const float* __restrict__ eps, int sample,
+                                      int B, int Z, float* __restrict__ mean, float* __restrict__ logvar,
+                                      T* __restrict__ z, float* __restrict__ kl_row) {
+    const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float klacc = 0.f;
+    for (int j = lane; j < Z; j += WAVE) {
+        float mu = bias_mean[j], lv = bias_lv[j];
+        for (int s = 0; s < nsplit; ++s) {
+            const float* h = heads + ((long long)s * B + row) * (2 * Z);
+            mu += h[j];
+            lv += h[Z + j];
+        }
+        mean[(long long)row * Z + j] = mu;
+        logvar[(long long)row * Z + j] = lv;
+        float zz = mu;
+        if (sample) zz = mu + expf(0.5f * lv) * eps[(long long)row * Z + j];
+        z[(long long)row * Z + j] = Elem<T>::from_f32(zz);
+        klacc += 1.0f + lv - mu * mu - expf(lv);
+    }
+    klacc = wave_sum(klacc);
+    if (lane == 0) kl_row[row] = -0.5f * klacc;
+}
+
+// reparam + KL backward: dz = sum_s dzs ; dmu = dz + beta*mu*inv_b*act ; dlv = dz*eps*.5*exp(.5lv) + beta*.5*(e^lv-1)*inv_b*act
+// act = 1 unless kl_tolerance clamps the row (tf.maximum passes the gradient to kl_b when kl_b >= tol*Z).
+template <typename T>
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit, const float* __restrict__ mean,
+                                      const float* __restrict__ logvar, const float* __restrict__ eps,
+                                      const float* __restrict__ kl_row, float beta, float kl_floor, float inv_b,
+                                      int B, int Z, T* __restrict__ dheads) {
+    const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float act = (kl_floor > 0.f && kl_row[row] < kl_floor) ? 0.f : 1.f;
+    for (int j = lane; j < Z; j += WAVE) {
+        float dz = 0.f;
+        for (int s = 0; s < nsplit; ++s) dz += dzs[((long long)s * B + row) * Z + j];
+        const float mu = mean[(long long)row * Z + j], lv = logvar[(long long)row * Z + j];
+        const float e = eps[(long long)row * Z + j];
+        const float dmu = dz + beta * mu * inv_b * act;
+        const float dlv = dz * e * 0.5f * expf(0.5f * lv) + beta * 0.5f * (expf(lv) - 1.0f) * inv_b * act;
+        dheads[(long long)row * (2 * Z) + j] = Elem<T>::from_f32(dmu);
+        dheads[(long long)row * (2 * Z) + Z + j] = Elem<T>::from_f32(dlv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reconstruction loss + dlogits (reference vae/models.py:11-22,123-128).  grid = (chunks, B), 256 threads x 8 px.
+//   kind 0: bce  max(x,0) - x*y + log1p(exp(-|x|))          d/dx = sigmoid(x) - y
+//   kind 1: bce_v2  -(y log(1e-10+s) + (1-y) log(1e-10+1-s))  d/dx = (-y/(1e-10+s) + (1-y)/(1e-10+1-s)) s(1-s)
+//   kind 2: mse  (y - s)^2                                    d/dx = 2 (s-y) s (1-s)
+// Row partial sums go to partial[b][chunk] (fixed order -> deterministic), dlogits are pre-scaled by inv_b.
+// ---------------------------------------------------------------------------------------------------
+constexpr int BCE_PER_THREAD = 8;
+constexpr int BCE_CHUNK = 256 * BCE_PER_THREAD;
+
+template <typename T>
+__global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
+                                                         const int* __restrict__ frame_idx, long long label_stride, int P,
+                                                         int kind, float inv_b, T* __restrict__ dlogits,
+                                                         float* __restrict__ partial, int nchunks) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long long fr = frame_idx ? (long long)frame_idx[b] : (long long)b;
+    const T* x = logits + (long long)b * P;
+    const float* y = labels + fr * label_stride;
+    T* dx = dlogits ? dlogits + (long long)b * P : nullptr;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < BCE_PER_THREAD; ++i) {
+        const int idx = chunk * BCE_CHUNK + i * 256 + threadIdx.x;
+        if (idx < P) {
+            const float xv = Elem<T>::to_f32(x[idx]), yv = y[idx];
+            float l, g;
+            if (kind == 0) {
+                const float e = expf(-fabsf(xv));
+                l = fmaxf(xv, 0.f) - xv * yv + log1pf(e);
+                const float s = xv >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                g = s - yv;
+            } else {
+                const float e = expf(-fabsf(xv));
+                const float s = xv >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                if (kind == 1) {
+                    l = -(yv * logf(1e-10f + s) + (1.0f - yv) * logf(1e-10f + 1.0f - s));
+                    g = (-yv / (1e-10f + s) + (1.0f - yv) / (1e-10f + 1.0f - s)) * s * (1.0f - s);
+                } else {
+                    const float d = yv - s;
+                    l = d * d;
+                    g = -2.0f * d * s * (1.0f - s);
+                }
+            }
+            acc += l;
+            if (dx) dx[idx] = Elem<T>::from_f32(g * inv_b);
+        }
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long long)b * nchunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// loss finalisation: recon = mean_b sum_chunk partial ; kl = mean_b max(kl_b, floor) ; fixed summation order.
+// out[0]=recon, out[1]=kl ; metrics[0..2] += (recon, kl, 1)  (the on-device tf.metrics.mean accumulators).
+// With data parallelism each rank calls this on its local rows with inv_b = 1/B_global and all-reduces out/metrics.
+__global__ void finalize_losses_kernel(const float* __restrict__ partial, int nchunks, const float* __restrict__ kl_row,
+                                       float kl_floor, int B, float inv_b, float* __restrict__ out,
+                                       float* __restrict__ metrics, float metric_weight) {
+    __shared__ float sr[256], sk[256];
+    float r = 0.f, k = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float rr = 0.f;
+        for (int c = 0; c < nchunks; ++c) rr += partial[(long long)b * nchunks + c];
+        r += rr;
+        k += fmaxf(kl_row[b], kl_floor > 0.f ? kl_floor : -3.0e38f);
+    }
+    sr[threadIdx.x] = r; sk[threadIdx.x] = k;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sr[threadIdx.x] += sr[threadIdx.x + o]; sk[threadIdx.x] += sk[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float recon = sr[0] * inv_b, kl = sk[0] * inv_b;
+        out[0] = recon; out[1] = kl;
+        if (metrics) { metrics[0] += recon; metrics[1] += kl; metrics[2] += metric_weight; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TF ApplyAdam over a flat fp32 buffer:  m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps)
+// alpha = lr*sqrt(1-b2^t)/(1-b1^t) comes from the host (fp32).  Optionally refreshes the bf16 shadow weights the
+// MFMA kernels read and clears the gradient for the next step's atomics (saves a memset + a cast pass).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                      float* __restrict__ g, long long n, float alpha, float omb1,
+                                                      float omb2, float epsilon, bf16_t* __restrict__ shadow, int clear_grad) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i], gv = ((f32x4*)g)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] += (gv[e] - mv[e]) * omb1;
+            vv[e] += (gv[e] * gv[e] - vv[e]) * omb2;
+            pv[e] -= (mv[e] * alpha) / (sqrtf(vv[e]) + epsilon);
+        }
+        ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+        if (clear_grad) { f32x4 zz = {0.f, 0.f, 0.f, 0.f}; ((f32x4*)g)[i] = zz; }
+        if (shadow) {
+            u16x4 s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = f32_to_bf16(pv[e]);
+            ((u16x4*)shadow)[i] = s;
+        }
+    }
+    // tail (n not a multiple of 4)
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gg = g[i], mm = m[i], vv = v[i], pp = p[i];
+        mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2; pp -= (mm * alpha) / (sqrtf(vv) + epsilon);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (clear_grad) g[i] = 0.f;
+        if (shadow) shadow[i] = f32_to_bf16(pp);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = f32_to_bf16(src[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column sums (BiasAddGrad): out[n] += sum_m x[m,n].  Two regimes: N <= 256 (flat, stride a multiple of N) and N > 256.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
+                                                           float* __restrict__ out) {
+    __shared__ float cs[256];
+    const int ntu = (256 / N) * N;                       // active threads: stride is a multiple of N -> fixed column per thread
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(M, r0 + (long long)rows_per_block);
+    float acc = 0.f;
+    if ((int)threadIdx.x < ntu) {
+        for (long long i = r0 * N + threadIdx.x; i < r1 * N; i += ntu) acc += Elem<T>::to_f32(x[i]);
+    }
+    cs[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        float s = 0.f;
+        for (int t = threadIdx.x; t < ntu; t += N) s += cs[t];
+        atomicAdd(&out[threadIdx.x], s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
+                                                          float* __restrict__ out) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(M, r0 + (long long)rows_per_block);
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < N; c += gridDim.y * 256) {
+        float acc = 0.f;
+        for (long long r = r0; r < r1; ++r) acc += Elem<T>::to_f32(x[r * N + c]);
+        atomicAdd(&out[c], acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_kernel(const T* __restrict__ x, float* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xv = Elem<T>::to_f32(x[i]);
+        out[i] = 1.0f / (1.0f + expf(-xv));
+    }
+}
+
+// verify_range (reference vae/models.py:24-30): flag[0] |= 1 if any element outside [lo, hi] or NaN
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long long n, float lo, float hi, int* __restrict__ flag) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        bad |= !(v >= lo && v <= hi);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+inline int grid_for(long long n, int per_block, int cap = 2048) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv,
+                          const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row) {
+    if (sample && !eps) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd: sampling needs eps");
+    dim3 g((B + 3) / 4), b(256);
+    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (float*)z, kl_row);
+    else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (bf16_t*)z, kl_row);
+    return mi_check_launch("reparam_kl_fwd");
+}
+
+int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar,
+                          const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads) {
+    dim3 g((B + 3) / 4), b(256);
+    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_bwd_kernel<float>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (float*)dheads);
+    else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (bf16_t*)dheads);
+    return mi_check_launch("reparam_kl_bwd");
+}
+
+int mi_recon_loss_chunks(int P) { return (P + BCE_CHUNK - 1) / BCE_CHUNK; }
+
+// logits [B,P] (T) vs labels (fp32 frames, optionally gathered through frame_idx) -> partial[B][chunks], dlogits [B,P] (T, may be null)
+int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride,
+                          int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial) {
+    const int nch = mi_recon_loss_chunks(P);
+    dim3 g(nch, B), b(256);
+    if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
+    if (dtype == MI_F32) hipLaunchKernelGGL(recon_loss_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (float*)dlogits, partial, nch);
+    else hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (bf16_t*)dlogits, partial, nch);
+    return mi_check_launch("recon_loss");
+}
+
+int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch,
+                           float* out2, float* metrics3, float metric_weight) {
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks, kl_row, kl_floor, B, inv_batch, out2, metrics3, metric_weight);
+    return mi_check_launch("finalize_losses");
+}
+
+int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2,
+                    float epsilon, void* bf16_shadow, int clear_grad) {
+    if ((((uintptr_t)param) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad)) & 15) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: buffers must be 16-byte aligned");
+    if (bf16_shadow && (((uintptr_t)bf16_shadow) & 7)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: bf16 shadow must be 8-byte aligned");
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, n, alpha,
+                       1.0f - beta1, 1.0f - beta2, epsilon, (bf16_t*)bf16_shadow, clear_grad);
+    return mi_check_launch("adam_tf");
+}
+
+int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    return mi_check_launch("cast_f32_bf16");
+}
+
+// out[N] += column sums of x[M,N]   (BiasAddGrad)
+int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out) {
+    if (M <= 0 || N <= 0) return MI_OK;
+    if (N <= 256) {
+        long long rows = (M + 1023) / 1024;
+        if (rows * N < 4096) rows = (4096 + N - 1) / N;
+        const int gx = (int)((M + rows - 1) / rows);
+        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
+        else hipLaunchKernelGGL(colsum_small_kernel<bf16_t>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+    } else {
+        long long rows = (M + 63) / 64;
+        if (rows < 8) rows = 8;
+        const int gx = (int)((M + rows - 1) / rows);
+        const int gy = (N + 255) / 256;
+        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_wide_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
+        else hipLaunchKernelGGL(colsum_wide_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+    }
+    return mi_check_launch("colsum");
+}
+
+int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n) {
+    if (dtype == MI_F32) hipLaunchKernelGGL(sigmoid_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, n);
+    else hipLaunchKernelGGL(sigmoid_kernel<bf16_t>, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, n);
+    return mi_check_launch("sigmoid");
+}
+
+int mi_range_check(void* stream, const float* x, long long n, float lo, float hi, int* flag) {
+    hipLaunchKernelGGL(range_check_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, x, n, lo, hi, flag);
+    return mi_check_launch("range_check");
+}
+
+}  // extern "C"

@@ -1,0 +1,9 @@
+// mi_internal.hpp — error plumbing shared by the launchers (not part of the public C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { MI_F32 = 0, MI_BF16 = 1 };
+enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_SHAPE = -2, MI_ERR_LAUNCH = -3, MI_ERR_STATE = -4 };
+
+int mi_fail(int code, const char* msg);          // records msg (thread-local) and returns code
+int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK / MI_ERR_LAUNCH

@@ -1,0 +1,56 @@
+"""Build libmi355_carla.so for gfx950 with hipcc (cross-compiles without a GPU). In-tree output so the
+artefact travels with the repo snapshot to the GPU box."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OBJ = os.path.join(ROOT, "build", "obj")
+LIB = os.path.join(HERE, "libmi355_carla.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    jobs = []
+    for s in sources():
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
+        if force or _newer(src, obj) or hdr_m > os.path.getmtime(obj):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        r = subprocess.run([hipcc] + FLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return src
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for done in ex.map(cc, jobs):
+            if verbose:
+                print("[mi355.build] compiled", os.path.basename(done), flush=True)
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
+    if force or jobs or not os.path.exists(LIB):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+        if verbose:
+            print("[mi355.build] linked", LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

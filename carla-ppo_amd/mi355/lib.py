@@ -1,0 +1,90 @@
+"""ctypes binding of libmi355_carla.so, generated from include/mi355_carla.h.
+
+There is NO fallback: if the shared library is missing the import of anything that needs it raises
+(the product path must fail loudly without the HIP extension).
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+HEADER = os.path.join(ROOT, "include", "mi355_carla.h")
+LIB_PATH = os.path.join(HERE, "libmi355_carla.so")
+
+MI_F32, MI_BF16 = 0, 1
+
+_CTYPES = {
+    "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
+    "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
+    "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p,
+    "int*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
+    "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
+}
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [(argtype_str, argname), ...])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?\w[\w\s]*?\**)\s*(mi_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        ret = re.sub(r"\s*\*", "*", ret)
+        arglist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"^(.*?)(\w+)$", a)
+                typ = re.sub(r"\s*\*\s*", "*", mm.group(1).strip())
+                arglist.append((typ, mm.group(2)))
+        protos[name] = (ret, arglist)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise MiError("libmi355_carla.so not found at %s — run `python __graft_entry__.py` (build()) first; "
+                          "there is no CPU fallback" % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self.cdll.mi_last_error.restype = ctypes.c_char_p
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self.cdll, name)          # AttributeError if the header declares a symbol the .so lacks
+            fn.restype = _CTYPES[ret]
+            fn.argtypes = [_CTYPES[t] for t, _ in args]
+            if ret == "int" and name not in ("mi_abi_version", "mi_recon_loss_chunks", "mi_ppo_loss_blocks",
+                                             "mi_ppo_loss_partial_floats") and not name.endswith(("_floats", "_bytes", "_count")):
+                setattr(self, name, self._checked(name, fn))
+            else:
+                setattr(self, name, fn)
+
+    def _checked(self, name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise MiError("%s failed (%d): %s" % (name, rc, self.cdll.mi_last_error().decode()))
+            return rc
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def get():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None -> int for ctypes."""
+    return None if t is None else t.data_ptr()

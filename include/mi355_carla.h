@@ -1,0 +1,95 @@
+/* mi355_carla.h — C ABI of libmi355_carla.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * ConvVAE + PPO hot path of bitsauce/Carla-ppo.
+ *
+ * The reference has no FFI layer (pure Python on TensorFlow 1.13); the boundary it exposes is the Python class
+ * surface of vae/models.py and ppo.py.  Those classes are re-implemented in carla-ppo_amd/{vae/models.py,ppo.py,utils.py}
+ * and call ONLY the functions below through ctypes.  Each entry cites the reference op(s) it replaces
+ * (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C; raw DEVICE pointers (from torch tensors' data_ptr()) and sizes; no torch types.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every call is asynchronous on it.
+ *   - return value: 0 = ok, negative = error (MI_ERR_*); message via mi_last_error() (thread local).
+ *   - no allocation inside the library: all buffers/workspaces are passed in (sizes via *_floats / *_bytes queries).
+ *   - dtype: 0 = fp32 storage + v_mfma_f32_32x32x2_f32 (parity mode), 1 = bf16 storage + v_mfma_f32_32x32x16_bf16
+ *     (throughput mode; fp32 accumulate, fp32 master weights / grads / optimiser state).
+ *   - layouts are TensorFlow's: activations NHWC, conv kernels HWIO [kh,kw,in,out], transposed-conv kernels
+ *     [kh,kw,out,in], dense kernels [in,out].  All convolutions are stride 2, VALID.
+ *
+ * The binding is generated from THIS file: carla-ppo_amd/mi355/lib.py parses the prototypes below.
+ */
+#ifndef MI355_CARLA_H
+#define MI355_CARLA_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_F32 0
+#define MI_BF16 1
+
+#define MI_OK 0
+#define MI_ERR_ARG (-1)
+#define MI_ERR_SHAPE (-2)
+#define MI_ERR_LAUNCH (-3)
+#define MI_ERR_STATE (-4)
+
+/* ---- library ---- */
+const char* mi_last_error(void);
+int mi_abi_version(void);
+int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ---- convolution family (implicit-GEMM on MFMA, LDS-staged tiles) ---- */
+/* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be fp32 frames gathered through frame_idx. */
+int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
+/* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
+int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
+/* Conv2DBackpropFilter: dw += im2col(x)^T dy (fp32 atomics) */
+int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw);
+/* tf.layers.conv2d_transpose k x k, s2, VALID + BiasAdd (+ Relu) — vae/models.py:261-264 */
+int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
+/* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
+int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, const void* mask, void* dx);
+/* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
+int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw);
+/* tf.layers.dense (MatMul + BiasAdd + Relu) and its input gradient — vae/models.py:97-98,259; utils.py:25-28; ppo.py:43-55.
+ * w_layout 0: W[K,N]; 1: W[N,K] (x * W^T).  nsplit > 1: split-K raw fp32 slabs out[nsplit][M][N]. */
+int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const void* w, int w_layout, int N, const float* bias, int relu, const void* mask, void* out, int out_f32, int nsplit);
+/* dense kernel gradient dw[K,N] += a^T dy */
+int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw);
+
+/* ---- VAE elementwise / reduction kernels ---- */
+/* Normal(mean, exp(.5 lv)).sample + kl_divergence — vae/models.py:7-9,101-105 (eps injected; TF RNG is unseeded) */
+int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row);
+int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar, const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads);
+/* bce_loss / bce_loss_v2 / mse_loss + reduce_sum(axis=1) + gradient — vae/models.py:11-22,123-128 */
+int mi_recon_loss_chunks(int P);
+int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial);
+/* reduce_mean over the batch, kl_tolerance clamp, tf.metrics.mean accumulators — vae/models.py:124-137,145-146 */
+int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight);
+/* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
+int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
+int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
+/* BiasAddGrad */
+int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out);
+/* tf.nn.sigmoid(reconstructed_logits) — vae/models.py:113 */
+int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n);
+/* verify_range — vae/models.py:24-30 */
+int mi_range_check(void* stream, const float* x, long long n, float lo, float hi, int* flag);
+
+/* ---- PPO kernels ---- */
+/* prob ratio, clipped surrogate, value loss, entropy, and their gradients wrt the heads — ppo.py:58-66,112-132 */
+int mi_ppo_loss_blocks(int M);
+int mi_ppo_loss_partial_floats(int M);
+int mi_ppo_loss_fwd_bwd(void* stream, const float* u, const float* u_old, const float* logstd, const float* logstd_old, const float* vraw, const float* actions, const float* returns, const float* advantage, const float* low, const float* high, int M, int A, float clip_eps, float value_scale, float entropy_scale, float inv_m, float grad_scale, float* du, float* dv, float* partial, float* losses5, float* dlogstd);
+/* action_mean rescale, Normal.sample, clip_by_value — ppo.py:47,58-62 */
+int mi_policy_head(void* stream, const float* u, const float* logstd, const float* noise, const float* low, const float* high, int M, int A, int greedy, float* action, float* mean_out);
+/* compute_gae — utils.py:45-50 (fp64, rounding sequence of numpy + scipy.signal.lfilter) */
+int mi_gae_scan(void* stream, const double* rewards, const double* values, const double* terminals, int R, int T, double gamma, double lam, double* adv);
+/* returns = adv + values; advantage normalisation — train.py:176-177 (fp64, population std, per row) */
+int mi_adv_normalize(void* stream, double* adv, const double* values, int R, int T, double* returns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_CARLA_H */

@@ -1,0 +1,397 @@
+"""Op-level parity: every C-ABI kernel launcher vs a float64 torch-CPU statement of the same TF op, on the layer
+geometries of the ConvVAE (odd sizes, k=5, C=3 and C=1 edge layers, fused minibatch gather) and the PPO MLP."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hip_helpers import DT, assert_close, dev, host, rounded, stream, tols  # noqa: E402
+from mi355 import lib as milib  # noqa: E402
+
+CONVS = [  # IH, IW, Cin, Cout, k
+    (80, 160, 3, 32, 4), (39, 79, 32, 64, 4), (18, 38, 64, 128, 4), (8, 18, 128, 256, 4)]
+DECONVS = [  # IH, IW, Cin, Cout, k
+    (3, 8, 256, 128, 4), (8, 18, 128, 64, 4), (18, 38, 64, 32, 5), (39, 79, 32, 3, 4), (39, 79, 32, 1, 4)]
+
+
+def _nchw(a):
+    return a.permute(0, 3, 1, 2)
+
+
+def _nhwc(a):
+    return a.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", CONVS)
+def test_conv_fwd_dgrad_wgrad(dt, geom):
+    L = milib.get()
+    code, td = DT[dt]
+    IH, IW, Ci, Co, k = geom
+    B = 3
+    rng = np.random.RandomState(Ci)
+    first = Ci == 3
+    x = rng.rand(5 if first else B, IH, IW, Ci).astype(np.float32)
+    idx = np.array([3, 0, 4], np.int32) if first else None
+    w = (rng.randn(k, k, Ci, Co) / np.sqrt(k * k * Ci)).astype(np.float32)
+    b = (0.1 * rng.randn(Co)).astype(np.float32)
+    OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
+    dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+    mask = rng.randn(B, IH, IW, Ci).astype(np.float32)
+
+    # reference in float64 on the values the kernel reads (frames stay fp32 in HBM but are staged as T)
+    xr = rounded(x[idx] if first else x, td).requires_grad_(True)
+    wr = rounded(w, td).requires_grad_(True)
+    y = F.conv2d(_nchw(xr), wr.permute(3, 2, 0, 1), torch.from_numpy(b).double(), stride=2)
+    yref = _nhwc(F.relu(y))
+    dyr = rounded(dy, td)
+    y.backward(_nchw(dyr))
+    dxref = xr.grad * (rounded(mask, td) > 0)
+    dwref = wr.grad
+
+    xd = dev(x, torch.float32 if first else td)
+    wd, bd = dev(w, td), dev(b)
+    out = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
+    L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), dev(idx, torch.int32).data_ptr() if first else None, int(first),
+                         B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, 1, out.data_ptr())
+    rt, at = tols(dt, float(yref.abs().max()))
+    assert_close(host(out), yref.detach().numpy(), rt, at, "conv fwd")
+
+    dyd = dev(dy, td)
+    dw = torch.zeros(k, k, Ci, Co, device="cuda")
+    idxd = dev(idx, torch.int32) if first else None
+    L.mi_conv2d_nhwc_wgrad(stream(), code, xd.data_ptr(), idxd.data_ptr() if first else None, int(first), B, IH, IW, Ci,
+                           dyd.data_ptr(), k, k, Co, dw.data_ptr())
+    rt, at = tols("f32" if dt == "f32" else "bf16", float(dwref.abs().max()))
+    assert_close(host(dw), dwref.numpy(), rt if dt == "f32" else 1e-4, at if dt == "f32" else 1e-4 * float(dwref.abs().max()), "conv wgrad")
+
+    if not first:                                        # conv1's input gradient is never needed
+        dx = torch.full((B, IH, IW, Ci), 7.0, device="cuda", dtype=td)
+        L.mi_conv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), k, k, Ci, IH, IW,
+                               dev(mask, td).data_ptr(), dx.data_ptr())
+        rt, at = tols(dt, float(dxref.abs().max()))
+        assert_close(host(dx), dxref.numpy(), rt, at, "conv dgrad")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", DECONVS)
+def test_deconv_fwd_dgrad_wgrad(dt, geom):
+    L = milib.get()
+    code, td = DT[dt]
+    IH, IW, Ci, Co, k = geom
+    B = 3
+    rng = np.random.RandomState(Co + k)
+    x = rng.randn(B, IH, IW, Ci).astype(np.float32)
+    w = (rng.randn(k, k, Co, Ci) / np.sqrt(k * k * Ci / 4)).astype(np.float32)          # [kh,kw,out,in]
+    b = (0.1 * rng.randn(Co)).astype(np.float32)
+    OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
+    dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+    mask = rng.randn(B, IH, IW, Ci).astype(np.float32)
+
+    xr = rounded(x, td).requires_grad_(True)
+    wr = rounded(w, td).requires_grad_(True)
+    y = F.conv_transpose2d(_nchw(xr), wr.permute(3, 2, 0, 1), torch.from_numpy(b).double(), stride=2)
+    assert y.shape[2:] == (OH, OW)
+    relu = Co > 3
+    yref = _nhwc(F.relu(y) if relu else y)
+    y.backward(_nchw(rounded(dy, td)))
+    dxref = xr.grad * (rounded(mask, td) > 0)
+    dwref = wr.grad
+
+    xd, wd, bd = dev(x, td), dev(w, td), dev(b)
+    out = torch.full((B, OH, OW, Co), 9.0, device="cuda", dtype=td)
+    L.mi_deconv2d_nhwc_fwd(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, int(relu), out.data_ptr())
+    rt, at = tols(dt, float(yref.abs().max()))
+    assert_close(host(out), yref.detach().numpy(), rt, at, "deconv fwd")
+
+    dyd = dev(dy, td)
+    dx = torch.full((B, IH, IW, Ci), 5.0, device="cuda", dtype=td)
+    L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), k, k, Ci, dev(mask, td).data_ptr(), dx.data_ptr())
+    rt, at = tols(dt, float(dxref.abs().max()))
+    assert_close(host(dx), dxref.numpy(), rt, at, "deconv dgrad")
+
+    dw = torch.zeros(k, k, Co, Ci, device="cuda")
+    L.mi_deconv2d_nhwc_wgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw.data_ptr())
+    s = float(dwref.abs().max())
+    assert_close(host(dw), dwref.numpy(), 1e-5 if dt == "f32" else 1e-4, (2e-5 if dt == "f32" else 1e-4) * s, "deconv wgrad")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_dgrad_into_larger_input(dt):
+    """conv2 reads a 39x79 map but its VALID s2 windows never touch the last row/col: their gradient must be 0."""
+    L = milib.get()
+    code, td = DT[dt]
+    rng = np.random.RandomState(0)
+    B, IH, IW, Ci, Co, k = 2, 39, 79, 32, 64, 4
+    dy = rng.randn(B, 18, 38, Co).astype(np.float32)
+    w = rng.randn(k, k, Ci, Co).astype(np.float32) * 0.05
+    dx = torch.full((B, IH, IW, Ci), 3.0, device="cuda", dtype=td)
+    L.mi_conv2d_nhwc_dgrad(stream(), code, dev(dy, td).data_ptr(), B, 18, 38, Co, dev(w, td).data_ptr(), k, k, Ci, IH, IW, None, dx.data_ptr())
+    g = host(dx)
+    assert (g[:, 38] == 0).all() and (g[:, :, 78] == 0).all() and np.abs(g[:, :38, :78]).max() > 0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(5, 6144, 128, 0, 12), (5, 64, 6144, 0, 1), (5, 128, 6144, 1, 1), (7, 6144, 64, 1, 8),
+                                   (32, 72, 500, 0, 1), (130, 500, 300, 0, 1), (32, 300, 2, 0, 1), (32, 300, 1, 0, 1),
+                                   (33, 304, 504, 1, 1)])
+def test_dense_gemm_variants(dt, shape):
+    L = milib.get()
+    code, td = DT[dt]
+    M, K, N, layout, nsplit = shape
+    if dt == "bf16" and (K % 8):
+        pytest.skip("bf16 vectors need K % 8 == 0")
+    rng = np.random.RandomState(M + N)
+    a = rng.randn(M, K).astype(np.float32)
+    w = (rng.randn(K, N) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32)
+    mask = rng.randn(M, N).astype(np.float32)
+    ref = rounded(a, td) @ rounded(w, td)
+    wd = dev(w if layout == 0 else np.ascontiguousarray(w.T), td)
+    if nsplit > 1:
+        out = torch.full((nsplit, M, N), 1.0, device="cuda")
+        L.mi_gemm_bias_act(stream(), code, dev(a, td).data_ptr(), M, K, wd.data_ptr(), layout, N, None, 0, None, out.data_ptr(), 1, nsplit)
+        got = host(out).sum(0)
+        assert_close(got, ref.numpy(), 1e-5, 3e-5 * float(ref.abs().max()), "split-K gemm")
+        return
+    ref = ref + torch.from_numpy(b).double()
+    ref = F.relu(ref) * (rounded(mask, td) > 0)
+    out = torch.empty(M, N, device="cuda", dtype=td)
+    L.mi_gemm_bias_act(stream(), code, dev(a, td).data_ptr(), M, K, wd.data_ptr(), layout, N, dev(b).data_ptr(), 1, dev(mask, td).data_ptr(), out.data_ptr(), 0, 1)
+    rt, at = tols(dt, float(ref.abs().max()))
+    assert_close(host(out), ref.numpy(), rt, at, "gemm+bias+relu+mask")
+    # fp32 output regardless of storage type
+    out32 = torch.empty(M, N, device="cuda")
+    L.mi_gemm_bias_act(stream(), code, dev(a, td).data_ptr(), M, K, wd.data_ptr(), layout, N, dev(b).data_ptr(), 0, None, out32.data_ptr(), 1, 1)
+    ref2 = rounded(a, td) @ rounded(w, td) + torch.from_numpy(b).double()
+    assert_close(host(out32), ref2.numpy(), 1e-5, 3e-5 * float(ref2.abs().max()), "gemm f32 out")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(6, 6144, 128), (6, 64, 6144), (40, 72, 500), (40, 500, 300), (40, 304, 2), (40, 304, 1), (2100, 64, 64)])
+def test_dense_wgrad(dt, shape):
+    L = milib.get()
+    code, td = DT[dt]
+    M, K, N = shape
+    rng = np.random.RandomState(K + N)
+    a, dy = rng.randn(M, K).astype(np.float32), rng.randn(M, N).astype(np.float32)
+    ref = rounded(a, td).T @ rounded(dy, td)
+    dw = torch.zeros(K, N, device="cuda")
+    L.mi_gemm_wgrad(stream(), code, dev(a, td).data_ptr(), dev(dy, td).data_ptr(), M, K, N, dw.data_ptr())
+    assert_close(host(dw), ref.numpy(), 1e-5, 3e-5 * float(ref.abs().max()), "dense wgrad")
+    L.mi_gemm_wgrad(stream(), code, dev(a, td).data_ptr(), dev(dy, td).data_ptr(), M, K, N, dw.data_ptr())      # accumulates
+    assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_reparam_kl_fwd_bwd(dt):
+    L = milib.get()
+    code, td = DT[dt]
+    rng = np.random.RandomState(0)
+    B, Z, ns = 37, 64, 3
+    heads = rng.randn(ns, B, 2 * Z).astype(np.float32) * 0.3
+    bm, bl = rng.randn(Z).astype(np.float32) * 0.1, rng.randn(Z).astype(np.float32) * 0.1
+    eps = rng.randn(B, Z).astype(np.float32)
+    dzs = rng.randn(2, B, Z).astype(np.float32)
+    beta, tol = 1.5, 0.0
+    h = torch.from_numpy(heads).double().sum(0)
+    mu = (h[:, :Z] + torch.from_numpy(bm).double()).requires_grad_(True)
+    lv = (h[:, Z:] + torch.from_numpy(bl).double()).requires_grad_(True)
+    z = mu + torch.exp(0.5 * lv) * torch.from_numpy(eps).double()
+    kl = -0.5 * (1 + lv - mu * mu - lv.exp()).sum(1)
+    loss = (z * torch.from_numpy(dzs).double().sum(0)).sum() + beta * kl.mean()
+    loss.backward()
+    mean = torch.empty(B, Z, device="cuda"); logvar = torch.empty(B, Z, device="cuda")
+    zd = torch.empty(B, Z, device="cuda", dtype=td); klr = torch.empty(B, device="cuda")
+    epsd = dev(eps)
+    L.mi_vae_reparam_kl_fwd(stream(), code, dev(heads).data_ptr(), ns, dev(bm).data_ptr(), dev(bl).data_ptr(), epsd.data_ptr(), 1, B, Z,
+                            mean.data_ptr(), logvar.data_ptr(), zd.data_ptr(), klr.data_ptr())
+    assert_close(host(mean), mu.detach().numpy(), 1e-6, 1e-6, "mean")
+    assert_close(host(klr), kl.detach().numpy(), 1e-5, 1e-5, "kl rows")
+    rt, at = tols(dt, float(z.abs().max()))
+    assert_close(host(zd), z.detach().numpy(), rt, at, "z")
+    dh = torch.empty(B, 2 * Z, device="cuda", dtype=td)
+    L.mi_vae_reparam_kl_bwd(stream(), code, dev(dzs).data_ptr(), 2, mean.data_ptr(), logvar.data_ptr(), epsd.data_ptr(), klr.data_ptr(),
+                            beta, tol, 1.0 / B, B, Z, dh.data_ptr())
+    ref = torch.cat([mu.grad, lv.grad], 1).numpy()
+    rt, at = tols(dt, float(np.abs(ref).max()))
+    assert_close(host(dh), ref, rt, at, "dheads")
+    # inference mode: z == mean, no eps needed
+    L.mi_vae_reparam_kl_fwd(stream(), code, dev(heads).data_ptr(), ns, dev(bm).data_ptr(), dev(bl).data_ptr(), None, 0, B, Z,
+                            mean.data_ptr(), logvar.data_ptr(), zd.data_ptr(), klr.data_ptr())
+    assert_close(host(zd), rounded(host(mean).astype(np.float32), td).numpy(), 0, 0, "z==mean")
+    # kl_tolerance: rows whose KL is below the floor get no KL gradient
+    floor = float(np.median(host(klr)))
+    L.mi_vae_reparam_kl_bwd(stream(), code, dev(np.zeros_like(dzs)).data_ptr(), 2, mean.data_ptr(), logvar.data_ptr(), epsd.data_ptr(), klr.data_ptr(),
+                            beta, floor, 1.0 / B, B, Z, dh.data_ptr())
+    g = host(dh)
+    below = host(klr) < floor
+    assert (g[below] == 0).all() and (np.abs(g[~below]).sum(1) > 0).all()
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_recon_loss_fwd_bwd(dt, kind):
+    L = milib.get()
+    code, td = DT[dt]
+    rng = np.random.RandomState(kind)
+    B, P = 5, 38400
+    logits = (rng.randn(B, P) * 3).astype(np.float32)
+    frames = rng.rand(8, P).astype(np.float32)
+    idx = np.array([7, 2, 2, 0, 5], np.int32)
+    x = rounded(logits, td).requires_grad_(True)
+    y = torch.from_numpy(frames[idx]).double()
+    if kind == 0:
+        per = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    elif kind == 1:
+        s = torch.sigmoid(x); per = -(y * torch.log(1e-10 + s) + (1 - y) * torch.log(1e-10 + 1 - s))
+    else:
+        per = (y - torch.sigmoid(x)) ** 2
+    rows = per.sum(1)
+    (rows.sum() / 16.0).backward()                       # inv_batch = 1/16 (global batch under data parallelism)
+    nch = L.mi_recon_loss_chunks(P)
+    partial = torch.zeros(B, nch, device="cuda")
+    dl = torch.empty(B, P, device="cuda", dtype=td)
+    L.mi_bce_logits_fwd_bwd(stream(), code, dev(logits, td).data_ptr(), dev(frames).data_ptr(), dev(idx, torch.int32).data_ptr(), P, B, P, kind,
+                            1.0 / 16.0, dl.data_ptr(), partial.data_ptr())
+    assert_close(host(partial).sum(1), rows.detach().numpy(), 2e-6, 1e-3, "row losses")
+    rt, at = tols(dt, float(x.grad.abs().max()))
+    assert_close(host(dl), x.grad.numpy(), rt, at, "dlogits")
+    klr = dev(rng.rand(B).astype(np.float32))
+    out2, met = torch.zeros(2, device="cuda"), torch.zeros(3, device="cuda")
+    for _ in range(2):
+        L.mi_vae_finalize_losses(stream(), partial.data_ptr(), nch, klr.data_ptr(), 0.5, B, 1.0 / B, out2.data_ptr(), met.data_ptr(), 1.0)
+    o = host(out2)
+    assert o[0] == pytest.approx(float(rows.mean()), rel=1e-5)
+    assert o[1] == pytest.approx(float(np.maximum(host(klr), 0.5).mean()), rel=1e-6)
+    assert np.allclose(host(met), [2 * o[0], 2 * o[1], 2.0], rtol=1e-6)
+
+
+def test_adam_tf_flat_bit_exact_vs_c_restatement():
+    import ctypes, os
+    L = milib.get()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = ctypes.CDLL(os.path.join(root, "oracle", "libgae_ref.so"))
+    ref.adam_tf_f32.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t] + [ctypes.c_float] * 4
+    rng = np.random.RandomState(0)
+    n = 100003
+    p, g = rng.randn(n).astype(np.float32), (rng.randn(n) * 10 ** rng.uniform(-6, 1, n)).astype(np.float32)
+    m, v = (rng.randn(n) * 0.1).astype(np.float32), (rng.rand(n) * 0.01).astype(np.float32)
+    npad = (n + 7) // 8 * 8
+    buf = [torch.zeros(npad, device="cuda") for _ in range(4)]
+    for t, a in zip(buf, (p, m, v, g)):
+        t[:n] = torch.from_numpy(a).cuda()
+    shadow = torch.zeros(npad, device="cuda", dtype=torch.bfloat16)
+    alpha = np.float32(1e-4 * np.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3))
+    L.mi_adam_tf_flat(stream(), buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr(), n, float(alpha), 0.9, 0.999, 1e-8, shadow.data_ptr(), 1)
+    pc, mc, vc = p.copy(), m.copy(), v.copy()
+    ref.adam_tf_f32(pc.ctypes.data, mc.ctypes.data, vc.ctypes.data, g.ctypes.data, n, alpha, np.float32(0.9), np.float32(0.999), np.float32(1e-8))
+    torch.cuda.synchronize()
+    assert np.array_equal(buf[0][:n].cpu().numpy(), pc) and np.array_equal(buf[1][:n].cpu().numpy(), mc) and np.array_equal(buf[2][:n].cpu().numpy(), vc)
+    assert float(buf[3].abs().max()) == 0.0
+    assert torch.equal(shadow[:n].cpu(), torch.from_numpy(pc).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("MN", [(3 * 12800, 3), (3 * 3081, 32), (1000, 64), (77, 256), (9, 6144), (40, 500), (40, 300), (40, 2), (40, 1), (5, 128)])
+def test_colsum(dt, MN):
+    L = milib.get()
+    code, td = DT[dt]
+    M, N = MN
+    x = np.random.RandomState(N).randn(M, N).astype(np.float32)
+    out = torch.ones(N, device="cuda")
+    L.mi_colsum(stream(), code, dev(x, td).data_ptr(), M, N, out.data_ptr())
+    ref = rounded(x, td).sum(0).numpy() + 1.0
+    assert_close(host(out), ref, 1e-5, 1e-4 * max(1.0, float(np.abs(ref).max())), "colsum")
+
+
+def test_sigmoid_range_check_cast():
+    L = milib.get()
+    x = np.random.RandomState(0).randn(1000).astype(np.float32) * 5
+    out = torch.empty(1000, device="cuda")
+    L.mi_sigmoid(stream(), milib.MI_F32, dev(x).data_ptr(), out.data_ptr(), 1000)
+    assert_close(host(out), 1 / (1 + np.exp(-x.astype(np.float64))), 1e-6, 1e-7, "sigmoid")
+    flag = torch.zeros(1, device="cuda", dtype=torch.int32)
+    ok = dev(np.random.rand(5000).astype(np.float32))
+    L.mi_range_check(stream(), ok.data_ptr(), 5000, 0.0, 1.0, flag.data_ptr())
+    assert int(flag.item()) == 0
+    ok[4321] = 1.5
+    L.mi_range_check(stream(), ok.data_ptr(), 5000, 0.0, 1.0, flag.data_ptr())
+    assert int(flag.item()) == 1
+    bf = torch.empty(1000, device="cuda", dtype=torch.bfloat16)
+    L.mi_cast_f32_to_bf16(stream(), dev(x).data_ptr(), bf.data_ptr(), 1000)
+    torch.cuda.synchronize()
+    assert torch.equal(bf.cpu(), torch.from_numpy(x).to(torch.bfloat16))
+
+
+def test_ppo_loss_and_head_vs_oracle_formulas():
+    from oracle import ppo_oracle as po
+    L = milib.get()
+    rng = np.random.RandomState(3)
+    M, A = 300, 2
+    u, uo = rng.randn(M, A).astype(np.float32), rng.randn(M, A).astype(np.float32)
+    uo = (u + 0.2 * uo).astype(np.float32)
+    ls, lso = np.array([-0.3, 0.1], np.float32), np.array([-0.25, 0.05], np.float32)
+    v, R, Ad = rng.randn(M).astype(np.float32), rng.randn(M).astype(np.float32), rng.randn(M).astype(np.float32)
+    act = rng.uniform(-1, 1, (M, A)).astype(np.float32)
+    low, high = np.array([-1, 0], np.float32), np.array([1, 1], np.float32)
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    lst = torch.tensor(ls, dtype=torch.float64, requires_grad=True)
+    vt = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    lo, hi = torch.tensor(low).double(), torch.tensor(high).double()
+    mean = lo + ((torch.tanh(ut) + 1) / 2) * (hi - lo)
+    mean_o = lo + ((torch.tanh(torch.tensor(uo).double()) + 1) / 2) * (hi - lo)
+    a = torch.tensor(act).double()
+    logp = po.normal_log_prob(a, mean, lst).sum(-1, keepdim=True)
+    logpo = po.normal_log_prob(a, mean_o, torch.tensor(lso).double()).sum(-1, keepdim=True)
+    ratio = torch.exp(logp - logpo)
+    adv = torch.tensor(Ad).double().unsqueeze(-1)
+    pl = torch.minimum(ratio * adv, torch.clamp(ratio, 0.8, 1.2) * adv).mean()
+    vl = ((vt - torch.tensor(R).double()) ** 2).mean() * 0.7
+    el = (0.5 + po.HALF_LOG_2PI + torch.log(torch.exp(lst))).sum() * 0.02
+    loss = -pl + vl - el
+    loss.backward()
+    du, dv = torch.empty(M, A, device="cuda"), torch.empty(M, device="cuda")
+    part = torch.zeros(L.mi_ppo_loss_partial_floats(M), device="cuda")
+    losses, dls = torch.zeros(5, device="cuda"), torch.zeros(A, device="cuda")
+    L.mi_ppo_loss_fwd_bwd(stream(), dev(u).data_ptr(), dev(uo).data_ptr(), dev(ls).data_ptr(), dev(lso).data_ptr(), dev(v).data_ptr(), dev(act).data_ptr(),
+                          dev(R).data_ptr(), dev(Ad).data_ptr(), dev(low).data_ptr(), dev(high).data_ptr(), M, A, 0.2, 0.7, 0.02, 1.0 / M, 1.0,
+                          du.data_ptr(), dv.data_ptr(), part.data_ptr(), losses.data_ptr(), dls.data_ptr())
+    got = host(losses)
+    assert np.allclose(got[:4], [float(pl), float(vl), float(el), float(loss)], rtol=2e-5, atol=1e-6)
+    assert got[4] == pytest.approx(float(ratio.mean()), rel=2e-5)
+    assert_close(host(du), ut.grad.numpy(), 2e-4, 1e-6, "du")
+    assert_close(host(dv), vt.grad.numpy(), 1e-5, 1e-7, "dv")
+    assert_close(host(dls), lst.grad.numpy(), 2e-4, 1e-6, "dlogstd")
+    noise = rng.randn(M, A).astype(np.float32)
+    actd, meand = torch.empty(M, A, device="cuda"), torch.empty(M, A, device="cuda")
+    L.mi_policy_head(stream(), dev(u).data_ptr(), dev(ls).data_ptr(), dev(noise).data_ptr(), dev(low).data_ptr(), dev(high).data_ptr(), M, A, 0, actd.data_ptr(), meand.data_ptr())
+    ref = np.clip(mean.detach().numpy() + np.exp(ls.astype(np.float64)) * noise, low, high)
+    assert_close(host(actd), ref, 1e-5, 1e-6, "sampled action")
+    assert_close(host(meand), mean.detach().numpy(), 1e-5, 1e-6, "action mean")
+
+
+def test_gae_scan_bit_exact_and_normalize():
+    from oracle import ppo_oracle as po
+    L = milib.get()
+    rng = np.random.RandomState(9)
+    R, T = 70, 128
+    rew = rng.uniform(0, 1, (R, T))
+    val = rng.randn(R, T + 1).astype(np.float32).astype(np.float64)
+    done = np.zeros((R, T)); done[::3, -1] = 1.0
+    adv = torch.empty(R, T, device="cuda", dtype=torch.float64)
+    vd = dev(val, torch.float64)
+    L.mi_gae_scan(stream(), dev(rew, torch.float64).data_ptr(), vd.data_ptr(), dev(done, torch.float64).data_ptr(), R, T, 0.99, 0.95, adv.data_ptr())
+    got = host(adv)
+    for r in range(R):
+        ref = po.compute_gae(list(rew[r]), list(val[r, :T].astype(np.float32)), np.float32(val[r, T]), list(done[r].astype(bool)), 0.99, 0.95)
+        assert np.array_equal(got[r], ref), r                         # bit-exact fp64
+    ret = torch.empty(R, T, device="cuda", dtype=torch.float64)
+    L.mi_adv_normalize(stream(), adv.data_ptr(), vd.data_ptr(), R, T, ret.data_ptr())
+    a2, r2 = host(adv), host(ret)
+    for r in range(0, R, 7):
+        rr, aa = po.returns_and_normalized_advantages(got[r].copy(), val[r, :T])
+        assert np.array_equal(r2[r], rr)
+        assert np.allclose(a2[r], aa, rtol=1e-12, atol=1e-12)
