@@ -1,0 +1,230 @@
+// ppo_engine.hip — PPO policy/value network: predict and one minibatch-SGD step behind the C ABI.
+// Mirrors PolicyGraph + PPO (reference ppo.py:16-66,112-147,218-251,275-276) with utils.build_mlp (utils.py:25-28):
+//   pi: s -> dense 500 relu -> dense 300 relu -> action_mean (tanh, rescaled to [low,high]) ; free action_logstd
+//   V : s -> dense 500 relu -> dense 300 relu -> value
+// fp32 storage + exact-fp32 MFMA (the net is 369 505 parameters; the step is launch-latency bound, not MFMA bound).
+// The state dimension is padded to a multiple of 8 on the device (zero rows in the first-layer kernels).
+#include <stdlib.h>
+#include "common.hpp"
+#include "mi_internal.hpp"
+#include "mi355_carla.h"
+
+using namespace mi;
+
+namespace {
+
+constexpr int PPO_TENSORS = 13;   // dense{k,b} dense_1{k,b} action_mean{k,b} action_logstd dense_2{k,b} dense_3{k,b} value{k,b}
+
+inline long long pad8(long long n) { return (n + 7) / 8 * 8; }
+
+struct PpoEngine {
+    MiPpoDesc d;
+    int kin;                                   // padded input dim
+    long long off[PPO_TENSORS], size[PPO_TENSORS], total;
+    float *params, *params_old, *grads, *m, *v;
+    char* ws;
+    // workspace offsets (bytes)
+    long long s_pad, h1, h2, g1, g2, u, vraw, h1o, h2o, uo, du, dv, dh2, dh1, dg2, dg1, partial, losses, mean, low, high, ws_total;
+    int last_M;
+    float* P(int t) const { return params + off[t]; }
+    float* PO(int t) const { return params_old + off[t]; }
+    float* G(int t) const { return grads + off[t]; }
+    void* at(long long o) const { return ws + o; }
+};
+
+void layout(PpoEngine& e) {
+    const MiPpoDesc& d = e.d;
+    e.kin = (d.input_dim + 7) / 8 * 8;
+    long long o = 0; int t = 0;
+    auto add = [&](long long n) { e.off[t] = o; e.size[t] = n; o += pad8(n); ++t; };
+    add((long long)e.kin * d.h1); add(d.h1); add((long long)d.h1 * d.h2); add(d.h2); add((long long)d.h2 * d.num_actions); add(d.num_actions);
+    add(d.num_actions);
+    add((long long)e.kin * d.h1); add(d.h1); add((long long)d.h1 * d.h2); add(d.h2); add(d.h2); add(1);
+    e.total = o;
+    const long long M = d.max_batch;
+    long long w = 0;
+    auto wa = [&](long long bytes) { long long r = w; w += (bytes + 255) / 256 * 256; return r; };
+    e.s_pad = wa(M * e.kin * 4);
+    e.h1 = wa(M * d.h1 * 4); e.h2 = wa(M * d.h2 * 4); e.g1 = wa(M * d.h1 * 4); e.g2 = wa(M * d.h2 * 4);
+    e.u = wa(M * d.num_actions * 4); e.vraw = wa(M * 4);
+    e.h1o = wa(M * d.h1 * 4); e.h2o = wa(M * d.h2 * 4); e.uo = wa(M * d.num_actions * 4);
+    e.du = wa(M * d.num_actions * 4); e.dv = wa(M * 4);
+    e.dh2 = wa(M * d.h2 * 4); e.dh1 = wa(M * d.h1 * 4); e.dg2 = wa(M * d.h2 * 4); e.dg1 = wa(M * d.h1 * 4);
+    e.partial = wa((long long)mi_ppo_loss_partial_floats((int)M) * 4);
+    e.losses = wa(256); e.mean = wa(M * d.num_actions * 4); e.low = wa(256); e.high = wa(256);
+    e.ws_total = w;
+}
+
+bool valid_desc(const MiPpoDesc* d) {
+    return d && d->max_batch >= 1 && d->input_dim >= 1 && d->num_actions >= 1 && d->num_actions <= 8 && d->h1 % 4 == 0 && d->h2 % 4 == 0 && d->h1 > 0 && d->h2 > 0;
+}
+
+// states [M, input_dim] -> zero-padded [M, kin]
+__global__ void pad_states_kernel(const float* __restrict__ s, int M, int din, int kin, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * kin) return;
+    const int r = i / kin, c = i - r * kin;
+    out[i] = c < din ? s[(long long)r * din + c] : 0.f;
+}
+
+// gradient through the two tiny heads back into the trunks (K = num_actions / 1 is below the MFMA vector width):
+//   dh2[m,j] = (h2>0) * sum_a du[m,a] * Wm[j,a] ;  dg2[m,j] = (g2>0) * dv[m] * Wv[j]
+__global__ void head_dgrad_kernel(const float* __restrict__ du, const float* __restrict__ dv, const float* __restrict__ Wm,
+                                  const float* __restrict__ Wv, const float* __restrict__ h2, const float* __restrict__ g2,
+                                  int M, int H, int A, float* __restrict__ dh2, float* __restrict__ dg2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H) return;
+    const int m = i / H, j = i - m * H;
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += du[(long long)m * A + a] * Wm[(long long)j * A + a];
+    dh2[i] = h2[i] > 0.f ? s : 0.f;
+    dg2[i] = g2[i] > 0.f ? dv[m] * Wv[j] : 0.f;
+}
+
+#define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
+
+int trunk_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, bool value_branch, void* h1, void* h2, void* u, void* vraw) {
+    const MiPpoDesc& d = e->d;
+    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->s_pad), M, e->kin, prm + off[0], 0, d.h1, prm + off[1], 1, nullptr, h1, 1, 1));
+    CK(mi_gemm_bias_act(st, MI_F32, h1, M, d.h1, prm + off[2], 0, d.h2, prm + off[3], 1, nullptr, h2, 1, 1));
+    CK(mi_gemm_bias_act(st, MI_F32, h2, M, d.h2, prm + off[4], 0, d.num_actions, prm + off[5], 0, nullptr, u, 1, 1));
+    if (value_branch) {
+        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->s_pad), M, e->kin, prm + off[7], 0, d.h1, prm + off[8], 1, nullptr, e->at(e->g1), 1, 1));
+        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->g1), M, d.h1, prm + off[9], 0, d.h2, prm + off[10], 1, nullptr, e->at(e->g2), 1, 1));
+        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->g2), M, d.h2, prm + off[11], 0, 1, prm + off[12], 0, nullptr, vraw, 1, 1));
+    }
+    return MI_OK;
+}
+
+int stage_states(PpoEngine* e, void* st, const float* states, int M) {
+    const int n = M * e->kin;
+    hipLaunchKernelGGL(pad_states_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, states, M, e->d.input_dim, e->kin, (float*)e->at(e->s_pad));
+    return mi_check_launch("pad_states");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_ppo_desc_size(void) { return (int)sizeof(MiPpoDesc); }
+int mi_ppo_tensor_count(void) { return PPO_TENSORS; }
+
+long long mi_ppo_param_floats(const MiPpoDesc* d) {
+    if (!valid_desc(d)) { mi_fail(MI_ERR_SHAPE, "mi_ppo_param_floats: bad descriptor (hidden sizes must be multiples of 4, 1..8 actions)"); return -1; }
+    PpoEngine e; e.d = *d; layout(e); return e.total;
+}
+
+// device order: dense{kernel [kin,h1], bias} dense_1{k,b} action_mean{k,b} action_logstd dense_2{k,b} dense_3{k,b} value{k,b}
+// (first-layer kernels carry kin - input_dim zero rows at the end)
+int mi_ppo_param_layout(const MiPpoDesc* d, long long* offsets, long long* sizes, int n) {
+    if (!valid_desc(d)) return mi_fail(MI_ERR_SHAPE, "mi_ppo_param_layout: bad descriptor");
+    if (n != PPO_TENSORS) return mi_fail(MI_ERR_ARG, "mi_ppo_param_layout: expected 13 entries");
+    PpoEngine e; e.d = *d; layout(e);
+    for (int i = 0; i < PPO_TENSORS; ++i) { offsets[i] = e.off[i]; sizes[i] = e.size[i]; }
+    return MI_OK;
+}
+
+long long mi_ppo_workspace_bytes(const MiPpoDesc* d) {
+    if (!valid_desc(d)) { mi_fail(MI_ERR_SHAPE, "mi_ppo_workspace_bytes: bad descriptor"); return -1; }
+    PpoEngine e; e.d = *d; layout(e); return e.ws_total;
+}
+
+void* mi_ppo_create(const MiPpoDesc* d, float* params, float* params_old, float* grads, float* adam_m, float* adam_v,
+                    void* workspace, long long workspace_bytes, const float* action_low, const float* action_high) {
+    if (!valid_desc(d)) { mi_fail(MI_ERR_SHAPE, "mi_ppo_create: bad descriptor"); return nullptr; }
+    PpoEngine* e = (PpoEngine*)calloc(1, sizeof(PpoEngine));
+    if (!e) { mi_fail(MI_ERR_STATE, "mi_ppo_create: out of host memory"); return nullptr; }
+    e->d = *d; layout(*e);
+    if (!params || !params_old || !workspace || workspace_bytes < e->ws_total || !action_low || !action_high) { free(e); mi_fail(MI_ERR_ARG, "mi_ppo_create: missing buffers or workspace too small"); return nullptr; }
+    if ((((uintptr_t)params) | ((uintptr_t)params_old) | ((uintptr_t)workspace) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_ppo_create: buffers must be 256-byte aligned"); return nullptr; }
+    e->params = params; e->params_old = params_old; e->grads = grads; e->m = adam_m; e->v = adam_v; e->ws = (char*)workspace;
+    // action bounds are host arrays (gym Box.low/high); keep a device copy in the workspace
+    if (hipMemcpy(e->at(e->low), action_low, d->num_actions * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->at(e->high), action_high, d->num_actions * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        free(e); mi_fail(MI_ERR_STATE, "mi_ppo_create: copying action bounds failed"); return nullptr;
+    }
+    return e;
+}
+
+void mi_ppo_destroy(void* h) { free(h); }
+
+// 0 losses[5] (policy, value, entropy, total, mean ratio)   1 action_mean [M,A] of the last predict
+void* mi_ppo_buffer(void* h, int which) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return nullptr;
+    return which == 0 ? e->at(e->losses) : which == 1 ? e->at(e->mean) : nullptr;
+}
+
+// PPO.update_old_policy (ppo.py:275-276): theta_old <- theta, one device copy of the flat buffer
+int mi_ppo_update_old(void* h, void* stream) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (hipMemcpyAsync(e->params_old, e->params, (size_t)e->total * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return mi_fail(MI_ERR_LAUNCH, "mi_ppo_update_old: copy failed");
+    return MI_OK;
+}
+
+// PPO.predict (ppo.py:231-251): states [M,input_dim] -> action [M,A] (sampled+clipped, or greedy mean), value [M]
+int mi_ppo_predict(void* h, void* stream, const float* states, int M, const float* noise, int greedy, float* action, float* value) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_predict: batch outside [1, max_batch]");
+    CK(stage_states(e, stream, states, M));
+    CK(trunk_fwd(e, stream, e->params, e->off, M, true, e->at(e->h1), e->at(e->h2), e->at(e->u), value));
+    return mi_policy_head(stream, (const float*)e->at(e->u), e->P(6), noise, (const float*)e->at(e->low), (const float*)e->at(e->high),
+                          M, e->d.num_actions, greedy, action, (float*)e->at(e->mean));
+}
+
+// Forward + loss + backward of one minibatch (the gradient half of PPO.train, ppo.py:218-229) into the flat gradient
+// buffer (zero on entry).  inv_m = 1/M_global, grad_scale = M_local/M_global (data parallel; 1 for a single GPU).
+int mi_ppo_forward_backward(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage,
+                            int M, float inv_m, float grad_scale) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_forward_backward: batch outside [1, max_batch]");
+    if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_ppo_forward_backward: engine created without a gradient buffer");
+    const MiPpoDesc& d = e->d;
+    void* st = stream;
+    const int A = d.num_actions;
+    CK(stage_states(e, st, states, M));
+    CK(trunk_fwd(e, st, e->params, e->off, M, true, e->at(e->h1), e->at(e->h2), e->at(e->u), e->at(e->vraw)));
+    CK(trunk_fwd(e, st, e->params_old, e->off, M, false, e->at(e->h1o), e->at(e->h2o), e->at(e->uo), nullptr));
+    CK(mi_ppo_loss_fwd_bwd(st, (const float*)e->at(e->u), (const float*)e->at(e->uo), e->P(6), e->PO(6), (const float*)e->at(e->vraw), actions, returns, advantage,
+                           (const float*)e->at(e->low), (const float*)e->at(e->high), M, A, d.clip_eps, d.value_scale, d.entropy_scale, inv_m, grad_scale,
+                           (float*)e->at(e->du), (float*)e->at(e->dv), (float*)e->at(e->partial), (float*)e->at(e->losses), e->G(6)));
+    // heads
+    CK(mi_colsum(st, MI_F32, e->at(e->du), M, A, e->G(5)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->h2), e->at(e->du), M, d.h2, A, e->G(4)));
+    CK(mi_colsum(st, MI_F32, e->at(e->dv), M, 1, e->G(12)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->g2), e->at(e->dv), M, d.h2, 1, e->G(11)));
+    {
+        const int n = M * d.h2;
+        hipLaunchKernelGGL(head_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)e->at(e->du), (const float*)e->at(e->dv), e->P(4), e->P(11),
+                           (const float*)e->at(e->h2), (const float*)e->at(e->g2), M, d.h2, A, (float*)e->at(e->dh2), (float*)e->at(e->dg2));
+        CK(mi_check_launch("head_dgrad"));
+    }
+    // policy trunk
+    CK(mi_colsum(st, MI_F32, e->at(e->dh2), M, d.h2, e->G(3)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->h1), e->at(e->dh2), M, d.h1, d.h2, e->G(2)));
+    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->dh2), M, d.h2, e->P(2), 1, d.h1, nullptr, 0, e->at(e->h1), e->at(e->dh1), 1, 1));
+    CK(mi_colsum(st, MI_F32, e->at(e->dh1), M, d.h1, e->G(1)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->s_pad), e->at(e->dh1), M, e->kin, d.h1, e->G(0)));
+    // value trunk
+    CK(mi_colsum(st, MI_F32, e->at(e->dg2), M, d.h2, e->G(10)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->g1), e->at(e->dg2), M, d.h1, d.h2, e->G(9)));
+    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->dg2), M, d.h2, e->P(9), 1, d.h1, nullptr, 0, e->at(e->g1), e->at(e->dg1), 1, 1));
+    CK(mi_colsum(st, MI_F32, e->at(e->dg1), M, d.h1, e->G(8)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->s_pad), e->at(e->dg1), M, e->kin, d.h1, e->G(7)));
+    e->last_M = M;
+    return MI_OK;
+}
+
+// tf.train.AdamOptimizer over the 13 policy/ variables (ppo.py:143-144); alpha folds lr*lr_decay^episode and the bias correction
+int mi_ppo_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_apply_adam: engine created without optimiser buffers");
+    return mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->total, alpha, beta1, beta2, epsilon, nullptr, 1);
+}
+
+}  // extern "C"

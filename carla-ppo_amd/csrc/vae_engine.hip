@@ -1,0 +1,351 @@
+// vae_engine.hip — ConvVAE training / inference step orchestration behind the C ABI (host C++ only; every
+// FLOP is in the kernels of gemm_core.hpp / elementwise.hip).  One engine = one model replica on one GPU.
+// The engine owns NO device memory: parameter / optimiser / workspace buffers are caller-provided (torch tensors).
+//
+// Mirrors the reference graph built in VAE.__init__ + ConvVAE (vae/models.py:85-142,249-266):
+//   4x conv k4 s2 relu -> flatten(H,W,C) -> [mean | logstd_sq] dense -> z = mean + exp(.5 lv) eps
+//   -> dense1 -> reshape(3,8,256) -> deconv k4,k4,k5 relu -> deconv4 k4 -> logits ; ELBO ; TF-Adam.
+#include <stdlib.h>
+#include <string.h>
+#include "common.hpp"
+#include "mi_internal.hpp"
+#include "mi355_carla.h"
+
+namespace {
+
+constexpr int NCONV = 4;
+constexpr int ENC_F[NCONV] = {32, 64, 128, 256};
+constexpr int DEC_F[3] = {128, 64, 32};
+constexpr int DEC_K[4] = {4, 4, 5, 4};
+constexpr int N_TENSORS = 20;   // conv1-4 (k,b) heads (k,b) dense1 (k,b) deconv1-4 (k,b)
+
+inline long long pad8(long long n) { return (n + 7) / 8 * 8; }
+
+struct Layout {
+    long long off[N_TENSORS], size[N_TENSORS], total;
+};
+
+struct Geom {
+    int ih[NCONV + 1], iw[NCONV + 1], c[NCONV + 1];      // encoder maps: index 0 = input, i = output of conv i
+    int dh[5], dw[5], dc[5];                              // decoder maps: index 0 = dense1 reshape, i = output of deconv i
+    int flat;
+};
+
+bool make_geom(const MiVaeDesc& d, Geom& g) {
+    g.ih[0] = d.ih; g.iw[0] = d.iw; g.c[0] = d.cin;
+    for (int i = 0; i < NCONV; ++i) {
+        if (g.ih[i] < 4 || g.iw[i] < 4) return false;
+        g.ih[i + 1] = (g.ih[i] - 4) / 2 + 1; g.iw[i + 1] = (g.iw[i] - 4) / 2 + 1; g.c[i + 1] = ENC_F[i];
+    }
+    g.flat = g.ih[4] * g.iw[4] * g.c[4];
+    g.dh[0] = g.ih[4]; g.dw[0] = g.iw[4]; g.dc[0] = g.c[4];
+    for (int i = 0; i < 4; ++i) {
+        g.dh[i + 1] = (g.dh[i] - 1) * 2 + DEC_K[i]; g.dw[i + 1] = (g.dw[i] - 1) * 2 + DEC_K[i];
+        g.dc[i + 1] = i < 3 ? DEC_F[i] : d.ct;
+    }
+    return true;
+}
+
+void make_layout(const MiVaeDesc& d, const Geom& g, Layout& L) {
+    long long o = 0;
+    int t = 0;
+    auto add = [&](long long n) { L.off[t] = o; L.size[t] = n; o += pad8(n); ++t; };
+    for (int i = 0; i < NCONV; ++i) { add(16LL * g.c[i] * g.c[i + 1]); add(g.c[i + 1]); }
+    add((long long)g.flat * 2 * d.z_dim); add(2 * d.z_dim);
+    add((long long)d.z_dim * g.flat); add(g.flat);
+    for (int i = 0; i < 4; ++i) { add((long long)DEC_K[i] * DEC_K[i] * g.dc[i + 1] * g.dc[i]); add(g.dc[i + 1]); }
+    L.total = o;
+}
+
+struct Workspace {
+    // byte offsets into the caller's workspace
+    long long act[NCONV + 1];          // act[i] = output of conv i (T)         (act[0] unused: frames stay in the dataset)
+    long long gact[NCONV + 1];         // gradient wrt pre-activation of conv i output (T)
+    long long dec[5];                  // dec[0] = dense1 output, dec[i] = output of deconv i (T); dec[4] = logits
+    long long gdec[5];
+    long long z, dheads;               // T
+    long long heads_slab, dz_slab, mean, logvar, kl_row, partial, out2, zf32;   // fp32
+    long long total;
+};
+
+struct VaeEngine {
+    MiVaeDesc d;
+    Geom g;
+    Layout L;
+    Workspace W;
+    float *params, *grads, *m, *v;
+    void* shadow;
+    char* ws;
+    int esz;                            // bytes per T
+    int ns_heads, ns_dz, nchunks;
+    int last_B;
+    const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
+    const float* bptr(int t) const { return params + L.off[t]; }
+    float* gptr(int t) const { return grads + L.off[t]; }
+    void* at(long long off) const { return ws + off; }
+};
+
+int pick_split(int M, int N, int K, int bk) {
+    const int tiles = ((M + 127) / 128) * (N <= 64 ? 1 : (N + 127) / 128);
+    int ns = 256 / (tiles > 0 ? tiles : 1);
+    if (ns < 1) ns = 1;
+    if (ns > 32) ns = 32;
+    while (ns > 1) {                    // every slab must own at least one K block
+        int len = (K + ns - 1) / ns; len = (len + bk - 1) / bk * bk;
+        if ((long long)len * (ns - 1) < K) break;
+        --ns;
+    }
+    return ns;
+}
+
+void make_workspace(VaeEngine& e) {
+    const MiVaeDesc& d = e.d; const Geom& g = e.g;
+    const long long B = d.max_batch;
+    long long o = 0;
+    auto add = [&](long long bytes) { long long r = o; o += (bytes + 255) / 256 * 256; return r; };
+    Workspace& W = e.W;
+    W.act[0] = W.gact[0] = 0;
+    for (int i = 1; i <= NCONV; ++i) {
+        const long long n = B * g.ih[i] * g.iw[i] * g.c[i];
+        W.act[i] = add(n * e.esz); W.gact[i] = add(n * e.esz);
+    }
+    for (int i = 0; i <= 4; ++i) {
+        const long long n = B * g.dh[i] * g.dw[i] * g.dc[i];
+        W.dec[i] = add(n * e.esz); W.gdec[i] = add(n * e.esz);
+    }
+    W.z = add(B * d.z_dim * e.esz); W.dheads = add(B * 2 * d.z_dim * e.esz);
+    W.heads_slab = add((long long)e.ns_heads * B * 2 * d.z_dim * 4);
+    W.dz_slab = add((long long)e.ns_dz * B * d.z_dim * 4);
+    W.mean = add(B * d.z_dim * 4); W.logvar = add(B * d.z_dim * 4); W.kl_row = add(B * 4);
+    W.partial = add(B * e.nchunks * 4); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
+    W.total = o;
+}
+
+bool init_engine(VaeEngine& e, const MiVaeDesc* desc) {
+    e.d = *desc;
+    if (!make_geom(e.d, e.g)) return false;
+    make_layout(e.d, e.g, e.L);
+    e.esz = e.d.dtype == MI_F32 ? 4 : 2;
+    const int bk = e.d.dtype == MI_F32 ? 16 : 32;
+    e.ns_heads = pick_split(e.d.max_batch, 2 * e.d.z_dim, e.g.flat, bk);
+    e.ns_dz = pick_split(e.d.max_batch, e.d.z_dim, e.g.flat, bk);
+    e.nchunks = mi_recon_loss_chunks(e.g.dh[4] * e.g.dw[4] * e.g.dc[4]);
+    make_workspace(e);
+    return true;
+}
+
+#define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
+
+int check_batch(const VaeEngine* e, int B) {
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (B < 1 || B > e->d.max_batch) return mi_fail(MI_ERR_ARG, "vae engine: batch outside [1, max_batch]");
+    return MI_OK;
+}
+
+// encoder: frames (fp32, optional gather) -> act[1..4] -> heads slabs -> mean/logvar/z/kl
+int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int B, const float* eps, int sample) {
+    const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    for (int i = 0; i < NCONV; ++i) {
+        const void* x = i == 0 ? (const void*)frames : e->at(e->W.act[i]);
+        CK(mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i],
+                              e->wptr(2 * i), e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
+    }
+    CK(mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wptr(8), 0, 2 * d.z_dim, nullptr, 0, nullptr,
+                        e->at(e->W.heads_slab), 1, e->ns_heads));
+    // split-K slabs are laid out [ns][B][2Z] with the CURRENT batch as the middle dimension
+    CK(mi_vae_reparam_kl_fwd(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
+                             B, d.z_dim, (float*)e->at(e->W.mean), (float*)e->at(e->W.logvar), e->at(e->W.z), (float*)e->at(e->W.kl_row)));
+    return MI_OK;
+}
+
+// decoder: z (T) -> dense1 -> deconv1..4 -> logits
+int run_decoder(VaeEngine* e, void* st, int B) {
+    const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    CK(mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wptr(10), 0, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
+    for (int i = 0; i < 4; ++i)
+        CK(mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
+                                DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1])));
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_vae_desc_size(void) { return (int)sizeof(MiVaeDesc); }
+int mi_vae_tensor_count(void) { return N_TENSORS; }
+
+long long mi_vae_param_floats(const MiVaeDesc* d) {
+    VaeEngine e;
+    if (!d || !init_engine(e, d)) { mi_fail(MI_ERR_SHAPE, "mi_vae_param_floats: unsupported geometry"); return -1; }
+    return e.L.total;
+}
+
+// offsets/sizes (in floats) of the 20 device tensors inside the flat buffer, device order:
+// conv1..4 {kernel,bias}, heads {kernel [flat,2Z] = [mean|logstd_sqare], bias [2Z]}, dense1 {kernel,bias}, deconv1..4 {kernel,bias}
+int mi_vae_param_layout(const MiVaeDesc* d, long long* offsets, long long* sizes, int n) {
+    VaeEngine e;
+    if (!d || !init_engine(e, d)) return mi_fail(MI_ERR_SHAPE, "mi_vae_param_layout: unsupported geometry");
+    if (n != N_TENSORS) return mi_fail(MI_ERR_ARG, "mi_vae_param_layout: expected 20 entries");
+    for (int i = 0; i < N_TENSORS; ++i) { offsets[i] = e.L.off[i]; sizes[i] = e.L.size[i]; }
+    return MI_OK;
+}
+
+long long mi_vae_workspace_bytes(const MiVaeDesc* d) {
+    VaeEngine e;
+    if (!d || !init_engine(e, d)) { mi_fail(MI_ERR_SHAPE, "mi_vae_workspace_bytes: unsupported geometry"); return -1; }
+    return e.W.total;
+}
+
+void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* bf16_shadow,
+                    void* workspace, long long workspace_bytes) {
+    VaeEngine* e = (VaeEngine*)calloc(1, sizeof(VaeEngine));
+    if (!e) { mi_fail(MI_ERR_STATE, "mi_vae_create: out of host memory"); return nullptr; }
+    if (!d || !init_engine(*e, d)) { free(e); mi_fail(MI_ERR_SHAPE, "mi_vae_create: unsupported geometry"); return nullptr; }
+    if (d->dtype != MI_F32 && d->dtype != MI_BF16) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: dtype must be 0 (f32) or 1 (bf16)"); return nullptr; }
+    if (d->dtype == MI_BF16 && !bf16_shadow) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: bf16 mode needs the shadow weight buffer"); return nullptr; }
+    if (!params || !workspace || workspace_bytes < e->W.total) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: missing buffers or workspace too small"); return nullptr; }
+    if ((((uintptr_t)params) | ((uintptr_t)workspace) | ((uintptr_t)bf16_shadow) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: buffers must be 256-byte aligned"); return nullptr; }
+    e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->ws = (char*)workspace;
+    e->last_B = 0;
+    return e;
+}
+
+void mi_vae_destroy(void* h) { free(h); }
+
+// bf16 mode: refresh the shadow weights from the fp32 masters (after load / init; Adam keeps them in sync afterwards)
+int mi_vae_sync_shadow(void* h, void* stream) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (e->d.dtype == MI_BF16) return mi_cast_f32_to_bf16(stream, e->params, e->shadow, e->L.total);
+    return MI_OK;
+}
+
+// device pointers into the workspace (valid after the corresponding call; fp32): 0 losses[2] (recon, kl), 1 mean [B,Z],
+// 2 logvar [B,Z], 3 kl_row [B];  4 logits [B,P] (T), 5 z [B,Z] (T)
+void* mi_vae_buffer(void* h, int which) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return nullptr;
+    switch (which) {
+        case 0: return e->at(e->W.out2);
+        case 1: return e->at(e->W.mean);
+        case 2: return e->at(e->W.logvar);
+        case 3: return e->at(e->W.kl_row);
+        case 4: return e->at(e->W.dec[4]);
+        case 5: return e->at(e->W.z);
+        default: return nullptr;
+    }
+}
+
+// Forward pass + ELBO terms of one minibatch: VAE.evaluate's per-batch sess.run (vae/models.py:226-229) and the
+// forward half of train_step (:213-216).  src/tgt: fp32 frame tables [n_frames, ...] on the device; idx: int32 [B] or null.
+// inv_batch = 1/B_global (data parallel: each rank passes its local rows).  want_grad: also write dlogits for backward.
+int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch,
+                   const float* eps, int sample, int want_grad, float* metrics3, float metric_weight) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    CK(run_encoder(e, stream, src, idx, B, eps, sample));
+    CK(run_decoder(e, stream, B));
+    const int P = g.dh[4] * g.dw[4] * g.dc[4];
+    CK(mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
+                             want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial)));
+    const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
+    CK(mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
+                              inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
+    e->last_B = B;
+    return MI_OK;
+}
+
+// Backward of the last mi_vae_forward(want_grad=1) into the flat fp32 gradient buffer (which must be zero on entry;
+// mi_vae_apply_adam clears it again).  part: 0 = everything, 1 = decoder half (deconv4..dense1 + dz), 2 = encoder half.
+// The two halves exist so the data-parallel host can all-reduce the decoder gradients while the encoder half runs.
+int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    const int B = e->last_B;
+    if (B < 1) return mi_fail(MI_ERR_STATE, "mi_vae_backward: no forward pass recorded");
+    if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_vae_backward: engine created without a gradient buffer");
+    const MiVaeDesc& d = e->d; const Geom& g = e->g; const Workspace& W = e->W;
+    void* st = stream;
+    if (part == 0 || part == 1) {
+        for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
+            const void* gy = e->at(W.gdec[i + 1]);
+            const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
+            CK(mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
+            CK(mi_deconv2d_nhwc_wgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i)));
+            CK(mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wptr(12 + 2 * i), DEC_K[i], DEC_K[i], g.dc[i],
+                                      i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
+        }
+        // dense1: h = z W1 + b1
+        CK(mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+        CK(mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+        CK(mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
+    }
+    if (part == 0 || part == 2) {
+        const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
+        CK(mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
+                                 eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
+        CK(mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+        CK(mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+        CK(mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
+        for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
+            const void* gy = e->at(W.gact[i + 1]);
+            const long long rows = (long long)B * g.ih[i + 1] * g.iw[i + 1];
+            CK(mi_colsum(st, d.dtype, gy, rows, g.c[i + 1], e->gptr(2 * i + 1)));
+            const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
+            CK(mi_conv2d_nhwc_wgrad(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i)));
+            if (i > 0)                                       // conv1's input gradient is never used
+                CK(mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
+                                        e->at(W.act[i]), e->at(W.gact[i])));
+        }
+    }
+    return MI_OK;
+}
+
+// tf.train.AdamOptimizer step over all 22 reference variables at once; alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
+int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_vae_apply_adam: engine created without optimiser buffers");
+    return mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, beta1, beta2, epsilon,
+                           e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1);
+}
+
+// VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32
+int mi_vae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    CK(run_encoder(e, stream, src, idx, B, nullptr, 0));
+    if (mean_out && hipMemcpyAsync(mean_out, e->at(e->W.mean), (size_t)B * e->d.z_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return mi_fail(MI_ERR_LAUNCH, "mi_vae_encode: copy failed");
+    return MI_OK;
+}
+
+// VAE.generate_from_latent (vae/models.py:188-191): z fp32 [B,Z] fed in place of the sample -> sigmoid(logits) [B,P] fp32
+int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    const long long n = (long long)B * d.z_dim;
+    if (d.dtype == MI_F32) {
+        if (hipMemcpyAsync(e->at(e->W.z), z, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return mi_fail(MI_ERR_LAUNCH, "mi_vae_decode: copy failed");
+    } else {
+        CK(mi_cast_f32_to_bf16(stream, z, e->at(e->W.z), n));
+    }
+    CK(run_decoder(e, stream, B));
+    return mi_sigmoid(stream, d.dtype, e->at(e->W.dec[4]), recon_out, (long long)B * g.dh[4] * g.dw[4] * g.dc[4]);
+}
+
+// VAE.reconstruct (vae/models.py:193-197): frames -> sigmoid(logits); samples z when sample=1 (training graph)
+int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    CK(run_encoder(e, stream, src, idx, B, eps, sample));
+    CK(run_decoder(e, stream, B));
+    const Geom& g = e->g;
+    return mi_sigmoid(stream, e->d.dtype, e->at(e->W.dec[4]), recon_out, (long long)B * g.dh[4] * g.dw[4] * g.dc[4]);
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""Host-side variable tables and initialisers (numpy), in TensorFlow's names, shapes and creation order.
+
+Reference: tf.layers defaults = glorot_uniform kernels / zero biases (vae/models.py:97-98,250-264; utils.py:25-28);
+action_mean kernel = variance_scaling(scale=0.1) (ppo.py:43-46); action_logstd = log(initial_std) (ppo.py:48).
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+ENC_FILTERS = (32, 64, 128, 256)
+DEC_FILTERS = (128, 64, 32)
+DEC_KERNELS = (4, 4, 5, 4)
+
+
+def conv_out(n, k=4):
+    return (n - k) // 2 + 1
+
+
+def encoded_shape(source_shape):
+    h, w = int(source_shape[0]), int(source_shape[1])
+    for _ in range(4):
+        h, w = conv_out(h), conv_out(w)
+    return (h, w, ENC_FILTERS[-1])
+
+
+def vae_variables(z_dim, source_shape, target_shape):
+    """name -> shape for the 22 trainable ConvVAE variables, TF creation order."""
+    v = OrderedDict()
+    cin = int(source_shape[-1])
+    for i, f in enumerate(ENC_FILTERS):
+        v["vae/encoder/conv%d/kernel" % (i + 1)] = (4, 4, cin, f)
+        v["vae/encoder/conv%d/bias" % (i + 1)] = (f,)
+        cin = f
+    enc = encoded_shape(source_shape)
+    flat = int(np.prod(enc))
+    v["vae/mean/kernel"] = (flat, z_dim)
+    v["vae/mean/bias"] = (z_dim,)
+    v["vae/logstd_sqare/kernel"] = (flat, z_dim)
+    v["vae/logstd_sqare/bias"] = (z_dim,)
+    v["vae/decoder/dense1/kernel"] = (z_dim, flat)
+    v["vae/decoder/dense1/bias"] = (flat,)
+    cin = enc[-1]
+    for i, (f, k) in enumerate(zip(DEC_FILTERS + (int(target_shape[-1]),), DEC_KERNELS)):
+        v["vae/decoder/deconv%d/kernel" % (i + 1)] = (k, k, f, cin)
+        v["vae/decoder/deconv%d/bias" % (i + 1)] = (f,)
+        cin = f
+    return v
+
+
+def ppo_variables(input_dim, num_actions, hidden=(500, 300), scope="policy"):
+    """name -> shape for the 13 trainable policy variables, TF creation order (ppo.py:42-55)."""
+    h1, h2 = hidden
+    v = OrderedDict()
+    v[scope + "/dense/kernel"] = (input_dim, h1)
+    v[scope + "/dense/bias"] = (h1,)
+    v[scope + "/dense_1/kernel"] = (h1, h2)
+    v[scope + "/dense_1/bias"] = (h2,)
+    v[scope + "/action_mean/kernel"] = (h2, num_actions)
+    v[scope + "/action_mean/bias"] = (num_actions,)
+    v[scope + "/action_logstd"] = (num_actions,)
+    v[scope + "/dense_2/kernel"] = (input_dim, h1)
+    v[scope + "/dense_2/bias"] = (h1,)
+    v[scope + "/dense_3/kernel"] = (h1, h2)
+    v[scope + "/dense_3/bias"] = (h2,)
+    v[scope + "/value/kernel"] = (h2, 1)
+    v[scope + "/value/bias"] = (1,)
+    return v
+
+
+def glorot_uniform(rng, shape):
+    receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+    limit = np.sqrt(6.0 / ((shape[-2] + shape[-1]) * receptive))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def variance_scaling_fan_in_truncnormal(rng, shape, scale):
+    stddev = np.sqrt(scale / shape[0]) / 0.87962566103423978      # TF's truncated-normal variance correction
+    x = rng.standard_normal(size=shape)
+    out = np.abs(x) > 2.0
+    while out.any():
+        x[out] = rng.standard_normal(size=int(out.sum()))
+        out = np.abs(x) > 2.0
+    return (x * stddev).astype(np.float32)
+
+
+def init_vae(seed, z_dim, source_shape, target_shape):
+    rng = np.random.RandomState(seed)
+    return OrderedDict((n, glorot_uniform(rng, s) if n.endswith("kernel") else np.zeros(s, np.float32))
+                       for n, s in vae_variables(z_dim, source_shape, target_shape).items())
+
+
+def init_ppo(seed, input_dim, num_actions, initial_std, initial_mean_factor=0.1, hidden=(500, 300)):
+    rng = np.random.RandomState(seed)
+    out = OrderedDict()
+    for n, s in ppo_variables(input_dim, num_actions, hidden).items():
+        if n.endswith("action_mean/kernel"):
+            out[n] = variance_scaling_fan_in_truncnormal(rng, s, initial_mean_factor)
+        elif n.endswith("kernel"):
+            out[n] = glorot_uniform(rng, s)
+        elif n.endswith("action_logstd"):
+            out[n] = np.full(s, np.log(initial_std), dtype=np.float32)
+        else:
+            out[n] = np.zeros(s, np.float32)
+    return out

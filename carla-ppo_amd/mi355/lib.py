@@ -21,7 +21,21 @@ _CTYPES = {
     "int*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
     "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
+    "long long*": ctypes.c_void_p, "void": None,
+    "const MiVaeDesc*": ctypes.c_void_p, "const MiPpoDesc*": ctypes.c_void_p,
 }
+
+
+class MiVaeDesc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("max_batch", ctypes.c_int), ("ih", ctypes.c_int), ("iw", ctypes.c_int),
+                ("cin", ctypes.c_int), ("ct", ctypes.c_int), ("z_dim", ctypes.c_int), ("loss_kind", ctypes.c_int),
+                ("beta", ctypes.c_float), ("kl_tolerance", ctypes.c_float)]
+
+
+class MiPpoDesc(ctypes.Structure):
+    _fields_ = [("max_batch", ctypes.c_int), ("input_dim", ctypes.c_int), ("num_actions", ctypes.c_int),
+                ("h1", ctypes.c_int), ("h2", ctypes.c_int), ("clip_eps", ctypes.c_float),
+                ("value_scale", ctypes.c_float), ("entropy_scale", ctypes.c_float)]
 
 
 class MiError(RuntimeError):
@@ -55,15 +69,19 @@ class _Lib:
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self.cdll.mi_last_error.restype = ctypes.c_char_p
+        self._check_structs = True
         for name, (ret, args) in self.protos.items():
             fn = getattr(self.cdll, name)          # AttributeError if the header declares a symbol the .so lacks
             fn.restype = _CTYPES[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
-            if ret == "int" and name not in ("mi_abi_version", "mi_recon_loss_chunks", "mi_ppo_loss_blocks",
-                                             "mi_ppo_loss_partial_floats") and not name.endswith(("_floats", "_bytes", "_count")):
+            if ret == "int" and not name.endswith(("_version", "_chunks", "_blocks", "_floats", "_bytes", "_count", "_size")):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)
+
+    def check_struct_sizes(self):
+        assert self.mi_vae_desc_size() == ctypes.sizeof(MiVaeDesc), "MiVaeDesc layout mismatch between header and binding"
+        assert self.mi_ppo_desc_size() == ctypes.sizeof(MiPpoDesc), "MiPpoDesc layout mismatch between header and binding"
 
     def _checked(self, name, fn):
         def call(*a):
@@ -82,6 +100,7 @@ def get():
     global _lib
     if _lib is None:
         _lib = _Lib()
+        _lib.check_struct_sizes()
     return _lib
 
 

@@ -1,0 +1,354 @@
+"""vae.models — drop-in for the reference's vae/models.py (VAE / ConvVAE / MlpVAE class surface), running on
+MI355X through libmi355_carla.so.  Same constructor keywords, attributes, method names, return conventions and
+error behaviour as the reference (file:line citations refer to the reference checkout):
+
+    VAE.__init__            vae/models.py:38-159      ConvVAE            vae/models.py:233-268
+    init_session            :161-170                  save / load_latest_checkpoint   :172-186
+    generate_from_latent    :188-191   (alias: decode)
+    reconstruct             :193-197                  encode             :199-202
+    get_step_idx            :204-205                  train_one_epoch    :207-218      evaluate   :220-231
+
+Differences that cannot be avoided: there is no tf.Session (init_session creates the device engine instead and
+`sess` is ignored); TF's unseeded reparameterisation noise is drawn on the device (or injected via `eps=` for
+parity runs); checkpoints are .npz bundles under the same directory layout and manifest.
+
+Host code is plumbing only: numpy in / numpy out, torch tensors as HBM handles; all arithmetic is HIP.
+"""
+import os
+
+import numpy as np
+
+from mi355 import checkpoint as ckpt
+from mi355 import dist as midist
+from mi355.init import init_vae, vae_variables
+
+
+# --- loss-function tokens: the reference passes these callables as `loss_fn=` (vae/train_vae.py:98-100) ---
+def bce_loss(labels=None, logits=None, targets=None):
+    """tf.nn.sigmoid_cross_entropy_with_logits (vae/models.py:11-15) — evaluated inside the fused HIP loss kernel."""
+    raise RuntimeError("bce_loss is a token selecting the fused HIP loss kernel; it is not evaluated on the host")
+
+
+def bce_loss_v2(labels=None, logits=None, targets=None, epsilon=1e-10):
+    """-(y log(eps+s) + (1-y) log(eps+1-s)) (vae/models.py:17-19)."""
+    raise RuntimeError("bce_loss_v2 is a token selecting the fused HIP loss kernel; it is not evaluated on the host")
+
+
+def mse_loss(labels=None, logits=None, targets=None):
+    """(labels - targets)**2 (vae/models.py:21-22)."""
+    raise RuntimeError("mse_loss is a token selecting the fused HIP loss kernel; it is not evaluated on the host")
+
+
+_LOSS_TOKENS = {bce_loss: "bce", bce_loss_v2: "bce_v2", mse_loss: "mse", "bce": "bce", "bce_v2": "bce_v2", "mse": "mse"}
+
+ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON = 0.9, 0.999, 1e-8       # tf.train.AdamOptimizer defaults
+
+
+def adam_alpha(lr, beta1_power, beta2_power):
+    """lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) in fp32, as the TF ApplyAdam kernel computes it."""
+    one = np.float32(1.0)
+    return np.float32(np.float32(lr) * np.sqrt(one - np.float32(beta2_power), dtype=np.float32) / (one - np.float32(beta1_power)))
+
+
+class VAE():
+    """Base variational autoencoder (reference vae/models.py:33-231)."""
+
+    def __init__(self, source_shape, target_shape, build_encoder_fn=None, build_decoder_fn=None,
+                 z_dim=512, beta=1.0, learning_rate=1e-4, lr_decay=0.98, kl_tolerance=0.0,
+                 model_dir=".", loss_fn=bce_loss, training=True, reuse=None,
+                 precision=None, seed=0, **kwargs):
+        self.source_shape = source_shape
+        self.target_shape = target_shape
+        self.z_dim = z_dim
+        self.beta = beta
+        self.kl_tolerance = kl_tolerance
+        self.learning_rate_value = learning_rate      # Adam gets the CONSTANT lr (vae/models.py:141) ...
+        self.lr_decay = lr_decay                      # ... the decayed value is only logged (:140)
+        self.training = training
+        if loss_fn not in _LOSS_TOKENS:
+            raise ValueError("loss_fn must be one of bce_loss, bce_loss_v2, mse_loss")
+        self.loss_name = _LOSS_TOKENS[loss_fn]
+        self.precision = precision or os.environ.get("MI355_PRECISION", "bf16")
+        if self.precision not in ("bf16", "fp32", "f32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.seed = seed
+        self._variables = vae_variables(int(z_dim), tuple(int(s) for s in source_shape), tuple(int(s) for s in target_shape))
+        self._init_values = None
+        self.step_idx = 0                              # vae/step_idx: epoch counter (vae/models.py:116-117)
+        self.beta1_power, self.beta2_power = np.float32(ADAM_BETA1), np.float32(ADAM_BETA2)
+        self.dev = None
+        self.sess = None
+        self._frames_cache = {}
+        self._eps_gen = None
+        self.train_writer = self.val_writer = None
+        self.last_train_metrics = self.last_val_metrics = None
+
+        # Setup model saver and dirs (vae/models.py:154-159)
+        self.model_dir = model_dir
+        self.checkpoint_dir = "{}/checkpoints/".format(self.model_dir)
+        self.log_dir = "{}/logs/".format(self.model_dir)
+        self.dirs = [self.checkpoint_dir, self.log_dir]
+        for d in self.dirs:
+            os.makedirs(d, exist_ok=True)
+
+    # ------------------------------------------------------------------ session / engine
+    def init_session(self, sess=None, init_logging=True):
+        """Reference: tf.Session() + global_variables_initializer (+ FileWriters).  Here: create the device engine,
+        initialise the variables (Glorot-uniform kernels, zero biases) and upload them.  Raises without a GPU."""
+        from mi355.vae_device import VaeDevice
+        self.sess = sess if sess is not None else self
+        self.dev = VaeDevice(self.source_shape, self.target_shape, self.z_dim, self.beta, self.kl_tolerance, self.loss_name,
+                             self.precision, max_batch=128 if self.training else 16, with_optimizer=self.training)
+        values = self._init_values or init_vae(self.seed, int(self.z_dim), self.dev.source_shape, self.dev.target_shape)
+        self.dev.load_params(values)
+        if midist.world_size() > 1:                    # replicas start identical: rank 0's values win
+            midist.broadcast(self.dev.params, 0)
+            self.dev.L.mi_vae_sync_shadow(self.dev.handle, self.dev.stream())
+        if init_logging:
+            from mi355.summary import SummaryWriter
+            self.train_writer = SummaryWriter(os.path.join(self.log_dir, "train"))
+            self.val_writer = SummaryWriter(os.path.join(self.log_dir, "val"))
+
+    def _need_dev(self):
+        if self.dev is None:
+            raise RuntimeError("call init_session() first")
+        return self.dev
+
+    # ------------------------------------------------------------------ state dict / checkpoints
+    def state_dict(self):
+        """All global variables under their TensorFlow names (what tf.train.Saver() would store)."""
+        dev = self._need_dev()
+        out = dict(dev.export_params())
+        if dev.with_optimizer:
+            m, v = dev.export_slots()
+            for k in m:
+                out[k + "/Adam"] = m[k]
+                out[k + "/Adam_1"] = v[k]
+            out["vae/beta1_power"] = np.float32(self.beta1_power)
+            out["vae/beta2_power"] = np.float32(self.beta2_power)
+        out["vae/step_idx"] = np.int32(self.step_idx)
+        return out
+
+    def load_state_dict(self, sd):
+        dev = self._need_dev()
+        dev.load_params({k: sd[k] for k in self._variables})
+        if dev.with_optimizer and all((k + "/Adam") in sd for k in self._variables):
+            dev.load_slots({k: sd[k + "/Adam"] for k in self._variables}, {k: sd[k + "/Adam_1"] for k in self._variables})
+            self.beta1_power = np.float32(sd.get("vae/beta1_power", ADAM_BETA1))
+            self.beta2_power = np.float32(sd.get("vae/beta2_power", ADAM_BETA2))
+        self.step_idx = int(sd.get("vae/step_idx", 0))
+
+    def set_weights(self, named):
+        """Load trainable variables (TF names/layouts) — used by parity tests and importers."""
+        if self.dev is None:
+            self._init_values = {k: np.asarray(v, np.float32) for k, v in named.items()}
+        else:
+            self.dev.load_params(named)
+
+    def save(self):
+        if midist.rank() == 0:
+            model_checkpoint = ckpt.save(self.checkpoint_dir, self.step_idx, self.state_dict())
+            print("Model checkpoint saved to {}".format(model_checkpoint))
+
+    def load_latest_checkpoint(self):
+        model_checkpoint = ckpt.latest(self.checkpoint_dir)
+        if model_checkpoint:
+            try:
+                self.load_state_dict(ckpt.load(model_checkpoint))
+                print("Model checkpoint restored from {}".format(model_checkpoint))
+                return True
+            except Exception as e:
+                print(e)
+                return False
+
+    # ------------------------------------------------------------------ data staging (plumbing)
+    def _frames(self, arr, n_feat, what, cache=False):
+        """HBM-resident fp32 copy [N, n_feat] of a host frame table; verify_range (vae/models.py:24-30,89-90) on upload.
+        cache=True (epoch loops only): the same host table is uploaded once and reused across epochs; a strided
+        content fingerprint guards against the caller mutating it in place."""
+        import torch
+        dev = self._need_dev()
+        a = arr if isinstance(arr, np.ndarray) and arr.dtype == np.float32 else np.asarray(arr, dtype=np.float32)
+        key = None
+        if cache and a.size:
+            flatv = a.reshape(-1)
+            finger = float(flatv[::max(1, flatv.size // 4096)].sum(dtype=np.float64))
+            key = (a.__array_interface__["data"][0], a.shape, a.strides, finger)
+            if key in self._frames_cache:
+                return self._frames_cache[key][0]
+        a2 = np.ascontiguousarray(a).reshape(len(a), -1)
+        if a2.shape[1] != n_feat:
+            raise ValueError("%s: expected %d values per frame, got shape %s" % (what, n_feat, a.shape))
+        t = torch.from_numpy(a2).to(dev.device)
+        if not dev.range_ok(t):
+            raise ValueError("verify_range: min= %r max= %r outside [0, 1] (%s)" % (float(a2.min()), float(a2.max()), what))
+        if key is not None:
+            if len(self._frames_cache) >= 4:
+                self._frames_cache.pop(next(iter(self._frames_cache)))
+            self._frames_cache[key] = (t, a)          # keep the host array alive so the address stays unique
+        return t
+
+    def _eps(self, n, eps=None):
+        import torch
+        dev = self._need_dev()
+        if eps is not None:
+            e = np.ascontiguousarray(np.asarray(eps, np.float32).reshape(n, int(self.z_dim)))
+            return torch.from_numpy(e).to(dev.device)
+        if self._eps_gen is None:
+            self._eps_gen = torch.Generator(device=dev.device)
+            self._eps_gen.manual_seed(0x5EED + midist.rank())
+        return torch.randn(n, int(self.z_dim), device=dev.device, generator=self._eps_gen)
+
+    def _src_feat(self):
+        return int(np.prod(self.dev.source_shape))
+
+    # ------------------------------------------------------------------ inference surface
+    def generate_from_latent(self, z):
+        """Feeds z in place of the sample; returns sigmoid(logits) [B, prod(target_shape)] (vae/models.py:188-191)."""
+        import torch
+        dev = self._need_dev()
+        z = np.ascontiguousarray(np.asarray(z, np.float32).reshape(-1, int(self.z_dim)))
+        out = torch.empty(len(z), dev.P, device=dev.device)
+        dev.decode(torch.from_numpy(z).to(dev.device), len(z), out)
+        return out.cpu().numpy()
+
+    decode = generate_from_latent                      # north-star alias
+
+    def reconstruct(self, source_states, eps=None):
+        """sigmoid(logits) per frame, reshaped with SOURCE shape as the reference does (vae/models.py:193-197)."""
+        import torch
+        dev = self._need_dev()
+        src = self._frames(np.asarray(source_states, np.float32), self._src_feat(), "source_states")
+        n = src.shape[0]
+        out = torch.empty(n, dev.P, device=dev.device)
+        e = self._eps(n, eps) if self.training else None
+        dev.reconstruct(src, None, n, e, 1 if self.training else 0, out)
+        return [s.reshape(self.source_shape) for s in out.cpu().numpy()]
+
+    def encode(self, source_states):
+        """Returns the MEAN, not a sample (vae/models.py:199-202)."""
+        import torch
+        dev = self._need_dev()
+        src = self._frames(np.asarray(source_states, np.float32), self._src_feat(), "source_states")
+        n = src.shape[0]
+        out = torch.empty(n, int(self.z_dim), device=dev.device)
+        dev.encode(src, None, n, out)
+        return out.cpu().numpy()
+
+    def get_step_idx(self):
+        return int(self.step_idx)
+
+    # ------------------------------------------------------------------ training surface
+    def _adam_step(self):
+        dev = self.dev
+        dev.apply_adam(adam_alpha(self.learning_rate_value, self.beta1_power, self.beta2_power), ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+        self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
+
+    def _train_minibatch(self, src, tgt, idx, n_local, inv_batch, eps):
+        """One SGD step on rows idx of the resident tables: forward, backward (decoder half first so its gradient
+        all-reduce overlaps the encoder half), gradient all-reduce, fused Adam."""
+        dev = self.dev
+        dev.forward(src, tgt, idx, n_local, inv_batch, eps, 1, 1)
+        if midist.world_size() > 1:
+            dev.backward(src, idx, eps, inv_batch, part=1)
+            w1 = midist.all_reduce_sum(dev.grads[dev.decoder_offset:], async_op=True)
+            dev.backward(src, idx, eps, inv_batch, part=2)
+            w2 = midist.all_reduce_sum(dev.grads[:dev.decoder_offset], async_op=True)
+            w1.wait()
+            w2.wait()
+        else:
+            dev.backward(src, idx, eps, inv_batch, part=0)
+        self._adam_step()
+
+    def train_step(self, source_states, target_states, eps=None):
+        """One explicit SGD step on a host minibatch (the reference's sess.run([train_step, ...]), vae/models.py:213-216).
+        Returns (reconstruction_loss, kl_loss) of this minibatch.  `eps` [B, z_dim] injects the reparameterisation noise."""
+        if not self.training:
+            raise RuntimeError("train_step on a VAE built with training=False")
+        dev = self._need_dev()
+        src = self._frames(source_states, self._src_feat(), "source_states")
+        tgt = src if target_states is source_states else self._frames(target_states, dev.P, "target_states")
+        n = src.shape[0]
+        e = self._eps(n, eps)
+        self._train_minibatch(src, tgt, None, n, 1.0 / n, e)
+        return tuple(float(x) for x in dev.losses.cpu().numpy())
+
+    def _epoch(self, source, target, batch_size, train, eps=None):
+        import torch
+        dev = self._need_dev()
+        src = self._frames(source, self._src_feat(), "source_states", cache=True)
+        tgt = src if target is source else self._frames(target, dev.P, "target_states", cache=True)
+        indices = np.arange(len(source))
+        np.random.shuffle(indices)                                   # legacy numpy RNG, as the reference (bit-exact index work)
+        dev.metrics.zero_()                                          # sess.run(tf.local_variables_initializer())
+        world, rank = midist.world_size(), midist.rank()
+        n_steps = source.shape[0] // batch_size                      # remainder dropped
+        lo, hi = midist.shard_bounds(batch_size, rank, world)
+        n_local = hi - lo
+        if n_steps > 0 and n_local > 0:
+            sel = indices[:n_steps * batch_size].reshape(n_steps, batch_size)[:, lo:hi]
+            idx_dev = torch.from_numpy(np.ascontiguousarray(sel.astype(np.int32))).to(dev.device)
+            for i in range(n_steps):
+                e = self._eps(n_local, None if eps is None else eps[i][lo:hi])
+                if train:
+                    self._train_minibatch(src, tgt, idx_dev[i], n_local, 1.0 / batch_size, e)
+                else:
+                    dev.forward(src, tgt, idx_dev[i], n_local, 1.0 / batch_size, e, 1 if self.training else 0, 0)
+        if world > 1:
+            midist.all_reduce_sum(dev.metrics)
+        m = dev.metrics.cpu().numpy()
+        cnt = max(float(m[2]), 1e-12)
+        return [float(m[0] / cnt), float(m[1] / cnt)] if m[2] > 0 else [0.0, 0.0]
+
+    def train_one_epoch(self, train_source, train_target, batch_size, eps=None):
+        """vae/models.py:207-218.  `eps` (optional, [steps, batch, z]) injects noise for parity runs."""
+        if not self.training:
+            raise RuntimeError("train_one_epoch on a VAE built with training=False")
+        self.last_train_metrics = self._epoch(train_source, train_target, batch_size, True, eps)
+        if self.train_writer is not None and midist.rank() == 0:
+            step = self.get_step_idx()
+            self.train_writer.add_scalar("vae/kl_loss", self.last_train_metrics[1], step)
+            self.train_writer.add_scalar("vae/reconstruction_loss", self.last_train_metrics[0], step)
+            self.train_writer.add_scalar("vae/learning_rate", self.learning_rate_value * self.lr_decay ** step, step)
+            self.train_writer.flush()
+        self.step_idx += 1
+
+    def evaluate(self, val_source, val_target, batch_size, eps=None):
+        """vae/models.py:220-231 — returns [mean reconstruction loss, mean kl loss]."""
+        self.last_val_metrics = self._epoch(val_source, val_target, batch_size, False, eps)
+        if self.val_writer is not None and midist.rank() == 0:
+            step = self.get_step_idx()
+            self.val_writer.add_scalar("vae/kl_loss", self.last_val_metrics[1], step)
+            self.val_writer.add_scalar("vae/reconstruction_loss", self.last_val_metrics[0], step)
+            self.val_writer.flush()
+        return list(self.last_val_metrics)
+
+
+class ConvVAE(VAE):
+    """Convolutional VAE (reference vae/models.py:233-268): 4x conv k4 s2 relu 32/64/128/256, dense heads,
+    dense 64->6144, deconv k4/k4/k5/k4 s2 128/64/32/C_t.  Adjusted, like the reference, to 160x80 frames."""
+
+    def __init__(self, source_shape, target_shape=None, **kwargs):
+        target_shape = source_shape if target_shape is None else target_shape
+        src = tuple(int(s) for s in source_shape)
+        tgt = tuple(int(s) for s in target_shape)
+        enc_h, enc_w = src[0], src[1]
+        for _ in range(4):
+            enc_h, enc_w = (enc_h - 4) // 2 + 1, (enc_w - 4) // 2 + 1
+        self.encoded_shape = (enc_h, enc_w, 256)
+        h, w = enc_h, enc_w
+        for k in (4, 4, 5, 4):
+            h, w = (h - 1) * 2 + k, (w - 1) * 2 + k
+        assert (h, w) == tgt[:2], f"{(h, w, tgt[2])} != {tgt}"       # vae/models.py:265
+        kwargs.pop("build_encoder_fn", None)
+        kwargs.pop("build_decoder_fn", None)
+        super().__init__(source_shape, target_shape, None, None, **kwargs)
+
+
+class MlpVAE(VAE):
+    """Multi-layer perceptron VAE (reference vae/models.py:271-299).  Not on the MI355X hot path yet
+    ("next"): constructing one raises instead of silently running something else."""
+
+    def __init__(self, source_shape, target_shape=None, encoder_sizes=(512, 256), decoder_sizes=(256, 512), **kwargs):
+        raise NotImplementedError("MlpVAE has no MI355X kernels yet (scope: SURVEY.md 8f item 2); use ConvVAE")

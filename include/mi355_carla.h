@@ -34,6 +34,29 @@ extern "C" {
 #define MI_ERR_LAUNCH (-3)
 #define MI_ERR_STATE (-4)
 
+
+/* ---- engine descriptors (all 4-byte fields; mirrored as ctypes.Structure in carla-ppo_amd/mi355/lib.py) ---- */
+typedef struct MiVaeDesc {
+    int dtype;          /* MI_F32 | MI_BF16 */
+    int max_batch;      /* largest per-GPU minibatch the workspace is sized for */
+    int ih, iw, cin;    /* source frame shape (80,160,3) — NHWC */
+    int ct;             /* target depth: 3 (rgb) or 1 (segmentation) */
+    int z_dim;
+    int loss_kind;      /* 0 bce_loss, 1 bce_loss_v2, 2 mse_loss (vae/models.py:11-22) */
+    float beta;
+    float kl_tolerance;
+} MiVaeDesc;
+
+typedef struct MiPpoDesc {
+    int max_batch;
+    int input_dim;      /* z_dim + measurements = 67 (train.py:85) */
+    int num_actions;    /* 2 */
+    int h1, h2;         /* (500, 300) for both pi and V trunks (ppo.py:18) */
+    float clip_eps;     /* epsilon */
+    float value_scale;
+    float entropy_scale;
+} MiPpoDesc;
+
 /* ---- library ---- */
 const char* mi_last_error(void);
 int mi_abi_version(void);
@@ -88,6 +111,44 @@ int mi_policy_head(void* stream, const float* u, const float* logstd, const floa
 int mi_gae_scan(void* stream, const double* rewards, const double* values, const double* terminals, int R, int T, double gamma, double lam, double* adv);
 /* returns = adv + values; advantage normalisation — train.py:176-177 (fp64, population std, per row) */
 int mi_adv_normalize(void* stream, double* adv, const double* values, int R, int T, double* returns);
+
+
+/* ---- ConvVAE engine: the graph of VAE.__init__ + ConvVAE (vae/models.py:85-142,249-266) on caller-owned buffers ---- */
+int mi_vae_desc_size(void);
+int mi_vae_tensor_count(void);
+long long mi_vae_param_floats(const MiVaeDesc* d);
+int mi_vae_param_layout(const MiVaeDesc* d, long long* offsets, long long* sizes, int n);
+long long mi_vae_workspace_bytes(const MiVaeDesc* d);
+void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* bf16_shadow, void* workspace, long long workspace_bytes);
+void mi_vae_destroy(void* h);
+int mi_vae_sync_shadow(void* h, void* stream);
+void* mi_vae_buffer(void* h, int which);
+/* forward + ELBO terms: the per-minibatch sess.run of VAE.evaluate (vae/models.py:226-229) / forward half of train_step (:213-216) */
+int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
+/* gradients of loss = recon + beta*kl wrt all 22 variables (optimizer.minimize, vae/models.py:142); part 0 all, 1 decoder, 2 encoder */
+int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part);
+int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
+/* VAE.encode / generate_from_latent (= north_star "decode") / reconstruct — vae/models.py:188-202 */
+int mi_vae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out);
+int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
+int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out);
+
+/* ---- PPO engine: PolicyGraph x2 + losses + Adam (ppo.py:16-66,112-147) ---- */
+int mi_ppo_desc_size(void);
+int mi_ppo_tensor_count(void);
+long long mi_ppo_param_floats(const MiPpoDesc* d);
+int mi_ppo_param_layout(const MiPpoDesc* d, long long* offsets, long long* sizes, int n);
+long long mi_ppo_workspace_bytes(const MiPpoDesc* d);
+void* mi_ppo_create(const MiPpoDesc* d, float* params, float* params_old, float* grads, float* adam_m, float* adam_v, void* workspace, long long workspace_bytes, const float* action_low, const float* action_high);
+void mi_ppo_destroy(void* h);
+void* mi_ppo_buffer(void* h, int which);
+/* PPO.update_old_policy — ppo.py:275-276 */
+int mi_ppo_update_old(void* h, void* stream);
+/* PPO.predict — ppo.py:231-251 */
+int mi_ppo_predict(void* h, void* stream, const float* states, int M, const float* noise, int greedy, float* action, float* value);
+/* gradient half + optimiser half of PPO.train (= north_star "learn") — ppo.py:218-229 */
+int mi_ppo_forward_backward(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, int M, float inv_m, float grad_scale);
+int mi_ppo_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
 
 #ifdef __cplusplus
 }

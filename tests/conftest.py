@@ -38,3 +38,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_device_tensors():
+    yield
+    try:
+        import hip_helpers
+        if hip_helpers._KEEP:
+            hip_helpers.keep_reset()
+    except Exception:
+        pass

@@ -16,6 +16,21 @@ def dev(a, tdtype=torch.float32):
     return t.to(device="cuda", dtype=tdtype).contiguous()
 
 
+_KEEP = []
+
+
+def P(t):
+    """data_ptr of a device tensor that is kept alive until the next keep_reset() (async launches must not see the
+    caching allocator hand a temporary's block to the next temporary)."""
+    _KEEP.append(t)
+    return t.data_ptr()
+
+
+def keep_reset():
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
 def rounded(a, tdtype):
     """numpy fp32 array rounded through the storage dtype (what the kernel actually reads) as float64."""
     t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(tdtype)

@@ -1,0 +1,152 @@
+"""Model-level parity of the drop-in PPO (HIP path through the C ABI) vs the CPU oracle; fp32 throughout,
+tolerance 1e-4 relative on losses, 2e-4 of each tensor's max on gradients; GAE bit-exact (fp64)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ppo_oracle as po  # noqa: E402
+from ppo import PPO  # noqa: E402
+import utils  # noqa: E402
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_pair(tmp_path, seed=2, **kw):
+    space = po.ActionSpace()
+    hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
+    hp.update(kw)
+    o = po.OraclePPO([67], space, seed=seed, **hp)
+    m = PPO(np.array([67]), space, model_dir=str(tmp_path), seed=seed, **hp)
+    m.set_weights(o.params)
+    m.init_session(init_logging=False)
+    return o, m
+
+
+def synth_rollout(T=128, seed=7):
+    rng = np.random.RandomState(seed)
+    states = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    states[:, 64] = rng.uniform(-1, 1, T); states[:, 65] = rng.uniform(0, 1, T); states[:, 66] = rng.uniform(0, 30, T)
+    rewards = list(rng.uniform(0, 1, T))
+    dones = [False] * T
+    return states, rewards, dones, rng
+
+
+def test_minibatch_gradients_and_losses(tmp_path):
+    o, m = make_pair(tmp_path)
+    rng = np.random.RandomState(5)
+    for k in o.params:                                   # theta != theta_old: ratio != 1, some samples clipped
+        o.params[k] = o.params[k] + (0.02 * rng.standard_normal(o.params[k].shape)).astype(np.float32)
+    m.set_weights(o.params)
+    s = (0.5 * rng.standard_normal((32, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (32, 2)).astype(np.float32)
+    R, A = rng.randn(32).astype(np.float32), rng.randn(32).astype(np.float32)
+    scal, grads = o.loss_and_grads(s, a, R, A)
+    d = m.dev
+    d.forward_backward(m._to_dev(s, (32, 67)), m._to_dev(a, (32, 2)), m._to_dev(R, (32,)), m._to_dev(A, (32,)), 32, 1 / 32.0, 1.0)
+    L = d.losses.cpu().numpy()
+    for got, key in zip(L, ("policy_loss", "value_loss", "entropy_loss", "loss", "ratio_mean")):
+        assert got == pytest.approx(scal[key], rel=1e-4, abs=1e-6), key
+    g = d.export_grads()
+    bad = {k: rel_err(g[k], grads[k]) for k in grads if rel_err(g[k], grads[k]) > 2e-4}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("epochs", [4, 3])
+def test_config3_full_update_matches_oracle(tmp_path, epochs):
+    """BASELINE config 3: horizon 128, minibatch 32, `epochs` epochs; the trainer's hot section (train.py:171-207)
+    driven through the drop-in API vs the oracle, same legacy-numpy permutations."""
+    o, m = make_pair(tmp_path)
+    states, rewards, dones, rng = synth_rollout()
+    noise = rng.standard_normal((128, 2)).astype(np.float32)
+    acts, vals = o.predict(states, noise=noise)
+    acts_g, vals_g = m.predict(states, noise=noise)
+    assert rel_err(acts_g, acts) < 1e-4 and rel_err(vals_g, vals) < 1e-4
+    _, last = o.predict(states[-1], greedy=True)
+    values = [np.float32(v) for v in vals]
+    np.random.seed(0)
+    logs, ret_o, adv_o = po.ppo_update(o, list(states), list(acts), values, rewards, dones, last, 0.99, 0.95, epochs, 32)
+    # --- product path: the reference trainer's lines restated with the drop-in modules ---
+    np.random.seed(0)
+    advantages = utils.compute_gae(rewards, values, last, dones, 0.99, 0.95)
+    assert np.array_equal(advantages, po.compute_gae(rewards, values, last, dones, 0.99, 0.95))        # bit-exact fp64
+    returns = advantages + values
+    advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    assert np.array_equal(returns, ret_o)
+    s_arr, a_arr = np.array(states), np.array(acts)
+    m.update_old_policy()
+    for _ in range(epochs):
+        indices = np.arange(128)
+        np.random.shuffle(indices)
+        for i in range(int(np.ceil(128 / 32))):
+            mb = indices[i * 32:(i + 1) * 32]
+            m.train(s_arr[mb], a_arr[mb], returns[mb], advantages[mb])
+    assert m.get_train_step_idx() == 4 * epochs
+    got = m.dev.export_params()
+    p0 = make_pair(tmp_path)[0].params
+    for k, v in o.params.items():
+        upd_ref, upd_got = v - p0[k], got[k] - p0[k]
+        scale = max(np.abs(upd_ref).max(), 1e-12)
+        assert np.abs(upd_got - upd_ref).max() / scale < 2e-2, (k, np.abs(upd_got - upd_ref).max(), scale)
+    last_losses = m.dev.losses.cpu().numpy()
+    assert last_losses[3] == pytest.approx(logs[-1]["loss"], rel=2e-3, abs=1e-5)
+
+
+def test_partial_minibatch_and_predict_shapes(tmp_path):
+    o, m = make_pair(tmp_path, seed=3)
+    rng = np.random.RandomState(0)
+    s = (0.5 * rng.standard_normal((5, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (5, 2)).astype(np.float32)
+    R, A = rng.randn(5), rng.randn(5)                       # float64 inputs are rounded to f32 at the feed
+    m.update_old_policy(); o.update_old_policy()
+    so = o.train(s, a, R, A)
+    sg = m.train_step(s, a, R, A)
+    assert sg["loss"] == pytest.approx(so["loss"], rel=1e-4, abs=1e-6) and sg["prob_ratio"] == pytest.approx(1.0, abs=1e-5)
+    act, val = m.predict(s[0], greedy=True)
+    ao, vo_ = o.predict(s[0], greedy=True)
+    assert act.shape == (2,) and np.ndim(val) == 0 and rel_err(act, ao) < 1e-3 and abs(val - vo_) < 1e-4 * max(1, abs(vo_))
+    act2, _ = m.predict(s[0])
+    assert (act2 >= np.array([-1, 0]) - 1e-6).all() and (act2 <= np.array([1, 1]) + 1e-6).all()
+    m.write_episodic_summaries()
+    assert m.get_episode_idx() == 1
+
+
+def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "ref_variables.json")))["ppo_agent"]
+    ref = {k: v for k, v in ref.items() if not k.startswith("vae/")}       # the agent checkpoint also carries the VAE graph
+    o, m = make_pair(tmp_path / "a")
+    rng = np.random.RandomState(1)
+    s, a = (0.5 * rng.standard_normal((8, 67))).astype(np.float32), rng.uniform(-1, 1, (8, 2)).astype(np.float32)
+    R, A = rng.randn(8).astype(np.float32), rng.randn(8).astype(np.float32)
+    m.update_old_policy()
+    m.train(s, a, R, A)
+    m.write_episodic_summaries()
+    sd = m.state_dict()
+    assert {k: list(np.shape(v)) for k, v in sd.items()} == {k: v["shape"] for k, v in ref.items()}
+    m.save()
+    m2 = PPO(np.array([67]), po.ActionSpace(), model_dir=str(tmp_path / "a"), learning_rate=1e-4, lr_decay=1.0, value_scale=1.0, initial_std=1.0)
+    m2.init_session(init_logging=False)
+    assert m2.load_latest_checkpoint() is True and m2.get_episode_idx() == 1 and m2.get_train_step_idx() == 1
+    l1, l2 = m.train_step(s, a, R, A), m2.train_step(s, a, R, A)
+    assert l1["loss"] == pytest.approx(l2["loss"], rel=1e-6)
+
+
+def test_gae_batched_rows_bit_exact_and_normalised(tmp_path):
+    rng = np.random.RandomState(3)
+    R, T = 33, 128
+    rew = rng.uniform(0, 1, (R, T))
+    val = rng.randn(R, T + 1).astype(np.float32)
+    done = np.zeros((R, T)); done[::4, -1] = 1
+    raw, ret, adv = utils.compute_gae_batched(rew, val, done, 0.99, 0.95, normalize=True)
+    for r in range(R):
+        ref = po.compute_gae(list(rew[r]), list(val[r, :T]), val[r, T], list(done[r].astype(bool)), 0.99, 0.95)
+        assert np.array_equal(raw[r], ref)
+        rr, aa = po.returns_and_normalized_advantages(ref.copy(), val[r, :T].astype(np.float64))
+        assert np.array_equal(ret[r], rr) and np.allclose(adv[r], aa, rtol=1e-12, atol=1e-12)
+    assert utils.compute_gae([], [], 0.0, [], 0.99, 0.95).shape == (0,)
