@@ -68,7 +68,33 @@ struct Workspace {
     long long total;
 };
 
+// ---- per-op HIP-event timing (bench.py's live roofline numbers; off by default) ----
+enum {
+    OP_CONV_FWD = 0, OP_HEADS_FWD = 4, OP_REPARAM_FWD = 5, OP_DENSE1_FWD = 6, OP_DECONV_FWD = 7, OP_RECON_LOSS = 11, OP_FINALIZE = 12,
+    OP_DECONV_BIAS = 13, OP_DECONV_WGRAD = 17, OP_DECONV_DGRAD = 21, OP_DENSE1_BIAS = 25, OP_DENSE1_WGRAD = 26, OP_DENSE1_DGRAD = 27,
+    OP_REPARAM_BWD = 28, OP_HEADS_BIAS = 29, OP_HEADS_WGRAD = 30, OP_HEADS_DGRAD = 31, OP_CONV_BIAS = 32, OP_CONV_WGRAD = 36,
+    OP_CONV_DGRAD = 40, OP_ADAM = 44, N_OPS = 45
+};
+const char* const OP_NAMES[N_OPS] = {
+    "conv1.fwd", "conv2.fwd", "conv3.fwd", "conv4.fwd", "heads.fwd", "reparam_kl.fwd", "dense1.fwd",
+    "deconv1.fwd", "deconv2.fwd", "deconv3.fwd", "deconv4.fwd", "recon_loss", "finalize_losses",
+    "deconv1.bias_grad", "deconv2.bias_grad", "deconv3.bias_grad", "deconv4.bias_grad",
+    "deconv1.wgrad", "deconv2.wgrad", "deconv3.wgrad", "deconv4.wgrad",
+    "deconv1.dgrad", "deconv2.dgrad", "deconv3.dgrad", "deconv4.dgrad",
+    "dense1.bias_grad", "dense1.wgrad", "dense1.dgrad", "reparam_kl.bwd", "heads.bias_grad", "heads.wgrad", "heads.dgrad",
+    "conv1.bias_grad", "conv2.bias_grad", "conv3.bias_grad", "conv4.bias_grad",
+    "conv1.wgrad", "conv2.wgrad", "conv3.wgrad", "conv4.wgrad",
+    "conv1.dgrad", "conv2.dgrad", "conv3.dgrad", "conv4.dgrad", "adam"};
+
+struct Timing {
+    int mode;            // 0 off, 1 every op, 2 only op_filter
+    int op_filter, cap, n;
+    hipEvent_t* ev;      // 2 per record
+    int* op;
+};
+
 struct VaeEngine {
+    Timing tm;
     MiVaeDesc d;
     Geom g;
     Layout L;
@@ -136,6 +162,17 @@ bool init_engine(VaeEngine& e, const MiVaeDesc* desc) {
 
 #define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
 
+inline bool tm_on(const VaeEngine* e, int id) {
+    return e->tm.mode && (e->tm.mode == 1 || e->tm.op_filter == id) && e->tm.n < e->tm.cap;
+}
+// timed op: HIP events recorded on the SAME stream the kernel is launched on
+#define TOP(e, st, id, call) do { \
+        const bool t__ = tm_on(e, id); \
+        if (t__) hipEventRecord(e->tm.ev[2 * e->tm.n], (hipStream_t)(st)); \
+        int rc__ = (call); \
+        if (t__) { hipEventRecord(e->tm.ev[2 * e->tm.n + 1], (hipStream_t)(st)); e->tm.op[e->tm.n] = (id); ++e->tm.n; } \
+        if (rc__ != MI_OK) return rc__; } while (0)
+
 int check_batch(const VaeEngine* e, int B) {
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
     if (B < 1 || B > e->d.max_batch) return mi_fail(MI_ERR_ARG, "vae engine: batch outside [1, max_batch]");
@@ -147,13 +184,13 @@ int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
     for (int i = 0; i < NCONV; ++i) {
         const void* x = i == 0 ? (const void*)frames : e->at(e->W.act[i]);
-        CK(mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i],
+        TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i],
                               e->wptr(2 * i), e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
     }
-    CK(mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wptr(8), 0, 2 * d.z_dim, nullptr, 0, nullptr,
+    TOP(e, st, OP_HEADS_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wptr(8), 0, 2 * d.z_dim, nullptr, 0, nullptr,
                         e->at(e->W.heads_slab), 1, e->ns_heads));
     // split-K slabs are laid out [ns][B][2Z] with the CURRENT batch as the middle dimension
-    CK(mi_vae_reparam_kl_fwd(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
+    TOP(e, st, OP_REPARAM_FWD, mi_vae_reparam_kl_fwd(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
                              B, d.z_dim, (float*)e->at(e->W.mean), (float*)e->at(e->W.logvar), e->at(e->W.z), (float*)e->at(e->W.kl_row)));
     return MI_OK;
 }
@@ -161,9 +198,9 @@ int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int
 // decoder: z (T) -> dense1 -> deconv1..4 -> logits
 int run_decoder(VaeEngine* e, void* st, int B) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
-    CK(mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wptr(10), 0, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
+    TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wptr(10), 0, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
     for (int i = 0; i < 4; ++i)
-        CK(mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
+        TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1])));
     return MI_OK;
 }
@@ -248,10 +285,10 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
     CK(run_encoder(e, stream, src, idx, B, eps, sample));
     CK(run_decoder(e, stream, B));
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
-    CK(mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
+    TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
                              want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial)));
     const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
-    CK(mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
+    TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
                               inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
     e->last_B = B;
     return MI_OK;
@@ -272,31 +309,31 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             const void* gy = e->at(W.gdec[i + 1]);
             const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
-            CK(mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
-            CK(mi_deconv2d_nhwc_wgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i)));
-            CK(mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wptr(12 + 2 * i), DEC_K[i], DEC_K[i], g.dc[i],
+            TOP(e, st, OP_DECONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
+            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i)));
+            TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wptr(12 + 2 * i), DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
         // dense1: h = z W1 + b1
-        CK(mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-        CK(mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
-        CK(mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
+        TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+        TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+        TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
     }
     if (part == 0 || part == 2) {
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
-        CK(mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
+        TOP(e, st, OP_REPARAM_BWD, mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
-        CK(mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-        CK(mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
-        CK(mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
+        TOP(e, st, OP_HEADS_BIAS, mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+        TOP(e, st, OP_HEADS_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+        TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             const void* gy = e->at(W.gact[i + 1]);
             const long long rows = (long long)B * g.ih[i + 1] * g.iw[i + 1];
-            CK(mi_colsum(st, d.dtype, gy, rows, g.c[i + 1], e->gptr(2 * i + 1)));
+            TOP(e, st, OP_CONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.c[i + 1], e->gptr(2 * i + 1)));
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            CK(mi_conv2d_nhwc_wgrad(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i)));
+            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i)));
             if (i > 0)                                       // conv1's input gradient is never used
-                CK(mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
+                TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));
         }
     }
@@ -308,8 +345,9 @@ int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float bet
     VaeEngine* e = (VaeEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_vae_apply_adam: engine created without optimiser buffers");
-    return mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, beta1, beta2, epsilon,
-                           e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1);
+    TOP(e, stream, OP_ADAM, mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, beta1, beta2, epsilon,
+                                            e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1));
+    return MI_OK;
 }
 
 // VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32
@@ -346,6 +384,52 @@ int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, 
     CK(run_decoder(e, stream, B));
     const Geom& g = e->g;
     return mi_sigmoid(stream, e->d.dtype, e->at(e->W.dec[4]), recon_out, (long long)B * g.dh[4] * g.dw[4] * g.dc[4]);
+}
+
+}  // extern "C"
+
+// ---- per-op timing API (HIP events on the launch stream) ----
+extern "C" {
+
+int mi_vae_op_count(void) { return N_OPS; }
+const char* mi_vae_op_name(int op) { return (op >= 0 && op < N_OPS) ? OP_NAMES[op] : ""; }
+
+// mode 1: time every op of the following steps; mode 2: only `op_filter`.  max_records bounds the event pool.
+int mi_vae_timing_begin(void* h, int mode, int op_filter, int max_records) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (e->tm.ev) return mi_fail(MI_ERR_STATE, "mi_vae_timing_begin: timing already active");
+    if (mode < 1 || mode > 2 || max_records < 1) return mi_fail(MI_ERR_ARG, "mi_vae_timing_begin: mode 1|2, max_records >= 1");
+    e->tm.ev = (hipEvent_t*)calloc(2 * (size_t)max_records, sizeof(hipEvent_t));
+    e->tm.op = (int*)calloc((size_t)max_records, sizeof(int));
+    if (!e->tm.ev || !e->tm.op) return mi_fail(MI_ERR_STATE, "mi_vae_timing_begin: out of host memory");
+    for (int i = 0; i < 2 * max_records; ++i)
+        if (hipEventCreate(&e->tm.ev[i]) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_timing_begin: hipEventCreate failed");
+    e->tm.cap = max_records; e->tm.n = 0; e->tm.op_filter = op_filter; e->tm.mode = mode;
+    return MI_OK;
+}
+
+// stops timing, waits for the recorded events and accumulates elapsed milliseconds / launch counts per op id
+int mi_vae_timing_collect(void* h, float* ms_sum, int* count, int n_ops) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (!e->tm.ev) return mi_fail(MI_ERR_STATE, "mi_vae_timing_collect: timing not active");
+    if (n_ops != N_OPS) return mi_fail(MI_ERR_ARG, "mi_vae_timing_collect: n_ops mismatch");
+    e->tm.mode = 0;
+    for (int i = 0; i < N_OPS; ++i) { ms_sum[i] = 0.f; count[i] = 0; }
+    int rc = MI_OK;
+    for (int r = 0; r < e->tm.n; ++r) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e->tm.ev[2 * r + 1]) != hipSuccess || hipEventElapsedTime(&ms, e->tm.ev[2 * r], e->tm.ev[2 * r + 1]) != hipSuccess) {
+            rc = mi_fail(MI_ERR_STATE, "mi_vae_timing_collect: event query failed");
+            break;
+        }
+        ms_sum[e->tm.op[r]] += ms; count[e->tm.op[r]] += 1;
+    }
+    for (int i = 0; i < 2 * e->tm.cap; ++i) hipEventDestroy(e->tm.ev[i]);
+    free(e->tm.ev); free(e->tm.op);
+    e->tm.ev = nullptr; e->tm.op = nullptr; e->tm.cap = e->tm.n = 0;
+    return rc;
 }
 
 }  // extern "C"

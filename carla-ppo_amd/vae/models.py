@@ -121,9 +121,9 @@ class VAE():
         out = dict(dev.export_params())
         if dev.with_optimizer:
             m, v = dev.export_slots()
-            for k in m:
-                out[k + "/Adam"] = m[k]
-                out[k + "/Adam_1"] = v[k]
+            for k in m:                                # slots are created inside variable_scope("vae") -> "vae/vae/..." in TF
+                out["vae/" + k + "/Adam"] = m[k]
+                out["vae/" + k + "/Adam_1"] = v[k]
             out["vae/beta1_power"] = np.float32(self.beta1_power)
             out["vae/beta2_power"] = np.float32(self.beta2_power)
         out["vae/step_idx"] = np.int32(self.step_idx)
@@ -132,8 +132,8 @@ class VAE():
     def load_state_dict(self, sd):
         dev = self._need_dev()
         dev.load_params({k: sd[k] for k in self._variables})
-        if dev.with_optimizer and all((k + "/Adam") in sd for k in self._variables):
-            dev.load_slots({k: sd[k + "/Adam"] for k in self._variables}, {k: sd[k + "/Adam_1"] for k in self._variables})
+        if dev.with_optimizer and all(("vae/" + k + "/Adam") in sd for k in self._variables):
+            dev.load_slots({k: sd["vae/" + k + "/Adam"] for k in self._variables}, {k: sd["vae/" + k + "/Adam_1"] for k in self._variables})
             self.beta1_power = np.float32(sd.get("vae/beta1_power", ADAM_BETA1))
             self.beta2_power = np.float32(sd.get("vae/beta2_power", ADAM_BETA2))
         self.step_idx = int(sd.get("vae/step_idx", 0))

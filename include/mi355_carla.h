@@ -133,6 +133,12 @@ int mi_vae_encode(void* h, void* stream, const float* src, const int* idx, int B
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
 int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
+/* per-op timing with HIP events recorded on the launch stream (bench.py's live roofline numbers) */
+int mi_vae_op_count(void);
+const char* mi_vae_op_name(int op);
+int mi_vae_timing_begin(void* h, int mode, int op_filter, int max_records);
+int mi_vae_timing_collect(void* h, float* ms_sum, int* count, int n_ops);
+
 /* ---- PPO engine: PolicyGraph x2 + losses + Adam (ppo.py:16-66,112-147) ---- */
 int mi_ppo_desc_size(void);
 int mi_ppo_tensor_count(void);
