@@ -75,7 +75,8 @@ def collect_timing(dev, n_ops):
 def cpu_baseline(batch, seed=0):
     """Oracle (port of the reference graph) SGD steps on the host cores: 1 warm-up + 3 timed steps of the same minibatch shape."""
     from oracle import vae_oracle as vo
-    cores = os.cpu_count() or 1
+    # 16 threads measured fastest for this graph on the GPU box's 2x EPYC 9575F (16: 515, 32: 474, 64: 273, 128: 151 frames/s)
+    cores = min(int(os.environ.get("MI355_CPU_BASELINE_THREADS", "16")), os.cpu_count() or 1)
     torch.set_num_threads(cores)
     o = vo.OracleVAE(seed=seed)
     rng = np.random.RandomState(1234)

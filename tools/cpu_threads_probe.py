@@ -1,0 +1,9 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from oracle import vae_oracle as vo
+fr = np.random.RandomState(0).rand(256,80,160,3).astype(np.float32); eps=np.zeros((256,64),np.float32)
+for th in (16, 32, 64, 128):
+    torch.set_num_threads(th)
+    o = vo.OracleVAE(seed=0); o.train_step(fr, fr, eps)
+    t=time.time(); o.train_step(fr, fr, eps); dt=time.time()-t
+    print("threads", th, "frames/s", 256/dt, flush=True)
