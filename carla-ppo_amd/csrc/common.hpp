@@ -27,6 +27,9 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// N consecutive elements moved as one naturally aligned vector access
+template <typename TT, int N> struct alignas(sizeof(TT) * N) PackN { TT v[N]; };
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __host__ __device__ __forceinline__ float to_f32(float v) { return v; }

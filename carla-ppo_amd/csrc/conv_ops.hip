@@ -143,15 +143,17 @@ extern "C" {
 
 // conv2d NHWC stride-2 VALID forward: out[B,OH,OW,Cout] = relu?(im2col(x) * W[kh,kw,ci,co] + bias)
 // replaces tf.layers.conv2d in ConvVAE.build_encoder (reference vae/models.py:250-253)
+// w_transposed = 1: w holds the kernel as [Cout][KH*KW*Cin] (K-contiguous: vector loads + conflict-free LDS staging)
 int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
-                       int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout,
+                       int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout,
                        int relu, void* out) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     GemmParams p = {};
     p.a = x; p.a_frame_idx = frame_idx;
     fill_conv_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
-    p.N = Cout; p.b = w; p.ldb = Cout; p.b_vec = vec_ok(w, Cout, dtype);
+    p.N = Cout; p.b = w; p.ldb = w_transposed ? p.K : Cout; p.b_vec = vec_ok(w, p.ldb, dtype);
     p.out = out; p.bias = bias; p.mask = nullptr; p.relu = relu; p.out_f32 = 0; p.ksplit_len = 0;
+    if (w_transposed) return conv_form_gemm<B_NK>((hipStream_t)stream, dtype, x_is_f32, p, 1);
     return conv_form_gemm<B_KN>((hipStream_t)stream, dtype, x_is_f32, p, 1);
 }
 
@@ -187,14 +189,16 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
 }
 
 // conv2d_transpose input gradient = plain stride-2 conv of dy with the same kernel read as HWIO [kh,kw,I=co,O=ci]
+// w_transposed = 1: w holds the kernel as [Cin][KH*KW*Cout]
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
-                           const void* w, int KH, int KW, int Cin, const void* mask, void* dx) {
+                           const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     GemmParams p = {};
     p.a = dy; p.a_frame_idx = nullptr;
     fill_conv_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));
-    p.N = Cin; p.b = w; p.ldb = Cin; p.b_vec = vec_ok(w, Cin, dtype);
+    p.N = Cin; p.b = w; p.ldb = w_transposed ? p.K : Cin; p.b_vec = vec_ok(w, p.ldb, dtype);
     p.out = dx; p.bias = nullptr; p.mask = mask; p.relu = 0; p.out_f32 = 0; p.ksplit_len = 0;
+    if (w_transposed) return conv_form_gemm<B_NK>((hipStream_t)stream, dtype, 0, p, 1);
     return conv_form_gemm<B_KN>((hipStream_t)stream, dtype, 0, p, 1);
 }
 

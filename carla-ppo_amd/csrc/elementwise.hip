@@ -211,6 +211,63 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__
     }
 }
 
+// vectorised variant for N % VEC == 0 (VEC = 16 B of T): each thread owns a fixed group of VEC columns
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
+                                                         float* __restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ float cs[256][VEC + 1];
+    const int gpr = N / VEC;                             // vector groups per row
+    const int ntu = (256 / gpr) * gpr;                   // active threads: stride is a whole number of rows
+    const long long v0 = (long long)blockIdx.x * rows_per_block * gpr;
+    const long long v1 = min(M, (long long)(blockIdx.x + 1) * rows_per_block) * gpr;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    if ((int)threadIdx.x < ntu) {
+        for (long long v = v0 + threadIdx.x; v < v1; v += ntu) {
+            const PackN<T, VEC> t = *(const PackN<T, VEC>*)(x + v * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += Elem<T>::to_f32(t.v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) cs[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        const int g = threadIdx.x / VEC, e = threadIdx.x % VEC;
+        float s = 0.f;
+        for (int t = g; t < ntu; t += gpr) s += cs[t][e];
+        atomicAdd(&out[threadIdx.x], s);
+    }
+}
+
+// K-contiguous ("transposed") copies of the [K,N] kernels: dst[off + n*K + k] = (T) src[off + k*N + n]
+struct TransposeBatch { long long off[16]; int K[16]; int N[16]; int tile0[17]; int count; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, const TransposeBatch tb) {
+    __shared__ float tile[32][33];
+    int t = 0;
+    while (t + 1 < tb.count && (int)blockIdx.x >= tb.tile0[t + 1]) ++t;
+    const int K = tb.K[t], N = tb.N[t];
+    const int tiles_n = (N + 31) / 32;
+    const int local = blockIdx.x - tb.tile0[t];
+    const int k0 = (local / tiles_n) * 32, n0 = (local % tiles_n) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const float* s = src + tb.off[t];
+    T* d = dst + tb.off[t];
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? s[(long long)k * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) d[(long long)n * K + k] = Elem<T>::from_f32(tile[tx][r]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
                                                           float* __restrict__ out) {
@@ -304,9 +361,33 @@ int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n) 
     return mi_check_launch("cast_f32_bf16");
 }
 
+int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count) {
+    if (count < 1 || count > 16) return mi_fail(MI_ERR_ARG, "mi_transpose_weights: 1 <= count <= 16");
+    TransposeBatch tb;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        if (K[i] < 1 || N[i] < 1) return mi_fail(MI_ERR_ARG, "mi_transpose_weights: empty tensor");
+        tb.off[i] = offsets[i]; tb.K[i] = K[i]; tb.N[i] = N[i]; tb.tile0[i] = tiles;
+        tiles += ((K[i] + 31) / 32) * ((N[i] + 31) / 32);
+    }
+    tb.tile0[count] = tiles; tb.count = count;
+    if (dtype == MI_F32) hipLaunchKernelGGL(transpose_weights_kernel<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, tb);
+    else hipLaunchKernelGGL(transpose_weights_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, tb);
+    return mi_check_launch("transpose_weights");
+}
+
 // out[N] += column sums of x[M,N]   (BiasAddGrad)
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out) {
     if (M <= 0 || N <= 0) return MI_OK;
+    const int vec = dtype == MI_F32 ? 4 : 8;
+    if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
+        long long rows = (M + 2047) / 2048;
+        if (rows * N < 8192) rows = (8192 + N - 1) / N;
+        const int gx = (int)((M + rows - 1) / rows);
+        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
+        else hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+        return mi_check_launch("colsum_vec");
+    }
     if (N <= 256) {
         long long rows = (M + 1023) / 1024;
         if (rows * N < 4096) rows = (4096 + N - 1) / N;

@@ -52,7 +52,6 @@ struct GemmParams {
     int ksplit_len;                  // K range per blockIdx.z (multiple of BK); 0 = single pass
 };
 
-template <typename TT, int N> struct alignas(sizeof(TT) * N) PackN { TT v[N]; };
 template <typename TT, int N, int ALIGN> struct PackU { TT v[N]; } __attribute__((packed, aligned(ALIGN)));
 
 template <typename T> struct Frag;
@@ -294,42 +293,79 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 bf[j] = *(const freg*)(&Bs[((wn * TN + j) * 32 + lrow) * PITCH + kk * 32 + lgrp * 16]);
+            // operands swapped on purpose: D[row = channel][col = pixel], so a lane owns ONE pixel (col = lane&31) and
+            // 16 channels of it -> the epilogue decodes one pixel address per lane and stores 4-channel vectors
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Frag<T>::mma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) Frag<T>::mma(bf[j], af[i], acc[i][j]);
         }
         if (more) { store_a(cur ^ 1); store_b(cur ^ 1); }
         __syncthreads();
     }
 
     // ---------------- epilogue ----------------
+    // lane owns pixel m = tile row lrow; acc[i][j][4q+t] = C[m][n_base + 8q + t], n_base = subtile + 4*lgrp
     const T* __restrict__ maskp = (const T*)p.mask;
+    const bool vec4 = (p.N & 3) == 0;                     // 4-channel groups never straddle N and stay vector-aligned
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + lrow;
+        if (m >= M) continue;
+        long long rowoff;
+        if constexpr (AMODE == A_CONV) {
+            rowoff = ((long long)(p.ksplit_len > 0 ? blockIdx.z : 0) * M + m) * p.N;
+        } else {
+            uint32_t b, rem, y, x;
+            p.dc_ohw[cls].divmod((uint32_t)m, b, rem);
+            p.dc_ow[cls].divmod(rem, y, x);
+            rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lgrp;
-            if (m >= M) continue;
-            long long rowoff;
-            if constexpr (AMODE == A_CONV) {
-                rowoff = ((long long)(p.ksplit_len > 0 ? blockIdx.z : 0) * M + m) * p.N;
-            } else {
-                uint32_t b, rem, y, x;
-                p.dc_ohw[cls].divmod((uint32_t)m, b, rem);
-                p.dc_ow[cls].divmod(rem, y, x);
-                rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
-            }
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 32 + lrow;
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
                 if (n >= p.N) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[n];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (maskp) v = Elem<T>::to_f32(maskp[rowoff + n]) > 0.f ? v : 0.f;
-                if (p.out_f32) ((float*)p.out)[rowoff + n] = v;
-                else ((T*)p.out)[rowoff + n] = Elem<T>::from_f32(v);
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
+                if (vec4) {
+                    if (p.bias) {
+                        const f32x4 bb = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] += bb[t];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+                    }
+                    if (maskp) {
+                        const PackN<T, 4> mk = *(const PackN<T, 4>*)(maskp + rowoff + n);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? v[t] : 0.f;
+                    }
+                    if (p.out_f32) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)((float*)p.out + rowoff + n) = o;
+                    } else {
+                        PackN<T, 4> o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::from_f32(v[t]);
+                        *(PackN<T, 4>*)((T*)p.out + rowoff + n) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (n + t >= p.N) continue;
+                        float x = v[t];
+                        if (p.bias) x += p.bias[n + t];
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (maskp) x = Elem<T>::to_f32(maskp[rowoff + n + t]) > 0.f ? x : 0.f;
+                        if (p.out_f32) ((float*)p.out)[rowoff + n + t] = x;
+                        else ((T*)p.out)[rowoff + n + t] = Elem<T>::from_f32(x);
+                    }
+                }
             }
         }
     }

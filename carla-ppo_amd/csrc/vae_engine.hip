@@ -101,11 +101,13 @@ struct VaeEngine {
     Workspace W;
     float *params, *grads, *m, *v;
     void* shadow;
+    void* wt;                           // K-contiguous ("transposed") copies of the 10 kernels, type T, same offsets
     char* ws;
     int esz;                            // bytes per T
     int ns_heads, ns_dz, nchunks;
     int last_B;
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
+    const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
     const float* bptr(int t) const { return params + L.off[t]; }
     float* gptr(int t) const { return grads + L.off[t]; }
     void* at(long long off) const { return ws + off; }
@@ -185,9 +187,9 @@ int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int
     for (int i = 0; i < NCONV; ++i) {
         const void* x = i == 0 ? (const void*)frames : e->at(e->W.act[i]);
         TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i],
-                              e->wptr(2 * i), e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
+                              e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
     }
-    TOP(e, st, OP_HEADS_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wptr(8), 0, 2 * d.z_dim, nullptr, 0, nullptr,
+    TOP(e, st, OP_HEADS_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wtptr(8), 1, 2 * d.z_dim, nullptr, 0, nullptr,
                         e->at(e->W.heads_slab), 1, e->ns_heads));
     // split-K slabs are laid out [ns][B][2Z] with the CURRENT batch as the middle dimension
     TOP(e, st, OP_REPARAM_FWD, mi_vae_reparam_kl_fwd(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
@@ -198,11 +200,23 @@ int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int
 // decoder: z (T) -> dense1 -> deconv1..4 -> logits
 int run_decoder(VaeEngine* e, void* st, int B) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
-    TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wptr(10), 0, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
+    TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wtptr(10), 1, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
     for (int i = 0; i < 4; ++i)
         TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1])));
     return MI_OK;
+}
+
+// K-contiguous copies of the 10 kernels (conv fwd, deconv dgrad, heads/dense1 fwd read them as the MFMA B operand)
+int refresh_transposed(VaeEngine* e, void* st) {
+    const Geom& g = e->g; const MiVaeDesc& d = e->d;
+    long long off[10]; int K[10], N[10];
+    int n = 0;
+    for (int i = 0; i < NCONV; ++i) { off[n] = e->L.off[2 * i]; K[n] = 16 * g.c[i]; N[n] = g.c[i + 1]; ++n; }
+    off[n] = e->L.off[8]; K[n] = g.flat; N[n] = 2 * d.z_dim; ++n;
+    off[n] = e->L.off[10]; K[n] = d.z_dim; N[n] = g.flat; ++n;
+    for (int i = 0; i < 4; ++i) { off[n] = e->L.off[12 + 2 * i]; K[n] = DEC_K[i] * DEC_K[i] * g.dc[i + 1]; N[n] = g.dc[i]; ++n; }
+    return mi_transpose_weights(st, d.dtype, e->params, e->wt, off, K, N, n);
 }
 
 }  // namespace
@@ -235,15 +249,15 @@ long long mi_vae_workspace_bytes(const MiVaeDesc* d) {
 }
 
 void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* bf16_shadow,
-                    void* workspace, long long workspace_bytes) {
+                    void* weights_t, void* workspace, long long workspace_bytes) {
     VaeEngine* e = (VaeEngine*)calloc(1, sizeof(VaeEngine));
     if (!e) { mi_fail(MI_ERR_STATE, "mi_vae_create: out of host memory"); return nullptr; }
     if (!d || !init_engine(*e, d)) { free(e); mi_fail(MI_ERR_SHAPE, "mi_vae_create: unsupported geometry"); return nullptr; }
     if (d->dtype != MI_F32 && d->dtype != MI_BF16) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: dtype must be 0 (f32) or 1 (bf16)"); return nullptr; }
     if (d->dtype == MI_BF16 && !bf16_shadow) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: bf16 mode needs the shadow weight buffer"); return nullptr; }
-    if (!params || !workspace || workspace_bytes < e->W.total) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: missing buffers or workspace too small"); return nullptr; }
+    if (!params || !weights_t || !workspace || workspace_bytes < e->W.total) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: missing buffers or workspace too small"); return nullptr; }
     if ((((uintptr_t)params) | ((uintptr_t)workspace) | ((uintptr_t)bf16_shadow) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: buffers must be 256-byte aligned"); return nullptr; }
-    e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->ws = (char*)workspace;
+    e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->wt = weights_t; e->ws = (char*)workspace;
     e->last_B = 0;
     return e;
 }
@@ -254,8 +268,8 @@ void mi_vae_destroy(void* h) { free(h); }
 int mi_vae_sync_shadow(void* h, void* stream) {
     VaeEngine* e = (VaeEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
-    if (e->d.dtype == MI_BF16) return mi_cast_f32_to_bf16(stream, e->params, e->shadow, e->L.total);
-    return MI_OK;
+    if (e->d.dtype == MI_BF16) CK(mi_cast_f32_to_bf16(stream, e->params, e->shadow, e->L.total));
+    return refresh_transposed(e, stream);
 }
 
 // device pointers into the workspace (valid after the corresponding call; fp32): 0 losses[2] (recon, kl), 1 mean [B,Z],
@@ -311,7 +325,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
             const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
             TOP(e, st, OP_DECONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
             TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i)));
-            TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wptr(12 + 2 * i), DEC_K[i], DEC_K[i], g.dc[i],
+            TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
         // dense1: h = z W1 + b1
@@ -347,7 +361,7 @@ int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float bet
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_vae_apply_adam: engine created without optimiser buffers");
     TOP(e, stream, OP_ADAM, mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, beta1, beta2, epsilon,
                                             e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1));
-    return MI_OK;
+    return refresh_transposed(e, stream);
 }
 
 // VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32

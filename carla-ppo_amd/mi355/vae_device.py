@@ -72,6 +72,7 @@ class VaeDevice:
         self.adam_m = z() if self.with_optimizer else None
         self.adam_v = z() if self.with_optimizer else None
         self.shadow = z(torch.bfloat16) if self.dtype == milib.MI_BF16 else None
+        self.weights_t = z(torch.bfloat16 if self.dtype == milib.MI_BF16 else torch.float32)     # K-contiguous kernel copies
         self.metrics = torch.zeros(3, device=self.device)
         self.decoder_offset = self.layout["vae/decoder/dense1/kernel"][0]   # grads[decoder_offset:] are ready first in backward
 
@@ -84,7 +85,7 @@ class VaeDevice:
         self.workspace = torch.empty(int(nbytes), device=self.device, dtype=torch.uint8)
         p = milib.ptr
         self.handle = self.L.mi_vae_create(ctypes.byref(d), p(self.params), p(self.grads), p(self.adam_m), p(self.adam_v),
-                                           p(self.shadow), p(self.workspace), int(nbytes))
+                                           p(self.shadow), p(self.weights_t), p(self.workspace), int(nbytes))
         if not self.handle:
             raise milib.MiError("mi_vae_create: " + self.L.cdll.mi_last_error().decode())
         self.max_batch = int(max_batch)

@@ -64,7 +64,7 @@ int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int ar
 
 /* ---- convolution family (implicit-GEMM on MFMA, LDS-staged tiles) ---- */
 /* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be fp32 frames gathered through frame_idx. */
-int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
+int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout, int relu, void* out);
 /* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
 /* Conv2DBackpropFilter: dw += im2col(x)^T dy (fp32 atomics) */
@@ -72,7 +72,7 @@ int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* fram
 /* tf.layers.conv2d_transpose k x k, s2, VALID + BiasAdd (+ Relu) — vae/models.py:261-264 */
 int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
-int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, const void* mask, void* dx);
+int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw);
 /* tf.layers.dense (MatMul + BiasAdd + Relu) and its input gradient — vae/models.py:97-98,259; utils.py:25-28; ppo.py:43-55.
@@ -93,6 +93,8 @@ int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, cons
 /* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
+/* K-contiguous copies of the [K,N] kernels for the MFMA B operand: dst[off + n*K + k] = (T) src[off + k*N + n], count <= 16 tensors */
+int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count);
 /* BiasAddGrad */
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out);
 /* tf.nn.sigmoid(reconstructed_logits) — vae/models.py:113 */
@@ -119,7 +121,7 @@ int mi_vae_tensor_count(void);
 long long mi_vae_param_floats(const MiVaeDesc* d);
 int mi_vae_param_layout(const MiVaeDesc* d, long long* offsets, long long* sizes, int n);
 long long mi_vae_workspace_bytes(const MiVaeDesc* d);
-void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* bf16_shadow, void* workspace, long long workspace_bytes);
+void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* bf16_shadow, void* weights_t, void* workspace, long long workspace_bytes);
 void mi_vae_destroy(void* h);
 int mi_vae_sync_shadow(void* h, void* stream);
 void* mi_vae_buffer(void* h, int which);

@@ -55,9 +55,18 @@ def test_conv_fwd_dgrad_wgrad(dt, geom):
     wd, bd = dev(w, td), dev(b)
     out = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
     L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), P(dev(idx, torch.int32)) if first else None, int(first),
-                         B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, 1, out.data_ptr())
+                         B, IH, IW, Ci, wd.data_ptr(), 0, bd.data_ptr(), k, k, Co, 1, out.data_ptr())
     rt, at = tols(dt, float(yref.abs().max()))
     assert_close(host(out), yref.detach().numpy(), rt, at, "conv fwd")
+    # K-contiguous kernel copy made by mi_transpose_weights: same result through the conflict-free B staging
+    wt = torch.zeros(k * k * Ci * Co, device="cuda", dtype=td)
+    offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Ci], np.int32), np.array([Co], np.int32)
+    L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+    assert torch.equal(wt.view(Co, k * k * Ci).cpu(), torch.from_numpy(w.reshape(-1, Co).T.copy()).to(td))
+    out2 = torch.empty_like(out)
+    L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), P(dev(idx, torch.int32)) if first else None, int(first),
+                         B, IH, IW, Ci, wt.data_ptr(), 1, bd.data_ptr(), k, k, Co, 1, out2.data_ptr())
+    assert_close(host(out2), yref.detach().numpy(), rt, at, "conv fwd (transposed kernel)")
 
     dyd = dev(dy, td)
     dw = torch.zeros(k, k, Ci, Co, device="cuda")
@@ -108,9 +117,15 @@ def test_deconv_fwd_dgrad_wgrad(dt, geom):
 
     dyd = dev(dy, td)
     dx = torch.full((B, IH, IW, Ci), 5.0, device="cuda", dtype=td)
-    L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), k, k, Ci, P(dev(mask, td)), dx.data_ptr())
+    L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), 0, k, k, Ci, P(dev(mask, td)), dx.data_ptr())
     rt, at = tols(dt, float(dxref.abs().max()))
     assert_close(host(dx), dxref.numpy(), rt, at, "deconv dgrad")
+    wt = torch.zeros(k * k * Co * Ci, device="cuda", dtype=td)
+    offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
+    L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+    dx2 = torch.full((B, IH, IW, Ci), 5.0, device="cuda", dtype=td)
+    L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, P(dev(mask, td)), dx2.data_ptr())
+    assert_close(host(dx2), dxref.numpy(), rt, at, "deconv dgrad (transposed kernel)")
 
     dw = torch.zeros(k, k, Co, Ci, device="cuda")
     L.mi_deconv2d_nhwc_wgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw.data_ptr())
