@@ -41,6 +41,12 @@ DEC = [(3, 8, 256, 128, 4), (8, 18, 128, 64, 4), (18, 38, 64, 32, 5), (39, 79, 3
 def op_work(name, B, esz, n_params):
     """Algorithmic work of one launch of op `name` at batch B: (flops, bytes, bound). SURVEY.md 8(d) per-frame figures x B."""
     layer, _, kind = name.partition(".")
+    # conv1 / deconv4 (K = 48 / N = 3): skinny streams, HBM bound per SURVEY 8(d): frame fp32 153 600 B, 39x79x32 map, 80x160x3 map
+    if layer in ("conv1", "deconv4") and kind in ("fwd", "dgrad", "wgrad"):
+        big = 38400.0 * (4 if layer == "conv1" else esz)            # frames are fp32, logits / dlogits are T
+        mid = 39 * 79 * 32.0 * esz
+        nbytes = {"fwd": big + mid, "wgrad": big + mid, "dgrad": big + 2 * mid}[kind]   # dgrad also reads the ReLU mask
+        return None, nbytes * B, "hbm"
     if layer.startswith("conv") and kind in ("fwd", "dgrad", "wgrad"):
         ih, iw, ci, co = ENC[int(layer[4]) - 1]
         oh, ow = (ih - 4) // 2 + 1, (iw - 4) // 2 + 1

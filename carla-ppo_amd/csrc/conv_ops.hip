@@ -96,7 +96,8 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
 
 int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks) {
     const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : WgradCfg<bf16_t>::BP;
-    const int gx = (p.Kc + 63) / 64, gy = (p.N + 63) / 64;
+    const bool wide = p.Kc > 64;                          // 128 kc rows per block: halves the re-reads of the small tensor
+    const int gx = wide ? (p.Kc + 127) / 128 : 1, gy = (p.N + 63) / 64;
     int splits = target_blocks / (gx * gy);
     if (splits < 1) splits = 1;
     int mps = (p.M + splits - 1) / splits;
@@ -107,19 +108,23 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     dim3 g(gx, gy, splits);
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
+#define WG_LAUNCH(T_, TIn_, VA_, AL_) do { \
+        if (wide) hipLaunchKernelGGL((wgrad_kernel<T_, TIn_, VA_, AL_, 128>), g, dim3(GEMM_NT), 0, st, p); \
+        else hipLaunchKernelGGL((wgrad_kernel<T_, TIn_, VA_, AL_, 64>), g, dim3(GEMM_NT), 0, st, p); } while (0)
     if (dtype == MI_F32) {
-        if (!p.merged && p.C % 4 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<float, float, 4, 16>), g, dim3(GEMM_NT), 0, st, p);
-        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<float, float, 4, 8>), g, dim3(GEMM_NT), 0, st, p);
+        if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(float, float, 4, 16);
+        else if (mergedok) WG_LAUNCH(float, float, 4, 8);
         else return mi_fail(MI_ERR_SHAPE, "wgrad (f32): channel count / alignment not supported");
     } else if (in_f32) {
-        if (!p.merged && p.C % 4 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, float, 4, 16>), g, dim3(GEMM_NT), 0, st, p);
-        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<bf16_t, float, 4, 8>), g, dim3(GEMM_NT), 0, st, p);
+        if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(bf16_t, float, 4, 16);
+        else if (mergedok) WG_LAUNCH(bf16_t, float, 4, 8);
         else return mi_fail(MI_ERR_SHAPE, "wgrad (bf16, fp32 input): channel count / alignment not supported");
     } else {
-        if (!p.merged && p.C % 8 == 0 && a16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, bf16_t, 8, 16>), g, dim3(GEMM_NT), 0, st, p);
-        else if (mergedok) hipLaunchKernelGGL((wgrad_kernel<bf16_t, bf16_t, 4, 4>), g, dim3(GEMM_NT), 0, st, p);
+        if (!p.merged && p.C % 8 == 0 && a16) WG_LAUNCH(bf16_t, bf16_t, 8, 16);
+        else if (mergedok) WG_LAUNCH(bf16_t, bf16_t, 4, 4);
         else return mi_fail(MI_ERR_SHAPE, "wgrad (bf16): channel count / alignment not supported");
     }
+#undef WG_LAUNCH
     return mi_check_launch("wgrad_kernel");
 }
 

@@ -381,8 +381,9 @@ int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float*
     if (M <= 0 || N <= 0) return MI_OK;
     const int vec = dtype == MI_F32 ? 4 : 8;
     if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
-        long long rows = (M + 2047) / 2048;
-        if (rows * N < 8192) rows = (8192 + N - 1) / N;
+        // <= 512 blocks: every block ends with N atomics on the same N addresses, so block count (not bytes) sets the floor
+        long long rows = (M + 511) / 512;
+        if (rows * N < 32768) rows = (32768 + N - 1) / N;
         const int gx = (int)((M + rows - 1) / rows);
         if (dtype == MI_F32) hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
         else hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
