@@ -1,5 +1,6 @@
 // conv_ops.hip — host launchers (C ABI) for the MFMA tile kernels in gemm_core.hpp.
 // Every conv on this path is NHWC, stride 2, VALID (reference vae/models.py:250-253,261-264).
+#include <stdlib.h>
 #include "gemm_core.hpp"
 #include "mi_internal.hpp"
 
@@ -38,10 +39,94 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
     p.div_kw = make_fastdiv(KW);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm2 (LDS-DMA tiles, gemm2_tile.hpp): taken whenever the layer is "wide" (whole 16-byte chunks per pixel), the
+// weights are K-contiguous and every tensor fits a 1 GiB buffer descriptor.  MI355_GEMM2=0 forces the first-generation
+// register-staged kernel (A/B comparisons, bisecting).
+// ---------------------------------------------------------------------------------------------------------------
+bool gemm2_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_GEMM2"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+template <typename T, int AMODE, int BMODE, bool UTAP>
+int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int gz) {
+    if (M_for_grid <= 0) return MI_OK;
+    if (p.N <= 32) {
+        dim3 g((M_for_grid + 255) / 256, 1, gz);
+        hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 256, 32, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+    } else if (p.N <= 64) {
+        dim3 g((M_for_grid + 127) / 128, 1, gz);
+        hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+    } else {
+        const int gx = (M_for_grid + 127) / 128;
+        if ((long long)gx * ((p.N + 127) / 128) * gz >= 384) {
+            dim3 g(gx, (p.N + 127) / 128, gz);
+            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+        } else {                                          // few tiles: narrower blocks fill the 256 CUs
+            dim3 g(gx, (p.N + 63) / 64, gz);
+            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+        }
+    }
+    return mi_check_launch("gemm2_kernel");
+}
+
+inline bool fits_desc(long long bytes) { return bytes > 0 && bytes < (long long)G2_OOB; }
+
+void copy_epilogue(Gemm2Params& q, const GemmParams& p) {
+    q.out = p.out; q.bias = p.bias; q.mask = p.mask; q.relu = p.relu; q.out_f32 = p.out_f32;
+}
+
+// conv-form (A_CONV x B_NK).  Returns 1 if launched, 0 if not eligible, <0 on error.
+int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
+    if (!gemm2_enabled() || p.a_frame_idx || p.ksplit_len > 0) return 0;
+    const int esz = dtype == MI_F32 ? 4 : 2;
+    const long long a_bytes = (long long)p.nbatch * p.a_frame_stride * esz, b_bytes = (long long)p.N * p.ldb * esz;
+    if ((p.C * esz) % 16 != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15) || (p.ldb * esz) % 16 != 0 || p.ldb < p.K) return 0;
+    if (!fits_desc(a_bytes) || !fits_desc(b_bytes)) return 0;
+    Gemm2Params q = {};
+    q.a = p.a; q.a_bytes = (uint32_t)a_bytes; q.b = p.b; q.b_bytes = (uint32_t)b_bytes;
+    q.IH = p.IH; q.IW = p.IW; q.C = p.C; q.OH = p.OH; q.OW = p.OW; q.KH = p.KH; q.KW = p.KW; q.stride = p.stride;
+    q.M = p.M; q.N = p.N; q.K = p.K; q.nbatch = p.nbatch;
+    q.run = p.KW * p.C; q.div_run = make_fastdiv(q.run); q.div_ohw = p.div_ohw; q.div_ow = p.div_ow;
+    q.ldb = p.ldb;
+    copy_epilogue(q, p);
+    int rc = dtype == MI_F32 ? launch_gemm2_tiles<float, A_CONV, B_NK, false>(st, q, q.M, 1)
+                             : launch_gemm2_tiles<bf16_t, A_CONV, B_NK, false>(st, q, q.M, 1);
+    return rc == MI_OK ? 1 : rc;
+}
+
+// gather-form transposed conv (A_DECONV x B_DECONV); p already carries the class geometry from deconv_form_gemm
+int try_deconv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p, int maxM) {
+    if (!gemm2_enabled()) return 0;
+    if (p.N <= 32) return 0;      // measured: narrow gather-form layers (deconv3/4 fwd, conv2 dgrad) are not faster on the DMA tiles
+    const int esz = dtype == MI_F32 ? 4 : 2;
+    const long long a_bytes = (long long)p.nbatch * p.a_frame_stride * esz, b_bytes = (long long)p.KH * p.KW * p.N * p.C * esz;
+    if ((p.C * esz) % 16 != 0 || p.KH > 6 || p.KW > 6 || !fits_desc(a_bytes) || !fits_desc(b_bytes)) return 0;
+    Gemm2Params q = {};
+    q.a = p.a; q.a_bytes = (uint32_t)a_bytes; q.b = p.b; q.b_bytes = (uint32_t)b_bytes;
+    q.IH = p.IH; q.IW = p.IW; q.C = p.C; q.OH = p.OH; q.OW = p.OW; q.KH = p.KH; q.KW = p.KW; q.stride = 2;
+    q.M = 0; q.N = p.N; q.K = 0; q.nbatch = p.nbatch;
+    for (int i = 0; i < 2; ++i) { q.OHc[i] = p.OHc[i]; q.OWc[i] = p.OWc[i]; q.Th[i] = p.Th[i]; q.Tw[i] = p.Tw[i]; q.dc_tw[i] = p.dc_tw[i]; }
+    for (int i = 0; i < 4; ++i) { q.dc_ohw[i] = p.dc_ohw[i]; q.dc_ow[i] = p.dc_ow[i]; }
+    q.dc_c = p.dc_c;
+    copy_epilogue(q, p);
+    const bool utap = (p.C * esz) % 128 == 0;
+    int rc;
+    if (dtype == MI_F32) rc = utap ? launch_gemm2_tiles<float, A_DECONV, B_DECONV, true>(st, q, maxM, 4) : launch_gemm2_tiles<float, A_DECONV, B_DECONV, false>(st, q, maxM, 4);
+    else rc = utap ? launch_gemm2_tiles<bf16_t, A_DECONV, B_DECONV, true>(st, q, maxM, 4) : launch_gemm2_tiles<bf16_t, A_DECONV, B_DECONV, false>(st, q, maxM, 4);
+    return rc == MI_OK ? 1 : rc;
+}
+
 // A_CONV GEMM with dtype/vector dispatch. in_f32: the A tensor is fp32 in HBM even when T = bf16 (input frames).
 template <int BMODE>
 int conv_form_gemm(hipStream_t st, int dtype, int in_f32, GemmParams& p, int gz) {
     const int C = p.C;
+    if (BMODE == B_NK && !(in_f32 && dtype != MI_F32)) {
+        const int r2 = try_conv_form_gemm2(st, dtype, p);
+        if (r2 != 0) return r2 > 0 ? MI_OK : r2;
+    }
     const bool a16 = (((uintptr_t)p.a) & 15) == 0;
     if (dtype == MI_F32) {
         if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<float, float, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
@@ -90,6 +175,10 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
     if (C % vb != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15))
         return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: input channels must be a multiple of the 16-byte vector and pointers 16-B aligned");
     if (KH < 2 || KW < 2) return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: kernel must be >= 2");
+    {
+        const int r2 = try_deconv_form_gemm2(st, dtype, p, maxM);
+        if (r2 != 0) return r2 > 0 ? MI_OK : r2;
+    }
     if (dtype == MI_F32) return launch_gemm_bn<float, float, A_DECONV, B_DECONV, 4, 16>(st, p, maxM, 4);
     return launch_gemm_bn<bf16_t, bf16_t, A_DECONV, B_DECONV, 8, 16>(st, p, maxM, 4);
 }

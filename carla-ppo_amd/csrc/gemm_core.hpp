@@ -3,9 +3,11 @@
 //   gemm_tile.hpp   gemm_kernel<A_CONV,...>    C[m,n] = sum_k im2col(X)[m,k] * W[k,n]    conv fwd, deconv dgrad, dense fwd/dgrad
 //                   gemm_kernel<A_DECONV,...>  stride-2 transposed conv in gather form, one GEMM per output-parity class
 //                                              (deconv fwd, conv dgrad)
+//   gemm2_tile.hpp  gemm2_kernel               same contractions for the wide layers: LDS-DMA tiles, XOR-swizzled LDS, 128-B K stages
 //   wgrad_tile.hpp  wgrad_kernel               dW[kc,n] += sum_m im2col(big)[m,kc] * small[m,n]   (conv/deconv/dense wgrad)
 //
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once
 #include "gemm_tile.hpp"
+#include "gemm2_tile.hpp"
 #include "wgrad_tile.hpp"

