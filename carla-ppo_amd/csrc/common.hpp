@@ -20,6 +20,9 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     union { uint32_t u; float f; } c; c.u = (uint32_t)v << 16; return c.f;
 }
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);          // gfx950: v_cvt_pk_bf16_f32 (round-to-nearest-even)
+#endif
     union { uint32_t u; float f; } c; c.f = f;
     uint32_t u = c.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
@@ -39,6 +42,17 @@ template <> struct Elem<bf16_t> {
     static __host__ __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
     static __host__ __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
 };
+
+// 4 consecutive fp32 values -> 4 storage elements (bf16: two v_cvt_pk_bf16_f32)
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ PackN<T, 4> pack4(const float (&v)[4]);
+template <> __device__ __forceinline__ PackN<float, 4> pack4<float>(const float (&v)[4]) {
+    PackN<float, 4> o; o.v[0] = v[0]; o.v[1] = v[1]; o.v[2] = v[2]; o.v[3] = v[3]; return o;
+}
+template <> __device__ __forceinline__ PackN<bf16_t, 4> pack4<bf16_t>(const float (&v)[4]) {
+    const f32x4 f = {v[0], v[1], v[2], v[3]};
+    return __builtin_bit_cast(PackN<bf16_t, 4>, __builtin_convertvector(f, bf16x4_t));
+}
 
 // ---- division by a runtime-invariant divisor: q = (n * mul) >> 40 style, exact for 0 <= n < 2^31 ----
 // host computes mul = floor(2^(31+s) / d) + 1 with s = ceil(log2 d); n*mul < 2^63.

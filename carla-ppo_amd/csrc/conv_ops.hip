@@ -44,10 +44,12 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
 // weights are K-contiguous and every tensor fits a 1 GiB buffer descriptor.  MI355_GEMM2=0 forces the first-generation
 // register-staged kernel (A/B comparisons, bisecting).
 // ---------------------------------------------------------------------------------------------------------------
+long long* g_trace = nullptr; int g_trace_cap = 0;
+int g_gemm2_on = -1;
+int g_tap_min = -2;
 bool gemm2_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MI355_GEMM2"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on != 0;
+    if (g_gemm2_on < 0) { const char* e = getenv("MI355_GEMM2"); g_gemm2_on = (e && e[0] == '0') ? 0 : 1; }
+    return g_gemm2_on != 0;
 }
 
 template <typename T, int AMODE, int BMODE, bool UTAP>
@@ -78,9 +80,88 @@ void copy_epilogue(Gemm2Params& q, const GemmParams& p) {
     q.out = p.out; q.bias = p.bias; q.mask = p.mask; q.relu = p.relu; q.out_f32 = p.out_f32;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// tapconv (raw-staged slot tiles, tapconv_tile.hpp): stride-2 k=4/5 layers with whole 16-byte chunks per pixel and enough
+// positions to fill the chip.  MI355_TAPCONV=0 disables it; MI355_TAPCONV_MINBLOCKS overrides the occupancy threshold.
+// ---------------------------------------------------------------------------------------------------------------
+int tapconv_minblocks() {
+    if (g_tap_min == -2) {
+        const char* e = getenv("MI355_TAPCONV");
+        if (e && e[0] == '0') g_tap_min = -1;
+        else { const char* m = getenv("MI355_TAPCONV_MINBLOCKS"); g_tap_min = m ? atoi(m) : 300; }
+    }
+    return g_tap_min;
+}
+
+template <typename T, int MODE, int TAPS>
+int launch_tapconv_t(hipStream_t st, const TapParams& q) {
+    const int gx = (q.MP + TC_BMT - 1) / TC_BMT;
+    if (q.NE >= 128) {
+        dim3 g(gx, (q.NE + 127) / 128, 1);
+        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS>), g, dim3(TC_NT), 0, st, q);
+    } else {
+        dim3 g(gx, (q.NE + 63) / 64, 1);
+        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 64, TAPS>), g, dim3(TC_NT), 0, st, q);
+    }
+    return mi_check_launch("tapconv_kernel");
+}
+template <typename T, int MODE>
+int launch_tapconv(hipStream_t st, const TapParams& q) {
+    return q.TH == 2 ? launch_tapconv_t<T, MODE, 2>(st, q) : launch_tapconv_t<T, MODE, 3>(st, q);
+}
+
+// mode TC_CONV: x[B,IH,IW,C] -> out[B,OH,OW,N], weights K-contiguous [N][KH*KW*C];  mode TC_GATHER: x[B,IH,IW,C] -> out[B,OH,OW,N],
+// weights [KH][KW][N][C].  Returns 1 launched, 0 not eligible, <0 error.
+int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
+                int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu) {
+    const int minblocks = tapconv_minblocks();
+    if (minblocks < 0) return 0;
+    const int esz = dtype == MI_F32 ? 4 : 2;
+    if (KH != KW || KH < 3 || KH > 6) return 0;
+    if ((C * esz) % 16 != 0 || (((uintptr_t)a) & 15) || (((uintptr_t)w) & 15)) return 0;
+    // coalesced epilogue: whole 16-byte chunks of one pixel's channels, 32-bit element offsets
+    if ((N * esz) % 16 != 0 || (((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15)) || (long long)B * OH * OW * N >= (1ll << 31)) return 0;
+    TapParams q = {};
+    q.TH = (KH + 1) / 2; q.TW = (KW + 1) / 2;
+    if (mode == TC_CONV) {
+        if ((ldb * esz) % 16 != 0 || ldb < KH * KW * C) return 0;
+        if (q.TH == 3 && minblocks > 1) return 0;        // measured: k=5 conv form (deconv3 dgrad) is faster on gemm2 (76 vs 93 us)
+        q.GH = OH + q.TH - 1; q.GW = OW + q.TW - 1; q.HY = q.HX = 0;
+        q.KC = 4 * C; q.NE = N;
+    } else {
+        if (N % 32 != 0) return 0;                        // a 32-wide output tile must stay inside one parity class
+        q.HY = q.TH - 1; q.HX = q.TW - 1;
+        q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX;
+        q.KC = C; q.NE = 4 * N;
+    }
+    if ((q.TH - 1) * q.GW + q.TW - 1 > TC_MAXHALO) return 0;
+    const long long MP = (long long)B * q.GH * q.GW;
+    const long long a_bytes = (long long)B * IH * IW * C * esz;
+    const long long b_bytes = (mode == TC_CONV ? (long long)N * ldb : (long long)KH * KW * N * C) * esz;
+    if (MP >= (1ll << 30) || !fits_desc(a_bytes) || !fits_desc(b_bytes)) return 0;
+    const long long blocks = ((MP + TC_BMT - 1) / TC_BMT) * ((q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64));
+    if (blocks < minblocks) return 0;
+    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.b = w; q.b_bytes = (uint32_t)b_bytes;
+    q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW;
+    q.MP = (int)MP; q.ldb = ldb;
+    q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
+    q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
+    q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
+    q.trace = g_trace; q.trace_cap = g_trace_cap;
+    int rc;
+    if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q) : launch_tapconv<float, TC_GATHER>(st, q);
+    else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q) : launch_tapconv<bf16_t, TC_GATHER>(st, q);
+    return rc == MI_OK ? 1 : rc;
+}
+
 // conv-form (A_CONV x B_NK).  Returns 1 if launched, 0 if not eligible, <0 on error.
 int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
-    if (!gemm2_enabled() || p.a_frame_idx || p.ksplit_len > 0) return 0;
+    if (p.a_frame_idx || p.ksplit_len > 0) return 0;
+    if (p.stride == 2 && !p.out_f32) {
+        const int r3 = try_tapconv(st, dtype, TC_CONV, p.a, p.b, p.nbatch, p.IH, p.IW, p.C, p.OH, p.OW, p.N, p.KH, p.KW, p.ldb, p.out, p.bias, p.mask, p.relu);
+        if (r3 != 0) return r3;
+    }
+    if (!gemm2_enabled()) return 0;
     const int esz = dtype == MI_F32 ? 4 : 2;
     const long long a_bytes = (long long)p.nbatch * p.a_frame_stride * esz, b_bytes = (long long)p.N * p.ldb * esz;
     if ((p.C * esz) % 16 != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15) || (p.ldb * esz) % 16 != 0 || p.ldb < p.K) return 0;
@@ -175,6 +256,10 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
     if (C % vb != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15))
         return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: input channels must be a multiple of the 16-byte vector and pointers 16-B aligned");
     if (KH < 2 || KW < 2) return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: kernel must be >= 2");
+    if (!p.out_f32) {
+        const int r3 = try_tapconv(st, dtype, TC_GATHER, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, 0, p.out, p.bias, p.mask, p.relu);
+        if (r3 != 0) return r3 > 0 ? MI_OK : r3;
+    }
     {
         const int r2 = try_deconv_form_gemm2(st, dtype, p, maxM);
         if (r2 != 0) return r2 > 0 ? MI_OK : r2;
@@ -234,6 +319,17 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 }  // namespace
 
 extern "C" {
+
+// debug: device buffer of int64 stamps, 32 per wave of every tapconv block (see tools/trace_tapconv.py); nullptr switches it off
+int mi_debug_set_trace(void* dev_ptr, int capacity_entries) { g_trace = (long long*)dev_ptr; g_trace_cap = dev_ptr ? capacity_entries : 0; return MI_OK; }
+
+int mi_set_tuning(int key, int value) {
+    int prev;
+    if (key == 0) { prev = gemm2_enabled() ? 1 : 0; g_gemm2_on = value ? 1 : 0; }
+    else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
+    else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
+    return prev;
+}
 
 // conv2d NHWC stride-2 VALID forward: out[B,OH,OW,Cout] = relu?(im2col(x) * W[kh,kw,ci,co] + bias)
 // replaces tf.layers.conv2d in ConvVAE.build_encoder (reference vae/models.py:250-253)

@@ -4,10 +4,12 @@
 //                   gemm_kernel<A_DECONV,...>  stride-2 transposed conv in gather form, one GEMM per output-parity class
 //                                              (deconv fwd, conv dgrad)
 //   gemm2_tile.hpp  gemm2_kernel               same contractions for the wide layers: LDS-DMA tiles, XOR-swizzled LDS, 128-B K stages
+//   tapconv_tile.hpp tapconv_kernel            stride-2 conv / transposed conv as a stride-1 tap conv on raw-staged slot tiles
 //   wgrad_tile.hpp  wgrad_kernel               dW[kc,n] += sum_m im2col(big)[m,kc] * small[m,n]   (conv/deconv/dense wgrad)
 //
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
+#include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"

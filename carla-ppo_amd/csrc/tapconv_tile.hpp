@@ -1,0 +1,377 @@
+// tapconv_tile.hpp — raw-staged MFMA kernel for the stride-2 conv / transposed-conv layers (gfx950, wave64).
+//
+// Both stride-2 forms on this path are stride-1 TAP convolutions on a half-resolution "slot" grid:
+//   conv form   (conv fwd, deconv dgrad):  out[b,oy,ox,n]       = sum_{ta,tb} sum_{ph,pw,c} x[b,2(oy+ta)+ph,2(ox+tb)+pw,c] W[2ta+ph,2tb+pw,c,n]
+//                                          slot (gy,gx) = the 2x2 pixel block (2gy+ph, 2gx+pw): 4C channels, N outputs
+//   gather form (deconv fwd, conv dgrad):  out[b,2y+ph,2x+pw,n] = sum_{th,tw} sum_c x[b,y-th,x-tw,c] W[ph+2th,pw+2tw,n,c]
+//                                          slot (gy,gx) = pixel (gy-HY, gx-HX): C channels, 4N outputs (the 4 output parities)
+// With slots numbered P = (b*GH + gy)*GW + gx, output position P needs slots P + ta*GW + tb, ta<TH, tb<TW (2x2 taps for k=4,
+// 3x3 with some all-zero weight blocks for k=5).  So a block
+//   * stages the slot range [P0, P0 + 256 + halo) of one 128-byte channel slice ONCE per slice (LDS-DMA, zero fill of
+//     everything outside the image by the buffer range check) instead of once per tap  -> 4-9x fewer bytes through the
+//     per-CU load path (~52 B/clk/CU from L2, the measured bound of the im2col-gather kernels),
+//   * streams one weight tile [BNE x 128 B] per (slice, tap) step,
+//   * computes a 256-position x BNE-output tile with 4 waves (128 x BNE/2 each, one wave per SIMD: 32 MFMAs per barrier
+//     cover the ~150 address/issue instructions of a step); tap shifts are plain LDS address offsets.
+// LDS rows are 128 B, XOR-swizzled on the DMA source side (chunk ^= (row >> 1) & 7) -> conflict-free ds_read_b128.
+// Rows of dummy positions (gy >= OH etc.) are computed and dropped in the epilogue.
+#pragma once
+#include "gemm2_tile.hpp"
+
+namespace mi {
+
+enum { TC_CONV = 0, TC_GATHER = 1 };
+constexpr int TC_BMT = 256;          // positions per block
+constexpr int TC_MAXHALO = 96;       // (TH-1)*GW + TW-1 must not exceed this
+constexpr int TC_NT = 512;           // threads per block: 8 waves (one wave per SIMD measured 1.4x slower: nothing hides its LDS latency)
+constexpr int TC_NBUF = 2;           // weight stages (double buffer)
+
+struct TapParams {
+    const void* a; uint32_t a_bytes;
+    const void* b; uint32_t b_bytes;
+    int B, IH, IW, C;                // input tensor
+    int OH, OW, N;                   // output tensor
+    int KH, KW;
+    int GH, GW, TH, TW, HY, HX;      // slot grid per image, taps, gather-form halos
+    int KC, NE, MP;                  // channels per slot (4C | C), effective outputs (N | 4N), B*GH*GW
+    int ldb;                         // conv form: row pitch (elements) of the K-contiguous weight copy [N][KH*KW*C]
+    FastDiv div_g, div_gw, div_n, div_2c, div_c;
+    void* out; const float* bias; const void* mask; int relu;
+    long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
+};
+
+// TAPS: taps per axis (2 for k <= 4, 3 for k = 5,6); the tap loop is unrolled so tap offsets / issue slots are literals
+template <typename T, int MODE, int BNE, int TAPS>
+__global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
+    constexpr int RB = 128;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int CHS = RB / ESZ;                         // channels per stage
+    constexpr int VE = 16 / ESZ;
+    constexpr int BMT = TC_BMT;
+    constexpr int MAXSLOT = BMT + TC_MAXHALO;             // 352, multiple of 8
+    constexpr int NWAVE = TC_NT / 64;
+    constexpr int NIA = (MAXSLOT / 8 + NWAVE - 1) / NWAVE; // A-tile DMA instructions per wave (upper bound: ceil(44 / 8) = 6)
+    constexpr int WN = 2, WM = NWAVE / WN;
+    constexpr int TM = BMT / WM / 32;                     // 2
+    constexpr int TN = BNE / WN / 32;                     // 2 | 1
+    constexpr int TPS = 256 / BNE;                        // taps per barrier step: 32 MFMAs per wave between barriers
+    constexpr int NSS = (TAPS * TAPS + TPS - 1) / TPS;    // steps per channel slice
+    constexpr int NJB = BNE / 8 / NWAVE;                  // B-tile DMA instructions per wave (8 rows each)
+    constexpr int ASTAGE = MAXSLOT * RB, BTILE = BNE * RB, BSTAGE = TPS * BTILE;
+    static_assert(TN >= 1 && NJB >= 1, "tile config");
+    typedef typename Frag<T>::reg freg;
+
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * ASTAGE + TC_NBUF * BSTAGE];
+    unsigned char* const Abase = lds;
+    unsigned char* const Bbase = lds + 2 * ASTAGE;
+
+    constexpr int NT = TAPS * TAPS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, lgrp = lane >> 5;
+    const int r8 = lane >> 3;
+
+    int tr_n = 0;
+    long long* const tr = p.trace ? p.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (tid >> 6)) * 32 : nullptr;   // 8 wave slots per block in the trace layout
+    const bool tr_on = tr && ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
+#define TC_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    TC_STAMP();
+    const int P0 = xcd_remap(blockIdx.x, gridDim.x) * BMT;
+    const int n0 = blockIdx.y * BNE;
+    const int halo = (TAPS - 1) * p.GW + TAPS - 1;
+    const int ninstrA = (BMT + halo + 7) >> 3;            // 8-slot DMA instructions covering the staged range
+    const int NCC = (p.KC + CHS - 1) / CHS;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, (int)p.b_bytes, 0x00020000);
+
+    // ---------------- A-tile DMA roles: instruction t = wave + NWAVE i fills slots 8t .. 8t+7 ----------------
+    // logical chunk of this thread: (lane & 7) ^ ((slot >> 1) & 7), slot = 8 (wave + NWAVE i) + r8  ->  independent of i
+    const int cchA = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    uint32_t offA[NIA];                                   // byte offset of the slot's first pixel (G2_OOB: slot outside every image)
+    uint32_t vmA[NIA];                                    // conv form: validity of the (ph,pw) sub-pixels, bit ph*2+pw
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int t = wave + NWAVE * i;
+        const int P = P0 + 8 * t + r8;
+        const bool ok = t < ninstrA && P < p.MP;
+        uint32_t g, gx, b, gy;
+        p.div_gw.divmod((uint32_t)(ok ? P : 0), g, gx);
+        p.div_g.divmod(g, b, gy);
+        if constexpr (MODE == TC_CONV) {
+            const int y0 = 2 * (int)gy, x0 = 2 * (int)gx;
+            uint32_t vm = 0;
+            if (ok) {
+                if (y0 < p.IH && x0 < p.IW) vm |= 1u;
+                if (y0 < p.IH && x0 + 1 < p.IW) vm |= 2u;
+                if (y0 + 1 < p.IH && x0 < p.IW) vm |= 4u;
+                if (y0 + 1 < p.IH && x0 + 1 < p.IW) vm |= 8u;
+            }
+            vmA[i] = vm;
+            offA[i] = (((b * p.IH + y0) * p.IW + x0) * p.C) * ESZ;
+        } else {
+            const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
+            const bool in = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            offA[i] = in ? (((b * p.IH + iy) * p.IW + ix) * p.C) * ESZ : G2_OOB;
+            vmA[i] = 0;
+        }
+    }
+    // per channel slice: this thread's chunk -> byte offset inside the slot (+ which sub-pixel it belongs to, conv form)
+    uint32_t sl_koff = 0, sl_bit = 0;
+    auto sliceA = [&](int cc) {
+        const int kc = cc * CHS + cchA * VE;
+        if constexpr (MODE == TC_CONV) {
+            uint32_t phh, r, pww, c;
+            p.div_2c.divmod((uint32_t)kc, phh, r);        // kc = ph*2C + pw*C + c ; (pw,c) is contiguous in memory
+            p.div_c.divmod(r, pww, c);
+            sl_koff = (phh * p.IW * p.C + r) * ESZ;
+            sl_bit = kc < p.KC ? 1u << (phh * 2 + pww) : 0u;
+        } else {
+            sl_koff = kc < p.KC ? (uint32_t)kc * ESZ : G2_OOB;
+        }
+    };
+    auto issueA = [&](int buf, int i) -> int {            // one DMA instruction (8 slots x 128 B) of the slice set up by sliceA
+        const int t = wave + NWAVE * i;
+        if (t >= ninstrA) return 0;                       // wave-uniform
+        uint32_t vo;
+        if constexpr (MODE == TC_CONV) vo = (vmA[i] & sl_bit) ? offA[i] + sl_koff : G2_OOB;
+        else vo = offA[i] + sl_koff;                      // G2_OOB + anything below 2^30 stays out of range
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(Abase + buf * ASTAGE + t * 1024), 16, (int)vo, 0, 0, 0);
+        return 1;
+    };
+
+    // ---------------- B-tile DMA roles: wave fills rows 8 (wave*NJB + j) .. +7 ----------------
+    int cchB[NJB];
+    uint32_t offB[NJB];                                   // row part of the weight offset (elements) or G2_OOB
+    int clsB[NJB];
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+        const int row = 8 * (wave * NJB + j) + r8;
+        cchB[j] = (lane & 7) ^ ((row >> 1) & 7);
+        const int ne = n0 + row;
+        if constexpr (MODE == TC_CONV) {
+            clsB[j] = 0;
+            offB[j] = ne < p.N ? (uint32_t)ne * (uint32_t)p.ldb : G2_OOB;
+        } else {
+            uint32_t cls, n;
+            p.div_n.divmod((uint32_t)ne, cls, n);
+            clsB[j] = (int)cls;
+            offB[j] = ne < p.NE ? n * (uint32_t)p.C : G2_OOB;
+        }
+    }
+    // weight chunk address = per-thread part (row, channel chunk; fixed within a slice) + wave-uniform tap part
+    uint32_t sb_off[NJB];                                 // element offset without the tap term, or G2_OOB
+    bool sb_h0[NJB], sb_w0[NJB];                          // may this chunk be used with the LAST tap row / column (k = 5: only even kh / kw exist there)
+    auto sliceB = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+            const int kc = cc * CHS + cchB[j] * VE;
+            const bool ok = kc < p.KC && offB[j] != G2_OOB;
+            if constexpr (MODE == TC_CONV) {
+                uint32_t phh, r, pww, c;
+                p.div_2c.divmod((uint32_t)kc, phh, r);
+                p.div_c.divmod(r, pww, c);
+                sb_off[j] = ok ? offB[j] + (phh * p.KW + pww) * p.C + c : G2_OOB;
+                sb_h0[j] = 2 * (TAPS - 1) + (int)phh < p.KH; sb_w0[j] = 2 * (TAPS - 1) + (int)pww < p.KW;
+            } else {
+                const int ch = clsB[j] >> 1, cw = clsB[j] & 1;
+                sb_off[j] = ok ? (uint32_t)((ch * p.KW + cw) * p.N) * (uint32_t)p.C + offB[j] + (uint32_t)kc : G2_OOB;
+                sb_h0[j] = ch + 2 * p.HY < p.KH; sb_w0[j] = cw + 2 * p.HX < p.KW;
+            }
+        }
+    };
+    auto issueB = [&](int tap, int buf) {                 // weight tile of (slice set up by sliceB, tap) -> LDS byte offset buf
+        const int ta = tap / TAPS, tb = tap - ta * TAPS;
+        // conv form: kh = 2 ta + ph ; gather form: kh = ph + 2 (HY - ta)   (same for kw)
+        const int th2 = MODE == TC_CONV ? 2 * ta : 2 * (p.HY - ta), tw2 = MODE == TC_CONV ? 2 * tb : 2 * (p.HX - tb);
+        const uint32_t tapoff = MODE == TC_CONV ? (uint32_t)((th2 * p.KW + tw2) * p.C) : (uint32_t)((th2 * p.KW + tw2) * p.N) * (uint32_t)p.C;
+        const bool last_h = MODE == TC_CONV ? ta == TAPS - 1 : ta == 0, last_w = MODE == TC_CONV ? tb == TAPS - 1 : tb == 0;
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+            const bool v = sb_off[j] != G2_OOB && (!last_h || sb_h0[j]) && (!last_w || sb_w0[j]);
+            const uint32_t vo = v ? (sb_off[j] + tapoff) * ESZ : G2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr)(Bbase + buf + (wave * NJB + j) * 1024), 16, (int)vo, 0, 0, 0);
+        }
+    };
+
+    // ---------------- main loop over (channel slice, tap) steps ----------------
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Double-buffered pipeline, one barrier per step of TPS taps (32 MFMAs per wave): at the top of a step everything issued
+    // during the previous step has had >= 2k cycles to land; the next step's weight tiles and a share of the next channel
+    // slice of the slot range are issued right after the barrier.
+    auto issue_step_B = [&](int ss, int stage) {          // the TPS weight tiles of step ss of the slice set up by sliceB
+#pragma unroll
+        for (int u = 0; u < TPS; ++u)
+            if (ss * TPS + u < NT) issueB(ss * TPS + u, stage * BSTAGE + u * BTILE);
+    };
+    sliceA(0);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) issueA(0, i);
+    sliceB(0);
+    issue_step_B(0, 0);
+    TC_STAMP();
+
+    // fragment-read offsets that do not depend on the tap
+    int boff[4][TN];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) boff[kk][j] = ((wn * TN + j) * 32 + lrow) * RB + (((kk * 2 + lgrp) ^ ((lrow >> 1) & 7)) << 4);
+    int q0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) q0[i] = (wm * TM + i) * 32 + lrow;
+
+    int stage = 0;
+    for (int cc = 0; cc < NCC; ++cc) {
+        const unsigned char* As = Abase + (cc & 1) * ASTAGE;
+        const bool more_a = cc + 1 < NCC;
+        if (more_a) sliceA(cc + 1);
+#pragma unroll
+        for (int ss = 0; ss < NSS; ++ss) {
+            __syncthreads();                              // this step's tiles have landed (vmcnt(0) + barrier); the other stage is free
+            if (cc == 0) TC_STAMP();
+            if (more_a) {
+#pragma unroll
+                for (int i = 0; i < NIA; ++i)
+                    if (i % NSS == ss) issueA((cc + 1) & 1, i);
+            }
+            if (ss + 1 < NSS) issue_step_B(ss + 1, stage ^ 1);
+            else if (more_a) { sliceB(cc + 1); issue_step_B(0, stage ^ 1); }
+            const unsigned char* Bst = Bbase + stage * BSTAGE;
+            stage ^= 1;
+#pragma unroll
+            for (int u = 0; u < TPS; ++u) {
+                const int tap = ss * TPS + u;
+                if (tap >= NT) continue;                  // literal after unrolling: padded tap of a 3x3 tap set
+                const int ta = tap / TAPS, tb = tap % TAPS;
+                const unsigned char* Bs = Bst + u * BTILE;
+                const int delta = ta * p.GW + tb;
+                int qrow[TM], qx[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int q = q0[i] + delta;
+                    qrow[i] = q * RB; qx[i] = (q >> 1) & 7;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int cl = kk * 2 + lgrp;
+                    freg af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = *(const freg*)(&As[qrow[i] + ((cl ^ qx[i]) << 4)]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = *(const freg*)(&Bs[boff[kk][j]]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) Frag<T>::mma(bf[j], af[i], acc[i][j]);   // D[row = output channel][col = position]
+                }
+            }
+        }
+    }
+
+    TC_STAMP();
+    // ---------------- epilogue: accumulators -> LDS [position][output] -> full-line coalesced 16-byte stores ----------------
+    // (a row-per-lane store of 8 bytes per lane at a 64..256-byte stride is store-ISSUE bound: 7-17k cycles per block measured
+    //  against ~1.8k per MFMA step; staged through LDS every store instruction writes 1 KB of whole 128-byte lines)
+    constexpr int PITCH = BNE * ESZ + 16;                 // +16 B: the 32 positions of a fragment column hit 16 distinct bank groups
+    constexpr int CP = BNE * ESZ / 16;                    // 16-byte chunks per position
+    unsigned char* const stg = lds;
+    int2* const pinfo = (int2*)(lds + BMT * PITCH);        // per position: element offset of its first output pixel, validity flags
+    static_assert(BMT * PITCH + BMT * 8 <= 2 * ASTAGE + TC_NBUF * BSTAGE, "epilogue staging fits the pipeline buffers");
+    __syncthreads();                                      // every wave is done reading the last step's tiles
+    if (tid < BMT) {
+        const int P = P0 + tid;
+        uint32_t g, gx, b, gy;
+        p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
+        p.div_g.divmod(g, b, gy);
+        int2 pi;
+        if constexpr (MODE == TC_CONV) {
+            pi.x = (int)(((b * p.OH + gy) * p.OW + gx) * p.N);
+            pi.y = (P < p.MP && (int)gy < p.OH && (int)gx < p.OW) ? 15 : 0;
+        } else {
+            const int oy = 2 * (int)gy, ox = 2 * (int)gx;
+            pi.x = (int)(((b * p.OH + oy) * p.OW + ox) * p.N);
+            const int vh0 = oy < p.OH, vh1 = oy + 1 < p.OH, vw0 = ox < p.OW, vw1 = ox + 1 < p.OW;
+            pi.y = P < p.MP ? ((vh0 & vw0) | ((vh0 & vw1) << 1) | ((vh1 & vw0) << 2) | ((vh1 & vw1) << 3)) : 0;   // bit = class ph*2+pw
+        }
+        pinfo[tid] = pi;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pos = (wm * TM + i) * 32 + lrow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cn = (wn * TN + j) * 32 + 4 * lgrp + 8 * q;       // output column inside the tile
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
+                if (p.bias) {
+                    int nb = n0 + cn;
+                    if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)nb) * p.N;
+                    if (n0 + cn < p.NE) {
+                        const f32x4 bb = *(const f32x4*)(p.bias + nb);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] += bb[t];
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+                }
+                *(PackN<T, 4>*)(stg + pos * PITCH + cn * ESZ) = pack4<T>(v);
+            }
+        }
+    }
+    __syncthreads();
+    TC_STAMP();
+    const T* __restrict__ maskp = (const T*)p.mask;
+    constexpr int NCH = BMT * CP / TC_NT;                 // chunks per thread
+    constexpr int GRP = NCH >= 8 ? 8 : NCH;               // chunks whose mask loads are in flight together
+#pragma unroll
+    for (int k0 = 0; k0 < NCH; k0 += GRP) {
+        long long off[GRP];
+        bool ok[GRP];
+        PackN<T, VE> mk[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int id = tid + (k0 + u) * TC_NT;
+            const int pos = id / CP, c16 = id % CP;
+            const int2 pi = pinfo[pos];
+            const int ne = n0 + c16 * VE;
+            int n = ne, sub = 0, cls = 0;
+            if constexpr (MODE == TC_GATHER) {
+                cls = (int)p.div_n.div((uint32_t)ne);
+                n = ne - cls * p.N;
+                sub = ((cls >> 1) * p.OW + (cls & 1)) * p.N;
+            }
+            ok[u] = ne < p.NE && ((pi.y >> cls) & 1);
+            off[u] = ok[u] ? (long long)pi.x + sub + n : 0;
+            if (maskp) mk[u] = *(const PackN<T, VE>*)(maskp + off[u]);       // offset 0 is always readable
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int id = tid + (k0 + u) * TC_NT;
+            const int pos = id / CP, c16 = id % CP;
+            PackN<T, VE> o = *(const PackN<T, VE>*)(stg + pos * PITCH + c16 * 16);
+            if (maskp) {
+#pragma unroll
+                for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[u].v[t]) > 0.f ? o.v[t] : (T)0;
+            }
+            if (ok[u]) *(PackN<T, VE>*)((T*)p.out + off[u]) = o;
+        }
+    }
+    TC_STAMP();
+#undef TC_STAMP
+}
+
+}  // namespace mi

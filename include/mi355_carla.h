@@ -61,6 +61,12 @@ typedef struct MiPpoDesc {
 const char* mi_last_error(void);
 int mi_abi_version(void);
 int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
+/* Kernel-selection knobs (process-global, not part of the reference surface; defaults come from the environment variables of
+ * the same meaning).  key 0: gemm2 LDS-DMA tiles on/off (MI355_GEMM2); key 1: minimum block count for the raw-staged
+ * tapconv kernel, -1 = never (MI355_TAPCONV / MI355_TAPCONV_MINBLOCKS).  Returns the previous value. */
+int mi_set_tuning(int key, int value);
+/* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
+int mi_debug_set_trace(void* dev_ptr, int capacity_entries);
 
 /* ---- convolution family (implicit-GEMM on MFMA, LDS-staged tiles) ---- */
 /* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be fp32 frames gathered through frame_idx. */

@@ -62,8 +62,19 @@ def test_train_step_losses_grads_and_adam(tmp_path, precision, storage, tol_loss
     assert rel_err(mean, fw["mean"].numpy()) < (1e-4 if precision == "fp32" else 2e-2)
     m.dev.backward(src, None, e, 1.0 / B, 0)
     g = m.dev.export_grads()
-    worst = {k: rel_err(g[k], grads[k]) for k in grads}
-    bad = {k: v for k, v in worst.items() if v > tol_grad}
+    if precision == "fp32":
+        worst = {k: rel_err(g[k], grads[k]) for k in grads}
+        bad = {k: v for k, v in worst.items() if v > tol_grad}
+    else:
+        # bf16 storage: ReLU masks of pre-activations within one bf16 ulp of zero flip with the fp32 summation order, so two
+        # correct kernels differ by whole gradient entries.  Accuracy statement that does not depend on the order: the device
+        # gradients are as close to the exact fp32 gradients as the oracle's own bf16-storage emulation is (within 2x + 1 %).
+        _, exact, _ = vo.vae_loss_and_grads(params, frames, frames, eps, beta=1.0, storage="fp32")
+        bad = {}
+        for k in grads:
+            e_dev, e_emul = rel_err(g[k], exact[k]), rel_err(grads[k], exact[k])
+            if e_dev > 2.0 * e_emul + 1e-2:
+                bad[k] = (e_dev, e_emul)
     assert not bad, bad
     # three full SGD steps: parameters track the oracle's TF-Adam trajectory
     o = vo.OracleVAE(params=params, storage=storage)
