@@ -45,6 +45,7 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
 // register-staged kernel (A/B comparisons, bisecting).
 // ---------------------------------------------------------------------------------------------------------------
 long long* g_trace = nullptr; int g_trace_cap = 0;
+int g_wgrad_skip = 0;
 int g_gemm2_on = -1;
 int g_tap_min = -2;
 bool gemm2_enabled() {
@@ -151,6 +152,71 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q) : launch_tapconv<float, TC_GATHER>(st, q);
     else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q) : launch_tapconv<bf16_t, TC_GATHER>(st, q);
+    return rc == MI_OK ? 1 : rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tapwgrad (tapwgrad_tile.hpp): bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles.
+// mi_set_tuning key 3 / MI355_TAPWGRAD=0 disables it.
+// ---------------------------------------------------------------------------------------------------------------
+int g_tapwgrad_on = -1;
+bool tapwgrad_enabled() {
+    if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
+    return g_tapwgrad_on != 0;
+}
+
+// a: slot-side tensor [B,IH,IW,C]; d: gradient tensor [B,OH,OW,N]; out: dW (conv form HWIO [kh,kw,C,N]; gather form [kh,kw,N,C])
+int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void* d, int B, int IH, int IW, int C, int OH, int OW, int N,
+                 int KH, int KW, float* out) {
+    if (!tapwgrad_enabled() || dtype != MI_BF16) return 0;
+    if (KH != KW || KH < 3 || KH > 6) return 0;
+    if ((((uintptr_t)a) & 15) || (((uintptr_t)d) & 15) || C % 8 != 0 || N % 8 != 0) return 0;
+    TapWgradParams q = {};
+    const int taps = (KH + 1) / 2;
+    int KCB, NEB;
+    if (mode == TC_CONV) {
+        if (taps != 2 || (4 * C) % 128 != 0 || N % 64 != 0) return 0;
+        q.GH = OH + 1; q.GW = OW + 1; q.HY = q.HX = 0; q.KC = 4 * C; q.NE = N; KCB = 128; NEB = 64;
+    } else {
+        q.HY = q.HX = taps - 1;
+        q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX; q.KC = C; q.NE = 4 * N;
+        if (taps == 2) { if (C % 128 != 0 || N % 64 != 0) return 0; KCB = 128; NEB = 64; }
+        else { if (C % 64 != 0 || N != 32) return 0; KCB = 64; NEB = 128; }
+    }
+    if ((taps - 1) * q.GW + taps - 1 > TC_MAXHALO) return 0;
+    const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * 2, d_bytes = (long long)B * OH * OW * N * 2;
+    if (MP >= (1ll << 30) || !fits_desc(a_bytes) || !fits_desc(d_bytes)) return 0;
+    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.d = d; q.d_bytes = (uint32_t)d_bytes;
+    q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
+    q.nkb = q.KC / KCB;
+    const int gy = q.nkb * (q.NE / NEB);
+    // (tap, 32-output tile) pairs of one block; gather form k = 5: a parity class only owns the taps its kh / kw reach
+    const int ntb = NEB / 32;
+    q.npairs = 0;
+    for (int tap = 0; tap < taps * taps; ++tap)
+        for (int nt = 0; nt < ntb; ++nt) {
+            bool valid = true;
+            if (mode == TC_GATHER && NEB == 4 * N) {      // tile nt is parity class nt (N == 32)
+                const int ta = tap / taps, tb = tap % taps;
+                valid = (nt >> 1) + 2 * (q.HY - ta) < KH && (nt & 1) + 2 * (q.HX - tb) < KW;
+            }
+            if (valid) { q.pair_tap[q.npairs] = (unsigned char)tap; q.pair_nt[q.npairs] = (unsigned char)nt; ++q.npairs; }
+        }
+    int splits = 256 / gy; if (splits < 1) splits = 1;
+    long long pps = (MP + splits - 1) / splits; pps = (pps + TW_BP - 1) / TW_BP * TW_BP;
+    splits = (int)((MP + pps - 1) / pps);
+    q.pos_per_split = (int)pps;
+    q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
+    q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
+    q.out = out;
+    dim3 g(splits, gy, 1);
+    if (mode == TC_CONV) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+    else if (taps == 2) hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+    else {
+        if (q.npairs > 32) return 0;
+        hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
+    }
+    const int rc = mi_check_launch("tapwgrad_kernel");
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -279,6 +345,7 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     if (mps < BP) mps = BP;
     splits = (p.M + mps - 1) / mps;
     p.m_per_split = mps;
+    p.debug_skip_out = g_wgrad_skip;
     dim3 g(gx, gy, splits);
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
@@ -327,6 +394,8 @@ int mi_set_tuning(int key, int value) {
     int prev;
     if (key == 0) { prev = gemm2_enabled() ? 1 : 0; g_gemm2_on = value ? 1 : 0; }
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
+    else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
+    else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }
@@ -361,6 +430,10 @@ int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH,
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
                          int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    if (!frame_idx && !x_is_f32) {
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw);
+        if (r3 != 0) return r3 > 0 ? MI_OK : r3;
+    }
     WgradParams p = {};
     p.big = x; p.frame_idx = frame_idx;
     fill_wgrad_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
@@ -396,6 +469,10 @@ int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int O
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                            const void* x, int KH, int KW, int Cin, float* dw) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
+    {
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw);
+        if (r3 != 0) return r3 > 0 ? MI_OK : r3;
+    }
     WgradParams p = {};
     p.big = dy; p.frame_idx = nullptr;
     fill_wgrad_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));

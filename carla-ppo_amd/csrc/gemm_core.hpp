@@ -7,9 +7,12 @@
 //   tapconv_tile.hpp tapconv_kernel            stride-2 conv / transposed conv as a stride-1 tap conv on raw-staged slot tiles
 //   wgrad_tile.hpp  wgrad_kernel               dW[kc,n] += sum_m im2col(big)[m,kc] * small[m,n]   (conv/deconv/dense wgrad)
 //
+//   tapwgrad_tile.hpp tapwgrad_kernel          bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles
+//
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
 #include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"
+#include "tapwgrad_tile.hpp"

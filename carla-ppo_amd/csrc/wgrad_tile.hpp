@@ -22,6 +22,7 @@ struct WgradParams {
     int s_vec;                       // vector loads of S legal (N % VB == 0, aligned)
     float* out;
     int m_per_split;                 // multiple of BP
+    int debug_skip_out;              // debug (mi_set_tuning key 2): drop the atomic accumulation to time the main loop alone
 };
 
 template <typename T> struct WgradCfg;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
     }
 
     if (nsteps <= 0) return;
+    if (p.debug_skip_out && acc[0][0] != 123.456f) return;
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
 #pragma unroll
