@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "gemm_core.hpp"
 #include "mi_internal.hpp"
+#include "mi355_carla.h"
 
 using namespace mi;
 
@@ -167,7 +168,7 @@ bool tapwgrad_enabled() {
 
 // a: slot-side tensor [B,IH,IW,C]; d: gradient tensor [B,OH,OW,N]; out: dW (conv form HWIO [kh,kw,C,N]; gather form [kh,kw,N,C])
 int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void* d, int B, int IH, int IW, int C, int OH, int OW, int N,
-                 int KH, int KW, float* out) {
+                 int KH, int KW, float* out, void* scratch, long long scratch_bytes) {
     if (!tapwgrad_enabled() || dtype != MI_BF16) return 0;
     if (KH != KW || KH < 3 || KH > 6) return 0;
     if ((((uintptr_t)a) & 15) || (((uintptr_t)d) & 15) || C % 8 != 0 || N % 8 != 0) return 0;
@@ -209,6 +210,12 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out;
+    q.trace = g_trace; q.trace_cap = g_trace_cap;
+    // partial sums per split in the caller's scratch (plain stores + one deterministic reduce) when it is large enough;
+    // otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
+    const long long n_out = (long long)KH * KW * C * N;
+    q.slabs = nullptr; q.slab_stride = n_out;
+    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && scratch_bytes >= (long long)splits * n_out * 4) q.slabs = (float*)scratch;
     dim3 g(splits, gy, 1);
     if (mode == TC_CONV) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     else if (taps == 2) hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
@@ -216,7 +223,11 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
         if (q.npairs > 32) return 0;
         hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
-    const int rc = mi_check_launch("tapwgrad_kernel");
+    int rc = mi_check_launch("tapwgrad_kernel");
+    if (rc == MI_OK && q.slabs) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n_out / 4 + 255) / 256 + 1)), dim3(256), 0, st, q.slabs, q.slab_stride, splits, n_out, out);
+        rc = mi_check_launch("reduce_slabs_kernel");
+    }
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -429,9 +440,15 @@ int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH,
 // conv2d filter gradient: dw[kh,kw,ci,co] += im2col(x)^T * dy      (TF Conv2DBackpropFilter), fp32 accumulate
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
                          int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw) {
+    return mi_conv2d_nhwc_wgrad_ws(stream, dtype, x, frame_idx, x_is_f32, B, IH, IW, Cin, dy, KH, KW, Cout, dw, nullptr, 0);
+}
+
+// same with caller-provided scratch (bytes): lets the bf16 kernel reduce its position splits without atomics (deterministic)
+int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
+                            int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     if (!frame_idx && !x_is_f32) {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw);
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     WgradParams p = {};
@@ -468,9 +485,14 @@ int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int O
 // conv2d_transpose filter gradient: dw[kh,kw,co,ci] += im2col(dy)^T * x
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                            const void* x, int KH, int KW, int Cin, float* dw) {
+    return mi_deconv2d_nhwc_wgrad_ws(stream, dtype, dy, B, OH, OW, Cout, x, KH, KW, Cin, dw, nullptr, 0);
+}
+
+int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                              const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw);
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     WgradParams p = {};

@@ -38,7 +38,26 @@ struct TapWgradParams {
     unsigned char pair_tap[TW_MAXPAIR], pair_nt[TW_MAXPAIR];
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     float* out;
+    float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
+    long long* trace; int trace_cap;   // debug stamps (mi_debug_set_trace)
 };
+
+// LDS-DMA issued through inline asm: hipcc drains every builtin LDS-DMA (s_waitcnt vmcnt(0)) in front of the next
+// ds_read_b64_tr_b16 it cannot prove disjoint, which would serialise prefetch and compute; asm loads are invisible to that
+// pass, so the step barrier carries an explicit vmcnt(0).  m0 = LDS byte address of lane 0's 16 bytes (wave-uniform).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 r;
+    r[0] = (uint32_t)b; r[1] = (uint32_t)(b >> 32) & 0xffffu; r[2] = bytes; r[3] = 0x00020000u;
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+__device__ __forceinline__ void dma16_asm(const u32x4 srd, uint32_t lds_addr, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(srd) : "memory", "m0");
+}
 
 // swizzle of the 16-byte chunk index by LDS row so that 4 consecutive rows x 64 B fall into 4 different bank quarters
 template <int CPR> __device__ __forceinline__ int tw_swz(int row) {
@@ -65,6 +84,11 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tr_n = 0;
+    long long* const tr = p.trace ? p.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (tid >> 6)) * 32 : nullptr;
+    const bool tr_on = tr && ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
+#define TW_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    TW_STAMP();
     const int kb = blockIdx.y % p.nkb, nb = blockIdx.y / p.nkb;
     const int kc0 = kb * KCB, ne0 = nb * NEB;
     const int Pbeg = blockIdx.x * p.pos_per_split;
@@ -74,8 +98,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     const int halo = (TAPS - 1) * p.GW + TAPS - 1;
     const int ninstrA = (TW_BP + halo + SPI_A - 1) / SPI_A;
 
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)p.d, 0, (int)p.d_bytes, 0x00020000);
+    const u32x4 rsA = make_srd(p.a, p.a_bytes), rsD = make_srd(p.d, p.d_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;   // LDS byte address of the array
 
     // ---------------- DMA roles ----------------
     // slot tile: instruction t = wave + 8 i fills rows SPI_A t ..; lane -> row SPI_A t + lane / CPA, physical chunk lane % CPA
@@ -105,14 +129,14 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
             d_koff = ((((cls >> 1) * p.OW + (cls & 1)) * p.N) + n) * ESZ;
         }
     }
-    auto issue = [&](int step, int buf) {
+    // one DMA instruction of step `step`'s tiles: idx < NIA -> slot tile, else gradient tile.  Called between the MFMA groups
+    // of the previous step so that the ~1.4k cycles the per-CU load path needs for a step's 70 KB hide behind the MFMAs.
+    auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
-        unsigned char* As = lds + buf * STAGE;
-        unsigned char* Ds = As + ASTAGE;
-#pragma unroll
-        for (int i = 0; i < NIA; ++i) {
-            const int t = wave + 8 * i;
-            if (t >= ninstrA) break;                      // wave-uniform
+        const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (idx < NIA) {
+            const int t = wave + 8 * idx;
+            if (t >= ninstrA) return;                     // wave-uniform
             const int P = Ps + SPI_A * t + rA;
             const bool ok = P < p.MP && a_kok;
             uint32_t g, gx, b, gy;
@@ -128,11 +152,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                 const bool v = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
                 vo = v ? (((b * p.IH + iy) * p.IW + ix) * p.C) * ESZ + a_koff : G2_OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(As + t * 1024), 16, (int)vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NID; ++i) {
-            const int t = wave + 8 * i;
+            dma16_asm(rsA, As + t * 1024, vo);
+        } else {
+            const int t = wave + 8 * (idx - NIA);
             const int P = Ps + SPI_D * t + rD;
             const bool ok = P < Pend && d_kok;
             uint32_t g, gx, b, gy;
@@ -147,9 +169,10 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                 const bool v = ok && oy < p.OH && ox < p.OW;
                 vo = v ? (((b * p.OH + 2 * gy) * p.OW + 2 * gx) * p.N) * ESZ + d_koff : G2_OOB;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_vptr)(Ds + t * 1024), 16, (int)vo, 0, 0, 0);
+            dma16_asm(rsD, Ds + t * 1024, vo);
         }
     };
+    constexpr int NDMA = NIA + NID, NKS = TW_BP / 16;
 
     // ---------------- this wave's (tap, output tile) pairs and their per-lane transpose-read offsets ----------------
     // transpose read (see tr_fragment in wgrad_tile.hpp): lane l supplies row r0 + (l>>5)*8 + ((l&15)>>2) (+4 for the high half),
@@ -185,17 +208,26 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
             for (int r = 0; r < 16; ++r) acc[q][kt][r] = 0.f;
 
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
-    issue(0, 0);
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+    TW_STAMP();
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        __syncthreads();                                  // this step's tiles have landed; the other stage is free
-        if (step + 1 < nsteps) issue(step + 1, cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the step's tiles has landed ...
+        __syncthreads();                                  // ... and so has everybody else's; the other stage is free
+        if (step < 4) TW_STAMP();
+        const bool more = step + 1 < nsteps;
         const uint32_t sbase = (uint32_t)(cur * STAGE);
 #pragma unroll
-        for (int ks = 0; ks < TW_BP / 16; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (more) {                                   // next step's loads, a few per MFMA group
+#pragma unroll
+                for (int i = ks; i < NDMA; i += NKS) issue_one(step + 1, cur ^ 1, i);
+            }
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
-                if (!pr_on[q]) continue;                  // wave-uniform
+                // no branch on pr_on here: a basic-block boundary inside the step makes hipcc drain the LDS-DMA queue
+                // (s_waitcnt vmcnt(0)) before the next transpose read; an unused pair slot recomputes pair 0 and is dropped
                 const uint32_t dof = sbase + doff[q] + ks * 16 * PD;
                 const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + dof));
                 const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + dof + 4 * PD));
@@ -220,6 +252,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         }
     }
 
+    TW_STAMP();
     // ---------------- accumulate into dW (fp32 atomics; a wave's 32 lanes of one register hit 128 contiguous bytes) ----------------
     const int lcol = lane & 31, lgrp = lane >> 5;
 #pragma unroll
@@ -248,8 +281,33 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                     ok = kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
                     idx = ((long long)(kh * p.KW + kw) * p.N + n) * p.C + kc;
                 }
-                if (ok) atomicAdd(&p.out[idx], acc[q][kt][r]);
+                if (ok) {
+                    if (p.slabs) p.slabs[(long long)blockIdx.x * p.slab_stride + idx] = acc[q][kt][r];
+                    else atomicAdd(&p.out[idx], acc[q][kt][r]);
+                }
             }
+        }
+    }
+    TW_STAMP();
+#undef TW_STAMP
+}
+
+// dW[i] += sum over the split slabs (deterministic order); every element of every slab was written by tapwgrad_kernel
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long long stride, int nslab, long long n, float* __restrict__ out) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i4 + 4 <= n) {
+#pragma unroll 8
+        for (int k = 0; k < nslab; ++k) s += *(const f32x4*)(slabs + k * stride + i4);
+        f32x4 o = *(f32x4*)(out + i4);
+        o += s;
+        *(f32x4*)(out + i4) = o;
+    } else {
+        for (long long i = i4; i < n; ++i) {
+            float a = 0.f;
+            for (int k = 0; k < nslab; ++k) a += slabs[k * stride + i];
+            out[i] += a;
         }
     }
 }

@@ -65,6 +65,7 @@ struct Workspace {
     long long gdec[5];
     long long z, dheads;               // T
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, out2, zf32;   // fp32
+    long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
     long long total;
 };
 
@@ -146,6 +147,9 @@ void make_workspace(VaeEngine& e) {
     W.dz_slab = add((long long)e.ns_dz * B * d.z_dim * 4);
     W.mean = add(B * d.z_dim * 4); W.logvar = add(B * d.z_dim * 4); W.kl_row = add(B * 4);
     W.partial = add(B * e.nchunks * 4); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
+    // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
+    W.scratch_bytes = d.dtype == MI_BF16 ? 64ll << 20 : 0;
+    W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
     W.total = o;
 }
 
@@ -324,7 +328,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
             const void* gy = e->at(W.gdec[i + 1]);
             const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
             TOP(e, st, OP_DECONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
-            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i)));
+            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes));
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
@@ -345,7 +349,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
             const long long rows = (long long)B * g.ih[i + 1] * g.iw[i + 1];
             TOP(e, st, OP_CONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.c[i + 1], e->gptr(2 * i + 1)));
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i)));
+            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));
