@@ -168,7 +168,7 @@ bool tapwgrad_enabled() {
 
 // a: slot-side tensor [B,IH,IW,C]; d: gradient tensor [B,OH,OW,N]; out: dW (conv form HWIO [kh,kw,C,N]; gather form [kh,kw,N,C])
 int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void* d, int B, int IH, int IW, int C, int OH, int OW, int N,
-                 int KH, int KW, float* out, void* scratch, long long scratch_bytes) {
+                 int KH, int KW, float* out, void* scratch, long long scratch_bytes, float* dbias) {
     if (!tapwgrad_enabled() || dtype != MI_BF16) return 0;
     if (KH != KW || KH < 3 || KH > 6) return 0;
     if ((((uintptr_t)a) & 15) || (((uintptr_t)d) & 15) || C % 8 != 0 || N % 8 != 0) return 0;
@@ -201,8 +201,13 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
                 const int ta = tap / taps, tb = tap % taps;
                 valid = (nt >> 1) + 2 * (q.HY - ta) < KH && (nt & 1) + 2 * (q.HX - tb) < KW;
             }
-            if (valid) { q.pair_tap[q.npairs] = (unsigned char)tap; q.pair_nt[q.npairs] = (unsigned char)nt; ++q.npairs; }
+            if (valid) {
+                bool first = true;
+                for (int k = 0; k < q.npairs; ++k) if (q.pair_nt[k] == nt) first = false;
+                q.pair_tap[q.npairs] = (unsigned char)tap; q.pair_nt[q.npairs] = (unsigned char)nt; q.pair_first[q.npairs] = first ? 1 : 0; ++q.npairs;
+            }
         }
+    q.dbias = dbias;
     int splits = 256 / gy; if (splits < 1) splits = 1;
     long long pps = (MP + splits - 1) / splits; pps = (pps + TW_BP - 1) / TW_BP * TW_BP;
     splits = (int)((MP + pps - 1) / pps);
@@ -228,6 +233,47 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n_out / 4 + 255) / 256 + 1)), dim3(256), 0, st, q.slabs, q.slab_stride, splits, n_out, out);
         rc = mi_check_launch("reduce_slabs_kernel");
     }
+    return rc == MI_OK ? 1 : rc;
+}
+
+// gather-form transposed conv into a narrow output (narrow_tile.hpp): 4N <= 32 output columns, 64- or 128-byte input pixels
+template <typename T, int TAPS, int CPR>
+int launch_gather_narrow(hipStream_t st, const TapParams& q) {
+    dim3 g((q.MP + GN_BMT - 1) / GN_BMT);
+    if (q.N == 3) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3>), g, dim3(GN_NT), 0, st, q);
+    else if (q.N == 1) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 1>), g, dim3(GN_NT), 0, st, q);
+    else hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 0>), g, dim3(GN_NT), 0, st, q);
+    return mi_check_launch("gather_narrow_kernel");
+}
+
+int g_narrow_on = -1;
+bool narrow_enabled() {
+    if (g_narrow_on < 0) { const char* e = getenv("MI355_NARROW"); g_narrow_on = (e && e[0] == '0') ? 0 : 1; }
+    return g_narrow_on != 0;
+}
+
+int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
+                      int KH, int KW, void* out, const float* bias, const void* mask, int relu) {
+    if (!narrow_enabled() || mask || 4 * N > 32 || KH != KW || KH < 3 || KH > 6) return 0;
+    const int esz = dtype == MI_F32 ? 4 : 2;
+    const int pa = C * esz;
+    if ((pa != 64 && pa != 128) || (((uintptr_t)a) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)out) & 3) || (2 * N * esz) % 4 != 0) return 0;
+    TapParams q = {};
+    q.TH = q.TW = (KH + 1) / 2; q.HY = q.HX = q.TH - 1;
+    q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX; q.KC = C; q.NE = 4 * N;
+    if ((q.TH - 1) * q.GW + q.TW - 1 > TC_MAXHALO) return 0;
+    const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * esz;
+    if (MP >= (1ll << 30) || !fits_desc(a_bytes)) return 0;
+    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.b = w; q.b_bytes = 0;
+    q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
+    q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
+    q.out = out; q.bias = bias; q.mask = nullptr; q.relu = relu;
+    int rc;
+    if (dtype == MI_F32) {
+        if (pa != 128) return 0;
+        rc = q.TH == 2 ? launch_gather_narrow<float, 2, 8>(st, q) : launch_gather_narrow<float, 3, 8>(st, q);
+    } else if (pa == 64) rc = q.TH == 2 ? launch_gather_narrow<bf16_t, 2, 4>(st, q) : launch_gather_narrow<bf16_t, 3, 4>(st, q);
+    else rc = q.TH == 2 ? launch_gather_narrow<bf16_t, 2, 8>(st, q) : launch_gather_narrow<bf16_t, 3, 8>(st, q);
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -334,6 +380,10 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
         return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: input channels must be a multiple of the 16-byte vector and pointers 16-B aligned");
     if (KH < 2 || KW < 2) return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: kernel must be >= 2");
     if (!p.out_f32) {
+        const int r4 = try_gather_narrow(st, dtype, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, p.out, p.bias, p.mask, p.relu);
+        if (r4 != 0) return r4 > 0 ? MI_OK : r4;
+    }
+    if (!p.out_f32) {
         const int r3 = try_tapconv(st, dtype, TC_GATHER, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, 0, p.out, p.bias, p.mask, p.relu);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
@@ -406,6 +456,7 @@ int mi_set_tuning(int key, int value) {
     if (key == 0) { prev = gemm2_enabled() ? 1 : 0; g_gemm2_on = value ? 1 : 0; }
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
+    else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
@@ -440,16 +491,21 @@ int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH,
 // conv2d filter gradient: dw[kh,kw,ci,co] += im2col(x)^T * dy      (TF Conv2DBackpropFilter), fp32 accumulate
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
                          int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw) {
-    return mi_conv2d_nhwc_wgrad_ws(stream, dtype, x, frame_idx, x_is_f32, B, IH, IW, Cin, dy, KH, KW, Cout, dw, nullptr, 0);
+    return mi_conv2d_nhwc_wgrad_ws(stream, dtype, x, frame_idx, x_is_f32, B, IH, IW, Cin, dy, KH, KW, Cout, dw, nullptr, 0, nullptr);
 }
 
 // same with caller-provided scratch (bytes): lets the bf16 kernel reduce its position splits without atomics (deterministic)
 int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
-                            int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes) {
+                            int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes,
+                            float* dbias) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     if (!frame_idx && !x_is_f32) {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes);
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
+    }
+    if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass
+        const int rcb = mi_colsum(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias);
+        if (rcb != MI_OK) return rcb;
     }
     WgradParams p = {};
     p.big = x; p.frame_idx = frame_idx;
@@ -485,15 +541,19 @@ int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int O
 // conv2d_transpose filter gradient: dw[kh,kw,co,ci] += im2col(dy)^T * x
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                            const void* x, int KH, int KW, int Cin, float* dw) {
-    return mi_deconv2d_nhwc_wgrad_ws(stream, dtype, dy, B, OH, OW, Cout, x, KH, KW, Cin, dw, nullptr, 0);
+    return mi_deconv2d_nhwc_wgrad_ws(stream, dtype, dy, B, OH, OW, Cout, x, KH, KW, Cin, dw, nullptr, 0, nullptr);
 }
 
 int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
-                              const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes) {
+                              const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes, float* dbias) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes);
+        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
+    }
+    if (dbias) {
+        const int rcb = mi_colsum(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias);
+        if (rcb != MI_OK) return rcb;
     }
     WgradParams p = {};
     p.big = dy; p.frame_idx = nullptr;

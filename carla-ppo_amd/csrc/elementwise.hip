@@ -4,6 +4,7 @@
 //   sigmoid, range check, loss finalisation / on-device epoch metric accumulators.
 #include "common.hpp"
 #include "mi_internal.hpp"
+#include "mi355_carla.h"
 
 using namespace mi;
 
@@ -71,52 +72,110 @@ __global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit,
 //   kind 2: mse  (y - s)^2                                    d/dx = 2 (s-y) s (1-s)
 // Row partial sums go to partial[b][chunk] (fixed order -> deterministic), dlogits are pre-scaled by inv_b.
 // ---------------------------------------------------------------------------------------------------
-constexpr int BCE_PER_THREAD = 8;
+// One thread owns 24 consecutive pixels-times-channels of one frame (three 16-byte logit vectors in bf16): 24 is a multiple of
+// every target depth on this path (3 = rgb, 1 = segmentation), so element j of a thread always belongs to channel j % Ct and
+// the BiasAddGrad of the last transposed conv (sum of dlogits per channel) folds into the same pass.  exp / log go to the
+// hardware transcendental units (v_exp_f32 / v_log_f32): the per-pixel terms are O(1), their absolute error ~1e-7.
+constexpr int BCE_PER_THREAD = 24;
 constexpr int BCE_CHUNK = 256 * BCE_PER_THREAD;
 
 template <typename T>
 __global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          const int* __restrict__ frame_idx, long long label_stride, int P,
                                                          int kind, float inv_b, T* __restrict__ dlogits,
-                                                         float* __restrict__ partial, int nchunks) {
+                                                         float* __restrict__ partial, int nchunks, int Ct, float* __restrict__ dbias) {
+    constexpr int VE = 16 / (int)sizeof(T);               // logits per 16-byte vector
+    constexpr int NV = BCE_PER_THREAD / VE;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const long long fr = frame_idx ? (long long)frame_idx[b] : (long long)b;
     const T* x = logits + (long long)b * P;
     const float* y = labels + fr * label_stride;
     T* dx = dlogits ? dlogits + (long long)b * P : nullptr;
+    const int e0 = chunk * BCE_CHUNK + threadIdx.x * BCE_PER_THREAD;
+    const bool vec = (P % BCE_PER_THREAD) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dx)) & 15) == 0;   // whole groups, aligned rows
     float acc = 0.f;
+    float gs[BCE_PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < BCE_PER_THREAD; ++i) {
-        const int idx = chunk * BCE_CHUNK + i * 256 + threadIdx.x;
-        if (idx < P) {
-            const float xv = Elem<T>::to_f32(x[idx]), yv = y[idx];
-            float l, g;
-            if (kind == 0) {
-                const float e = expf(-fabsf(xv));
-                l = fmaxf(xv, 0.f) - xv * yv + log1pf(e);
-                const float s = xv >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-                g = s - yv;
-            } else {
-                const float e = expf(-fabsf(xv));
-                const float s = xv >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-                if (kind == 1) {
-                    l = -(yv * logf(1e-10f + s) + (1.0f - yv) * logf(1e-10f + 1.0f - s));
-                    g = (-yv / (1e-10f + s) + (1.0f - yv) / (1e-10f + 1.0f - s)) * s * (1.0f - s);
-                } else {
-                    const float d = yv - s;
-                    l = d * d;
-                    g = -2.0f * d * s * (1.0f - s);
-                }
+    for (int j = 0; j < BCE_PER_THREAD; ++j) gs[j] = 0.f;
+    if (e0 < P) {
+        float xv[BCE_PER_THREAD], yv[BCE_PER_THREAD];
+        if (vec) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const PackN<T, VE> t = *(const PackN<T, VE>*)(x + e0 + v * VE);
+#pragma unroll
+                for (int k = 0; k < VE; ++k) xv[v * VE + k] = Elem<T>::to_f32(t.v[k]);
             }
-            acc += l;
-            if (dx) dx[idx] = Elem<T>::from_f32(g * inv_b);
+#pragma unroll
+            for (int v = 0; v < BCE_PER_THREAD / 4; ++v) {
+                const f32x4 t = *(const f32x4*)(y + e0 + v * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) yv[v * 4 + k] = t[k];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BCE_PER_THREAD; ++j) {
+                const bool in = e0 + j < P;
+                xv[j] = in ? Elem<T>::to_f32(x[e0 + j]) : 0.f; yv[j] = in ? y[e0 + j] : 0.f;
+            }
+        }
+        T gq[BCE_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < BCE_PER_THREAD; ++j) {
+            float l, g;
+            const float e = __expf(-fabsf(xv[j]));
+            const float r = __frcp_rn(1.0f + e);
+            const float s = xv[j] >= 0.f ? r : e * r;
+            if (kind == 0) {
+                l = fmaxf(xv[j], 0.f) - xv[j] * yv[j] + __logf(1.0f + e);
+                g = s - yv[j];
+            } else if (kind == 1) {
+                l = -(yv[j] * __logf(1e-10f + s) + (1.0f - yv[j]) * __logf(1e-10f + 1.0f - s));
+                g = (-yv[j] / (1e-10f + s) + (1.0f - yv[j]) / (1e-10f + 1.0f - s)) * s * (1.0f - s);
+            } else {
+                const float d = yv[j] - s;
+                l = d * d;
+                g = -2.0f * d * s * (1.0f - s);
+            }
+            const bool in = vec || e0 + j < P;
+            acc += in ? l : 0.f;
+            gq[j] = Elem<T>::from_f32(g * inv_b);
+            gs[j] = in ? Elem<T>::to_f32(gq[j]) : 0.f;       // the bias gradient sums the STORED (rounded) values, like BiasAddGrad of dlogits
+        }
+        if (dx) {
+            if (vec) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    PackN<T, VE> t;
+#pragma unroll
+                    for (int k = 0; k < VE; ++k) t.v[k] = gq[v * VE + k];
+                    *(PackN<T, VE>*)(dx + e0 + v * VE) = t;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BCE_PER_THREAD; ++j) if (e0 + j < P) dx[e0 + j] = gq[j];
+            }
         }
     }
-    __shared__ float red[4];
+    __shared__ float red[4][4];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    // channel sums: Ct divides 24 and e0 is a multiple of 24, so element j is channel j % Ct (Ct <= 3 handled here)
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (dbias) {
+#pragma unroll
+        for (int j = 0; j < BCE_PER_THREAD; ++j) {
+            const int c = Ct == 1 ? 0 : (Ct == 2 ? j % 2 : j % 3);
+            if (c == 0) c0 += gs[j]; else if (c == 1) c1 += gs[j]; else c2 += gs[j];
+        }
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = acc; red[threadIdx.x >> 6][1] = c0; red[threadIdx.x >> 6][2] = c1; red[threadIdx.x >> 6][3] = c2; }
     __syncthreads();
-    if (threadIdx.x == 0) partial[(long long)b * nchunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) partial[(long long)b * nchunks + chunk] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    if (dbias && threadIdx.x >= 1 && threadIdx.x <= Ct) {
+        const int c = threadIdx.x;
+        atomicAdd(&dbias[c - 1], (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
 }
 
 // loss finalisation: recon = mean_b sum_chunk partial ; kl = mean_b max(kl_b, floor) ; fixed summation order.
@@ -333,11 +392,18 @@ int mi_recon_loss_chunks(int P) { return (P + BCE_CHUNK - 1) / BCE_CHUNK; }
 // logits [B,P] (T) vs labels (fp32 frames, optionally gathered through frame_idx) -> partial[B][chunks], dlogits [B,P] (T, may be null)
 int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride,
                           int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial) {
+    return mi_bce_logits_fwd_bwd_bias(stream, dtype, logits, labels, frame_idx, label_stride, B, P, loss_kind, inv_batch, dlogits, partial, 1, nullptr);
+}
+
+// same + BiasAddGrad of the producing layer fused: dbias[c] += sum over frames and pixels of the stored dlogits, c = element % channels
+int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride,
+                               int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial, int channels, float* dbias) {
     const int nch = mi_recon_loss_chunks(P);
     dim3 g(nch, B), b(256);
     if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
-    if (dtype == MI_F32) hipLaunchKernelGGL(recon_loss_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (float*)dlogits, partial, nch);
-    else hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (bf16_t*)dlogits, partial, nch);
+    if (dbias && (channels < 1 || channels > 3 || !dlogits)) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd_bias: fused bias gradient needs 1..3 channels and dlogits");
+    if (dtype == MI_F32) hipLaunchKernelGGL(recon_loss_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (float*)dlogits, partial, nch, channels, dbias);
+    else hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (bf16_t*)dlogits, partial, nch, channels, dbias);
     return mi_check_launch("recon_loss");
 }
 

@@ -9,6 +9,8 @@
 //
 //   tapwgrad_tile.hpp tapwgrad_kernel          bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles
 //
+//   narrow_tile.hpp  gather_narrow_kernel      transposed conv into a 1..8-channel output (logits)
+//
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once
 #include "gemm_tile.hpp"
@@ -16,3 +18,4 @@
 #include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"
 #include "tapwgrad_tile.hpp"
+#include "narrow_tile.hpp"

@@ -35,7 +35,8 @@ struct TapWgradParams {
     int nkb;                         // channel blocks (blockIdx.y = nb * nkb + kb)
     int pos_per_split;               // multiple of TW_BP
     int npairs;                      // (tap, output tile) pairs of a block, dealt round-robin to the 8 waves
-    unsigned char pair_tap[TW_MAXPAIR], pair_nt[TW_MAXPAIR];
+    unsigned char pair_tap[TW_MAXPAIR], pair_nt[TW_MAXPAIR], pair_first[TW_MAXPAIR];   // first: first pair of its output tile
+    float* dbias;                    // optional fused bias gradient: dbias[n] += sum over positions (and parities) of dy
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     float* out;
     float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int tcol = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     int pr_tap[PPW], pr_nt[PPW];
-    bool pr_on[PPW];
+    bool pr_on[PPW], pr_bias[PPW];
     uint32_t aoff[PPW][KT], doff[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         pr_on[q] = pi < p.npairs;
         pr_tap[q] = pr_on[q] ? p.pair_tap[pi] : 0;
         pr_nt[q] = pr_on[q] ? p.pair_nt[pi] : 0;
+        pr_bias[q] = pr_on[q] && p.dbias && kb == 0 && p.pair_first[pi];
         const int ta = pr_tap[q] / TAPS, tb = pr_tap[q] % TAPS;
         const int row = trow + ta * p.GW + tb;            // + 16 per k-step and + 4 for the high half keep (row & 3)
 #pragma unroll
@@ -206,6 +208,18 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][kt][r] = 0.f;
+
+    // fused bias gradient: column sums of the gradient tile = (all-ones rows) x D on the matrix core, one extra MFMA per
+    // k-step in the first pair of every output tile of the kb == 0 blocks; row 0 of the result carries the sums
+    f32x16 accb[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[q][r] = 0.f;
+    bool any_bias = false;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) any_bias = any_bias || pr_bias[q];
+    const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
 #pragma unroll
@@ -234,6 +248,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                 u16x8 df;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { df[e] = (unsigned short)dlo[e]; df[4 + e] = (unsigned short)dhi[e]; }
+                if (any_bias)                             // wave-uniform, constant over the kernel (waves without a bias job skip the MFMA)
+                    accb[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, df), accb[q], 0, 0, 0);
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
                     const uint32_t aof = sbase + aoff[q][kt] + ks * 16 * PA;
@@ -253,6 +269,15 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     }
 
     TW_STAMP();
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        if (!pr_bias[q] || lane >= 32) continue;
+        const int ne = ne0 + pr_nt[q] * 32 + lane;
+        if (ne >= p.NE) continue;
+        int n = ne;
+        if constexpr (MODE == TC_GATHER) n = ne - (int)p.div_n.div((uint32_t)ne) * p.N;
+        atomicAdd(&p.dbias[n], accb[q][0]);
+    }
     // ---------------- accumulate into dW (fp32 atomics; a wave's 32 lanes of one register hit 128 contiguous bytes) ----------------
     const int lcol = lane & 31, lgrp = lane >> 5;
 #pragma unroll

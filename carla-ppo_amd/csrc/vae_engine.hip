@@ -107,6 +107,7 @@ struct VaeEngine {
     int esz;                            // bytes per T
     int ns_heads, ns_dz, nchunks;
     int last_B;
+    int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
     const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
     const float* bptr(int t) const { return params + L.off[t]; }
@@ -303,8 +304,14 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
     CK(run_encoder(e, stream, src, idx, B, eps, sample));
     CK(run_decoder(e, stream, B));
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
-    TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
-                             want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial)));
+    // the BiasAddGrad of deconv4 (sum of dlogits per target channel) rides on the loss pass when the gradient is wanted
+    const bool fuse_b4 = want_grad && e->grads && d.ct <= 3;
+    if (fuse_b4 && e->b4_fused)
+        return mi_fail(MI_ERR_STATE, "mi_vae_forward(want_grad=1): the previous forward's gradient was never consumed by mi_vae_backward "
+                                     "(its deconv4 bias gradient is already in the gradient buffer)");
+    e->b4_fused = fuse_b4 ? 1 : 0;
+    TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd_bias(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
+                             want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial), d.ct, fuse_b4 ? e->gptr(19) : nullptr));
     const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
     TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
                               inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
@@ -327,11 +334,12 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             const void* gy = e->at(W.gdec[i + 1]);
             const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
-            TOP(e, st, OP_DECONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.dc[i + 1], e->gptr(13 + 2 * i)));
-            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes));
+            (void)rows;                                      // BiasAddGrad is fused into the filter-gradient call below
+            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
+        e->b4_fused = 0;
         // dense1: h = z W1 + b1
         TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
         TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
@@ -347,9 +355,9 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             const void* gy = e->at(W.gact[i + 1]);
             const long long rows = (long long)B * g.ih[i + 1] * g.iw[i + 1];
-            TOP(e, st, OP_CONV_BIAS + i, mi_colsum(st, d.dtype, gy, rows, g.c[i + 1], e->gptr(2 * i + 1)));
+            (void)rows;
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes));
+            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));

@@ -64,7 +64,7 @@ int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int ar
 /* Kernel-selection knobs (process-global, not part of the reference surface; defaults come from the environment variables of
  * the same meaning).  key 0: gemm2 LDS-DMA tiles on/off (MI355_GEMM2); key 1: minimum block count for the raw-staged
  * tapconv kernel, -1 = never (MI355_TAPCONV / MI355_TAPCONV_MINBLOCKS); key 2: debug, drop the wgrad_kernel atomics;
- * key 3: raw-staged bf16 weight-gradient kernel on/off (MI355_TAPWGRAD).  Returns the previous value. */
+ * key 3: raw-staged bf16 weight-gradient kernel on/off (MI355_TAPWGRAD); key 4: narrow-layer kernels on/off (MI355_NARROW).  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);
@@ -76,15 +76,16 @@ int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
 /* Conv2DBackpropFilter: dw += im2col(x)^T dy (fp32 atomics) */
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw);
-/* same, with caller scratch for the split reduction of the bf16 kernel (no atomics, deterministic); scratch may be NULL */
-int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes);
+/* same, with caller scratch for the split reduction of the bf16 kernel (no atomics, deterministic; may be NULL) and, when dbias != NULL,
+ * the BiasAddGrad of the same layer (dbias[n] += sum dy) fused into the kernel where it is eligible, else run as mi_colsum */
+int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes, float* dbias);
 /* tf.layers.conv2d_transpose k x k, s2, VALID + BiasAdd (+ Relu) — vae/models.py:261-264 */
 int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw);
-int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes);
+int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes, float* dbias);
 /* tf.layers.dense (MatMul + BiasAdd + Relu) and its input gradient — vae/models.py:97-98,259; utils.py:25-28; ppo.py:43-55.
  * w_layout 0: W[K,N]; 1: W[N,K] (x * W^T).  nsplit > 1: split-K raw fp32 slabs out[nsplit][M][N]. */
 int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const void* w, int w_layout, int N, const float* bias, int relu, const void* mask, void* out, int out_f32, int nsplit);
@@ -98,6 +99,8 @@ int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int ns
 /* bce_loss / bce_loss_v2 / mse_loss + reduce_sum(axis=1) + gradient — vae/models.py:11-22,123-128 */
 int mi_recon_loss_chunks(int P);
 int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial);
+/* same + the BiasAddGrad of the layer that produced the logits: dbias[c] += sum of the stored dlogits of channel c (channels = 1..3) */
+int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial, int channels, float* dbias);
 /* reduce_mean over the batch, kl_tolerance clamp, tf.metrics.mean accumulators — vae/models.py:124-137,145-146 */
 int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight);
 /* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
