@@ -277,6 +277,33 @@ int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, i
     return rc == MI_OK ? 1 : rc;
 }
 
+// filter gradient of a k x k, s2 layer with a 1..3-channel narrow side and a 32-channel wide side (narrow_tile.hpp), bf16 wide tensor.
+// narrow: [*,IH,IW,Cs] (fp32 frames, optionally gathered, or bf16); wide: [B,OH,OW,32]; out [KH*KW*Cs][32] fp32 (+=)
+int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f32, const int* frame_idx, const void* wide,
+                     int B, int IH, int IW, int Cs, int OH, int OW, int Nwide, int KH, int KW, float* out, float* dbias) {
+    if (!narrow_enabled() || dtype != MI_BF16) return 0;
+    const int run = KW * Cs;
+    if (Nwide != 32 || KH > 4 || run > 12 || run % 4 != 0 || KH * run > 64 || (((uintptr_t)wide) & 15)) return 0;
+    if ((((uintptr_t)narrow) & (narrow_f32 ? 7 : 3)) || ((long long)IW * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0) return 0;
+    if ((2 * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0 || ((long long)IH * IW * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0) return 0;
+    const long long M = (long long)B * OH * OW, s_bytes = M * 32 * 2;
+    if (M >= (1ll << 26) || !fits_desc(s_bytes)) return 0;
+    NarrowWgradParams q = {};
+    q.src = narrow; q.frame_idx = frame_idx; q.frame_stride = (long long)IH * IW * Cs;
+    q.s = wide; q.s_bytes = (uint32_t)s_bytes;
+    q.B = B; q.IH = IH; q.IW = IW; q.Cs = Cs; q.OH = OH; q.OW = OW; q.KH = KH; q.KW = KW; q.M = (int)M;
+    int blocks = 768;
+    long long ppb = (M + blocks - 1) / blocks; ppb = (ppb + NW_BP - 1) / NW_BP * NW_BP;
+    blocks = (int)((M + ppb - 1) / ppb);
+    q.pix_per_block = (int)ppb;
+    q.div_ohw = make_fastdiv(OH * OW); q.div_ow = make_fastdiv(OW);
+    q.out = out; q.dbias = dbias;
+    if (narrow_f32) hipLaunchKernelGGL(narrow_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, q);
+    else hipLaunchKernelGGL(narrow_wgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, q);
+    const int rc = mi_check_launch("narrow_wgrad_kernel");
+    return rc == MI_OK ? 1 : rc;
+}
+
 // conv-form (A_CONV x B_NK).  Returns 1 if launched, 0 if not eligible, <0 on error.
 int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
     if (p.a_frame_idx || p.ksplit_len > 0) return 0;
@@ -499,6 +526,10 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
                             int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes,
                             float* dbias) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    {
+        const int r4 = try_narrow_wgrad((hipStream_t)stream, dtype, x, x_is_f32 || dtype == MI_F32, frame_idx, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, dbias);
+        if (r4 != 0) return r4 > 0 ? MI_OK : r4;
+    }
     if (!frame_idx && !x_is_f32) {
         const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
@@ -547,6 +578,10 @@ int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int O
 int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                               const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes, float* dbias) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
+    {   // deconv with a narrow OUTPUT: dW[kh,kw,co,ci] = sum patches(dy)[.,(kh,kw,co)] x[.,ci]; its bias gradient is not a by-product here
+        const int r4 = dbias ? 0 : try_narrow_wgrad((hipStream_t)stream, dtype, dy, 0, nullptr, x, B, OH, OW, Cout, IH, IW, Cin, KH, KW, dw, nullptr);
+        if (r4 != 0) return r4 > 0 ? MI_OK : r4;
+    }
     {
         const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;

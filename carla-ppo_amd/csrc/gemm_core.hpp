@@ -10,6 +10,7 @@
 //   tapwgrad_tile.hpp tapwgrad_kernel          bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles
 //
 //   narrow_tile.hpp  gather_narrow_kernel      transposed conv into a 1..8-channel output (logits)
+//                    narrow_wgrad_kernel       filter gradient of the layers with a 1..3-channel side (conv1, deconv4)
 //
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once

@@ -10,6 +10,7 @@
 //                          write adjacent bytes.
 #pragma once
 #include "tapconv_tile.hpp"
+#include "tapwgrad_tile.hpp"
 
 namespace mi {
 
@@ -159,6 +160,166 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
         if (p.bias) v += p.bias[n];
         if (p.relu) v = fmaxf(v, 0.f);
         out[j] = Elem<T>::from_f32(v);
+    }
+}
+
+}  // namespace mi
+
+namespace mi {
+
+// =====================================================================================================================
+// narrow_wgrad_kernel — filter gradient of the k x k, s2 layers whose NARROW side has Cs = 1..3 channels:
+//   conv1   dW[kh,kw,cs,n]  = sum_pix frame[b, 2oy+kh, 2ox+kw, cs] * dy[b,oy,ox,n]     (frames fp32, gathered through frame_idx)
+//   deconv4 dW[kh,kw,co,ci] = sum_pix dlogits[b, 2iy+kh, 2ix+kw, co] * x[b,iy,ix,ci]   (dlogits bf16)
+// Both are [KH*KW*Cs <= 64] x [32] outer-product sums over ~1.6 M pixels of the 32-channel tensor: HBM-bound (read both
+// tensors once).  Per 64-pixel step a block builds the im2col rows [pixel][64] (bf16, one thread per (pixel, kh): KW*Cs
+// contiguous source values) and DMA-stages the 64 x 32 wide-tensor rows; the four waves each take 16 pixels of the reduction
+// (transpose reads -> 2 MFMAs + the optional all-ones MFMA for the bias gradient); the waves' partial tiles are added in
+// LDS at the end and leave as one set of atomics per block.
+// =====================================================================================================================
+struct NarrowWgradParams {
+    const void* src; const int* frame_idx; long long frame_stride;    // narrow tensor, elements per frame
+    const void* s; uint32_t s_bytes;                                  // wide tensor [B,OH,OW,32] bf16
+    int B, IH, IW, Cs, OH, OW, KH, KW;
+    int M, pix_per_block;                                             // M = B*OH*OW ; multiple of 64
+    FastDiv div_ohw, div_ow;
+    float* out; float* dbias;
+};
+
+constexpr int NW_BP = 64;            // pixels per step
+
+template <typename TS>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradParams p) {
+    constexpr int PA = 128, PS = 64;                      // LDS row pitch: im2col rows (64 bf16), wide rows (32 bf16)
+    constexpr int ASTG = NW_BP * PA, SSTG = NW_BP * PS, STAGE = ASTG + SSTG;
+    constexpr int RED = 4 * 3 * 1024 * 4;                 // cross-wave reduction scratch (reuses the stage buffers)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE > RED ? 2 * STAGE : RED];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mbeg = blockIdx.x * p.pix_per_block;
+    const int mend = min(p.M, mbeg + p.pix_per_block);
+    if (mbeg >= mend) return;
+    const int nsteps = (mend - mbeg + NW_BP - 1) / NW_BP;
+    const int run = p.KW * p.Cs;                          // contiguous source values per (pixel, kh): 4 | 8 | 12
+    const int ngrp = run >> 2;
+
+    const u32x4 rsS = make_srd(p.s, p.s_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const TS* __restrict__ src = (const TS*)p.src;
+
+    // im2col role: thread -> (pixel tp = tid / 4, kernel row kh = tid % 4)
+    const int tp = tid >> 2, kh = tid & 3;
+    // wide-tensor DMA role: wave fills rows 16 wave .. +15 of the 64 x 64 B tile; lane -> row lane / 4, chunk lane % 4
+    const int srow = 16 * wave + (lane >> 2);
+    const int schunk = lane & 3;                          // 64-byte rows: the 4 rows x 64 B of a half-wave transpose read are 256 contiguous bytes, no swizzle needed
+
+    float v[12];
+    auto load_src = [&](int step) {
+        const int m = mbeg + step * NW_BP + tp;
+        const bool ok = m < mend && kh < p.KH;
+        uint32_t b, rem, y, x;
+        p.div_ohw.divmod((uint32_t)(ok ? m : 0), b, rem);
+        p.div_ow.divmod(rem, y, x);
+        const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+        const TS* row = src + fr * p.frame_stride + ((long long)(2 * y + kh) * p.IW + 2 * x) * p.Cs;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const bool gok = ok && g < ngrp;
+            const PackU<TS, 4, (int)sizeof(TS) * 2> t = *(const PackU<TS, 4, (int)sizeof(TS) * 2>*)(gok ? row + 4 * g : src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f;
+                if constexpr (sizeof(TS) == 4) f = (float)t.v[e]; else f = bf16_to_f32((bf16_t)t.v[e]);
+                v[4 * g + e] = gok ? f : 0.f;
+            }
+        }
+    };
+    auto store_src = [&](int buf) {                       // 12 bf16 of im2col row tp at columns kh*run .. ; rows are zero beyond KH*run
+        unsigned char* As = lds + buf * STAGE;
+        const int sw = ((tp >> 1) & 1) << 2;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (g >= ngrp) break;
+            const int col = kh * run + 4 * g;             // multiple of 4 elements = 8 bytes
+            const float f4[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *(PackN<bf16_t, 4>*)(As + tp * PA + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2) = pack4<bf16_t>(f4);
+        }
+    };
+    auto issue_s = [&](int step, int buf) {
+        const int m = mbeg + step * NW_BP + srow;
+        const uint32_t vo = m < mend ? ((uint32_t)m * 32u + (uint32_t)schunk * 8u) * 2u : G2_OOB;
+        dma16_asm(rsS, lds0 + buf * STAGE + ASTG + wave * 1024, vo);
+    };
+
+    // zero both im2col stages once (columns >= KH*run stay zero; so do pixels past the range, they are stored as zeros anyway)
+    for (int i = tid; i < 2 * STAGE / 16; i += 256) *(f32x4*)(lds + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // (only the stage part)
+    __syncthreads();
+
+    // transpose-read offsets (tr_fragment layout): row = (lane>>5)*8 + ((lane&15)>>2), column = ((lane>>4)&1)*16 + (lane&3)*4
+    const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2) + 16 * wave;     // this wave's 16 pixels of the step
+    const int tcol = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    uint32_t aoff[2], soff;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int col = kt * 32 + tcol;
+        aoff[kt] = (uint32_t)(trow * PA + ((((col >> 3) ^ (((trow >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
+    }
+    soff = (uint32_t)(ASTG + trow * PS + tcol * 2);
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    typedef __attribute__((address_space(3))) s16x4* lds_v4;
+
+    load_src(0); issue_s(0, 0); store_src(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < nsteps;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wide rows of this step (DMA issued one iteration ago) have landed
+        __syncthreads();                                  // ... for every wave; im2col rows of this step were written last iteration
+        if (more) { load_src(step + 1); issue_s(step + 1, cur ^ 1); }
+        const uint32_t sb = (uint32_t)(cur * STAGE);
+        u16x8 sf;
+        {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + soff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + soff + 4 * PS));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sf[e] = (unsigned short)lo[e]; sf[4 + e] = (unsigned short)hi[e]; }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + aoff[kt]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + aoff[kt] + 4 * PA));
+            u16x8 af;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { af[e] = (unsigned short)lo[e]; af[4 + e] = (unsigned short)hi[e]; }
+            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, sf), acc[kt], 0, 0, 0);
+        }
+        if (p.dbias) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, sf), acc[2], 0, 0, 0);
+        if (more) store_src(cur ^ 1);                     // stage cur^1 was last read in step-1 (before this step's barrier)
+    }
+
+    // cross-wave reduction in LDS, then one set of atomics per block: acc[kt][r] -> kc = kt*32 + (r&3) + 8(r>>2) + 4(lane>>5), n = lane&31
+    __syncthreads();
+    float* red = (float*)lds;                             // [wave][3][16][64]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + k) * 16 + r) * 64 + lane] = acc[k][r];
+    __syncthreads();
+    const int kcn = p.KH * run;
+    for (int i = tid; i < 3 * 16 * 64; i += 256) {
+        const float sum = (red[i] + red[3 * 1024 + i]) + (red[2 * 3 * 1024 + i] + red[3 * 3 * 1024 + i]);
+        const int k = i >> 10, r = (i >> 6) & 15, l = i & 63;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = l & 31;
+        if (k < 2) {
+            const int kc = k * 32 + row;
+            if (kc < kcn) atomicAdd(&p.out[kc * 32 + n], sum);
+        } else if (p.dbias && row == 0) atomicAdd(&p.dbias[n], sum);
     }
 }
 
