@@ -304,6 +304,32 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     return rc == MI_OK ? 1 : rc;
 }
 
+// conv k x k, s2 from a 1..3-channel tensor into exactly 32 channels (narrow_tile.hpp): conv1 fwd, deconv4 dgrad
+int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, const int* frame_idx, const void* wt, int B, int IH, int IW, int Cs,
+                    int KH, int KW, int Cout, const float* bias, int relu, const void* mask, void* out) {
+    if (!narrow_enabled() || Cout != 32 || KH != KW || KH > 4) return 0;
+    const int run = KW * Cs, K = KH * run;
+    if (run % 4 != 0 || K > 48) return 0;
+    const int ssz = src_f32 ? 4 : 2, esz = dtype == MI_F32 ? 4 : 2;
+    if (dtype == MI_F32 && !src_f32) return 0;
+    if ((((uintptr_t)src) & (2 * ssz - 1)) || ((long long)IW * Cs * ssz) % (2 * ssz) != 0 || (2 * Cs * ssz) % (2 * ssz) != 0 || ((long long)IH * IW * Cs * ssz) % (2 * ssz) != 0) return 0;
+    if ((((uintptr_t)wt) & 15) || (K * esz) % 16 != 0 || (((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15)) || (bias && (((uintptr_t)bias) & 15))) return 0;
+    const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    const long long M = (long long)B * OH * OW;
+    if (M >= (1ll << 30)) return 0;
+    NarrowConvParams q = {};
+    q.src = src; q.frame_idx = frame_idx; q.frame_stride = (long long)IH * IW * Cs; q.w = wt;
+    q.B = B; q.IH = IH; q.IW = IW; q.Cs = Cs; q.OH = OH; q.OW = OW; q.KH = KH; q.KW = KW; q.M = (int)M;
+    q.div_ohw = make_fastdiv(OH * OW); q.div_ow = make_fastdiv(OW); q.div_g3 = make_fastdiv(run / 4);
+    q.bias = bias; q.relu = relu; q.mask = mask; q.out = out;
+    dim3 g((unsigned)((M + 127) / 128));
+    if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
+    else if (src_f32) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, q);
+    const int rc = mi_check_launch("narrow_conv_kernel");
+    return rc == MI_OK ? 1 : rc;
+}
+
 // conv-form (A_CONV x B_NK).  Returns 1 if launched, 0 if not eligible, <0 on error.
 int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
     if (p.a_frame_idx || p.ksplit_len > 0) return 0;
@@ -496,6 +522,10 @@ int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_
                        int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout,
                        int relu, void* out) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    if (w_transposed) {
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 || dtype == MI_F32, frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out);
+        if (r4 != 0) return r4 > 0 ? MI_OK : r4;
+    }
     GemmParams p = {};
     p.a = x; p.a_frame_idx = frame_idx;
     fill_conv_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
@@ -560,6 +590,10 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                            const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
+    if (w_transposed) {
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, dy, dtype == MI_F32, nullptr, w, B, OH, OW, Cout, KH, KW, Cin, nullptr, 0, mask, dx);
+        if (r4 != 0) return r4 > 0 ? MI_OK : r4;
+    }
     GemmParams p = {};
     p.a = dy; p.a_frame_idx = nullptr;
     fill_conv_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));

@@ -11,6 +11,7 @@
 //
 //   narrow_tile.hpp  gather_narrow_kernel      transposed conv into a 1..8-channel output (logits)
 //                    narrow_wgrad_kernel       filter gradient of the layers with a 1..3-channel side (conv1, deconv4)
+//                    narrow_conv_kernel        conv from a 1..3-channel tensor into 32 channels (conv1 fwd, deconv4 dgrad)
 //
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once

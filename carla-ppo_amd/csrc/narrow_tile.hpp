@@ -324,3 +324,134 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
 }
 
 }  // namespace mi
+
+namespace mi {
+
+// =====================================================================================================================
+// narrow_conv_kernel — conv k4 s2 FROM a 1..3-channel tensor into 32 channels (conv1 fwd: fp32 frames gathered through
+// frame_idx; deconv4 dgrad: bf16 dlogits, with the ReLU-grad mask of the layer below).  K = KH*KW*Cs = 48 (16 for one
+// channel): three MFMA k-steps per 32 output pixels.  Waves are fully independent (no block barrier): a lane builds its
+// half of its pixel's 48-value patch straight from global memory (6 groups of 4 contiguous values; neighbouring pixels
+// overlap, L1 absorbs the re-reads), the K-contiguous weight copy (3 KB) sits in registers, and the 32 x 32 result leaves
+// through a wave-private LDS transpose as two 16-byte vectors per lane: every store instruction writes 1 KB of full lines.
+// Latency is hidden by occupancy (one 32-pixel tile per wave, ~6 waves per SIMD), which is all an HBM-bound layer needs.
+// =====================================================================================================================
+struct NarrowConvParams {
+    const void* src; const int* frame_idx; long long frame_stride;    // narrow input [*,IH,IW,Cs]
+    const void* w;                                                    // K-contiguous weights [32][KH*KW*Cs], T
+    int B, IH, IW, Cs, OH, OW, KH, KW, M;
+    FastDiv div_ohw, div_ow, div_g3;
+    const float* bias; int relu; const void* mask; void* out;         // out / mask [B,OH,OW,32], T
+};
+
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void narrow_conv_kernel(const NarrowConvParams p) {
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int VE = 16 / ESZ;
+    constexpr int OPITCH = 32 * ESZ + 16;                 // output transpose: 32 channels per pixel + 16 B pad
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 32 * OPITCH];
+    typedef typename Frag<T>::reg freg;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lgrp = lane >> 5;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    if (m0 >= p.M) return;
+    const int K = p.KH * p.KW * p.Cs, run = p.KW * p.Cs, gpr = run >> 2;      // gpr: 4-value groups per kernel row (3 | 1)
+    const int NS = sizeof(T) == 2 ? 3 : 6;                // MFMA k-steps covered below: ceil(48 / (32-byte chunk pair))
+    constexpr int KPS = 32 / ESZ;                         // k values per step (two 16-byte chunks): 16 bf16 | 8 f32
+    constexpr int GPL = KPS / 8;                          // 4-value groups per lane per step: 2 | 1
+
+    // ---- this lane's pixel ----
+    const int m = m0 + lrow;
+    const bool mok = m < p.M;
+    uint32_t b, rem, y, x;
+    p.div_ohw.divmod((uint32_t)(mok ? m : 0), b, rem);
+    p.div_ow.divmod(rem, y, x);
+    const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+    const TS* __restrict__ src = (const TS*)p.src;
+    const TS* pix = src + fr * p.frame_stride + ((long long)(2 * y) * p.IW + 2 * x) * p.Cs;
+
+    // ---- operands ----
+    freg wf[6], xf[6];
+    const T* __restrict__ W = (const T*)p.w;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        if (s >= NS) break;
+        const int k0 = s * KPS + lgrp * (KPS / 2);        // first k of this lane's chunk (VE consecutive k)
+        // weights: row n = lrow
+        {
+            const bool ok = k0 < K;
+            freg v = *(const freg*)(ok ? W + lrow * K + k0 : W);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = ok ? v[e] : (decltype(v[0] + 0))0;
+            wf[s] = v;
+        }
+        // patch: VE consecutive k = GPL groups of 4 values; group q = k / 4 -> kernel row q / gpr, offset (q % gpr) * 4
+        float pv[VE];
+#pragma unroll
+        for (int gi = 0; gi < GPL; ++gi) {
+            const int q = (k0 >> 2) + gi;
+            uint32_t kh, qr;
+            p.div_g3.divmod((uint32_t)q, kh, qr);
+            const bool ok = mok && 4 * q < K;
+            const PackU<TS, 4, (int)sizeof(TS) * 2> t = *(const PackU<TS, 4, (int)sizeof(TS) * 2>*)(ok ? pix + (long long)kh * p.IW * p.Cs + qr * 4 : src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f;
+                if constexpr (sizeof(TS) == 4) f = (float)t.v[e]; else f = bf16_to_f32((bf16_t)t.v[e]);
+                pv[4 * gi + e] = ok ? f : 0.f;
+            }
+        }
+        freg xv;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            if constexpr (sizeof(T) == 2) xv[e] = f32_to_bf16(pv[e]); else xv[e] = pv[e];
+        }
+        xf[s] = xv;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        if (s >= NS) break;
+        Frag<T>::mma(wf[s], xf[s], acc);                  // D[row = channel][col = pixel]
+    }
+
+    // ---- epilogue: +bias, ReLU -> wave-private [pixel][32] -> 16-byte vectors (ReLU-grad mask applied there) ----
+    unsigned char* ot = lds + wave * 32 * OPITCH;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const int n = 8 * qd + 4 * lgrp;
+        float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+        if (p.bias) {
+            const f32x4 bb = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] += bb[t];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        *(PackN<T, 4>*)(ot + lrow * OPITCH + n * ESZ) = pack4<T>(v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPP = 32 * ESZ / 16;                    // 16-byte chunks per pixel (4 | 8)
+    const T* __restrict__ maskp = (const T*)p.mask;
+#pragma unroll
+    for (int k = 0; k < 32 * CPP / 64; ++k) {
+        const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
+        if (m0 + px >= p.M) continue;
+        PackN<T, VE> o = *(const PackN<T, VE>*)(ot + px * OPITCH + c16 * 16);
+        const long long off = (long long)(m0 + px) * 32 + c16 * VE;
+        if (maskp) {
+            const PackN<T, VE> mk = *(const PackN<T, VE>*)(maskp + off);
+#pragma unroll
+            for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
+        }
+        *(PackN<T, VE>*)((T*)p.out + off) = o;
+    }
+}
+
+}  // namespace mi
