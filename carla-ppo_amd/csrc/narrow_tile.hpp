@@ -172,50 +172,50 @@ namespace mi {
 //   conv1   dW[kh,kw,cs,n]  = sum_pix frame[b, 2oy+kh, 2ox+kw, cs] * dy[b,oy,ox,n]     (frames fp32, gathered through frame_idx)
 //   deconv4 dW[kh,kw,co,ci] = sum_pix dlogits[b, 2iy+kh, 2ix+kw, co] * x[b,iy,ix,ci]   (dlogits bf16)
 // Both are [KH*KW*Cs <= 64] x [32] outer-product sums over ~1.6 M pixels of the 32-channel tensor: HBM-bound (read both
-// tensors once).  Per 64-pixel step a block builds the im2col rows [pixel][64] (bf16, one thread per (pixel, kh): KW*Cs
-// contiguous source values) and DMA-stages the 64 x 32 wide-tensor rows; the four waves each take 16 pixels of the reduction
-// (transpose reads -> 2 MFMAs + the optional all-ones MFMA for the bias gradient); the waves' partial tiles are added in
-// LDS at the end and leave as one set of atomics per block.
+// tensors once).  Per 16-pixel step a WAVE builds the im2col rows [pixel][64] (bf16, one lane per (pixel, kh): KW*Cs
+// contiguous source values) and DMA-stages the 16 x 32 wide-tensor rows, then runs 2 MFMAs on transpose-read operands (+ the
+// optional all-ones MFMA for the bias gradient).  Waves never synchronise inside the loop; the four partial tiles of a block
+// are added in LDS at the end and leave as one set of atomics per block.
 // =====================================================================================================================
 struct NarrowWgradParams {
     const void* src; const int* frame_idx; long long frame_stride;    // narrow tensor, elements per frame
     const void* s; uint32_t s_bytes;                                  // wide tensor [B,OH,OW,32] bf16
     int B, IH, IW, Cs, OH, OW, KH, KW;
-    int M, pix_per_block;                                             // M = B*OH*OW ; multiple of 64
+    int M, pix_per_block;                                             // M = B*OH*OW ; pixels per WAVE, multiple of 16
     FastDiv div_ohw, div_ow;
     float* out; float* dbias;
+    float* slabs;                                                     // optional [gridDim.x][NW_SLAB] per-block partial sums (then reduce_slabs_kernel)
 };
 
-constexpr int NW_BP = 64;            // pixels per step
+constexpr int NW_SLAB = 64 * 32 + 32;  // dW rows (padded to 64) x 32, then the 32 bias sums
+constexpr int NW_BP = 16;            // pixels per wave step
 
 template <typename TS>
 __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradParams p) {
     constexpr int PA = 128, PS = 64;                      // LDS row pitch: im2col rows (64 bf16), wide rows (32 bf16)
-    constexpr int ASTG = NW_BP * PA, SSTG = NW_BP * PS, STAGE = ASTG + SSTG;
-    constexpr int RED = 4 * 3 * 1024 * 4;                 // cross-wave reduction scratch (reuses the stage buffers)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE > RED ? 2 * STAGE : RED];
+    constexpr int WSTG = NW_BP * PA + NW_BP * PS;         // per wave: one im2col tile + one wide-row tile = 3 KB
+    constexpr int RED = 3 * 1024 * 4;                     // cross-wave reduction buffer
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * WSTG + RED];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mbeg = blockIdx.x * p.pix_per_block;
+    // every wave owns a contiguous pixel range and runs on its own (no block barrier until the final reduction): memory
+    // latency is hidden by the ~20 resident waves per CU, not by a per-wave software pipeline
+    const int wid = blockIdx.x * 4 + wave;
+    const int mbeg = min(p.M, wid * p.pix_per_block);     // pix_per_block: pixels per WAVE here (multiple of 16)
     const int mend = min(p.M, mbeg + p.pix_per_block);
-    if (mbeg >= mend) return;
     const int nsteps = (mend - mbeg + NW_BP - 1) / NW_BP;
     const int run = p.KW * p.Cs;                          // contiguous source values per (pixel, kh): 4 | 8 | 12
     const int ngrp = run >> 2;
 
-    const u32x4 rsS = make_srd(p.s, p.s_bytes);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    unsigned char* const wl = lds + wave * WSTG;          // this wave's tiles: [0, 2 KB) im2col, then 1 KB of wide rows
     const TS* __restrict__ src = (const TS*)p.src;
 
-    // im2col role: thread -> (pixel tp = tid / 4, kernel row kh = tid % 4)
-    const int tp = tid >> 2, kh = tid & 3;
-    // wide-tensor DMA role: wave fills rows 16 wave .. +15 of the 64 x 64 B tile; lane -> row lane / 4, chunk lane % 4
-    const int srow = 16 * wave + (lane >> 2);
-    const int schunk = lane & 3;                          // 64-byte rows: the 4 rows x 64 B of a half-wave transpose read are 256 contiguous bytes, no swizzle needed
-
-    float v[12];
-    auto load_src = [&](int step) {
+    const int tp = lane >> 2, kh = lane & 3;              // im2col role: (pixel of the step, kernel row)
+    // Everything is fetched with ordinary loads (in-order return, so hipcc's own vmcnt(N) bookkeeping lets the loads of the
+    // next two steps stay in flight while this step is consumed): 12 source values + one 16-byte piece of the wide rows per lane.
+    struct StepRegs { float v[12]; f32x4 s; };
+    auto load_step = [&](int step, StepRegs& R) {
         const int m = mbeg + step * NW_BP + tp;
         const bool ok = m < mend && kh < p.KH;
         uint32_t b, rem, y, x;
@@ -231,41 +231,38 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
             for (int e = 0; e < 4; ++e) {
                 float f;
                 if constexpr (sizeof(TS) == 4) f = (float)t.v[e]; else f = bf16_to_f32((bf16_t)t.v[e]);
-                v[4 * g + e] = gok ? f : 0.f;
+                R.v[4 * g + e] = gok ? f : 0.f;
             }
         }
+        // wide rows: lane -> row lane / 4 (pixel tp), 16-byte chunk lane % 4 (= kh)
+        const bool sok = m < mend;
+        const f32x4 sv = *(const f32x4*)((const unsigned char*)p.s + (sok ? ((long long)m * 32 + kh * 8) * 2 : 0));
+        R.s = sok ? sv : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto store_src = [&](int buf) {                       // 12 bf16 of im2col row tp at columns kh*run .. ; rows are zero beyond KH*run
-        unsigned char* As = lds + buf * STAGE;
+    auto store_step = [&](const StepRegs& R) {            // im2col row tp, columns kh*run .. (columns >= KH*run stay zero) + the wide-row piece
         const int sw = ((tp >> 1) & 1) << 2;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             if (g >= ngrp) break;
             const int col = kh * run + 4 * g;             // multiple of 4 elements = 8 bytes
-            const float f4[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-            *(PackN<bf16_t, 4>*)(As + tp * PA + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2) = pack4<bf16_t>(f4);
+            const float f4[4] = {R.v[4 * g], R.v[4 * g + 1], R.v[4 * g + 2], R.v[4 * g + 3]};
+            *(PackN<bf16_t, 4>*)(wl + tp * PA + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2) = pack4<bf16_t>(f4);
         }
-    };
-    auto issue_s = [&](int step, int buf) {
-        const int m = mbeg + step * NW_BP + srow;
-        const uint32_t vo = m < mend ? ((uint32_t)m * 32u + (uint32_t)schunk * 8u) * 2u : G2_OOB;
-        dma16_asm(rsS, lds0 + buf * STAGE + ASTG + wave * 1024, vo);
+        *(f32x4*)(wl + NW_BP * PA + tp * PS + kh * 16) = R.s;
     };
 
-    // zero both im2col stages once (columns >= KH*run stay zero; so do pixels past the range, they are stored as zeros anyway)
-    for (int i = tid; i < 2 * STAGE / 16; i += 256) *(f32x4*)(lds + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // (only the stage part)
-    __syncthreads();
+    for (int i = lane; i < NW_BP * PA / 16; i += 64) *(f32x4*)(wl + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // zero the im2col tile once
 
     // transpose-read offsets (tr_fragment layout): row = (lane>>5)*8 + ((lane&15)>>2), column = ((lane>>4)&1)*16 + (lane&3)*4
-    const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2) + 16 * wave;     // this wave's 16 pixels of the step
+    const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int tcol = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
-    uint32_t aoff[2], soff;
+    uint32_t aoff[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int col = kt * 32 + tcol;
         aoff[kt] = (uint32_t)(trow * PA + ((((col >> 3) ^ (((trow >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
     }
-    soff = (uint32_t)(ASTG + trow * PS + tcol * 2);
+    const uint32_t soff = (uint32_t)(NW_BP * PA + trow * PS + tcol * 2);
 
     f32x16 acc[3];
 #pragma unroll
@@ -275,51 +272,66 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
     const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
 
-    load_src(0); issue_s(0, 0); store_src(0);
-    for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
-        const bool more = step + 1 < nsteps;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wide rows of this step (DMA issued one iteration ago) have landed
-        __syncthreads();                                  // ... for every wave; im2col rows of this step were written last iteration
-        if (more) { load_src(step + 1); issue_s(step + 1, cur ^ 1); }
-        const uint32_t sb = (uint32_t)(cur * STAGE);
+    auto compute = [&]() {
         u16x8 sf;
         {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + soff));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + soff + 4 * PS));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wl + soff));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wl + soff + 4 * PS));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { sf[e] = (unsigned short)lo[e]; sf[4 + e] = (unsigned short)hi[e]; }
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + aoff[kt]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + sb + aoff[kt] + 4 * PA));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wl + aoff[kt]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(wl + aoff[kt] + 4 * PA));
             u16x8 af;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { af[e] = (unsigned short)lo[e]; af[4 + e] = (unsigned short)hi[e]; }
             acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, sf), acc[kt], 0, 0, 0);
         }
         if (p.dbias) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, sf), acc[2], 0, 0, 0);
-        if (more) store_src(cur ^ 1);                     // stage cur^1 was last read in step-1 (before this step's barrier)
+    };
+
+    // 3-deep register pipeline (steps s, s+1, s+2 in flight); out-of-range steps load nothing and store zeros
+    StepRegs R0, R1, R2;
+    load_step(0, R0); load_step(1, R1);
+    for (int step = 0; step < nsteps; step += 3) {
+        load_step(step + 2, R2);
+        store_step(R0); compute();
+        if (step + 1 < nsteps) { load_step(step + 3, R0); store_step(R1); compute(); }
+        if (step + 2 < nsteps) { load_step(step + 4, R1); store_step(R2); compute(); }
     }
 
-    // cross-wave reduction in LDS, then one set of atomics per block: acc[kt][r] -> kc = kt*32 + (r&3) + 8(r>>2) + 4(lane>>5), n = lane&31
-    __syncthreads();
-    float* red = (float*)lds;                             // [wave][3][16][64]
+    // cross-wave reduction (waves take turns on one 12 KB buffer), then one set of atomics per block:
+    // acc[k][r] -> kc = k*32 + (r&3) + 8(r>>2) + 4(lane>>5), n = lane&31 ; k == 2: all-ones rows (bias gradient)
+    float* red = (float*)(lds + 4 * WSTG);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((wave * 3 + k) * 16 + r) * 64 + lane] = acc[k][r];
-    __syncthreads();
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* q = &red[(k * 16 + r) * 64 + lane];
+                    *q = w == 0 ? acc[k][r] : *q + acc[k][r];
+                }
+        }
+        __syncthreads();
+    }
+    // same-address atomics from ~1300 blocks serialise (~60 ns each): with scratch the block writes its partial sums plainly
     const int kcn = p.KH * run;
     for (int i = tid; i < 3 * 16 * 64; i += 256) {
-        const float sum = (red[i] + red[3 * 1024 + i]) + (red[2 * 3 * 1024 + i] + red[3 * 3 * 1024 + i]);
+        const float sum = red[i];
         const int k = i >> 10, r = (i >> 6) & 15, l = i & 63;
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = l & 31;
         if (k < 2) {
             const int kc = k * 32 + row;
-            if (kc < kcn) atomicAdd(&p.out[kc * 32 + n], sum);
-        } else if (p.dbias && row == 0) atomicAdd(&p.dbias[n], sum);
+            if (p.slabs) p.slabs[(long long)blockIdx.x * NW_SLAB + kc * 32 + n] = sum;
+            else if (kc < kcn) atomicAdd(&p.out[kc * 32 + n], sum);
+        } else if (row == 0) {
+            if (p.slabs) p.slabs[(long long)blockIdx.x * NW_SLAB + 64 * 32 + n] = sum;
+            else if (p.dbias) atomicAdd(&p.dbias[n], sum);
+        }
     }
 }
 

@@ -260,6 +260,24 @@ __global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
                     const int q = q0[i] + delta;
                     qrow[i] = q * RB; qx[i] = (q >> 1) & 7;
                 }
+                // k = 5 (3x3 taps): the last tap row / column only reaches the even kernel rows / columns, so a 32-output tile
+                // whose rows all have an odd kh (kw) there meets an all-zero weight tile: skip it (wave-uniform, per tile)
+                bool live[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) live[j] = true;
+                if constexpr (TAPS == 3 && MODE == TC_GATHER) {
+                    if (p.N >= 32) {                      // a 32-wide tile lies inside one parity class
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int cls = (int)p.div_n.div((uint32_t)(n0 + (wn * TN + j) * 32));
+                            live[j] = !((ta == 0 && (cls >> 1) + 2 * p.HY >= p.KH) || (tb == 0 && (cls & 1) + 2 * p.HX >= p.KW));
+                        }
+                    }
+                }
+                bool any_live = false;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) any_live = any_live || live[j];
+                if (!any_live) continue;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int cl = kk * 2 + lgrp;
@@ -271,7 +289,8 @@ __global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) Frag<T>::mma(bf[j], af[i], acc[i][j]);   // D[row = output channel][col = position]
+                        for (int j = 0; j < TN; ++j)
+                            if (live[j]) Frag<T>::mma(bf[j], af[i], acc[i][j]);   // D[row = output channel][col = position]
                 }
             }
         }

@@ -317,24 +317,40 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #undef TW_STAMP
 }
 
-// dW[i] += sum over the split slabs (deterministic order); every element of every slab was written by tapwgrad_kernel
+// dW[i] += sum over the split slabs.  blockIdx.y takes every gridDim.y-th slab so small outputs still fill the chip;
+// with gridDim.y == 1 the result is a plain read-modify-write in a fixed order (deterministic), otherwise the gridDim.y
+// partial sums meet in a handful of atomics per element.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long long stride, int nslab, long long n, float* __restrict__ out) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int k0 = blockIdx.y, kstep = gridDim.y;
     if (i4 + 4 <= n) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int k = 0; k < nslab; ++k) s += *(const f32x4*)(slabs + k * stride + i4);
-        f32x4 o = *(f32x4*)(out + i4);
-        o += s;
-        *(f32x4*)(out + i4) = o;
+        for (int k = k0; k < nslab; k += kstep) s += *(const f32x4*)(slabs + k * stride + i4);
+        if (kstep == 1) {
+            f32x4 o = *(f32x4*)(out + i4);
+            o += s;
+            *(f32x4*)(out + i4) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(out + i4 + e, s[e]);
+        }
     } else {
         for (long long i = i4; i < n; ++i) {
             float a = 0.f;
-            for (int k = 0; k < nslab; ++k) a += slabs[k * stride + i];
-            out[i] += a;
+            for (int k = k0; k < nslab; k += kstep) a += slabs[k * stride + i];
+            if (kstep == 1) out[i] += a; else atomicAdd(out + i, a);
         }
     }
+}
+
+// host helper: pick gridDim.y so that about 1024 blocks run
+inline dim3 reduce_slabs_grid(long long n, int nslab) {
+    const unsigned gx = (unsigned)((n / 4 + 255) / 256 + 1);
+    unsigned gy = 1;
+    while (gx * gy < 512 && (int)(gy * 2) <= nslab / 4) gy *= 2;
+    return dim3(gx, gy, 1);
 }
 
 }  // namespace mi
