@@ -215,6 +215,17 @@ def main():
             ach = nbytes / avg_s
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach / 1e9, "peak": PEAK["hbm"] / 1e9, "unit": "GB/s", "frac": ach / PEAK["hbm"],
                         "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches_timed": int(cnt_d[di]), "algorithmic_bytes_per_launch": nbytes}
+    # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction),
+    # measured offline on this same workload and committed under profiles/ (PMC counters cannot be read from inside the bench)
+    if roofline is not None:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for op, rec in tj["ops"].items():
+                if dominant in [x.strip().split(" ")[0] for x in op.split("/")]:
+                    roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json: " + tj["provenance"]
+        except Exception:
+            pass
     losses = dev.losses.cpu().numpy()
 
     if rank == 0:

@@ -205,3 +205,36 @@ def test_full_batch_properties_b512(tmp_path, precision):
     # gradient wrt deconv4 bias = mean_b sum_pix (0.5 - y): sign of the update is its negative
     gsign = np.sign((0.5 - frames.reshape(-1, 3)).sum(0))
     assert np.array_equal(np.sign(db), -gsign)
+
+
+def test_kernel_generations_agree_at_batch_512(tmp_path):
+    """BASELINE configs[1] size (batch 512, bf16): one forward + backward on the production dispatch (tapconv / tapwgrad / narrow
+    kernels) and on the first-generation kernels.  Losses agree to 1e-5; every gradient tensor agrees to bf16 storage noise
+    (ReLU-mask flips of near-zero pre-activations, see test_train_step_losses_grads_and_adam) -- a size-independent check that the
+    raw-staged kernels handle full-size grids, split ranges and the slab reduction exactly like the simple ones."""
+    from mi355 import lib as milib
+    L = milib.get()
+    B = 512
+    rng = np.random.RandomState(5)
+    frames = (rng.randint(0, 256, (B, 80, 160, 3)).astype(np.float32) / 255.0)
+    eps = rng.standard_normal((B, 64)).astype(np.float32)
+    params = trained_like_params()
+
+    def run(cfg):
+        prev = {k: L.mi_set_tuning(k, v) for k, v in cfg.items()}
+        try:
+            m = make(tmp_path, "bf16", params=params)
+            src = m._frames(frames, 38400, "src")
+            e = m._eps(B, eps)
+            m.dev.forward(src, src, None, B, 1.0 / B, e, 1, 1)
+            m.dev.backward(src, None, e, 1.0 / B, 0)
+            return m.dev.losses.cpu().numpy().copy(), m.dev.export_grads()
+        finally:
+            for k, v in prev.items():
+                L.mi_set_tuning(k, v)
+
+    l_new, g_new = run({0: 1, 1: 300, 3: 1, 4: 1})
+    l_old, g_old = run({0: 0, 1: -1, 3: 0, 4: 0})
+    assert abs(l_new[0] / l_old[0] - 1) < 1e-5 and abs(l_new[1] / l_old[1] - 1) < 2e-3, (l_new, l_old)
+    bad = {k: rel_err(g_new[k], g_old[k]) for k in g_old if rel_err(g_new[k], g_old[k]) > 3e-2}
+    assert not bad, bad
