@@ -108,6 +108,9 @@ struct VaeEngine {
     int ns_heads, ns_dz, nchunks;
     int last_B;
     int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
+    hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
+    hipEvent_t ev_ready, ev_done;
+    int side_ok;
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
     const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
     const float* bptr(int t) const { return params + L.off[t]; }
@@ -267,7 +270,11 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
     return e;
 }
 
-void mi_vae_destroy(void* h) { free(h); }
+void mi_vae_destroy(void* h) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
+    free(h);
+}
 
 // bf16 mode: refresh the shadow weights from the fp32 masters (after load / init; Adam keeps them in sync afterwards)
 int mi_vae_sync_shadow(void* h, void* stream) {
@@ -330,38 +337,60 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_vae_backward: engine created without a gradient buffer");
     const MiVaeDesc& d = e->d; const Geom& g = e->g; const Workspace& W = e->W;
     void* st = stream;
+    // The filter (+bias) gradient of a layer and its input gradient only share their INPUT (the gradient of the layer's output), so the
+    // filter gradients run on a second stream, each one released by an event recorded on the caller's stream when its operand is ready.
+    // Every kernel on this path fills a whole CU (150 KB of LDS), so the gain is in the tails: a 342-block launch leaves 2/3 of the
+    // chip idle in its second round, which the neighbouring launch now fills.  MI355_BWD_STREAMS=0 serialises everything again.
+    static int two_streams = -1;
+    if (two_streams < 0) { const char* ev = getenv("MI355_BWD_STREAMS"); two_streams = (ev && ev[0] == '0') ? 0 : 1; }
+    if (two_streams && !e->side_ok) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
+        else e->side_ok = -1;
+    }
+    const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
+    void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
+    auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
+        if (fork) { hipEventRecord(e->ev_ready, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_ready, 0); }
+    };
+    auto join = [&]() {
+        if (fork) { hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent((hipStream_t)st, e->ev_done, 0); }
+    };
     if (part == 0 || part == 1) {
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             const void* gy = e->at(W.gdec[i + 1]);
-            const long long rows = (long long)B * g.dh[i + 1] * g.dw[i + 1];
-            (void)rows;                                      // BiasAddGrad is fused into the filter-gradient call below
-            TOP(e, st, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
+            release();                                       // gy is complete on st (loss pass / previous input gradient)
+            // BiasAddGrad is fused into the filter-gradient call
+            TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
         e->b4_fused = 0;
         // dense1: h = z W1 + b1
-        TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-        TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+        release();
+        TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+        TOP(e, sw, OP_DENSE1_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
+        join();
     }
     if (part == 0 || part == 2) {
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
         TOP(e, st, OP_REPARAM_BWD, mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
-        TOP(e, st, OP_HEADS_BIAS, mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-        TOP(e, st, OP_HEADS_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+        release();
+        TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+        TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             const void* gy = e->at(W.gact[i + 1]);
-            const long long rows = (long long)B * g.ih[i + 1] * g.iw[i + 1];
-            (void)rows;
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            TOP(e, st, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes, e->gptr(2 * i + 1)));
+            release();
+            TOP(e, sw, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sw, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));
         }
+        join();
     }
     return MI_OK;
 }
