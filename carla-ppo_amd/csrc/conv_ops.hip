@@ -95,21 +95,27 @@ int tapconv_minblocks() {
     return g_tap_min;
 }
 
-template <typename T, int MODE, int TAPS>
-int launch_tapconv_t(hipStream_t st, const TapParams& q) {
-    const int gx = (q.MP + TC_BMT - 1) / TC_BMT;
+int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
+
+template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
+int launch_tapconv_v(hipStream_t st, const TapParams& q) {
+    const int gx = (q.MP + BMT - 1) / BMT;
     if (q.NE >= 128) {
         dim3 g(gx, (q.NE + 127) / 128, 1);
-        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS>), g, dim3(TC_NT), 0, st, q);
+        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
     } else {
         dim3 g(gx, (q.NE + 63) / 64, 1);
-        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 64, TAPS>), g, dim3(TC_NT), 0, st, q);
+        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 64, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
     }
     return mi_check_launch("tapconv_kernel");
 }
+template <typename T, int MODE, int TAPS>
+int launch_tapconv_t(hipStream_t st, const TapParams& q, bool small_tile) {
+    return small_tile ? launch_tapconv_v<T, MODE, TAPS, 128, 48>(st, q) : launch_tapconv_v<T, MODE, TAPS, TC_BMT, TC_MAXHALO>(st, q);
+}
 template <typename T, int MODE>
-int launch_tapconv(hipStream_t st, const TapParams& q) {
-    return q.TH == 2 ? launch_tapconv_t<T, MODE, 2>(st, q) : launch_tapconv_t<T, MODE, 3>(st, q);
+int launch_tapconv(hipStream_t st, const TapParams& q, bool small_tile) {
+    return q.TH == 2 ? launch_tapconv_t<T, MODE, 2>(st, q, small_tile) : launch_tapconv_t<T, MODE, 3>(st, q, small_tile);
 }
 
 // mode TC_CONV: x[B,IH,IW,C] -> out[B,OH,OW,N], weights K-contiguous [N][KH*KW*C];  mode TC_GATHER: x[B,IH,IW,C] -> out[B,OH,OW,N],
@@ -150,9 +156,11 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     q.trace = g_trace; q.trace_cap = g_trace_cap;
+    const int halo = (q.TH - 1) * q.GW + q.TW - 1;
+    const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && false));
     int rc;
-    if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q) : launch_tapconv<float, TC_GATHER>(st, q);
-    else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q) : launch_tapconv<bf16_t, TC_GATHER>(st, q);
+    if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
+    else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q, small_tile) : launch_tapconv<bf16_t, TC_GATHER>(st, q, small_tile);
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -293,7 +301,9 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     q.src = narrow; q.frame_idx = frame_idx; q.frame_stride = (long long)IH * IW * Cs;
     q.s = wide; q.s_bytes = (uint32_t)s_bytes;
     q.B = B; q.IH = IH; q.IW = IW; q.Cs = Cs; q.OH = OH; q.OW = OW; q.KH = KH; q.KW = KW; q.M = (int)M;
-    long long nwave = 256 * 20;                            // ~20 resident waves per CU: occupancy hides the load latency
+    static int wpc = -1;                                   // resident waves per CU the grid is sized for (131 registers -> 3 per SIMD)
+    if (wpc < 0) { const char* e = getenv("MI355_NW_WAVES"); wpc = e ? atoi(e) : 12; }
+    long long nwave = 256ll * wpc;                         // one wave-range per resident wave: a single round, no tail
     long long ppw = (M + nwave - 1) / nwave; ppw = (ppw + NW_BP - 1) / NW_BP * NW_BP;
     nwave = (M + ppw - 1) / ppw;
     const int blocks = (int)((nwave + 3) / 4);
@@ -519,6 +529,7 @@ int mi_set_tuning(int key, int value) {
     if (key == 0) { prev = gemm2_enabled() ? 1 : 0; g_gemm2_on = value ? 1 : 0; }
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
+    else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");

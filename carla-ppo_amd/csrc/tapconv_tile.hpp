@@ -16,6 +16,7 @@
 // LDS rows are 128 B, XOR-swizzled on the DMA source side (chunk ^= (row >> 1) & 7) -> conflict-free ds_read_b128.
 // Rows of dummy positions (gy >= OH etc.) are computed and dropped in the epilogue.
 #pragma once
+#include <type_traits>
 #include "gemm2_tile.hpp"
 
 namespace mi {
@@ -40,21 +41,24 @@ struct TapParams {
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
 };
 
-// TAPS: taps per axis (2 for k <= 4, 3 for k = 5,6); the tap loop is unrolled so tap offsets / issue slots are literals
-template <typename T, int MODE, int BNE, int TAPS>
-__global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
+// TAPS: taps per axis (2 for k <= 4, 3 for k = 5,6); the tap loop is unrolled so tap offsets / issue slots are literals.
+// BMT x MAXHALO: positions per block and the largest tap reach it can stage.  256 x 96: 8 waves, 155 KB of LDS, one block per CU.
+// 128 x 48: 4 waves, 77 KB, TWO independent blocks per CU: one block's prologue / epilogue / barrier waits are covered by the
+// other block's MFMAs (the big tile leaves 25-45 % of a block's life MFMA-idle with nothing to overlap it).
+template <typename T, int MODE, int BNE, int TAPS, int BMT, int MAXHALO>
+__global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
+    constexpr int TC_NT = BMT * 2;                        // threads: one wave per 32 positions x 2 output halves
     constexpr int RB = 128;
     constexpr int ESZ = (int)sizeof(T);
     constexpr int CHS = RB / ESZ;                         // channels per stage
     constexpr int VE = 16 / ESZ;
-    constexpr int BMT = TC_BMT;
-    constexpr int MAXSLOT = BMT + TC_MAXHALO;             // 352, multiple of 8
+    constexpr int MAXSLOT = BMT + MAXHALO;                // 352 | 176, multiple of 8
     constexpr int NWAVE = TC_NT / 64;
     constexpr int NIA = (MAXSLOT / 8 + NWAVE - 1) / NWAVE; // A-tile DMA instructions per wave (upper bound: ceil(44 / 8) = 6)
     constexpr int WN = 2, WM = NWAVE / WN;
     constexpr int TM = BMT / WM / 32;                     // 2
     constexpr int TN = BNE / WN / 32;                     // 2 | 1
-    constexpr int TPS = 256 / BNE;                        // taps per barrier step: 32 MFMAs per wave between barriers
+    constexpr int TPS = BMT / BNE;                        // taps per barrier step: 32 (16 for the small tile) MFMAs per wave between barriers
     constexpr int NSS = (TAPS * TAPS + TPS - 1) / TPS;    // steps per channel slice
     constexpr int NJB = BNE / 8 / NWAVE;                  // B-tile DMA instructions per wave (8 rows each)
     constexpr int ASTAGE = MAXSLOT * RB, BTILE = BNE * RB, BSTAGE = TPS * BTILE;
@@ -229,36 +233,57 @@ __global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) q0[i] = (wm * TM + i) * 32 + lrow;
 
-    int stage = 0;
-    for (int cc = 0; cc < NCC; ++cc) {
-        const unsigned char* As = Abase + (cc & 1) * ASTAGE;
+    // LDS read addresses are computed ONCE (the address arithmetic of 48-80 fragment reads per step was ~2/3 of the step's VALU
+    // instructions and the kernel is VALU-issue bound, not MFMA bound): a[tap][i][kk] for 2x2 taps (32 VGPRs), per (tap, i) row /
+    // swizzle terms otherwise.  Slice / stage parities are template arguments (the slice loop is unrolled by two) so that the
+    // buffer bases fold into the 16-bit offset field of ds_read_b128.
+    constexpr bool PRE = TAPS == 2;
+    uint32_t aaddr[PRE ? NT : 1][TM][4];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int q = q0[i] + (tap / TAPS) * p.GW + (tap % TAPS);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) aaddr[tap][i][kk] = (uint32_t)(q * RB + ((((kk * 2 + lgrp) ^ ((q >> 1) & 7))) << 4));
+            }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) boff[kk][j] += 2 * ASTAGE;          // weight stages follow the two slot stages
+
+    auto slice_body = [&](int cc, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;        // cc & 1
         const bool more_a = cc + 1 < NCC;
         if (more_a) sliceA(cc + 1);
 #pragma unroll
         for (int ss = 0; ss < NSS; ++ss) {
+            const int stage = (PAR * NSS + ss) & 1;       // literal after unrolling: (global step index) & 1
             __syncthreads();                              // this step's tiles have landed (vmcnt(0) + barrier); the other stage is free
             if (cc == 0) TC_STAMP();
             if (more_a) {
 #pragma unroll
                 for (int i = 0; i < NIA; ++i)
-                    if (i % NSS == ss) issueA((cc + 1) & 1, i);
+                    if (i % NSS == ss) issueA(PAR ^ 1, i);
             }
             if (ss + 1 < NSS) issue_step_B(ss + 1, stage ^ 1);
             else if (more_a) { sliceB(cc + 1); issue_step_B(0, stage ^ 1); }
-            const unsigned char* Bst = Bbase + stage * BSTAGE;
-            stage ^= 1;
 #pragma unroll
             for (int u = 0; u < TPS; ++u) {
                 const int tap = ss * TPS + u;
                 if (tap >= NT) continue;                  // literal after unrolling: padded tap of a 3x3 tap set
                 const int ta = tap / TAPS, tb = tap % TAPS;
-                const unsigned char* Bs = Bst + u * BTILE;
-                const int delta = ta * p.GW + tb;
+                const int aconst = PAR * ASTAGE, bconst = stage * BSTAGE + u * BTILE;      // literals
                 int qrow[TM], qx[TM];
+                if constexpr (!PRE) {
+                    const int delta = ta * p.GW + tb;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int q = q0[i] + delta;
-                    qrow[i] = q * RB; qx[i] = (q >> 1) & 7;
+                    for (int i = 0; i < TM; ++i) {
+                        const int q = q0[i] + delta;
+                        qrow[i] = q * RB; qx[i] = (q >> 1) & 7;
+                    }
                 }
                 // k = 5 (3x3 taps): the last tap row / column only reaches the even kernel rows / columns, so a 32-output tile
                 // whose rows all have an odd kh (kw) there meets an all-zero weight tile: skip it (wave-uniform, per tile)
@@ -280,12 +305,14 @@ __global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
                 if (!any_live) continue;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int cl = kk * 2 + lgrp;
                     freg af[TM], bf[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[i] = *(const freg*)(&As[qrow[i] + ((cl ^ qx[i]) << 4)]);
+                    for (int i = 0; i < TM; ++i) {
+                        if constexpr (PRE) af[i] = *(const freg*)(lds + aaddr[tap][i][kk] + aconst);
+                        else af[i] = *(const freg*)(lds + qrow[i] + ((((kk * 2 + lgrp) ^ qx[i])) << 4) + aconst);
+                    }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = *(const freg*)(&Bs[boff[kk][j]]);
+                    for (int j = 0; j < TN; ++j) bf[j] = *(const freg*)(lds + boff[kk][j] + bconst);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -294,6 +321,10 @@ __global__ __launch_bounds__(TC_NT) void tapconv_kernel(const TapParams p) {
                 }
             }
         }
+    };
+    for (int cc = 0; cc < NCC; cc += 2) {
+        slice_body(cc, std::integral_constant<int, 0>());
+        if (cc + 1 < NCC) slice_body(cc + 1, std::integral_constant<int, 1>());
     }
 
     TC_STAMP();

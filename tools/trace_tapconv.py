@@ -57,7 +57,22 @@ def run(name, trace):
     t = buf.cpu().numpy().reshape(-1, 8, 32)
     return us, t
 
+LAYERS.update({"conv3.dgrad": ("cdgrad", 18, 38, 64, 128, 4), "conv4.dgrad": ("cdgrad", 8, 18, 128, 256, 4), "deconv1.fwd": ("deconv", 3, 8, 256, 128, 4),
+               "conv4.fwd": ("conv", 8, 18, 128, 256, 4), "deconv1.dgrad": ("ddgrad", 3, 8, 256, 128, 4)})
 name = sys.argv[1] if len(sys.argv) > 1 else "conv2.fwd"
+if name == "variants":                                     # timing only: big tile vs small tile vs gemm2 for every layer
+    for nm in LAYERS:
+        res = []
+        for label, cfg in (("big", {5: 1, 1: 1}), ("small", {5: 2, 1: 1}), ("gemm2", {1: -1})):
+            prev = {k: L.mi_set_tuning(k, v) for k, v in cfg.items()}
+            us, _ = run(nm, False)
+            for k, v in prev.items():
+                L.mi_set_tuning(k, v)
+            res.append("%s %.1f" % (label, us))
+        print("%-14s %s" % (nm, "   ".join(res)))
+    sys.exit(0)
+if len(sys.argv) > 2:
+    L.mi_set_tuning(5, int(sys.argv[2])); L.mi_set_tuning(1, 1)
 for nm in ([name] if name != "all" else list(LAYERS)):
     us, t = run(nm, True)
     used = t[:, 0, 0] != 0
