@@ -260,8 +260,12 @@ bool narrow_enabled() {
     return g_narrow_on != 0;
 }
 
+struct NarrowLoss {                                       // optional fused reconstruction loss of gather_narrow_kernel
+    const float* labels; const int* idx; long long stride; int kind; float inv_b; void* dlogits; float* lpart; float* bpart; int cap; int nblocks;
+};
+
 int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
-                      int KH, int KW, void* out, const float* bias, const void* mask, int relu) {
+                      int KH, int KW, void* out, const float* bias, const void* mask, int relu, NarrowLoss* loss = nullptr) {
     if (!narrow_enabled() || mask || 4 * N > 32 || KH != KW || KH < 3 || KH > 6) return 0;
     const int esz = dtype == MI_F32 ? 4 : 2;
     const int pa = C * esz;
@@ -276,6 +280,14 @@ int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, i
     q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.out = out; q.bias = bias; q.mask = nullptr; q.relu = relu;
+    if (loss) {
+        const int nblk = (int)((MP + GN_BMT - 1) / GN_BMT);
+        if ((N != 1 && N != 3) || (OW & 1) || nblk > loss->cap || (((uintptr_t)loss->labels) & 7) || (loss->stride * 4) % 8 != 0 ||
+            (loss->dlogits && (((uintptr_t)loss->dlogits) & 3))) return 0;
+        q.labels = loss->labels; q.lab_idx = loss->idx; q.lab_stride = loss->stride; q.loss_kind = loss->kind; q.inv_b = loss->inv_b;
+        q.dlogits = loss->dlogits; q.lpart = loss->lpart; q.bpart = loss->bpart;
+        loss->nblocks = nblk;
+    }
     int rc;
     if (dtype == MI_F32) {
         if (pa != 128) return 0;
@@ -604,6 +616,21 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
     p.a = x; p.b = w; p.ldb = 0; p.b_vec = 1;
     p.out = out; p.bias = bias; p.mask = nullptr; p.relu = relu; p.out_f32 = 0;
     return deconv_form_gemm((hipStream_t)stream, dtype, p, B, IH, IW, Cin, OH, OW, Cout, KH, KW);
+}
+
+// conv2d_transpose into narrow logits + fused reconstruction loss (see the header); *n_partial = 0: not eligible, nothing launched
+int mi_deconv2d_nhwc_fwd_bce(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout,
+                             void* logits, const float* labels, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits,
+                             float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial) {
+    if (!n_partial || !labels || !loss_partial || !bias_partial) return mi_fail(MI_ERR_ARG, "mi_deconv2d_nhwc_fwd_bce: missing buffers");
+    *n_partial = 0;
+    if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_deconv2d_nhwc_fwd_bce: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
+    const int OH = (IH - 1) * 2 + KH, OW = (IW - 1) * 2 + KW;
+    NarrowLoss L = {labels, frame_idx, label_stride, loss_kind, inv_batch, dlogits, loss_partial, bias_partial, partial_capacity, 0};
+    const int r = try_gather_narrow((hipStream_t)stream, dtype, x, w, B, IH, IW, Cin, OH, OW, Cout, KH, KW, logits, bias, nullptr, 0, &L);
+    if (r < 0) return r;
+    if (r > 0) *n_partial = L.nblocks;
+    return MI_OK;
 }
 
 // conv2d_transpose input gradient = plain stride-2 conv of dy with the same kernel read as HWIO [kh,kw,I=co,O=ci]

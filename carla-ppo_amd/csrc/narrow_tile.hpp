@@ -35,8 +35,10 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
     constexpr int OPITCH = 36;                            // floats per position in the output transpose (32 + pad)
     typedef typename Frag<T>::reg freg;
 
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[MAXSLOT * PA + 4 * 32 * OPITCH * 4];
-    float* const otile = (float*)(lds + MAXSLOT * PA);
+    constexpr int OTILE = 4 * 32 * OPITCH * 4;            // the output transpose reuses the slot tile (after a block barrier)
+    constexpr int LBUF = MAXSLOT * PA > OTILE ? MAXSLOT * PA : OTILE;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LBUF + 64];       // + 16 floats for the fused-loss block reduction
+    float* const otile = (float*)lds;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
     }
 
     // ---- epilogue: D -> wave-private [position][32] floats -> one lane per (position, output-row parity) ----
+    __syncthreads();                                      // every wave is done reading the slot tile
     float* ot = otile + wave * 32 * OPITCH;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -118,18 +121,19 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
     }
     __builtin_amdgcn_wave_barrier();                      // same wave, in-order LDS queue: no wait needed, only keep the order
     const int P = P0 + wave * 32 + lrow;
-    if (P >= p.MP) return;
     uint32_t g, gx, b, gy;
-    p.div_gw.divmod((uint32_t)P, g, gx);
+    p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
     p.div_g.divmod(g, b, gy);
     const int ph = lgrp;
     const int oy = 2 * (int)gy + ph, ox = 2 * (int)gx;
-    if (oy >= p.OH || ox >= p.OW) return;
+    const bool live = P < p.MP && oy < p.OH && ox < p.OW;
     const int npx = ox + 1 < p.OW ? 2 : 1;                // output pixels of this lane (pw = 0, 1)
     T* __restrict__ out = (T*)p.out + (((long long)b * p.OH + oy) * p.OW + ox) * p.N;
     const float* src = ot + lrow * OPITCH + ph * 2 * p.N;
+    float lsum = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;   // fused loss: this lane's loss terms and per-channel dlogits sums
+    bool done = !live;
     if constexpr (NOUT > 0) {
-        if (npx == 2) {                                   // 2 N contiguous elements = ND dwords, adjacent lanes adjacent bytes
+        if (live && npx == 2) {                           // 2 N contiguous elements = ND dwords, adjacent lanes adjacent bytes
             constexpr int CNT = 2 * NOUT;
             constexpr int ND = CNT * ESZ / 4;
             float v[CNT];
@@ -150,16 +154,74 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
             uint32_t* o32 = (uint32_t*)out;
 #pragma unroll
             for (int d = 0; d < ND; ++d) o32[d] = w[d];
-            return;
+            if (p.labels) {
+                // reconstruction loss on the STORED logits (vae/models.py:11-22,123-128; same math as recon_loss_kernel)
+                const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
+                const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
+                float yv[CNT];
+                if constexpr (CNT % 2 == 0 && NOUT % 1 == 0) {
+#pragma unroll
+                    for (int d = 0; d < CNT / 2; ++d) {
+                        const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
+                        yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
+                    }
+                }
+                T gq[CNT];
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) {
+                    float xv;
+                    if constexpr (ESZ == 2) xv = bf16_to_f32((bf16_t)(j & 1 ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu)); else xv = v[j];
+                    const float e = __expf(-fabsf(xv));
+                    const float r = __frcp_rn(1.0f + e);
+                    const float sg = xv >= 0.f ? r : e * r;
+                    float l, gr;
+                    if (p.loss_kind == 0) { l = fmaxf(xv, 0.f) - xv * yv[j] + __logf(1.0f + e); gr = sg - yv[j]; }
+                    else if (p.loss_kind == 1) {
+                        l = -(yv[j] * __logf(1e-10f + sg) + (1.0f - yv[j]) * __logf(1e-10f + 1.0f - sg));
+                        gr = (-yv[j] / (1e-10f + sg) + (1.0f - yv[j]) / (1e-10f + 1.0f - sg)) * sg * (1.0f - sg);
+                    } else { const float dd = yv[j] - sg; l = dd * dd; gr = -2.0f * dd * sg * (1.0f - sg); }
+                    lsum += l;
+                    gq[j] = Elem<T>::from_f32(gr * p.inv_b);
+                    const float gst = Elem<T>::to_f32(gq[j]);
+                    const int c = j % NOUT;
+                    if (c == 0) gs0 += gst; else if (c == 1) gs1 += gst; else gs2 += gst;
+                }
+                if (p.dlogits) {
+                    uint32_t dw[ND];
+                    if constexpr (ESZ == 2) {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) dw[d] = (uint32_t)gq[2 * d] | ((uint32_t)gq[2 * d + 1] << 16);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) dw[d] = __builtin_bit_cast(uint32_t, gq[d]);
+                    }
+                    uint32_t* d32 = (uint32_t*)((T*)p.dlogits + (((long long)b * p.OH + oy) * p.OW + ox) * p.N);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) d32[d] = dw[d];
+                }
+            }
+            done = true;
         }
     }
-    const int cnt = npx * p.N;
-    for (int j = 0; j < cnt; ++j) {
-        const int n = j >= p.N ? j - p.N : j;
-        float v = src[j];
-        if (p.bias) v += p.bias[n];
-        if (p.relu) v = fmaxf(v, 0.f);
-        out[j] = Elem<T>::from_f32(v);
+    if (!done) {                                          // generic path (odd OW edge, other N): element stores, no fused loss
+        const int cnt = npx * p.N;
+        for (int j = 0; j < cnt; ++j) {
+            const int n = j >= p.N ? j - p.N : j;
+            float v = src[j];
+            if (p.bias) v += p.bias[n];
+            if (p.relu) v = fmaxf(v, 0.f);
+            out[j] = Elem<T>::from_f32(v);
+        }
+    }
+    if (p.labels) {                                       // block partials (fixed order -> deterministic; mi_vae_finalize_losses_flat adds them up)
+        lsum = wave_sum(lsum); gs0 = wave_sum(gs0); gs1 = wave_sum(gs1); gs2 = wave_sum(gs2);
+        float* red = (float*)(lds + LBUF);
+        if (lane == 0) { red[wave * 4 + 0] = lsum; red[wave * 4 + 1] = gs0; red[wave * 4 + 2] = gs1; red[wave * 4 + 3] = gs2; }
+        __syncthreads();
+        if (tid < 4) {
+            const float t = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
+            if (tid == 0) p.lpart[blockIdx.x] = t; else p.bpart[(long long)blockIdx.x * 4 + tid - 1] = t;
+        }
     }
 }
 

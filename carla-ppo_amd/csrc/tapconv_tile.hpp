@@ -39,6 +39,11 @@ struct TapParams {
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     void* out; const float* bias; const void* mask; int relu;
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
+    // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
+    const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
+    int loss_kind; float inv_b;
+    void* dlogits;                     // d loss / d logits * inv_b, same layout as out (nullptr: loss only)
+    float* lpart; float* bpart;        // per block: loss partial sum; 4 floats of per-channel dlogits sums
 };
 
 // TAPS: taps per axis (2 for k <= 4, 3 for k = 5,6); the tap loop is unrolled so tap offsets / issue slots are literals.

@@ -64,7 +64,7 @@ struct Workspace {
     long long dec[5];                  // dec[0] = dense1 output, dec[i] = output of deconv i (T); dec[4] = logits
     long long gdec[5];
     long long z, dheads;               // T
-    long long heads_slab, dz_slab, mean, logvar, kl_row, partial, out2, zf32;   // fp32
+    long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
     long long total;
 };
@@ -105,7 +105,7 @@ struct VaeEngine {
     void* wt;                           // K-contiguous ("transposed") copies of the 10 kernels, type T, same offsets
     char* ws;
     int esz;                            // bytes per T
-    int ns_heads, ns_dz, nchunks;
+    int ns_heads, ns_dz, nchunks, partial_cap;
     int last_B;
     int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
@@ -150,7 +150,8 @@ void make_workspace(VaeEngine& e) {
     W.heads_slab = add((long long)e.ns_heads * B * 2 * d.z_dim * 4);
     W.dz_slab = add((long long)e.ns_dz * B * d.z_dim * 4);
     W.mean = add(B * d.z_dim * 4); W.logvar = add(B * d.z_dim * 4); W.kl_row = add(B * 4);
-    W.partial = add(B * e.nchunks * 4); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
+    e.partial_cap = (int)(B * 64 > B * e.nchunks ? B * 64 : B * e.nchunks);   // loss partial sums: per (frame, chunk) or per block of the fused decoder tail
+    W.partial = add((long long)e.partial_cap * 4); W.bpart = add((long long)e.partial_cap * 16); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
     W.scratch_bytes = d.dtype == MI_BF16 ? 64ll << 20 : 0;
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
@@ -206,10 +207,10 @@ int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int
 }
 
 // decoder: z (T) -> dense1 -> deconv1..4 -> logits
-int run_decoder(VaeEngine* e, void* st, int B) {
+int run_decoder(VaeEngine* e, void* st, int B, int last = 4) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
     TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wtptr(10), 1, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < last; ++i)
         TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1])));
     return MI_OK;
@@ -309,19 +310,30 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
     CK(check_batch(e, B));
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
     CK(run_encoder(e, stream, src, idx, B, eps, sample));
-    CK(run_decoder(e, stream, B));
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
+    const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
     // the BiasAddGrad of deconv4 (sum of dlogits per target channel) rides on the loss pass when the gradient is wanted
     const bool fuse_b4 = want_grad && e->grads && d.ct <= 3;
     if (fuse_b4 && e->b4_fused)
         return mi_fail(MI_ERR_STATE, "mi_vae_forward(want_grad=1): the previous forward's gradient was never consumed by mi_vae_backward "
                                      "(its deconv4 bias gradient is already in the gradient buffer)");
     e->b4_fused = fuse_b4 ? 1 : 0;
-    TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd_bias(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
-                             want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial), d.ct, fuse_b4 ? e->gptr(19) : nullptr));
-    const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
-    TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
-                              inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
+    // decoder tail: deconv4 with the reconstruction loss fused into its epilogue where the narrow kernel is eligible (logits are still written)
+    CK(run_decoder(e, stream, B, 3));
+    int nblk = 0;
+    TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
+                                            e->at(e->W.dec[4]), tgt, idx, (long long)P, d.loss_kind, inv_batch, want_grad ? e->at(e->W.gdec[4]) : nullptr,
+                                            (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk));
+    if (nblk > 0) {
+        TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses_flat(stream, (const float*)e->at(e->W.partial), nblk, (const float*)e->at(e->W.kl_row), kl_floor, B, inv_batch,
+                                       (float*)e->at(e->W.out2), metrics3, metric_weight, (const float*)e->at(e->W.bpart), nblk, d.ct, fuse_b4 ? e->gptr(19) : nullptr));
+    } else {
+        TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4], 0, e->at(e->W.dec[4])));
+        TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd_bias(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
+                                 want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial), d.ct, fuse_b4 ? e->gptr(19) : nullptr));
+        TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
+                                  inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
+    }
     e->last_B = B;
     return MI_OK;
 }

@@ -82,6 +82,11 @@ int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* fram
 int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes, float* dbias);
 /* tf.layers.conv2d_transpose k x k, s2, VALID + BiasAdd (+ Relu) — vae/models.py:261-264 */
 int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out);
+/* conv2d_transpose into the 1- or 3-channel logits WITH the reconstruction loss of vae/models.py:11-22,123-128 fused into its epilogue
+ * (labels: fp32 target frames [*, OH*OW*Cout], optional gather through frame_idx): writes logits, dlogits (NULL = loss only), one loss
+ * partial per block into loss_partial[] and 4 floats of per-channel dlogits sums per block into bias_partial[].  *n_partial = number of
+ * blocks written, or 0 when the layer is not eligible for the fused kernel (nothing was launched: call the two ops separately). */
+int mi_deconv2d_nhwc_fwd_bce(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, void* logits, const float* labels, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
@@ -104,6 +109,8 @@ int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const flo
 int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial, int channels, float* dbias);
 /* reduce_mean over the batch, kl_tolerance clamp, tf.metrics.mean accumulators — vae/models.py:124-137,145-146 */
 int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight);
+/* same over a flat list of loss partial sums; optionally folds per-block channel sums [n][4] of a fused loss pass into dbias */
+int mi_vae_finalize_losses_flat(void* stream, const float* partial, int n_partial, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight, const float* bias_partial, int n_bias_partial, int channels, float* dbias);
 /* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);

@@ -269,6 +269,55 @@ def test_reparam_kl_fwd_bwd(dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("Co,kind", [(3, 0), (3, 2), (1, 0), (1, 1)])
+def test_deconv_fwd_with_fused_reconstruction_loss(dt, Co, kind):
+    """mi_deconv2d_nhwc_fwd_bce (deconv4 + loss in one kernel) against the float64 statement of the two reference ops
+    (tf.layers.conv2d_transpose, vae/models.py:264; bce / bce_v2 / mse + reduce_sum, :11-22,123-128): logits, dlogits, the loss
+    and the per-channel dlogits sums (BiasAddGrad), with the target frames gathered through frame_idx."""
+    import ctypes
+    L = milib.get()
+    code, td = DT[dt]
+    IH, IW, Ci, k, B = 39, 79, 32, 4, 3
+    OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
+    rng = np.random.RandomState(Co * 10 + kind)
+    x = rng.randn(B, IH, IW, Ci).astype(np.float32)
+    w = (rng.randn(k, k, Co, Ci) / np.sqrt(4 * Ci)).astype(np.float32)
+    b = (0.1 * rng.randn(Co)).astype(np.float32)
+    frames = rng.rand(5, OH * OW * Co).astype(np.float32)
+    idx = np.array([4, 0, 3], np.int32)
+    inv_b = 1.0 / 8.0
+    xr, wr = rounded(x, td), rounded(w, td)
+    y = F.conv_transpose2d(_nchw(xr), wr.permute(3, 2, 0, 1), torch.from_numpy(b).double(), stride=2)
+    logits_ref = rounded(_nhwc(y).float().numpy(), td).requires_grad_(True)            # the loss reads the STORED logits
+    t = torch.from_numpy(frames[idx]).double().reshape(B, OH, OW, Co)
+    if kind == 0:
+        per = torch.clamp(logits_ref, min=0) - logits_ref * t + torch.log1p(torch.exp(-logits_ref.abs()))
+    elif kind == 1:
+        sg = torch.sigmoid(logits_ref); per = -(t * torch.log(1e-10 + sg) + (1 - t) * torch.log(1e-10 + 1 - sg))
+    else:
+        per = (t - torch.sigmoid(logits_ref)) ** 2
+    (per.sum() * inv_b).backward()
+    cap = 4096
+    lp, bp = torch.zeros(cap, device="cuda"), torch.zeros(cap, 4, device="cuda")
+    logits = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
+    dl = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
+    n = ctypes.c_int(0)
+    L.mi_deconv2d_nhwc_fwd_bce(stream(), code, P(dev(x, td)), B, IH, IW, Ci, P(dev(w, td)), P(dev(b)), k, k, Co, logits.data_ptr(),
+                               P(dev(frames)), P(dev(idx, torch.int32)), OH * OW * Co, kind, inv_b, dl.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap,
+                               ctypes.addressof(n))
+    torch.cuda.synchronize()
+    assert 0 < n.value <= cap, "the 32 -> %d channel layer is eligible for the fused kernel" % Co
+    rt, at = tols(dt, float(logits_ref.abs().max()))
+    assert_close(host(logits), _nhwc(y).detach().numpy(), rt, at, "logits")
+    assert abs(float(lp[:n.value].double().sum()) / float(per.sum()) - 1) < (1e-5 if dt == "f32" else 3e-3)
+    rt, at = tols(dt, float(logits_ref.grad.abs().max()))
+    assert_close(host(dl), logits_ref.grad.numpy(), rt, at, "dlogits")
+    bias_ref = logits_ref.grad.sum((0, 1, 2)).numpy()
+    got = bp[:n.value, :Co].double().sum(0).cpu().numpy()
+    assert_close(got, bias_ref, 2e-3 if dt == "bf16" else 1e-5, 2e-3 * float(np.abs(bias_ref).max()) + 1e-7, "fused bias gradient")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_recon_loss_fwd_bwd(dt, kind):
     L = milib.get()
