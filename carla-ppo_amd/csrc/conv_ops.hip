@@ -157,7 +157,11 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     q.trace = g_trace; q.trace_cap = g_trace_cap;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
-    const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && false));
+    // measured (tools/trace_tapconv.py variants): the 128-position tile wins 5-12 % where the 256-position grid is only 1.3-3 rounds
+    // of blocks (tile quantisation), loses a little on the 4-column grids and ties on the big grids
+    const int gy_t = (q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64);
+    const bool auto_small = false && blocks >= 300 && blocks <= 1000 && gy_t <= 2;   // in the full step the gain of the isolated runs does not show: off
+    const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
     else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q, small_tile) : launch_tapconv<bf16_t, TC_GATHER>(st, q, small_tile);
