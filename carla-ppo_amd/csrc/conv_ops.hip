@@ -687,6 +687,12 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
 // nsplit > 1: split-K, raw fp32 partial slabs out[nsplit][M][N] (bias/act/mask must be unset; consumer reduces).
 int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const void* w, int w_layout, int N,
                      const float* bias, int relu, const void* mask, void* out, int out_f32, int nsplit) {
+    if (dtype == MI_F32 && w_layout == 0 && nsplit <= 1 && !mask && M <= 256 && K % 4 == 0 && gemm2_enabled() &&
+        ((((uintptr_t)a) | ((uintptr_t)out)) & 15) == 0) {                 // small-M fp32 dense layer (PPO): K split across the waves of a block
+        DenseSmallParams q = {(const float*)a, (const float*)w, bias, (float*)out, M, N, K, relu};
+        hipLaunchKernelGGL(dense_smallm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, q);
+        return mi_check_launch("dense_smallm_kernel");
+    }
     GemmParams p = {};
     p.a = a; p.a_frame_idx = nullptr;
     fill_conv_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);

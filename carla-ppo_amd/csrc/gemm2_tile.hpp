@@ -189,3 +189,63 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
 }
 
 }  // namespace mi
+
+namespace mi {
+
+// =====================================================================================================================
+// dense_smallm_kernel — out[M,N] = act(x[M,K] W[K,N] + b) in exact fp32 for SMALL M (the PPO minibatch: 32 rows).  The tile
+// kernels give such a layer 4 blocks that walk K serially (46-80 us, launch-latency class); here one block owns a 32 x 32 output
+// tile, its four waves each take a quarter of K (operands straight from global / L2: x rows as 16-byte vectors, W rows coalesced
+// across the 32 columns), and the four partial tiles meet in LDS.  ~3 us per layer.
+// =====================================================================================================================
+struct DenseSmallParams {
+    const float* x; const float* w; const float* bias; float* out;
+    int M, N, K, relu;
+};
+
+__global__ __launch_bounds__(256) void dense_smallm_kernel(const DenseSmallParams p) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lgrp = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int ksteps = (p.K + 7) / 8;                     // 8 k per step (two 4-float chunks: lane group g takes chunk g)
+    const int per = (ksteps + 3) / 4;
+    const int sb = wave * per, se = min(ksteps, sb + per);
+    const int m = m0 + lrow, n = n0 + lrow;
+    const bool mok = m < p.M, nok = n < p.N;
+    const float* xrow = p.x + (long long)(mok ? m : 0) * p.K;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s = sb; s < se; ++s) {
+        const int k = s * 8 + lgrp * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b;
+        if (mok && k + 4 <= p.K) a = *(const f32x4*)(xrow + k);
+        else if (mok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = k + e < p.K ? xrow[k + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (nok && k + e < p.K) ? p.w[(long long)(k + e) * p.N + n] : 0.f;
+        Frag<float>::mma(a, b, acc);                      // D[row = m][col = n]
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]));
+            const int mm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lgrp;
+            if (mm < p.M && nok) {
+                if (p.bias) v += p.bias[n];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.out[(long long)mm * p.N + n] = v;
+            }
+        }
+    }
+}
+
+}  // namespace mi
