@@ -95,6 +95,7 @@ int tapconv_minblocks() {
     return g_tap_min;
 }
 
+int g_tap_direct = 1;                                      // tapconv epilogue: 1 registers -> 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
 int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
 
 template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
@@ -155,12 +156,13 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
+    q.direct_epilogue = (g_tap_direct && N % 16 == 0) ? 1 : 0;
     q.trace = g_trace; q.trace_cap = g_trace_cap;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
     // measured (tools/trace_tapconv.py variants): the 128-position tile wins 5-12 % where the 256-position grid is only 1.3-3 rounds
     // of blocks (tile quantisation), loses a little on the 4-column grids and ties on the big grids
     const int gy_t = (q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64);
-    const bool auto_small = false && blocks >= 300 && blocks <= 1000 && gy_t <= 2;   // in the full step the gain of the isolated runs does not show: off
+    const bool auto_small = blocks >= 300 && blocks <= 1000 && gy_t <= 2;
     const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
@@ -546,6 +548,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
     else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
+    else if (key == 6) { prev = g_tap_direct; g_tap_direct = value ? 1 : 0; }
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");

@@ -85,16 +85,60 @@ __device__ __forceinline__ void store_tile(const P& p, const f32x16 (&acc)[TM][T
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 32 + lrow;
-        if (m >= M) continue;
+        const bool rowok = m < M;
         long long rowoff;
         if constexpr (AMODE == A_CONV) {
-            rowoff = ((long long)zslab * M + m) * p.N;
+            rowoff = ((long long)zslab * M + (rowok ? m : 0)) * p.N;
         } else {
             uint32_t b, rem, y, x;
-            p.dc_ohw[cls].divmod((uint32_t)m, b, rem);
+            p.dc_ohw[cls].divmod((uint32_t)(rowok ? m : 0), b, rem);
             p.dc_ow[cls].divmod(rem, y, x);
             rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
         }
+        if constexpr (sizeof(T) == 2) {
+            // bf16, whole 16-channel groups: pair the 4-channel groups of the two half-waves with v_permlane32_swap and write 16 bytes per
+            // lane (row-per-lane 8-byte stores are store-issue bound, see tapconv_tile.hpp); must be wave-uniform: all lanes swap
+            if ((p.N & 15) == 0 && !p.out_f32) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nt = n0 + (wn * TN + j) * 32;
+                    if (nt >= p.N) continue;              // wave-uniform
+#pragma unroll
+                    for (int mq = 0; mq < 2; ++mq) {
+                        float va[4], vb[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { va[t] = acc[i][j][8 * mq + t]; vb[t] = acc[i][j][8 * mq + 4 + t]; }
+                        if (p.bias) {
+                            const f32x4 ba = *(const f32x4*)(p.bias + nt + 4 * lgrp + 16 * mq), bb = *(const f32x4*)(p.bias + nt + 4 * lgrp + 16 * mq + 8);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { va[t] += ba[t]; vb[t] += bb[t]; }
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { va[t] = fmaxf(va[t], 0.f); vb[t] = fmaxf(vb[t], 0.f); }
+                        }
+                        const PackN<T, 4> pa = pack4<T>(va), pb = pack4<T>(vb);
+                        uint32_t ax = (uint32_t)pa.v[0] | ((uint32_t)pa.v[1] << 16), ay = (uint32_t)pa.v[2] | ((uint32_t)pa.v[3] << 16);
+                        uint32_t bx = (uint32_t)pb.v[0] | ((uint32_t)pb.v[1] << 16), by = (uint32_t)pb.v[2] | ((uint32_t)pb.v[3] << 16);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = r0[0]; bx = r0[1];
+                        auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = r1[0]; by = r1[1];
+                        const long long off = rowoff + nt + 16 * mq + 8 * lgrp;
+                        uint32_t w4[4] = {ax, ay, bx, by};
+                        if (maskp) {
+                            const PackN<uint32_t, 4> mk = *(const PackN<uint32_t, 4>*)(maskp + (rowok ? off : 0));
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const short lo = (short)(mk.v[d] & 0xffffu), hi = (short)(mk.v[d] >> 16);
+                                w4[d] = (lo > 0 ? w4[d] & 0xffffu : 0u) | (hi > 0 ? w4[d] & 0xffff0000u : 0u);
+                            }
+                        }
+                        if (rowok) *(PackN<uint32_t, 4>*)((T*)p.out + off) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
+                    }
+                }
+                continue;
+            }
+        }
+        if (!rowok) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll

@@ -38,6 +38,7 @@ struct TapParams {
     int ldb;                         // conv form: row pitch (elements) of the K-contiguous weight copy [N][KH*KW*C]
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     void* out; const float* bias; const void* mask; int relu;
+    int direct_epilogue;             // 1: registers -> 16-byte stores (half-wave swap), 0: LDS-staged coalesced stores
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
     // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
     const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
@@ -332,6 +333,84 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
         if (cc + 1 < NCC) slice_body(cc + 1, std::integral_constant<int, 1>());
     }
 
+    if (p.direct_epilogue) {
+        // ---------------- direct epilogue: per lane one position (col lrow of each 32-position subtile); the 4-channel groups q of a
+        // 32-output tile alternate between the two half-waves (lane: channels 8q+4*lgrp ..+3), so one v_permlane32_swap per dword turns
+        // each PAIR of groups into 16 contiguous bytes per lane (lower half: channels 16m..16m+7, upper half: 16m+8..16m+15): two
+        // 16-byte stores per tile instead of an LDS round trip with two block barriers (fp32: a group already is 16 bytes).
+        TC_STAMP();
+        const T* __restrict__ maskp = (const T*)p.mask;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int P = P0 + (wm * TM + i) * 32 + lrow;
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
+            p.div_g.divmod(g, b, gy);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ne0 = n0 + (wn * TN + j) * 32;  // wave-uniform; a 32-wide output tile never straddles a parity class
+                int oy, ox, nb;
+                if constexpr (MODE == TC_CONV) { oy = (int)gy; ox = (int)gx; nb = ne0; }
+                else {
+                    const uint32_t cls = p.div_n.div((uint32_t)ne0);
+                    nb = ne0 - (int)cls * p.N;
+                    oy = 2 * (int)gy + (int)(cls >> 1); ox = 2 * (int)gx + (int)(cls & 1);
+                }
+                const bool ok = P < p.MP && ne0 < p.NE && oy < p.OH && ox < p.OW;
+                const long long rowoff = (((long long)b * p.OH + oy) * p.OW + ox) * p.N + nb;
+                float v[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[q][t] = acc[i][j][4 * q + t];
+                    if (p.bias) {
+                        const f32x4 bb = *(const f32x4*)(p.bias + nb + 4 * lgrp + 8 * q);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[q][t] += bb[t];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[q][t] = fmaxf(v[q][t], 0.f);
+                    }
+                }
+                if constexpr (ESZ == 2) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        PackN<T, 4> pa = pack4<T>(v[2 * m]), pb = pack4<T>(v[2 * m + 1]);
+                        uint32_t ax = (uint32_t)pa.v[0] | ((uint32_t)pa.v[1] << 16), ay = (uint32_t)pa.v[2] | ((uint32_t)pa.v[3] << 16);
+                        uint32_t bx = (uint32_t)pb.v[0] | ((uint32_t)pb.v[1] << 16), by = (uint32_t)pb.v[2] | ((uint32_t)pb.v[3] << 16);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = r0[0]; bx = r0[1];
+                        auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = r1[0]; by = r1[1];
+                        const long long off = rowoff + 16 * m + 8 * lgrp;      // lower half: channels 16m.., upper half: 16m+8..
+                        uint32_t w4[4] = {ax, ay, bx, by};
+                        if (maskp) {
+                            const PackN<uint32_t, 4> mk = *(const PackN<uint32_t, 4>*)(maskp + (ok ? off : 0));
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {           // bf16 > 0  <=>  signed 16-bit pattern > 0
+                                const short lo = (short)(mk.v[d] & 0xffffu), hi = (short)(mk.v[d] >> 16);
+                                w4[d] = (lo > 0 ? w4[d] & 0xffffu : 0u) | (hi > 0 ? w4[d] & 0xffff0000u : 0u);
+                            }
+                        }
+                        if (ok) *(PackN<uint32_t, 4>*)((T*)p.out + off) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long long off = rowoff + 4 * lgrp + 8 * q;
+                        PackN<T, 4> o = pack4<T>(v[q]);
+                        if (maskp) {
+                            const PackN<T, 4> mk = *(const PackN<T, 4>*)(maskp + (ok ? off : 0));
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
+                        }
+                        if (ok) *(PackN<T, 4>*)((T*)p.out + off) = o;
+                    }
+                }
+            }
+        }
+        TC_STAMP();
+        return;
+    }
     TC_STAMP();
     // ---------------- epilogue: accumulators -> LDS [position][output] -> full-line coalesced 16-byte stores ----------------
     // (a row-per-lane store of 8 bytes per lane at a 64..256-byte stride is store-ISSUE bound: 7-17k cycles per block measured
