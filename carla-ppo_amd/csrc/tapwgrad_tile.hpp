@@ -258,7 +258,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                     u16x8 af;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { af[e] = (unsigned short)alo[e]; af[4 + e] = (unsigned short)ahi[e]; }
-                    // conv form: D[row = channel][col = output] (HWIO: outputs contiguous); gather form: D[row = output][col = channel]
+                    // orientation: the 32 lanes of a register are 32 CONTIGUOUS elements of dW (coalesced 128-byte stores into the slabs):
+                    // conv form (HWIO): rows = channels, col = output; gather form ([kh,kw,N,C]): rows = outputs, col = channel.
+                    // (the transposed choice gives 16-byte stores per lane but at a 256..1024-byte stride: measured 40 % slower on conv2)
                     if constexpr (MODE == TC_CONV)
                         acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, df), acc[q][kt], 0, 0, 0);
                     else
@@ -269,8 +271,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     }
 
     TW_STAMP();
+    const int lcol = lane & 31, lgrp = lane >> 5;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
+    for (int q = 0; q < PPW; ++q) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
         if (!pr_bias[q] || lane >= 32) continue;
         const int ne = ne0 + pr_nt[q] * 32 + lane;
         if (ne >= p.NE) continue;
@@ -278,8 +281,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         if constexpr (MODE == TC_GATHER) n = ne - (int)p.div_n.div((uint32_t)ne) * p.N;
         atomicAdd(&p.dbias[n], accb[q][0]);
     }
-    // ---------------- accumulate into dW (fp32 atomics; a wave's 32 lanes of one register hit 128 contiguous bytes) ----------------
-    const int lcol = lane & 31, lgrp = lane >> 5;
+    // ---------------- dW: register r of a lane is row (r&3) + 8(r>>2) + 4 lgrp, column lcol; the row -> kernel-tap decode is done once
+    // per group of 4 registers (4 consecutive rows share it: C and N are multiples of 4) ----------------
+    float* const dst = p.slabs ? p.slabs + (long long)blockIdx.x * p.slab_stride : p.out;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         if (!pr_on[q]) continue;
@@ -287,28 +291,36 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lgrp;
-                long long idx; bool ok;
-                if constexpr (MODE == TC_CONV) {
-                    const int kc = kc0 + kt * 32 + rr, ne = ne0 + pr_nt[q] * 32 + lcol;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int row = 8 * g4 + 4 * lgrp;
+                long long base; bool ok;
+                if constexpr (MODE == TC_CONV) {          // rows = channels kc = (ph, pw, c); column = output
+                    const int kc = kc0 + kt * 32 + row, ne = ne0 + pr_nt[q] * 32 + lcol;
                     uint32_t phh, rem, pww, c;
-                    p.div_2c.divmod((uint32_t)kc, phh, rem);
+                    p.div_2c.divmod((uint32_t)(kc < p.KC ? kc : 0), phh, rem);
                     p.div_c.divmod(rem, pww, c);
                     const int kh = 2 * ta + (int)phh, kw = 2 * tb + (int)pww;
                     ok = kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
-                    idx = ((long long)(kh * p.KW + kw) * p.C + c) * p.N + ne;
-                } else {
-                    const int ne = ne0 + pr_nt[q] * 32 + rr, kc = kc0 + kt * 32 + lcol;
+                    base = ((long long)(kh * p.KW + kw) * p.C + c) * p.N + ne;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!ok) continue;
+                        if (p.slabs) dst[base + (long long)t * p.N] = acc[q][kt][4 * g4 + t];
+                        else atomicAdd(dst + base + (long long)t * p.N, acc[q][kt][4 * g4 + t]);
+                    }
+                } else {                                  // rows = outputs ne = (class, n); column = channel
+                    const int ne = ne0 + pr_nt[q] * 32 + row, kc = kc0 + kt * 32 + lcol;
                     uint32_t cls, n;
-                    p.div_n.divmod((uint32_t)ne, cls, n);
+                    p.div_n.divmod((uint32_t)(ne < p.NE ? ne : 0), cls, n);
                     const int kh = (int)(cls >> 1) + 2 * (p.HY - ta), kw = (int)(cls & 1) + 2 * (p.HX - tb);
                     ok = kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
-                    idx = ((long long)(kh * p.KW + kw) * p.N + n) * p.C + kc;
-                }
-                if (ok) {
-                    if (p.slabs) p.slabs[(long long)blockIdx.x * p.slab_stride + idx] = acc[q][kt][r];
-                    else atomicAdd(&p.out[idx], acc[q][kt][r]);
+                    base = ((long long)(kh * p.KW + kw) * p.N + n) * p.C + kc;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!ok) continue;
+                        if (p.slabs) dst[base + (long long)t * p.C] = acc[q][kt][4 * g4 + t];
+                        else atomicAdd(dst + base + (long long)t * p.C, acc[q][kt][4 * g4 + t]);
+                    }
                 }
             }
         }
