@@ -47,6 +47,7 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
 // ---------------------------------------------------------------------------------------------------------------
 long long* g_trace = nullptr; int g_trace_cap = 0;
 int g_wgrad_skip = 0;
+int g_tap_stagger = 0;
 int g_gemm2_on = -1;
 int g_tap_min = -2;
 bool gemm2_enabled() {
@@ -95,7 +96,7 @@ int tapconv_minblocks() {
     return g_tap_min;
 }
 
-int g_tap_direct = 1;                                      // tapconv epilogue: 1 registers -> 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
+int g_tap_direct = 2;                                      // tapconv epilogue: 2 registers -> quad-transposed 16-byte stores (whole 64-byte lines), 1 -> per-pixel 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
 int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
 
 template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
@@ -156,7 +157,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
-    q.direct_epilogue = (g_tap_direct && N % 16 == 0) ? 1 : 0;
+    q.direct_epilogue = (g_tap_direct && N % 32 == 0) ? g_tap_direct : 0;       // a 32-output tile is all valid or all out of range
     q.trace = g_trace; q.trace_cap = g_trace_cap;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
     // measured (tools/trace_tapconv.py variants): the 128-position tile wins 5-12 % where the 256-position grid is only 1.3-3 rounds
@@ -164,6 +165,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     const int gy_t = (q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64);
     const bool auto_small = blocks >= 300 && blocks <= 1000 && gy_t <= 2;
     const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
+    q.stagger = (!small_tile && blocks >= 512) ? g_tap_stagger : 0;   // one block per CU and at least two rounds
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
     else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q, small_tile) : launch_tapconv<bf16_t, TC_GATHER>(st, q, small_tile);
@@ -175,6 +177,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // mi_set_tuning key 3 / MI355_TAPWGRAD=0 disables it.
 // ---------------------------------------------------------------------------------------------------------------
 int g_tapwgrad_on = -1;
+int g_tapwgrad_split = 1;
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
     return g_tapwgrad_on != 0;
@@ -229,23 +232,36 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out;
-    q.trace = g_trace; q.trace_cap = g_trace_cap;
-    // partial sums per split in the caller's scratch (plain stores + one deterministic reduce) when it is large enough;
-    // otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
-    const long long n_out = (long long)KH * KW * C * N;
-    q.slabs = nullptr; q.slab_stride = n_out;
-    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && scratch_bytes >= (long long)splits * n_out * 4) q.slabs = (float*)scratch;
+    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg_cheap_addr = g_wgrad_skip == 2;
+    // partial sums per split in the caller's scratch (accumulator-order 16-byte stores + one reduce that does the dW index decode)
+    // when it is large enough; otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
+    const int kt_tiles = taps == 2 ? 4 : 2;
+    const long long slab_floats = (long long)gy * q.npairs * kt_tiles * 1024;
+    q.slabs = nullptr; q.slab_stride = slab_floats;
+    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * 4 && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
     dim3 g(splits, gy, 1);
-    if (mode == TC_CONV) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
-    else if (taps == 2) hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+    const bool split = g_tapwgrad_split && taps == 2 && q.npairs == 8;   // wave = (tap, position half): fewer LDS reads per MFMA
+    if (mode == TC_CONV) {
+        if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        else hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+    } else if (taps == 2) {
+        if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        else hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+    }
     else {
         if (q.npairs > 32) return 0;
         hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
     int rc = mi_check_launch("tapwgrad_kernel");
     if (rc == MI_OK && q.slabs) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(n_out, splits), dim3(256), 0, st, q.slabs, q.slab_stride, splits, n_out, out);
-        rc = mi_check_launch("reduce_slabs_kernel");
+        const int ngroups = (int)(slab_floats / 4);
+        unsigned ry = 1;                                  // slabs per thread chain: keep about 512 blocks in flight
+        while ((unsigned)(ngroups / 256 + 1) * ry < 512 && (int)(ry * 2) <= splits / 4) ry *= 2;
+        const dim3 rg((unsigned)((ngroups + 255) / 256), ry, 1);
+        if (mode == TC_CONV) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, q, splits, ngroups);
+        else if (taps == 2) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, q, splits, ngroups);
+        else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, q, splits, ngroups);
+        rc = mi_check_launch("reduce_tiled_kernel");
     }
     return rc == MI_OK ? 1 : rc;
 }
@@ -548,9 +564,11 @@ int mi_set_tuning(int key, int value) {
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
     else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
-    else if (key == 6) { prev = g_tap_direct; g_tap_direct = value ? 1 : 0; }
+    else if (key == 6) { prev = g_tap_direct; g_tap_direct = value < 0 || value > 2 ? 2 : value; }
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
+    else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }
+    else if (key == 8) { prev = g_tap_stagger; g_tap_stagger = value < 0 ? 0 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

@@ -40,6 +40,7 @@ struct TapParams {
     void* out; const float* bias; const void* mask; int relu;
     int direct_epilogue;             // 1: registers -> 16-byte stores (half-wave swap), 0: LDS-staged coalesced stores
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
+    int stagger;                       // cycles the first-round blocks on odd CUs wait before starting (0 = off), see tapconv_kernel
     // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
     const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
     int loss_kind; float inv_b;
@@ -86,6 +87,16 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     long long* const tr = p.trace ? p.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (tid >> 6)) * 32 : nullptr;   // 8 wave slots per block in the trace layout
     const bool tr_on = tr && ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
 #define TC_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    // Every block does the same work, so the 256 CUs run in lockstep: all load, all compute, all store -- the store burst of a round
+    // (256 x 64 KB) runs at the HBM write rate while no MFMA is busy, and vice versa.  Delaying the FIRST block of every second CU by
+    // about half a block period puts the two halves of the chip in anti-phase for the rest of the launch (all periods are equal).
+    if (p.stagger > 0 && blockIdx.y * gridDim.x + blockIdx.x < 256) {
+        const unsigned cu = __builtin_amdgcn_s_getreg((3 << 11) | (8 << 6) | 4);   // HW_ID.cu_id
+        if (cu & 1) {
+            const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     TC_STAMP();
     const int P0 = xcd_remap(blockIdx.x, gridDim.x) * BMT;
     const int n0 = blockIdx.y * BNE;
@@ -207,13 +218,6 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
 
     // ---------------- main loop over (channel slice, tap) steps ----------------
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     // Double-buffered pipeline, one barrier per step of TPS taps (32 MFMAs per wave): at the top of a step everything issued
     // during the previous step has had >= 2k cycles to land; the next step's weight tiles and a share of the next channel
     // slice of the slot range are issued right after the barrier.
@@ -328,82 +332,151 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
             }
         }
     };
+    // the accumulators start at the bias of their output channel (register r of a lane: channel 4 lgrp + 8 (r >> 2) + (r & 3) of the
+    // 32-output tile): no bias loads between the stores of the epilogue -- a load there makes the wave wait for the stores before it
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x16 b16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = 0.f;
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ne = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
+                if (ne < p.NE) {
+                    int nb = ne;
+                    if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)ne) * p.N;
+                    const f32x4 bb = *(const f32x4*)(p.bias + nb);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b16[4 * q + t] = bb[t];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = b16;
+    }
     for (int cc = 0; cc < NCC; cc += 2) {
         slice_body(cc, std::integral_constant<int, 0>());
         if (cc + 1 < NCC) slice_body(cc + 1, std::integral_constant<int, 1>());
     }
 
     if (p.direct_epilogue) {
-        // ---------------- direct epilogue: per lane one position (col lrow of each 32-position subtile); the 4-channel groups q of a
-        // 32-output tile alternate between the two half-waves (lane: channels 8q+4*lgrp ..+3), so one v_permlane32_swap per dword turns
-        // each PAIR of groups into 16 contiguous bytes per lane (lower half: channels 16m..16m+7, upper half: 16m+8..16m+15): two
-        // 16-byte stores per tile instead of an LDS round trip with two block barriers (fp32: a group already is 16 bytes).
+        // ---------------- direct epilogue (bias is already in the accumulators) ----------------
+        // Per lane one position (col lrow of each 32-position subtile); the 4-channel groups g of a 32-output tile alternate between
+        // the two half-waves (lane: channels 8g + 4 lgrp ..+3).
+        //   mode 1: one v_permlane32_swap per dword turns each PAIR of groups into 16 contiguous bytes per lane (lower half: channels
+        //           16m .. 16m+7, upper half: 16m+8 .. 16m+15): two 16-byte stores per subtile, 64 separate 16-byte pieces per instruction.
+        //   mode 2: three lane-bit <-> register-bit exchanges (g0 <-> lane bit 0 and g1 <-> lane bit 1 by quad DPP, q0 <-> half-wave by
+        //           v_permlane32_swap) leave lane (c = lane & 3, h' = lane >> 5) with channels 8c .. 8c+7 of pixel 4k + 2s + h' in slot s:
+        //           the four lanes of a quad write the four 16-byte chunks of ONE pixel's 64 bytes.
+        // Phase 1 computes every store address and issues ALL ReluGrad-mask loads; phase 2 only converts and stores.  (A load between the
+        // stores makes the wave wait for the acknowledgement of the stores before it -- vmcnt counts both: 8k cycles per block measured.)
         TC_STAMP();
         const T* __restrict__ maskp = (const T*)p.mask;
+        constexpr bool PK = ESZ == 2;                      // 16-byte units of 8 bf16; fp32: a 4-channel group already is 16 bytes
+        constexpr int NU = PK ? 2 : 4;                     // store units per subtile and lane
+        const bool quad = PK && p.direct_epilogue == 2;
+        uint32_t uoff[TM][TN][NU]; bool uok[TM][TN][NU];
+        PackN<uint32_t, 4> umk[TM][TN][NU];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int P = P0 + (wm * TM + i) * 32 + lrow;
-            uint32_t g, gx, b, gy;
-            p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
-            p.div_g.divmod(g, b, gy);
+            // pixel(s) this lane stores: its own column of the subtile, or (quad) pixels 4k + 2u + (lane >> 5)
+            uint32_t pb[2], pgy[2], pgx[2]; bool pin[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int P = P0 + (wm * TM + i) * 32 + (quad ? (lrow & ~3) + 2 * u + lgrp : lrow);
+                pin[u] = P < p.MP;
+                uint32_t g;
+                p.div_gw.divmod((uint32_t)(pin[u] ? P : 0), g, pgx[u]);
+                p.div_g.divmod(g, pb[u], pgy[u]);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ne0 = n0 + (wn * TN + j) * 32;  // wave-uniform; a 32-wide output tile never straddles a parity class
-                int oy, ox, nb;
-                if constexpr (MODE == TC_CONV) { oy = (int)gy; ox = (int)gx; nb = ne0; }
-                else {
+                int nb = ne0, dy = 0, dx = 0;
+                if constexpr (MODE == TC_GATHER) {
                     const uint32_t cls = p.div_n.div((uint32_t)ne0);
-                    nb = ne0 - (int)cls * p.N;
-                    oy = 2 * (int)gy + (int)(cls >> 1); ox = 2 * (int)gx + (int)(cls & 1);
+                    nb = ne0 - (int)cls * p.N; dy = (int)(cls >> 1); dx = (int)(cls & 1);
                 }
-                const bool ok = P < p.MP && ne0 < p.NE && oy < p.OH && ox < p.OW;
-                const long long rowoff = (((long long)b * p.OH + oy) * p.OW + ox) * p.N + nb;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int s = quad ? u : 0;
+                    const int oy = MODE == TC_CONV ? (int)pgy[s] : 2 * (int)pgy[s] + dy, ox = MODE == TC_CONV ? (int)pgx[s] : 2 * (int)pgx[s] + dx;
+                    uok[i][j][u] = pin[s] && ne0 < p.NE && oy < p.OH && ox < p.OW;
+                    const uint32_t ch = quad ? 8 * (lane & 3) : PK ? 16 * u + 8 * lgrp : 4 * lgrp + 8 * u;
+                    uoff[i][j][u] = uok[i][j][u] ? ((pb[s] * p.OH + oy) * p.OW + ox) * p.N + nb + ch : 0u;   // < 2^31 elements (host check)
+                    if (maskp) umk[i][j][u] = *(const PackN<uint32_t, 4>*)(maskp + uoff[i][j][u]);            // offset 0 is always readable
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
                 float v[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[q][t] = acc[i][j][4 * q + t];
-                    if (p.bias) {
-                        const f32x4 bb = *(const f32x4*)(p.bias + nb + 4 * lgrp + 8 * q);
+                    for (int t = 0; t < 4; ++t) v[g][t] = p.relu ? fmaxf(acc[i][j][4 * g + t], 0.f) : acc[i][j][4 * g + t];
+                if constexpr (PK) {
+                    uint32_t w[4][2];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[q][t] += bb[t];
+                    for (int g = 0; g < 4; ++g) {
+                        const PackN<T, 4> pk = pack4<T>(v[g]);
+                        w[g][0] = (uint32_t)pk.v[0] | ((uint32_t)pk.v[1] << 16); w[g][1] = (uint32_t)pk.v[2] | ((uint32_t)pk.v[3] << 16);
                     }
-                    if (p.relu) {
+                    if (quad) {
+                        const bool b0 = lane & 1;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[q][t] = fmaxf(v[q][t], 0.f);
+                        for (int x = 0; x < 2; ++x)             // register bit g0 <-> lane bit 0
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const uint32_t a = w[2 * x][d], b = w[2 * x + 1][d];
+                                const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b0 ? a : b), 0xB1, 0xF, 0xF, true);
+                                w[2 * x][d] = b0 ? t : a; w[2 * x + 1][d] = b0 ? b : t;
+                            }
                     }
-                }
-                if constexpr (ESZ == 2) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        PackN<T, 4> pa = pack4<T>(v[2 * m]), pb = pack4<T>(v[2 * m + 1]);
-                        uint32_t ax = (uint32_t)pa.v[0] | ((uint32_t)pa.v[1] << 16), ay = (uint32_t)pa.v[2] | ((uint32_t)pa.v[3] << 16);
-                        uint32_t bx = (uint32_t)pb.v[0] | ((uint32_t)pb.v[1] << 16), by = (uint32_t)pb.v[2] | ((uint32_t)pb.v[3] << 16);
-                        auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = r0[0]; bx = r0[1];
-                        auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = r1[0]; by = r1[1];
-                        const long long off = rowoff + 16 * m + 8 * lgrp;      // lower half: channels 16m.., upper half: 16m+8..
-                        uint32_t w4[4] = {ax, ay, bx, by};
+                    for (int x = 0; x < 2; ++x)                 // register bit 0 (g0, or q0 after the exchange above) <-> half-wave
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
+                            w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
+                        }
+                    if (quad) {
+                        const bool b1 = lane & 2;
+#pragma unroll
+                        for (int x = 0; x < 2; ++x)             // register bit g1 <-> lane bit 1
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const uint32_t a = w[x][d], b = w[2 + x][d];
+                                const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b1 ? a : b), 0x4E, 0xF, 0xF, true);
+                                w[x][d] = b1 ? t : a; w[2 + x][d] = b1 ? b : t;
+                            }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {               // unit u = registers (2u, 2u + 1)
+                        uint32_t w4[4] = {w[2 * u][0], w[2 * u][1], w[2 * u + 1][0], w[2 * u + 1][1]};
                         if (maskp) {
-                            const PackN<uint32_t, 4> mk = *(const PackN<uint32_t, 4>*)(maskp + (ok ? off : 0));
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) {           // bf16 > 0  <=>  signed 16-bit pattern > 0
-                                const short lo = (short)(mk.v[d] & 0xffffu), hi = (short)(mk.v[d] >> 16);
+                            for (int d = 0; d < 4; ++d) {       // bf16 > 0  <=>  signed 16-bit pattern > 0
+                                const uint32_t mkd = umk[i][j][u].v[d];
+                                const short lo = (short)(mkd & 0xffffu), hi = (short)(mkd >> 16);
                                 w4[d] = (lo > 0 ? w4[d] & 0xffffu : 0u) | (hi > 0 ? w4[d] & 0xffff0000u : 0u);
                             }
                         }
-                        if (ok) *(PackN<uint32_t, 4>*)((T*)p.out + off) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
+                        if (uok[i][j][u]) *(PackN<uint32_t, 4>*)((T*)p.out + uoff[i][j][u]) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const long long off = rowoff + 4 * lgrp + 8 * q;
-                        PackN<T, 4> o = pack4<T>(v[q]);
+                    for (int u = 0; u < 4; ++u) {
+                        PackN<T, 4> o = pack4<T>(v[u]);
                         if (maskp) {
-                            const PackN<T, 4> mk = *(const PackN<T, 4>*)(maskp + (ok ? off : 0));
+                            const PackN<T, 4> mk = __builtin_bit_cast(PackN<T, 4>, umk[i][j][u]);
 #pragma unroll
                             for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
                         }
-                        if (ok) *(PackN<T, 4>*)((T*)p.out + off) = o;
+                        if (uok[i][j][u]) *(PackN<T, 4>*)((T*)p.out + uoff[i][j][u]) = o;
                     }
                 }
             }
@@ -449,15 +522,6 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
                 float v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
-                if (p.bias) {
-                    int nb = n0 + cn;
-                    if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)nb) * p.N;
-                    if (n0 + cn < p.NE) {
-                        const f32x4 bb = *(const f32x4*)(p.bias + nb);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] += bb[t];
-                    }
-                }
                 if (p.relu) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);

@@ -15,6 +15,7 @@
 //   * one block per CU: the reduction over positions is split ~256 ways in total, 4x fewer fp32 atomics than wgrad_kernel.
 // fp32 (parity mode) stays on wgrad_kernel: the transpose read is a 16-bit instruction.
 #pragma once
+#include <type_traits>
 #include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"
 
@@ -41,6 +42,7 @@ struct TapWgradParams {
     float* out;
     float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
     long long* trace; int trace_cap;   // debug stamps (mi_debug_set_trace)
+    int dbg_cheap_addr;                // debug (mi_set_tuning key 2 == 2): trivial DMA addresses, wrong results, shows the cost of the address arithmetic
 };
 
 // LDS-DMA issued through inline asm: hipcc drains every builtin LDS-DMA (s_waitcnt vmcnt(0)) in front of the next
@@ -65,10 +67,37 @@ template <int CPR> __device__ __forceinline__ int tw_swz(int row) {
     return CPR == 16 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;
 }
 
+// dW element of accumulator row group (rows row .. row + 3 at column lcol) of the tile (tap, kt, nt) of block column (kc0, ne0):
+// index of the first of the 4 rows, the stride between them, and whether the group exists (C and N are multiples of 4)
+template <int MODE, int TAPS>
+__device__ __forceinline__ bool tw_dw_index(const TapWgradParams& p, int kc0, int ne0, int tap, int kt, int nt, int row, int lcol, long long& base, long long& stride) {
+    const int ta = tap / TAPS, tb = tap % TAPS;
+    if constexpr (MODE == TC_CONV) {                      // rows = channels kc = (ph, pw, c); column = output
+        const int kc = kc0 + kt * 32 + row, ne = ne0 + nt * 32 + lcol;
+        uint32_t phh, rem, pww, c;
+        p.div_2c.divmod((uint32_t)(kc < p.KC ? kc : 0), phh, rem);
+        p.div_c.divmod(rem, pww, c);
+        const int kh = 2 * ta + (int)phh, kw = 2 * tb + (int)pww;
+        base = ((long long)(kh * p.KW + kw) * p.C + c) * p.N + ne; stride = p.N;
+        return kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
+    } else {                                              // rows = outputs ne = (class, n); column = channel
+        const int ne = ne0 + nt * 32 + row, kc = kc0 + kt * 32 + lcol;
+        uint32_t cls, n;
+        p.div_n.divmod((uint32_t)(ne < p.NE ? ne : 0), cls, n);
+        const int kh = (int)(cls >> 1) + 2 * (p.HY - ta), kw = (int)(cls & 1) + 2 * (p.HX - tb);
+        base = ((long long)(kh * p.KW + kw) * p.N + n) * p.C + kc; stride = p.C;
+        return kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
+    }
+}
+
 // MODE: TC_CONV | TC_GATHER;  KT: 32-channel tiles per block (KCB = 32 KT);  NTB: 32-output tiles per block (NEB = 32 NTB);
 // PPW: (tap, output tile) pairs per wave (accumulators: PPW * KT tiles)
-template <int MODE, int TAPS, int KT, int NTB, int PPW>
+// SPLIT (needs 4 taps x NTB == 2, PPW == NTB): wave = (tap, position half); a wave keeps the KT x NTB tiles of its tap over its 64
+// positions of every step, so a slot fragment is read from LDS once for both output tiles (48 instead of 80 transpose reads per
+// 32 MFMAs); the two halves meet in LDS at the end.
+template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false>
 __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p) {
+    static_assert(!SPLIT || (TAPS == 2 && NTB == 2 && PPW == NTB), "split layout: 4 taps x 2 position halves = 8 waves");
     typedef bf16_t T;
     constexpr int ESZ = 2, VE = 8;
     constexpr int KCB = 32 * KT, NEB = 32 * NTB;
@@ -135,6 +164,13 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
         const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (p.dbg_cheap_addr) {
+            const int t = wave + 8 * (idx < NIA ? idx : idx - NIA);
+            if (idx < NIA && t >= ninstrA) return;
+            const uint32_t vo = (uint32_t)((Ps * 64 + t * 1024 + lane * 16) & 0xFFFFF);
+            if (idx < NIA) dma16_asm(rsA, As + t * 1024, vo); else dma16_asm(rsD, Ds + t * 1024, vo);
+            return;
+        }
         if (idx < NIA) {
             const int t = wave + 8 * idx;
             if (t >= ninstrA) return;                     // wave-uniform
@@ -173,23 +209,30 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
             dma16_asm(rsD, Ds + t * 1024, vo);
         }
     };
-    constexpr int NDMA = NIA + NID, NKS = TW_BP / 16;
+    constexpr int NDMA = NIA + NID, NKS = SPLIT ? TW_BP / 32 : TW_BP / 16;   // k16-steps a wave runs per position step
 
     // ---------------- this wave's (tap, output tile) pairs and their per-lane transpose-read offsets ----------------
     // transpose read (see tr_fragment in wgrad_tile.hpp): lane l supplies row r0 + (l>>5)*8 + ((l&15)>>2) (+4 for the high half),
     // element column e0 + ((l>>4)&1)*16 + (l&3)*4, and receives 8 consecutive rows of column e0 + (l & 31).
-    const int trow = (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int trow0 = (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int tcol = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
     int pr_tap[PPW], pr_nt[PPW];
     bool pr_on[PPW], pr_bias[PPW];
     uint32_t aoff[PPW][KT], doff[PPW];
+    const int half = SPLIT ? (wave & 1) : 0;             // SPLIT: positions 64 half .. 64 half + 63 of every step
+    const int trow = trow0 + 64 * half;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        const int pi = wave + 8 * q;
-        pr_on[q] = pi < p.npairs;
-        pr_tap[q] = pr_on[q] ? p.pair_tap[pi] : 0;
-        pr_nt[q] = pr_on[q] ? p.pair_nt[pi] : 0;
-        pr_bias[q] = pr_on[q] && p.dbias && kb == 0 && p.pair_first[pi];
+        if constexpr (SPLIT) {
+            pr_on[q] = true; pr_tap[q] = wave >> 1; pr_nt[q] = q;
+            pr_bias[q] = p.dbias && kb == 0 && (wave >> 1) == 0;
+        } else {
+            const int pi = wave + 8 * q;
+            pr_on[q] = pi < p.npairs;
+            pr_tap[q] = pr_on[q] ? p.pair_tap[pi] : 0;
+            pr_nt[q] = pr_on[q] ? p.pair_nt[pi] : 0;
+            pr_bias[q] = pr_on[q] && p.dbias && kb == 0 && p.pair_first[pi];
+        }
         const int ta = pr_tap[q] / TAPS, tb = pr_tap[q] % TAPS;
         const int row = trow + ta * p.GW + tb;            // + 16 per k-step and + 4 for the high half keep (row & 3)
 #pragma unroll
@@ -225,51 +268,72 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
     TW_STAMP();
-    for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the step's tiles has landed ...
-        __syncthreads();                                  // ... and so has everybody else's; the other stage is free
-        if (step < 4) TW_STAMP();
-        const bool more = step + 1 < nsteps;
-        const uint32_t sbase = (uint32_t)(cur * STAGE);
+    // One "unit" = the fragments one group of MFMAs needs: (k16-step, pair) in the pair layout (1 gradient + KT slot fragments,
+    // KT MFMAs), a whole k16-step in the split layout (NTB gradient + KT slot fragments, NTB KT MFMAs).  The fragments of unit
+    // u + 1 are read from LDS BEFORE the MFMAs of unit u are issued (explicit register double buffering): with two waves per
+    // SIMD nothing else hides the ~100+ cycles of a transpose read.
+    constexpr int ND = SPLIT ? PPW : 1;
+    constexpr int NU = SPLIT ? NKS : NKS * PPW;
+    constexpr int NKI = NKS;                              // k16-steps that carry DMA issue (bunching them into the first half: measured 8 % slower)
+    constexpr bool PIPE = SPLIT || PPW <= 2;              // the 9-tap config (4 pairs + 4 bias accumulators per wave) has no registers left for it
+    struct Frag { u16x8 d[ND]; u16x8 a[KT]; };
+    auto tr_read = [&](uint32_t off, int pitch) -> u16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + off + 4 * pitch));
+        u16x8 f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (more) {                                   // next step's loads, a few per MFMA group
+        for (int e = 0; e < 4; ++e) { f[e] = (unsigned short)lo[e]; f[4 + e] = (unsigned short)hi[e]; }
+        return f;
+    };
+    auto load_unit = [&](Frag& f, uint32_t sbase, int u) {
+        const int ks = SPLIT ? u : u / PPW, q = SPLIT ? 0 : u % PPW;
 #pragma unroll
-                for (int i = ks; i < NDMA; i += NKS) issue_one(step + 1, cur ^ 1, i);
-            }
+        for (int j = 0; j < ND; ++j) f.d[j] = tr_read(sbase + doff[SPLIT ? j : q] + ks * 16 * PD, PD);
 #pragma unroll
-            for (int q = 0; q < PPW; ++q) {
-                // no branch on pr_on here: a basic-block boundary inside the step makes hipcc drain the LDS-DMA queue
-                // (s_waitcnt vmcnt(0)) before the next transpose read; an unused pair slot recomputes pair 0 and is dropped
-                const uint32_t dof = sbase + doff[q] + ks * 16 * PD;
-                const s16x4 dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + dof));
-                const s16x4 dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + dof + 4 * PD));
-                u16x8 df;
+        for (int kt = 0; kt < KT; ++kt) f.a[kt] = tr_read(sbase + aoff[q][kt] + ks * 16 * PA, PA);
+    };
+    auto run_steps = [&](auto bias_c) {
+        constexpr bool BIAS = decltype(bias_c)::value;    // wave-uniform and constant over the kernel: two copies of the loop, no branch in it
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the step's tiles has landed ...
+            __syncthreads();                                  // ... and so has everybody else's; the other stage is free
+            if (step < 4) TW_STAMP();
+            const bool more = step + 1 < nsteps;
+            const uint32_t sbase = (uint32_t)(cur * STAGE);
+            Frag fr[2];
+            if constexpr (PIPE) load_unit(fr[0], sbase, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { df[e] = (unsigned short)dlo[e]; df[4 + e] = (unsigned short)dhi[e]; }
-                if (any_bias)                             // wave-uniform, constant over the kernel (waves without a bias job skip the MFMA)
-                    accb[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, df), accb[q], 0, 0, 0);
+            for (int u = 0; u < NU; ++u) {
+                const int ks = SPLIT ? u : u / PPW, q0 = SPLIT ? 0 : u % PPW;
+                if (more && (SPLIT || q0 == 0) && ks < NKI) { // next step's loads, a few per k16-step
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const uint32_t aof = sbase + aoff[q][kt] + ks * 16 * PA;
-                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + aof));
-                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + aof + 4 * PA));
-                    u16x8 af;
+                    for (int i = ks; i < NDMA; i += NKI) issue_one(step + 1, cur ^ 1, i);
+                }
+                if constexpr (!PIPE) load_unit(fr[u & 1], sbase, u);
+                else if (u + 1 < NU) load_unit(fr[(u + 1) & 1], sbase, u + 1);
+                const Frag& f = fr[u & 1];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { af[e] = (unsigned short)alo[e]; af[4 + e] = (unsigned short)ahi[e]; }
-                    // orientation: the 32 lanes of a register are 32 CONTIGUOUS elements of dW (coalesced 128-byte stores into the slabs):
-                    // conv form (HWIO): rows = channels, col = output; gather form ([kh,kw,N,C]): rows = outputs, col = channel.
-                    // (the transposed choice gives 16-byte stores per lane but at a 256..1024-byte stride: measured 40 % slower on conv2)
-                    if constexpr (MODE == TC_CONV)
-                        acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, df), acc[q][kt], 0, 0, 0);
-                    else
-                        acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, df), __builtin_bit_cast(bf16x8, af), acc[q][kt], 0, 0, 0);
+                for (int j = 0; j < ND; ++j) {
+                    const int q = SPLIT ? j : q0;
+                    // no branch on pr_on: an unused pair slot recomputes pair 0 and is dropped
+                    if constexpr (BIAS)
+                        accb[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, f.d[j]), accb[q], 0, 0, 0);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        // orientation: the 32 lanes of a register are 32 CONTIGUOUS elements of dW (coalesced 128-byte stores into the slabs):
+                        // conv form (HWIO): rows = channels, col = output; gather form ([kh,kw,N,C]): rows = outputs, col = channel.
+                        // (the transposed choice gives 16-byte stores per lane but at a 256..1024-byte stride: measured 40 % slower on conv2)
+                        if constexpr (MODE == TC_CONV)
+                            acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[kt]), __builtin_bit_cast(bf16x8, f.d[j]), acc[q][kt], 0, 0, 0);
+                        else
+                            acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.d[j]), __builtin_bit_cast(bf16x8, f.a[kt]), acc[q][kt], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
-
+    };
+    if (any_bias) run_steps(std::true_type{}); else run_steps(std::false_type{});
     TW_STAMP();
     const int lcol = lane & 31, lgrp = lane >> 5;
 #pragma unroll
@@ -283,50 +347,85 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     }
     // ---------------- dW: register r of a lane is row (r&3) + 8(r>>2) + 4 lgrp, column lcol; the row -> kernel-tap decode is done once
     // per group of 4 registers (4 consecutive rows share it: C and N are multiples of 4) ----------------
-    float* const dst = p.slabs ? p.slabs + (long long)blockIdx.x * p.slab_stride : p.out;
+    // with caller scratch: partial sums of this position split go to its slab in ACCUMULATOR order, [block column][pair][kt][row group]
+    // [lane][4 rows] (one contiguous 1 KiB store per wave-instruction); reduce_tiled_kernel sums the slabs and does the decode.
+    // Without scratch: fp32 atomics straight into dW.
+    auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
+        if (p.slabs) {
+            float* const dst = p.slabs + (long long)blockIdx.x * p.slab_stride + ((long long)(blockIdx.y * p.npairs + pi) * KT) * 1024 + lane * 4;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        if (!pr_on[q]) continue;
-        const int ta = pr_tap[q] / TAPS, tb = pr_tap[q] % TAPS;
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
+                    *(f32x4*)(dst + (kt * 4 + g4) * 256) = v;
+                }
+            return;
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int row = 8 * g4 + 4 * lgrp;
-                long long base; bool ok;
-                if constexpr (MODE == TC_CONV) {          // rows = channels kc = (ph, pw, c); column = output
-                    const int kc = kc0 + kt * 32 + row, ne = ne0 + pr_nt[q] * 32 + lcol;
-                    uint32_t phh, rem, pww, c;
-                    p.div_2c.divmod((uint32_t)(kc < p.KC ? kc : 0), phh, rem);
-                    p.div_c.divmod(rem, pww, c);
-                    const int kh = 2 * ta + (int)phh, kw = 2 * tb + (int)pww;
-                    ok = kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
-                    base = ((long long)(kh * p.KW + kw) * p.C + c) * p.N + ne;
+                long long base, stride;
+                const bool ok = tw_dw_index<MODE, TAPS>(p, kc0, ne0, tap, kt, nt, 8 * g4 + 4 * lgrp, lcol, base, stride);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!ok) continue;
-                        if (p.slabs) dst[base + (long long)t * p.N] = acc[q][kt][4 * g4 + t];
-                        else atomicAdd(dst + base + (long long)t * p.N, acc[q][kt][4 * g4 + t]);
-                    }
-                } else {                                  // rows = outputs ne = (class, n); column = channel
-                    const int ne = ne0 + pr_nt[q] * 32 + row, kc = kc0 + kt * 32 + lcol;
-                    uint32_t cls, n;
-                    p.div_n.divmod((uint32_t)(ne < p.NE ? ne : 0), cls, n);
-                    const int kh = (int)(cls >> 1) + 2 * (p.HY - ta), kw = (int)(cls & 1) + 2 * (p.HX - tb);
-                    ok = kc < p.KC && ne < p.NE && kh < p.KH && kw < p.KW;
-                    base = ((long long)(kh * p.KW + kw) * p.N + n) * p.C + kc;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!ok) continue;
-                        if (p.slabs) dst[base + (long long)t * p.C] = acc[q][kt][4 * g4 + t];
-                        else atomicAdd(dst + base + (long long)t * p.C, acc[q][kt][4 * g4 + t]);
-                    }
-                }
+                for (int t = 0; t < 4; ++t)
+                    if (ok) atomicAdd(p.out + base + t * stride, tiles[kt][4 * g4 + t]);
             }
+        }
+    };
+    if constexpr (SPLIT) {
+        // the two position halves of a tap meet in LDS: half h keeps output tile h and hands the other one to its partner wave
+        constexpr int WSZ = KT * 16 * 64;                 // floats per wave (16 KB at KT = 4)
+        static_assert(8 * WSZ * 4 <= 2 * STAGE, "reduction scratch");
+        __syncthreads();                                  // the stage tiles are dead
+        float* const red = (float*)lds;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave * WSZ + (kt * 16 + r) * 64 + lane] = half ? acc[0][kt][r] : acc[1][kt][r];
+        __syncthreads();
+        f32x16 fin[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[kt][r] = (half ? acc[1][kt][r] : acc[0][kt][r]) + red[(wave ^ 1) * WSZ + (kt * 16 + r) * 64 + lane];
+        emit(fin, wave >> 1, half, (wave >> 1) * 2 + half);
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            if (!pr_on[q]) continue;
+            emit(acc[q], pr_tap[q], pr_nt[q], wave + 8 * q);
         }
     }
     TW_STAMP();
 #undef TW_STAMP
+}
+
+// dW += sum over the position-split slabs written in accumulator order by tapwgrad_kernel.  One thread per 16-byte group
+// (block column, pair, kt, row group, lane); blockIdx.y takes every gridDim.y-th slab so that small filters still fill the chip:
+// gridDim.y == 1 is a plain read-modify-write in a fixed order (deterministic), otherwise the partial sums meet in atomics.
+template <int MODE, int TAPS, int KT, int NTB>
+__global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams p, int nslab, int ngroups) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= ngroups) return;
+    const int lane = gid & 63, g4 = (gid >> 6) & 3;
+    const int slot = gid >> 8;                            // (block column * npairs + pair) * KT + kt
+    const int kt = slot % KT, bp = slot / KT;
+    const int pi = bp % p.npairs, by = bp / p.npairs;
+    const int kb = by % p.nkb, nb = by / p.nkb;
+    long long base, stride;
+    const bool ok = tw_dw_index<MODE, TAPS>(p, kb * 32 * KT, nb * 32 * NTB, p.pair_tap[pi], kt, p.pair_nt[pi], 8 * g4 + 4 * (lane >> 5), lane & 31, base, stride);
+    if (!ok) return;
+    const float* src = p.slabs + (long long)gid * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = blockIdx.y; k < nslab; k += gridDim.y) s += *(const f32x4*)(src + k * p.slab_stride);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (gridDim.y == 1) p.out[base + t * stride] += s[t];
+        else atomicAdd(p.out + base + t * stride, s[t]);
+    }
 }
 
 // dW[i] += sum over the split slabs.  blockIdx.y takes every gridDim.y-th slab so small outputs still fill the chip;

@@ -209,9 +209,11 @@ def test_full_batch_properties_b512(tmp_path, precision):
 
 def test_kernel_generations_agree_at_batch_512(tmp_path):
     """BASELINE configs[1] size (batch 512, bf16): one forward + backward on the production dispatch (tapconv / tapwgrad / narrow
-    kernels) and on the first-generation kernels.  Losses agree to 1e-5; every gradient tensor agrees to bf16 storage noise
-    (ReLU-mask flips of near-zero pre-activations, see test_train_step_losses_grads_and_adam) -- a size-independent check that the
-    raw-staged kernels handle full-size grids, split ranges and the slab reduction exactly like the simple ones."""
+    kernels) and on the first-generation kernels, both against the fp32 engine as truth.  Losses agree to 1e-5.  Gradients: the two
+    bf16 paths differ from each other by bf16 storage noise (ReLU-mask flips of near-zero pre-activations, largest right after the
+    64-d bottleneck: dense1 / deconv1 see 3-4 % between any two bf16 accumulation orders and 6-7 % against fp32), so the criterion
+    is that the production path is no further from the fp32 gradients than the simple kernels are -- a size-independent check that
+    the raw-staged kernels handle full-size grids, split ranges and the slab reduction exactly like the simple ones."""
     from mi355 import lib as milib
     L = milib.get()
     B = 512
@@ -220,10 +222,10 @@ def test_kernel_generations_agree_at_batch_512(tmp_path):
     eps = rng.standard_normal((B, 64)).astype(np.float32)
     params = trained_like_params()
 
-    def run(cfg):
+    def run(cfg, precision="bf16"):
         prev = {k: L.mi_set_tuning(k, v) for k, v in cfg.items()}
         try:
-            m = make(tmp_path, "bf16", params=params)
+            m = make(tmp_path, precision, params=params)
             src = m._frames(frames, 38400, "src")
             e = m._eps(B, eps)
             m.dev.forward(src, src, None, B, 1.0 / B, e, 1, 1)
@@ -233,8 +235,14 @@ def test_kernel_generations_agree_at_batch_512(tmp_path):
             for k, v in prev.items():
                 L.mi_set_tuning(k, v)
 
+    l_ref, g_ref = run({}, "fp32")
     l_new, g_new = run({0: 1, 1: 300, 3: 1, 4: 1})
     l_old, g_old = run({0: 0, 1: -1, 3: 0, 4: 0})
     assert abs(l_new[0] / l_old[0] - 1) < 1e-5 and abs(l_new[1] / l_old[1] - 1) < 2e-3, (l_new, l_old)
-    bad = {k: rel_err(g_new[k], g_old[k]) for k in g_old if rel_err(g_new[k], g_old[k]) > 3e-2}
+    assert abs(l_new[0] / l_ref[0] - 1) < 1e-4, (l_new, l_ref)
+    bad = {}
+    for k in g_ref:
+        e_new, e_old = rel_err(g_new[k], g_ref[k]), rel_err(g_old[k], g_ref[k])
+        if e_new > 1.25 * e_old + 2e-3 or rel_err(g_new[k], g_old[k]) > 8e-2:
+            bad[k] = (e_new, e_old, rel_err(g_new[k], g_old[k]))
     assert not bad, bad

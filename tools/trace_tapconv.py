@@ -7,7 +7,7 @@ for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
 import numpy as np, torch
 from mi355 import lib as milib
 L = milib.get()
-B = 512
+B = int(os.environ.get("TRACE_B", "512"))
 bf = torch.bfloat16
 st = torch.cuda.current_stream().cuda_stream
 LAYERS = {  # kind, IH, IW, Cin, Cout, k
@@ -63,12 +63,22 @@ name = sys.argv[1] if len(sys.argv) > 1 else "conv2.fwd"
 if name == "variants":                                     # timing only: big tile vs small tile vs gemm2 for every layer
     for nm in LAYERS:
         res = []
-        for label, cfg in (("direct-epi", {5: 1, 1: 1, 6: 1}), ("staged-epi", {5: 1, 1: 1, 6: 0}), ("small+direct", {5: 2, 1: 1, 6: 1}), ("gemm2", {1: -1})):
+        for label, cfg in (("quad-epi", {5: 1, 1: 1, 6: 2}), ("direct-epi", {5: 1, 1: 1, 6: 1}), ("staged-epi", {5: 1, 1: 1, 6: 0}), ("small+quad", {5: 2, 1: 1, 6: 2}), ("gemm2", {1: -1})):
             prev = {k: L.mi_set_tuning(k, v) for k, v in cfg.items()}
             us, _ = run(nm, False)
             for k, v in prev.items():
                 L.mi_set_tuning(k, v)
             res.append("%s %.1f" % (label, us))
+        print("%-14s %s" % (nm, "   ".join(res)))
+    sys.exit(0)
+if name == "stagger":                                      # timing only: start stagger (mi_set_tuning key 8) sweep on the big-tile layers
+    for nm in ("deconv3.fwd", "conv2.dgrad", "conv2.fwd", "deconv2.fwd", "conv3.dgrad"):
+        res = []
+        for sg in (0, 3000, 6000, 9000, 12000, 16000):
+            prev = L.mi_set_tuning(8, sg)
+            us, _ = run(nm, False)
+            L.mi_set_tuning(8, prev)
+            res.append("%d: %.1f" % (sg, us))
         print("%-14s %s" % (nm, "   ".join(res)))
     sys.exit(0)
 if len(sys.argv) > 2:

@@ -6,23 +6,27 @@ for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
 import numpy as np, torch
 from mi355 import lib as milib
 L = milib.get()
+if len(sys.argv) > 2:
+    L.mi_set_tuning(int(sys.argv[1]), int(sys.argv[2]))       # e.g. "7 0": wave = (tap, output tile) layout
 B = 512
 bf = torch.bfloat16
 st = torch.cuda.current_stream().cuda_stream
 LAYERS = {"conv2.wgrad": ("conv", 39, 79, 32, 64, 4), "conv3.wgrad": ("conv", 18, 38, 64, 128, 4), "conv4.wgrad": ("conv", 8, 18, 128, 256, 4),
           "deconv3.wgrad": ("deconv", 18, 38, 64, 32, 5), "deconv2.wgrad": ("deconv", 8, 18, 128, 64, 4), "deconv1.wgrad": ("deconv", 3, 8, 256, 128, 4)}
+scr = torch.zeros(64 << 20, dtype=torch.uint8, device="cuda")     # the engine's split-reduction scratch
+db = torch.zeros(256, device="cuda")
 for nm, (kind, IH, IW, Ci, Co, k) in LAYERS.items():
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     if kind == "conv":
         OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
         x = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).to(bf); dy = torch.randn(B, OH, OW, Co, device="cuda", generator=g).to(bf)
         dw = torch.zeros(k, k, Ci, Co, device="cuda")
-        f = lambda: L.mi_conv2d_nhwc_wgrad(st, 1, x.data_ptr(), None, 0, B, IH, IW, Ci, dy.data_ptr(), k, k, Co, dw.data_ptr())
+        f = lambda: L.mi_conv2d_nhwc_wgrad_ws(st, 1, x.data_ptr(), None, 0, B, IH, IW, Ci, dy.data_ptr(), k, k, Co, dw.data_ptr(), scr.data_ptr(), scr.numel(), db.data_ptr())
     else:
         OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
         x = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).to(bf); dy = torch.randn(B, OH, OW, Co, device="cuda", generator=g).to(bf)
         dw = torch.zeros(k, k, Co, Ci, device="cuda")
-        f = lambda: L.mi_deconv2d_nhwc_wgrad(st, 1, dy.data_ptr(), B, OH, OW, Co, x.data_ptr(), k, k, Ci, dw.data_ptr())
+        f = lambda: L.mi_deconv2d_nhwc_wgrad_ws(st, 1, dy.data_ptr(), B, OH, OW, Co, x.data_ptr(), k, k, Ci, dw.data_ptr(), scr.data_ptr(), scr.numel(), db.data_ptr())
     for _ in range(3):
         f()
     torch.cuda.synchronize()
@@ -47,6 +51,6 @@ for nm, (kind, IH, IW, Ci, Co, k) in LAYERS.items():
     lab = ["setup+issue0"]
     for i in range((nst - 3) // 2):
         lab += ["s%d.barrier" % i if i == 0 else "s%d.compute(prev)+barrier" % i, "s%d.issue" % i]
-    lab += ["remaining steps", "atomics"]
+    lab += ["remaining steps", "dW stores"]
     print("%s: %.1f us/launch, %d blocks, lifetime mean %.0f (min %.0f max %.0f) cycles" % (nm, us, t.shape[0], tot.mean(), tot.min(), tot.max()))
     print("   " + "  ".join("%s=%.0f" % (n, v) for n, v in zip(lab, d)))
