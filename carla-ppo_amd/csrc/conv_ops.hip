@@ -96,7 +96,7 @@ int tapconv_minblocks() {
     return g_tap_min;
 }
 
-int g_tap_direct = 2;                                      // tapconv epilogue: 2 registers -> quad-transposed 16-byte stores (whole 64-byte lines), 1 -> per-pixel 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
+int g_tap_direct = 1;                                      // tapconv epilogue: 1 registers -> 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
 int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
 
 template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
@@ -157,8 +157,8 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
-    q.direct_epilogue = (g_tap_direct && N % 32 == 0) ? g_tap_direct : 0;       // a 32-output tile is all valid or all out of range
-    q.trace = g_trace; q.trace_cap = g_trace_cap;
+    q.direct_epilogue = (g_tap_direct && N % 32 == 0) ? 1 : 0;       // a 32-output tile is all valid or all out of range
+    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg = g_wgrad_skip;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
     // measured (tools/trace_tapconv.py variants): the 128-position tile wins 5-12 % where the 256-position grid is only 1.3-3 rounds
     // of blocks (tile quantisation), loses a little on the 4-column grids and ties on the big grids
@@ -178,6 +178,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // ---------------------------------------------------------------------------------------------------------------
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
+int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
     return g_tapwgrad_on != 0;
@@ -225,7 +226,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
             }
         }
     q.dbias = dbias;
-    int splits = 256 / gy; if (splits < 1) splits = 1;
+    int splits = g_tapwgrad_blocks / gy; if (splits < 1) splits = 1;
     long long pps = (MP + splits - 1) / splits; pps = (pps + TW_BP - 1) / TW_BP * TW_BP;
     splits = (int)((MP + pps - 1) / pps);
     q.pos_per_split = (int)pps;
@@ -564,10 +565,11 @@ int mi_set_tuning(int key, int value) {
     else if (key == 1) { prev = tapconv_minblocks(); g_tap_min = value < 0 ? -1 : value; }
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
     else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
-    else if (key == 6) { prev = g_tap_direct; g_tap_direct = value < 0 || value > 2 ? 2 : value; }
+    else if (key == 6) { prev = g_tap_direct; g_tap_direct = value ? 1 : 0; }
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }
+    else if (key == 9) { prev = g_tapwgrad_blocks; g_tapwgrad_blocks = value < 16 ? 16 : value; }
     else if (key == 8) { prev = g_tap_stagger; g_tap_stagger = value < 0 ? 0 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;

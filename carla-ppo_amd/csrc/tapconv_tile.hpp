@@ -41,6 +41,7 @@ struct TapParams {
     int direct_epilogue;             // 1: registers -> 16-byte stores (half-wave swap), 0: LDS-staged coalesced stores
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
     int stagger;                       // cycles the first-round blocks on odd CUs wait before starting (0 = off), see tapconv_kernel
+    int dbg;                           // debug (mi_set_tuning key 2): 3 = direct epilogue without its stores, 4 = without the MFMA steps (wrong results)
     // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
     const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
     int loss_kind; float inv_b;
@@ -363,51 +364,57 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     if (p.direct_epilogue) {
         // ---------------- direct epilogue (bias is already in the accumulators) ----------------
         // Per lane one position (col lrow of each 32-position subtile); the 4-channel groups g of a 32-output tile alternate between
-        // the two half-waves (lane: channels 8g + 4 lgrp ..+3).
-        //   mode 1: one v_permlane32_swap per dword turns each PAIR of groups into 16 contiguous bytes per lane (lower half: channels
-        //           16m .. 16m+7, upper half: 16m+8 .. 16m+15): two 16-byte stores per subtile, 64 separate 16-byte pieces per instruction.
-        //   mode 2: three lane-bit <-> register-bit exchanges (g0 <-> lane bit 0 and g1 <-> lane bit 1 by quad DPP, q0 <-> half-wave by
-        //           v_permlane32_swap) leave lane (c = lane & 3, h' = lane >> 5) with channels 8c .. 8c+7 of pixel 4k + 2s + h' in slot s:
-        //           the four lanes of a quad write the four 16-byte chunks of ONE pixel's 64 bytes.
+        // the two half-waves (lane: channels 8g + 4 lgrp ..+3).  One v_permlane32_swap per dword turns each PAIR of groups into 16
+        // contiguous bytes per lane (lower half: channels 16m .. 16m+7, upper half: 16m+8 .. 16m+15): two 16-byte stores per subtile.
+        // (Measured: regrouping the lanes further so that a quad writes one whole 64-byte line changes nothing -- with the stores
+        // removed altogether the epilogue is 10 % shorter; it is bound by its own VALU work at two waves per SIMD.  Hence: no runtime
+        // selects per value (ReLU is a max against 0 or -inf), one branch for the whole ReluGrad mask, addresses = one pixel base per
+        // subtile row + wave-uniform class / channel terms.)
         // Phase 1 computes every store address and issues ALL ReluGrad-mask loads; phase 2 only converts and stores.  (A load between the
-        // stores makes the wave wait for the acknowledgement of the stores before it -- vmcnt counts both: 8k cycles per block measured.)
+        // stores makes the wave wait for the acknowledgement of the stores before it -- vmcnt counts both.)
         TC_STAMP();
         const T* __restrict__ maskp = (const T*)p.mask;
         constexpr bool PK = ESZ == 2;                      // 16-byte units of 8 bf16; fp32: a 4-channel group already is 16 bytes
         constexpr int NU = PK ? 2 : 4;                     // store units per subtile and lane
-        const bool quad = PK && p.direct_epilogue == 2;
-        uint32_t uoff[TM][TN][NU]; bool uok[TM][TN][NU];
+        const int lo = p.relu ? 0 : (int)0x80000000;      // negative floats are negative integers
+        uint32_t uoff[TM][TN][NU]; bool uok[TM][TN];
         PackN<uint32_t, 4> umk[TM][TN][NU];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            // pixel(s) this lane stores: its own column of the subtile, or (quad) pixels 4k + 2u + (lane >> 5)
-            uint32_t pb[2], pgy[2], pgx[2]; bool pin[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int P = P0 + (wm * TM + i) * 32 + (quad ? (lrow & ~3) + 2 * u + lgrp : lrow);
-                pin[u] = P < p.MP;
-                uint32_t g;
-                p.div_gw.divmod((uint32_t)(pin[u] ? P : 0), g, pgx[u]);
-                p.div_g.divmod(g, pb[u], pgy[u]);
-            }
+            const int P = P0 + (wm * TM + i) * 32 + lrow;
+            const bool pin = P < p.MP;
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)(pin ? P : 0), g, gx);
+            p.div_g.divmod(g, b, gy);
+            // element offset of the slot's first output pixel, and which of its (up to 4) pixels exist
+            const int oy0 = MODE == TC_CONV ? (int)gy : 2 * (int)gy, ox0 = MODE == TC_CONV ? (int)gx : 2 * (int)gx;
+            const uint32_t pbase = ((b * p.OH + oy0) * p.OW + ox0) * p.N;        // < 2^31 elements (host check)
+            const bool vy0 = pin && oy0 < p.OH, vx0 = ox0 < p.OW, vy1 = pin && oy0 + 1 < p.OH, vx1 = ox0 + 1 < p.OW;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ne0 = n0 + (wn * TN + j) * 32;  // wave-uniform; a 32-wide output tile never straddles a parity class
-                int nb = ne0, dy = 0, dx = 0;
+                int sub = ne0;                             // wave-uniform element offset of the tile inside the slot's pixels
+                bool ok = vy0 && vx0;
                 if constexpr (MODE == TC_GATHER) {
-                    const uint32_t cls = p.div_n.div((uint32_t)ne0);
-                    nb = ne0 - (int)cls * p.N; dy = (int)(cls >> 1); dx = (int)(cls & 1);
+                    const int cls = (int)p.div_n.div((uint32_t)ne0);
+                    sub = ((cls >> 1) * p.OW + (cls & 1)) * p.N + ne0 - cls * p.N;
+                    ok = ((cls >> 1) ? vy1 : vy0) && ((cls & 1) ? vx1 : vx0);
                 }
+                uok[i][j] = ok && ne0 < p.NE;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int s = quad ? u : 0;
-                    const int oy = MODE == TC_CONV ? (int)pgy[s] : 2 * (int)pgy[s] + dy, ox = MODE == TC_CONV ? (int)pgx[s] : 2 * (int)pgx[s] + dx;
-                    uok[i][j][u] = pin[s] && ne0 < p.NE && oy < p.OH && ox < p.OW;
-                    const uint32_t ch = quad ? 8 * (lane & 3) : PK ? 16 * u + 8 * lgrp : 4 * lgrp + 8 * u;
-                    uoff[i][j][u] = uok[i][j][u] ? ((pb[s] * p.OH + oy) * p.OW + ox) * p.N + nb + ch : 0u;   // < 2^31 elements (host check)
-                    if (maskp) umk[i][j][u] = *(const PackN<uint32_t, 4>*)(maskp + uoff[i][j][u]);            // offset 0 is always readable
+                    const uint32_t ch = PK ? 16 * u + 8 * lgrp : 4 * lgrp + 8 * u;
+                    uoff[i][j][u] = uok[i][j] ? pbase + (uint32_t)sub + ch : 0u;
                 }
             }
+        }
+        if (maskp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) umk[i][j][u] = *(const PackN<uint32_t, 4>*)(maskp + uoff[i][j][u]);   // offset 0 is always readable
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -417,7 +424,11 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[g][t] = p.relu ? fmaxf(acc[i][j][4 * g + t], 0.f) : acc[i][j][4 * g + t];
+                    for (int t = 0; t < 4; ++t) {               // ReLU as ONE v_max_i32 on the bit pattern (fmaxf costs a canonicalising max on top)
+                        const float a = acc[i][j][4 * g + t];   // (a copy: __builtin_bit_cast applied to the vector element itself reads element 0)
+                        const int bits = __builtin_bit_cast(int, a);
+                        v[g][t] = __builtin_bit_cast(float, bits > lo ? bits : lo);
+                    }
                 if constexpr (PK) {
                     uint32_t w[4][2];
 #pragma unroll
@@ -425,48 +436,27 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
                         const PackN<T, 4> pk = pack4<T>(v[g]);
                         w[g][0] = (uint32_t)pk.v[0] | ((uint32_t)pk.v[1] << 16); w[g][1] = (uint32_t)pk.v[2] | ((uint32_t)pk.v[3] << 16);
                     }
-                    if (quad) {
-                        const bool b0 = lane & 1;
 #pragma unroll
-                        for (int x = 0; x < 2; ++x)             // register bit g0 <-> lane bit 0
-#pragma unroll
-                            for (int d = 0; d < 2; ++d) {
-                                const uint32_t a = w[2 * x][d], b = w[2 * x + 1][d];
-                                const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b0 ? a : b), 0xB1, 0xF, 0xF, true);
-                                w[2 * x][d] = b0 ? t : a; w[2 * x + 1][d] = b0 ? b : t;
-                            }
-                    }
-#pragma unroll
-                    for (int x = 0; x < 2; ++x)                 // register bit 0 (g0, or q0 after the exchange above) <-> half-wave
+                    for (int x = 0; x < 2; ++x)                 // register bit g0 <-> half-wave
 #pragma unroll
                         for (int d = 0; d < 2; ++d) {
                             auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
                             w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
                         }
-                    if (quad) {
-                        const bool b1 = lane & 2;
+                    if (maskp) {                                // bf16 > 0  <=>  signed 16-bit pattern > 0: 0 / 0xffff per half by packed integer ops
 #pragma unroll
-                        for (int x = 0; x < 2; ++x)             // register bit g1 <-> lane bit 1
+                        for (int g = 0; g < 4; ++g)
 #pragma unroll
                             for (int d = 0; d < 2; ++d) {
-                                const uint32_t a = w[x][d], b = w[2 + x][d];
-                                const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)(b1 ? a : b), 0x4E, 0xF, 0xF, true);
-                                w[x][d] = b1 ? t : a; w[2 + x][d] = b1 ? b : t;
+                                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                                const s16x2 mk = __builtin_bit_cast(s16x2, umk[i][j][g >> 1].v[2 * (g & 1) + d]);
+                                const s16x2 one = __builtin_elementwise_min(__builtin_elementwise_max(mk, (s16x2){0, 0}), (s16x2){1, 1});   // v_pk_max_i16, v_pk_min_i16
+                                w[g][d] &= __builtin_bit_cast(uint32_t, (s16x2){0, 0} - one);                                           // 0xffff where the mask is positive
                             }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {               // unit u = registers (2u, 2u + 1)
-                        uint32_t w4[4] = {w[2 * u][0], w[2 * u][1], w[2 * u + 1][0], w[2 * u + 1][1]};
-                        if (maskp) {
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {       // bf16 > 0  <=>  signed 16-bit pattern > 0
-                                const uint32_t mkd = umk[i][j][u].v[d];
-                                const short lo = (short)(mkd & 0xffffu), hi = (short)(mkd >> 16);
-                                w4[d] = (lo > 0 ? w4[d] & 0xffffu : 0u) | (hi > 0 ? w4[d] & 0xffff0000u : 0u);
-                            }
-                        }
-                        if (uok[i][j][u]) *(PackN<uint32_t, 4>*)((T*)p.out + uoff[i][j][u]) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
-                    }
+                    for (int u = 0; u < 2; ++u)                 // unit u = registers (2u, 2u + 1)
+                        if (uok[i][j] && p.dbg != 3) *(PackN<uint32_t, 4>*)((T*)p.out + uoff[i][j][u]) = PackN<uint32_t, 4>{{w[2 * u][0], w[2 * u][1], w[2 * u + 1][0], w[2 * u + 1][1]}};
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -476,7 +466,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
                         }
-                        if (uok[i][j][u]) *(PackN<T, 4>*)((T*)p.out + uoff[i][j][u]) = o;
+                        if (uok[i][j]) *(PackN<T, 4>*)((T*)p.out + uoff[i][j][u]) = o;
                     }
                 }
             }

@@ -383,7 +383,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
         TOP(e, sw, OP_DENSE1_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
-        join();
+        if (part == 1) join();                               // a full backward joins once, at its end: nothing below reads a filter gradient
     }
     if (part == 0 || part == 2) {
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
@@ -396,8 +396,12 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             const void* gy = e->at(W.gact[i + 1]);
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            release();
-            TOP(e, sw, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sw, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i), e->at(W.scratch), W.scratch_bytes, e->gptr(2 * i + 1)));
+            // conv1 has no input gradient, so the caller's stream would idle while the (longer) filter-gradient stream drains: its
+            // filter gradient runs there instead -- without the shared split scratch, which the side stream may still be using
+            void* sg = i == 0 ? st : sw;
+            if (i > 0) release();
+            TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
+                                                                   (i == 0 && fork) ? nullptr : e->at(W.scratch), (i == 0 && fork) ? 0 : W.scratch_bytes, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));

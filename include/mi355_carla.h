@@ -68,7 +68,8 @@ int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int ar
  * key 5: tapconv tile (0 auto, 1 = 256 positions / 1 block per CU, 2 = 128 positions / 2 blocks per CU);
  * key 6: tapconv epilogue (1 = registers -> 16-byte stores through a half-wave swap, 0 = LDS-staged coalesced stores);
  * key 7: tapwgrad wave layout for 2x2-tap layers (1 = wave per (tap, position half), 0 = wave per (tap, output tile));
- * key 8: tapconv start stagger in shader cycles for the first block of every second CU (0 = off).  Returns the previous value. */
+ * key 8: tapconv start stagger in shader cycles for the first block of every second CU (0 = off; measured: no gain);
+ * key 9: tapwgrad target block count (position splits x block columns; default 256 = one block per CU).  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);

@@ -7,6 +7,8 @@ for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
 import numpy as np, torch
 from mi355 import lib as milib
 L = milib.get()
+if os.environ.get("TRACE_DBG"):
+    L.mi_set_tuning(2, int(os.environ["TRACE_DBG"]))     # 3: direct epilogue without its stores
 B = int(os.environ.get("TRACE_B", "512"))
 bf = torch.bfloat16
 st = torch.cuda.current_stream().cuda_stream
