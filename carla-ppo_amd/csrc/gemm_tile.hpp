@@ -82,62 +82,88 @@ __device__ __forceinline__ void store_tile(const P& p, const f32x16 (&acc)[TM][T
                                            int lrow, int lgrp, int M, int cls, int ph, int pw, int zslab) {
     const T* __restrict__ maskp = (const T*)p.mask;
     const bool vec4 = (p.N & 3) == 0;                     // 4-channel groups never straddle N and stay vector-aligned
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 32 + lrow;
-        const bool rowok = m < M;
-        long long rowoff;
-        if constexpr (AMODE == A_CONV) {
-            rowoff = ((long long)zslab * M + (rowok ? m : 0)) * p.N;
-        } else {
+    auto row_offset = [&](int m, bool rowok) -> long long {
+        if constexpr (AMODE == A_CONV) return ((long long)zslab * M + (rowok ? m : 0)) * p.N;
+        else {
             uint32_t b, rem, y, x;
             p.dc_ohw[cls].divmod((uint32_t)(rowok ? m : 0), b, rem);
             p.dc_ow[cls].divmod(rem, y, x);
-            rowoff = (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
+            return (((long long)b * p.OH + (2 * y + ph)) * p.OW + (2 * x + pw)) * p.N;
         }
-        if constexpr (sizeof(T) == 2) {
-            // bf16, whole 16-channel groups: pair the 4-channel groups of the two half-waves with v_permlane32_swap and write 16 bytes per
-            // lane (row-per-lane 8-byte stores are store-issue bound, see tapconv_tile.hpp); must be wave-uniform: all lanes swap
-            if ((p.N & 15) == 0 && !p.out_f32) {
+    };
+    if constexpr (sizeof(T) == 2) {
+        // bf16, whole 16-channel groups (wave-uniform condition: all lanes swap): pair the 4-channel groups of the two half-waves with
+        // v_permlane32_swap and write 16 bytes per lane.  Two phases: every address, bias vector and ReluGrad-mask vector is requested
+        // first, then the results are converted and stored back to back -- a load between two stores makes the wave wait for the
+        // acknowledgement of the earlier stores (vmcnt counts both), which cost more than the whole main loop of the small layers.
+        if ((p.N & 15) == 0 && !p.out_f32) {
+            long long off[TM][TN][2]; bool ok[TM][TN];
+            PackN<uint32_t, 4> mk[TM][TN][2];
+            f32x4 bs[TN][2][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nt = n0 + (wn * TN + j) * 32;
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bs[j][mq][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && nt < p.N) bs[j][mq][h] = *(const f32x4*)(p.bias + nt + 4 * lgrp + 16 * mq + 8 * h);
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + (wm * TM + i) * 32 + lrow;
+                const bool rowok = m < M;
+                const long long rowoff = row_offset(m, rowok);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int nt = n0 + (wn * TN + j) * 32;
-                    if (nt >= p.N) continue;              // wave-uniform
+                    ok[i][j] = rowok && nt < p.N;
+#pragma unroll
+                    for (int mq = 0; mq < 2; ++mq) {
+                        off[i][j][mq] = ok[i][j] ? rowoff + nt + 16 * mq + 8 * lgrp : 0;
+                        if (maskp) mk[i][j][mq] = *(const PackN<uint32_t, 4>*)(maskp + off[i][j][mq]);     // offset 0 is always readable
+                    }
+                }
+            }
+            const int lo = p.relu ? 0 : (int)0x80000000;  // ReLU as ONE integer max on the bit pattern (negative floats are negative integers)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int mq = 0; mq < 2; ++mq) {
                         float va[4], vb[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) { va[t] = acc[i][j][8 * mq + t]; vb[t] = acc[i][j][8 * mq + 4 + t]; }
-                        if (p.bias) {
-                            const f32x4 ba = *(const f32x4*)(p.bias + nt + 4 * lgrp + 16 * mq), bb = *(const f32x4*)(p.bias + nt + 4 * lgrp + 16 * mq + 8);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) { va[t] += ba[t]; vb[t] += bb[t]; }
-                        }
-                        if (p.relu) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) { va[t] = fmaxf(va[t], 0.f); vb[t] = fmaxf(vb[t], 0.f); }
+                        for (int t = 0; t < 4; ++t) {
+                            const float a = acc[i][j][8 * mq + t] + bs[j][mq][0][t], b = acc[i][j][8 * mq + 4 + t] + bs[j][mq][1][t];
+                            const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+                            va[t] = __builtin_bit_cast(float, ia > lo ? ia : lo); vb[t] = __builtin_bit_cast(float, ib > lo ? ib : lo);
                         }
                         const PackN<T, 4> pa = pack4<T>(va), pb = pack4<T>(vb);
                         uint32_t ax = (uint32_t)pa.v[0] | ((uint32_t)pa.v[1] << 16), ay = (uint32_t)pa.v[2] | ((uint32_t)pa.v[3] << 16);
                         uint32_t bx = (uint32_t)pb.v[0] | ((uint32_t)pb.v[1] << 16), by = (uint32_t)pb.v[2] | ((uint32_t)pb.v[3] << 16);
                         auto r0 = __builtin_amdgcn_permlane32_swap(ax, bx, false, false); ax = r0[0]; bx = r0[1];
                         auto r1 = __builtin_amdgcn_permlane32_swap(ay, by, false, false); ay = r1[0]; by = r1[1];
-                        const long long off = rowoff + nt + 16 * mq + 8 * lgrp;
                         uint32_t w4[4] = {ax, ay, bx, by};
                         if (maskp) {
-                            const PackN<uint32_t, 4> mk = *(const PackN<uint32_t, 4>*)(maskp + (rowok ? off : 0));
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const short lo = (short)(mk.v[d] & 0xffffu), hi = (short)(mk.v[d] >> 16);
-                                w4[d] = (lo > 0 ? w4[d] & 0xffffu : 0u) | (hi > 0 ? w4[d] & 0xffff0000u : 0u);
+                            for (int d = 0; d < 4; ++d) {       // bf16 > 0  <=>  signed 16-bit pattern > 0
+                                const short lo16 = (short)(mk[i][j][mq].v[d] & 0xffffu), hi16 = (short)(mk[i][j][mq].v[d] >> 16);
+                                w4[d] = (lo16 > 0 ? w4[d] & 0xffffu : 0u) | (hi16 > 0 ? w4[d] & 0xffff0000u : 0u);
                             }
                         }
-                        if (rowok) *(PackN<uint32_t, 4>*)((T*)p.out + off) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
+                        if (ok[i][j]) *(PackN<uint32_t, 4>*)((T*)p.out + off[i][j][mq]) = PackN<uint32_t, 4>{{w4[0], w4[1], w4[2], w4[3]}};
                     }
-                }
-                continue;
-            }
+            return;
         }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + lrow;
+        const bool rowok = m < M;
+        const long long rowoff = row_offset(m, rowok);
         if (!rowok) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

@@ -69,6 +69,34 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
         }
     }
 
+    // ---- this lane's output pixels (epilogue role: position lrow of the wave's 32, output-row parity lgrp) and, for the fused
+    // reconstruction loss, their label values: requested NOW so that the fp32 frame gather (HBM latency) runs under the tile DMA and
+    // the MFMAs -- loaded in the epilogue it sat between the logits store and the dlogits store and waited for the former's
+    // acknowledgement on top of its own latency ----
+    const int P = P0 + wave * 32 + lrow;
+    uint32_t g, gx, b, gy;
+    p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
+    p.div_g.divmod(g, b, gy);
+    const int ph = lgrp;
+    const int oy = 2 * (int)gy + ph, ox = 2 * (int)gx;
+    const bool live = P < p.MP && oy < p.OH && ox < p.OW;
+    const int npx = ox + 1 < p.OW ? 2 : 1;                // output pixels of this lane (pw = 0, 1)
+    constexpr int CNTL = NOUT > 0 ? 2 * NOUT : 2;
+    float yv[CNTL];
+#pragma unroll
+    for (int j = 0; j < CNTL; ++j) yv[j] = 0.f;
+    if constexpr (NOUT > 0) {
+        if (p.labels && live && npx == 2) {
+            const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
+            const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
+#pragma unroll
+            for (int d = 0; d < CNTL / 2; ++d) {
+                const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
+                yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
+            }
+        }
+    }
+
     // ---- weights: fragment (tap, kk) of lane (row ne = lrow, chunk 2 kk + lgrp) straight from global / L2 ----
     freg wf[NT][NKK];
     {
@@ -120,14 +148,6 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
         *(f32x4*)(ot + lrow * OPITCH + 8 * qd + 4 * lgrp) = v;
     }
     __builtin_amdgcn_wave_barrier();                      // same wave, in-order LDS queue: no wait needed, only keep the order
-    const int P = P0 + wave * 32 + lrow;
-    uint32_t g, gx, b, gy;
-    p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
-    p.div_g.divmod(g, b, gy);
-    const int ph = lgrp;
-    const int oy = 2 * (int)gy + ph, ox = 2 * (int)gx;
-    const bool live = P < p.MP && oy < p.OH && ox < p.OW;
-    const int npx = ox + 1 < p.OW ? 2 : 1;                // output pixels of this lane (pw = 0, 1)
     T* __restrict__ out = (T*)p.out + (((long long)b * p.OH + oy) * p.OW + ox) * p.N;
     const float* src = ot + lrow * OPITCH + ph * 2 * p.N;
     float lsum = 0.f, gs0 = 0.f, gs1 = 0.f, gs2 = 0.f;   // fused loss: this lane's loss terms and per-channel dlogits sums
@@ -156,16 +176,7 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
             for (int d = 0; d < ND; ++d) o32[d] = w[d];
             if (p.labels) {
                 // reconstruction loss on the STORED logits (vae/models.py:11-22,123-128; same math as recon_loss_kernel)
-                const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
-                const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
-                float yv[CNT];
-                if constexpr (CNT % 2 == 0 && NOUT % 1 == 0) {
-#pragma unroll
-                    for (int d = 0; d < CNT / 2; ++d) {
-                        const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
-                        yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
-                    }
-                }
+                // (labels yv[]: requested at the top of the kernel)
                 T gq[CNT];
 #pragma unroll
                 for (int j = 0; j < CNT; ++j) {
@@ -513,16 +524,24 @@ __global__ __launch_bounds__(256) void narrow_conv_kernel(const NarrowConvParams
     __builtin_amdgcn_wave_barrier();
     constexpr int CPP = 32 * ESZ / 16;                    // 16-byte chunks per pixel (4 | 8)
     const T* __restrict__ maskp = (const T*)p.mask;
+    constexpr int NK = 32 * CPP / 64;
+    PackN<T, VE> mk[NK];                                  // every mask vector is requested before the first store (a load behind a store
+    if (maskp) {                                          //  waits for the store's acknowledgement: vmcnt counts both)
 #pragma unroll
-    for (int k = 0; k < 32 * CPP / 64; ++k) {
+        for (int k = 0; k < NK; ++k) {
+            const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
+            mk[k] = *(const PackN<T, VE>*)(maskp + (m0 + px < p.M ? (long long)(m0 + px) * 32 + c16 * VE : 0));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
         const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
         if (m0 + px >= p.M) continue;
         PackN<T, VE> o = *(const PackN<T, VE>*)(ot + px * OPITCH + c16 * 16);
         const long long off = (long long)(m0 + px) * 32 + c16 * VE;
         if (maskp) {
-            const PackN<T, VE> mk = *(const PackN<T, VE>*)(maskp + off);
 #pragma unroll
-            for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
+            for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[k].v[t]) > 0.f ? o.v[t] : (T)0;
         }
         *(PackN<T, VE>*)((T*)p.out + off) = o;
     }

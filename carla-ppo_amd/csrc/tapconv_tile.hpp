@@ -101,6 +101,22 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     TC_STAMP();
     const int P0 = xcd_remap(blockIdx.x, gridDim.x) * BMT;
     const int n0 = blockIdx.y * BNE;
+    // bias of this lane's output channels (register r of a lane: channel 4 lgrp + 8 (r >> 2) + (r & 3) of a 32-output tile), requested
+    // first so that it is back long before the accumulators are initialised with it: no bias loads between the stores of the epilogue
+    // (a load there makes the wave wait for the stores before it) and no load latency in front of the first step either
+    f32x4 bias4[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bias4[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ne = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
+            if (p.bias && ne < p.NE) {
+                int nb = ne;
+                if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)ne) * p.N;
+                bias4[j][q] = *(const f32x4*)(p.bias + nb);
+            }
+        }
     const int halo = (TAPS - 1) * p.GW + TAPS - 1;
     const int ninstrA = (BMT + halo + 7) >> 3;            // 8-slot DMA instructions covering the staged range
     const int NCC = (p.KC + CHS - 1) / CHS;
@@ -333,26 +349,14 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
             }
         }
     };
-    // the accumulators start at the bias of their output channel (register r of a lane: channel 4 lgrp + 8 (r >> 2) + (r & 3) of the
-    // 32-output tile): no bias loads between the stores of the epilogue -- a load there makes the wave wait for the stores before it
+    // the accumulators start at the bias of their output channel (loaded at the top of the kernel)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         f32x16 b16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) b16[r] = 0.f;
-        if (p.bias) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ne = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
-                if (ne < p.NE) {
-                    int nb = ne;
-                    if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)ne) * p.N;
-                    const f32x4 bb = *(const f32x4*)(p.bias + nb);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) b16[4 * q + t] = bb[t];
-                }
-            }
-        }
+            for (int t = 0; t < 4; ++t) b16[4 * q + t] = bias4[j][q][t];
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i][j] = b16;
     }
