@@ -178,6 +178,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // ---------------------------------------------------------------------------------------------------------------
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
+int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
@@ -340,15 +341,25 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     if (wpc < 0) { const char* e = getenv("MI355_NW_WAVES"); wpc = e ? atoi(e) : 12; }
     long long nwave = 256ll * wpc;                         // one wave-range per resident wave: a single round, no tail
     long long ppw = (M + nwave - 1) / nwave; ppw = (ppw + NW_BP - 1) / NW_BP * NW_BP;
+    if ((long long)OH * OW < NW_BP) return 0;
+    if (ppw > 2ll * OH * OW) ppw = 2ll * OH * OW / NW_BP * NW_BP;   // a wave's range touches at most 3 frames (their indices are looked up once)
     nwave = (M + ppw - 1) / ppw;
-    const int blocks = (int)((nwave + 3) / 4);
+    const int nwv = g_nw_waves >= 12 ? 12 : g_nw_waves >= 8 ? 8 : 4;
+    const int blocks = (int)((nwave + nwv - 1) / nwv);
     q.pix_per_block = (int)ppw;
     q.div_ohw = make_fastdiv(OH * OW); q.div_ow = make_fastdiv(OW);
-    q.out = out; q.dbias = dbias;
+    q.out = out; q.dbias = dbias; q.dbg_skip_out = g_wgrad_skip == 1;
     q.slabs = (scratch && (((uintptr_t)scratch) & 15) == 0 && (((uintptr_t)out) & 15) == 0 && (!dbias || (((uintptr_t)dbias) & 15) == 0) &&
                scratch_bytes >= (long long)blocks * NW_SLAB * 4) ? (float*)scratch : nullptr;
-    if (narrow_f32) hipLaunchKernelGGL(narrow_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(narrow_wgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, q);
+    const bool g3 = KW * q.Cs == 12;                     // the 4 x 4 x 3-channel layers: fixed-shape loop body (one basic block)
+#define NW_LAUNCH(TS_, NWV_) do { \
+        const dim3 g((unsigned)((nwave + NWV_ - 1) / NWV_)), t(NWV_ * 64); \
+        if (g3 && q.dbias) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 1, NWV_>), g, t, 0, st, q); \
+        else if (g3) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 0, NWV_>), g, t, 0, st, q); \
+        else hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 0, -1, NWV_>), g, t, 0, st, q); } while (0)
+    if (narrow_f32) { if (g_nw_waves >= 12) NW_LAUNCH(float, 12); else if (g_nw_waves >= 8) NW_LAUNCH(float, 8); else NW_LAUNCH(float, 4); }
+    else { if (g_nw_waves >= 12) NW_LAUNCH(bf16_t, 12); else if (g_nw_waves >= 8) NW_LAUNCH(bf16_t, 8); else NW_LAUNCH(bf16_t, 4); }
+#undef NW_LAUNCH
     int rc = mi_check_launch("narrow_wgrad_kernel");
     if (rc == MI_OK && q.slabs) {
         const long long n_out = (long long)KH * run * 32;
@@ -570,6 +581,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }
     else if (key == 9) { prev = g_tapwgrad_blocks; g_tapwgrad_blocks = value < 16 ? 16 : value; }
+    else if (key == 10) { prev = g_nw_waves; g_nw_waves = value; }
     else if (key == 8) { prev = g_tap_stagger; g_tap_stagger = value < 0 ? 0 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;

@@ -258,28 +258,46 @@ struct NarrowWgradParams {
     FastDiv div_ohw, div_ow;
     float* out; float* dbias;
     float* slabs;                                                     // optional [gridDim.x][NW_SLAB] per-block partial sums (then reduce_slabs_kernel)
+    int dbg_skip_out;                                                 // debug (mi_set_tuning key 2 == 1): drop the final atomics (wrong results): shows their cost
 };
 
 constexpr int NW_SLAB = 64 * 32 + 32;  // dW rows (padded to 64) x 32, then the 32 bias sums
 constexpr int NW_BP = 16;            // pixels per wave step
 
-template <typename TS>
-__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradParams p) {
+// NGRP: 4-value groups per (pixel, kernel row) known at compile time (3 for the 4 x 4 x 3-channel layers), 0 = runtime;
+// BIAS: 1 = with the all-ones MFMA of the bias gradient, 0 = without, -1 = runtime.  With both fixed the 3-step loop body is ONE basic
+// block, which is what lets hipcc keep partial `s_waitcnt vmcnt(N)` counts across the back edge: with branches in the body (and with
+// the frame-index lookup as a dependent load inside it) every step drained the whole load queue and the "3-deep" pipeline ran 1 deep.
+// NWV: waves per block.  All blocks run one equal share of the pixels and finish together, so their final atomics (2080 addresses, one
+// add per block and address) queue up at the end: 18 us of a 73 us launch with 747 four-wave blocks; 12-wave blocks (one per CU) cut the
+// queue depth by three.
+constexpr int NW_WAVES = 12;
+template <typename TS, int NGRP = 0, int BIAS = -1, int NWV = NW_WAVES>
+__global__ __launch_bounds__(NWV * 64) void narrow_wgrad_kernel(const NarrowWgradParams p) {
     constexpr int PA = 128, PS = 64;                      // LDS row pitch: im2col rows (64 bf16), wide rows (32 bf16)
     constexpr int WSTG = NW_BP * PA + NW_BP * PS;         // per wave: one im2col tile + one wide-row tile = 3 KB
     constexpr int RED = 3 * 1024 * 4;                     // cross-wave reduction buffer
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * WSTG + RED];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NWV * WSTG + RED];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // every wave owns a contiguous pixel range and runs on its own (no block barrier until the final reduction): memory
     // latency is hidden by the ~20 resident waves per CU, not by a per-wave software pipeline
-    const int wid = blockIdx.x * 4 + wave;
+    const int wid = blockIdx.x * NWV + wave;
     const int mbeg = min(p.M, wid * p.pix_per_block);     // pix_per_block: pixels per WAVE here (multiple of 16)
     const int mend = min(p.M, mbeg + p.pix_per_block);
     const int nsteps = (mend - mbeg + NW_BP - 1) / NW_BP;
     const int run = p.KW * p.Cs;                          // contiguous source values per (pixel, kh): 4 | 8 | 12
-    const int ngrp = run >> 2;
+    const int ngrp = NGRP > 0 ? NGRP : run >> 2;
+    // frame gather: the (at most three: the host keeps a wave's range within 2 x OH x OW pixels) frames this wave's pixel range
+    // touches are looked up ONCE, here
+    const uint32_t b0 = p.div_ohw.div((uint32_t)(mbeg < p.M ? mbeg : 0));
+    long long fr3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t bb = min(b0 + (uint32_t)k, (uint32_t)(p.B - 1));
+        fr3[k] = p.frame_idx ? (long long)p.frame_idx[bb] : (long long)bb;
+    }
 
     unsigned char* const wl = lds + wave * WSTG;          // this wave's tiles: [0, 2 KB) im2col, then 1 KB of wide rows
     const TS* __restrict__ src = (const TS*)p.src;
@@ -287,30 +305,28 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
     const int tp = lane >> 2, kh = lane & 3;              // im2col role: (pixel of the step, kernel row)
     // Everything is fetched with ordinary loads (in-order return, so hipcc's own vmcnt(N) bookkeeping lets the loads of the
     // next two steps stay in flight while this step is consumed): 12 source values + one 16-byte piece of the wide rows per lane.
-    struct StepRegs { float v[12]; f32x4 s; };
+    // (the loaded vectors are kept RAW: converting or zero-filling them at load time would be a use of the load result inside the same
+    //  iteration, i.e. a wait for it before the back edge -- the validity flags travel with them and are applied in store_step)
+    typedef PackU<TS, 4, (int)sizeof(TS) * 2> SrcVec;
+    struct StepRegs { SrcVec raw[3]; f32x4 s; bool ok; bool sok; };
     auto load_step = [&](int step, StepRegs& R) {
         const int m = mbeg + step * NW_BP + tp;
         const bool ok = m < mend && kh < p.KH;
         uint32_t b, rem, y, x;
         p.div_ohw.divmod((uint32_t)(ok ? m : 0), b, rem);
         p.div_ow.divmod(rem, y, x);
-        const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+        const long long fr = b == b0 ? fr3[0] : (b == b0 + 1 ? fr3[1] : fr3[2]);
         const TS* row = src + fr * p.frame_stride + ((long long)(2 * y + kh) * p.IW + 2 * x) * p.Cs;
+        R.ok = ok;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const bool gok = ok && g < ngrp;
-            const PackU<TS, 4, (int)sizeof(TS) * 2> t = *(const PackU<TS, 4, (int)sizeof(TS) * 2>*)(gok ? row + 4 * g : src);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f;
-                if constexpr (sizeof(TS) == 4) f = (float)t.v[e]; else f = bf16_to_f32((bf16_t)t.v[e]);
-                R.v[4 * g + e] = gok ? f : 0.f;
-            }
+            R.raw[g] = *(const SrcVec*)(gok ? row + 4 * g : src);
         }
         // wide rows: lane -> row lane / 4 (pixel tp), 16-byte chunk lane % 4 (= kh)
         const bool sok = m < mend;
-        const f32x4 sv = *(const f32x4*)((const unsigned char*)p.s + (sok ? ((long long)m * 32 + kh * 8) * 2 : 0));
-        R.s = sok ? sv : f32x4{0.f, 0.f, 0.f, 0.f};
+        R.sok = sok;
+        R.s = *(const f32x4*)((const unsigned char*)p.s + (sok ? ((long long)m * 32 + kh * 8) * 2 : 0));
     };
     auto store_step = [&](const StepRegs& R) {            // im2col row tp, columns kh*run .. (columns >= KH*run stay zero) + the wide-row piece
         const int sw = ((tp >> 1) & 1) << 2;
@@ -318,10 +334,16 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
         for (int g = 0; g < 3; ++g) {
             if (g >= ngrp) break;
             const int col = kh * run + 4 * g;             // multiple of 4 elements = 8 bytes
-            const float f4[4] = {R.v[4 * g], R.v[4 * g + 1], R.v[4 * g + 2], R.v[4 * g + 3]};
+            float f4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float f;
+                if constexpr (sizeof(TS) == 4) f = (float)R.raw[g].v[e]; else f = bf16_to_f32((bf16_t)R.raw[g].v[e]);
+                f4[e] = R.ok ? f : 0.f;
+            }
             *(PackN<bf16_t, 4>*)(wl + tp * PA + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2) = pack4<bf16_t>(f4);
         }
-        *(f32x4*)(wl + NW_BP * PA + tp * PS + kh * 16) = R.s;
+        *(f32x4*)(wl + NW_BP * PA + tp * PS + kh * 16) = R.sok ? R.s : f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     for (int i = lane; i < NW_BP * PA / 16; i += 64) *(f32x4*)(wl + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};   // zero the im2col tile once
@@ -362,24 +384,24 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
             for (int e = 0; e < 4; ++e) { af[e] = (unsigned short)lo[e]; af[4 + e] = (unsigned short)hi[e]; }
             acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, sf), acc[kt], 0, 0, 0);
         }
-        if (p.dbias) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, sf), acc[2], 0, 0, 0);
+        if (BIAS > 0 || (BIAS < 0 && p.dbias)) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, sf), acc[2], 0, 0, 0);
     };
 
     // 3-deep register pipeline (steps s, s+1, s+2 in flight); out-of-range steps load nothing and store zeros
     StepRegs R0, R1, R2;
     load_step(0, R0); load_step(1, R1);
-    for (int step = 0; step < nsteps; step += 3) {
+    for (int step = 0; step < nsteps; step += 3) {       // steps past the range load nothing and add zeros: no branch in the body
         load_step(step + 2, R2);
         store_step(R0); compute();
-        if (step + 1 < nsteps) { load_step(step + 3, R0); store_step(R1); compute(); }
-        if (step + 2 < nsteps) { load_step(step + 4, R1); store_step(R2); compute(); }
+        load_step(step + 3, R0); store_step(R1); compute();
+        load_step(step + 4, R1); store_step(R2); compute();
     }
 
     // cross-wave reduction (waves take turns on one 12 KB buffer), then one set of atomics per block:
     // acc[k][r] -> kc = k*32 + (r&3) + 8(r>>2) + 4(lane>>5), n = lane&31 ; k == 2: all-ones rows (bias gradient)
-    float* red = (float*)(lds + 4 * WSTG);
+    float* red = (float*)(lds + NWV * WSTG);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWV; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -393,7 +415,8 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const NarrowWgradPara
     }
     // same-address atomics from ~1300 blocks serialise (~60 ns each): with scratch the block writes its partial sums plainly
     const int kcn = p.KH * run;
-    for (int i = tid; i < 3 * 16 * 64; i += 256) {
+    if (p.dbg_skip_out) return;
+    for (int i = tid; i < 3 * 16 * 64; i += NWV * 64) {
         const float sum = red[i];
         const int k = i >> 10, r = (i >> 6) & 15, l = i & 63;
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), n = l & 31;
