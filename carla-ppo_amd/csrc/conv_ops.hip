@@ -178,6 +178,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // ---------------------------------------------------------------------------------------------------------------
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
+int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
@@ -582,6 +583,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }
     else if (key == 9) { prev = g_tapwgrad_blocks; g_tapwgrad_blocks = value < 16 ? 16 : value; }
     else if (key == 10) { prev = g_nw_waves; g_nw_waves = value; }
+    else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
     else if (key == 8) { prev = g_tap_stagger; g_tap_stagger = value < 0 ? 0 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
@@ -756,7 +758,7 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
     const int vb = dtype == MI_F32 ? 4 : 8;
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
-    return launch_wgrad((hipStream_t)stream, dtype, 0, p, 512);
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks);
 }
 
 }  // extern "C"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Assemble profiles/<name>.md + profiles/r01_pmc_traffic.json from the files one GPU call leaves in gpurun_out/:
     prof_<tag>.md (rocprofv3 --kernel-trace --stats via tools/rocpd_summary.py), pmc_<tag>_sq.md / _fetch.md / _write.md (tools/pmc_pass.sh),
-    bench_<tag>_full.json (bench.py).   usage: python tools/make_profile.py <tag> <out-name> "<title>" """
+    bench_<tag>_full.json (bench.py), timeline_<tag>.md (tools/timeline.sh; optional).  tools/profile_round.sh produces all of them.   usage: python tools/make_profile.py <tag> <out-name> "<title>" """
 import json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 tag, outname, title = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -10,6 +10,8 @@ sq = open(R + "gpurun_out/pmc_%s_sq.md" % tag).read()
 fe = open(R + "gpurun_out/pmc_%s_fetch.md" % tag).read()
 wr = open(R + "gpurun_out/pmc_%s_write.md" % tag).read()
 bench = json.load(open(R + "gpurun_out/bench_%s_full.json" % tag))
+tl_path = R + "gpurun_out/timeline_%s.md" % tag
+timeline = open(tl_path).read() if os.path.exists(tl_path) else "(not collected)"
 
 def rows(md):
     out = []
@@ -27,8 +29,9 @@ NAMES = [("tapconv_kernel<bf16, 1, 128, 3, 256, 96>", "1848x1x1", "deconv3.fwd")
          ("tapconv_kernel<bf16, 1, 128, 2, 128, 48>", "800x2x1", "deconv2.fwd / conv3.dgrad"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "100x4x1", "deconv1.fwd / conv4.dgrad"),
          ("tapconv_kernel<bf16, 0, 128, 2, 128, 48>", "684x1x1", "conv3.fwd / deconv2.dgrad"), ("tapconv_kernel<bf16, 0, 64, 2, 256, 96>", "1482x1x1", "conv2.fwd"),
          ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "2736x1x1", "deconv3.dgrad"), ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "96x4x1", "conv4.fwd / deconv1.dgrad"),
-         ("tapwgrad_kernel<1, 3, 2, 4, 4>", "247x1x1", "deconv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 1>", "247x1x1", "conv2.wgrad"),
-         ("narrow_wgrad_kernel<float>", None, "conv1.wgrad (+bias)"), ("narrow_wgrad_kernel<bf16>", None, "deconv4.wgrad"),
+         ("tapwgrad_kernel<1, 3, 2, 4, 4, false>", "247x1x1", "deconv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "247x1x1", "conv2.wgrad"),
+         ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "63x4x1", "conv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "16x16x1", "conv4.wgrad"),
+         ("narrow_wgrad_kernel<float, 3, 1, 12>", None, "conv1.wgrad (+bias)"), ("narrow_wgrad_kernel<bf16, 3, 0, 12>", None, "deconv4.wgrad"),
          ("narrow_conv_kernel<bf16, float>", None, "conv1.fwd"), ("narrow_conv_kernel<bf16, bf16>", None, "deconv4.dgrad"),
          ("gather_narrow_kernel<bf16, 2, 4, 3>", None, "deconv4.fwd + loss")]
 lines, traffic = [], {}
@@ -69,6 +72,10 @@ conv1 kernels may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv
 
 %s
 
+## One training step, dispatch by dispatch (separate `rocprofv3 --kernel-trace` run; queue 1 = caller's stream, the other = filter-gradient stream)
+
+%s
+
 ## PMC pass 1 (SQ / GRBM), averaged per dispatch
 
 %s
@@ -80,7 +87,7 @@ conv1 kernels may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv
 ## PMC pass 3 (WRITE_SIZE, KB)
 
 %s
-""" % (title, json.dumps(bench), "\n".join(lines), stats, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
+""" % (title, json.dumps(bench), "\n".join(lines), stats, timeline, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
 open(R + "profiles/%s.md" % outname, "w").write(doc)
 json.dump({"provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, batch 512 bf16; FETCH_SIZE doubled per MI355X_MICROARCH.md",
            "ops": traffic}, open(R + "profiles/r01_pmc_traffic.json", "w"), indent=1)
