@@ -30,3 +30,35 @@ extern "C" int mi_device_info(int device, int* cu_count, int* wave_size, char* a
     if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
     return MI_OK;
 }
+
+// CRC-32C (Castagnoli) of a host buffer, slicing-by-8: the checksum of TensorFlow's tensor-bundle checkpoints (every tensor in the
+// .data shard and every block of the .index table carries one, tensorflow/core/lib/hash/crc32c.h).  `crc` = running value (0 to start).
+// Host-side I/O helper of the checkpoint reader / writer (mi355/tf_bundle.py); no device work.
+static uint32_t g_crc_tab[8][256];
+static bool g_crc_init = false;
+static void crc32c_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        g_crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+    g_crc_init = true;
+}
+extern "C" unsigned int mi_crc32c(unsigned int crc, const void* data, long long n) {
+    if (!g_crc_init) crc32c_init();                      // idempotent: a racing second initialiser writes the same values
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = ~crc;
+    while (n > 0 && (((uintptr_t)p) & 7)) { c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w ^= c;
+        c = g_crc_tab[7][w & 0xff] ^ g_crc_tab[6][(w >> 8) & 0xff] ^ g_crc_tab[5][(w >> 16) & 0xff] ^ g_crc_tab[4][(w >> 24) & 0xff] ^
+            g_crc_tab[3][(w >> 32) & 0xff] ^ g_crc_tab[2][(w >> 40) & 0xff] ^ g_crc_tab[1][(w >> 48) & 0xff] ^ g_crc_tab[0][(w >> 56) & 0xff];
+        p += 8; n -= 8;
+    }
+    while (n-- > 0) c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return ~c;
+}

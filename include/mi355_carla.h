@@ -61,6 +61,9 @@ typedef struct MiPpoDesc {
 const char* mi_last_error(void);
 int mi_abi_version(void);
 int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
+/* CRC-32C of a HOST buffer (running value in, 0 to start): the checksum of the reference's TensorFlow bundle checkpoints
+ * (tf.train.Saver files written / read by vae/models.py:154,172-186 and ppo.py:184,202-216); used by mi355/tf_bundle.py.  Returns the crc. */
+unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
 /* Kernel-selection knobs (process-global, not part of the reference surface; defaults come from the environment variables of
  * the same meaning).  key 0: gemm2 LDS-DMA tiles on/off (MI355_GEMM2); key 1: minimum block count for the raw-staged
  * tapconv kernel, -1 = never (MI355_TAPCONV / MI355_TAPCONV_MINBLOCKS); key 2: debug, drop the wgrad_kernel atomics;

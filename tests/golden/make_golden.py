@@ -12,6 +12,7 @@ Outputs (all small, committed):
   ref_event_scalars.json  first/last/min scalar values logged by the reference's own VAE training runs
                        (parsed from the TensorBoard event files). Coarse known-answers: the untrained
                        validation reconstruction loss must be ~= n_pixels*ln2.
+  ref_index/*.index    the three shipped TF bundle index files, verbatim (golden bytes for mi355/tf_bundle.py)
   real_frames_u8.npy   16 real CARLA frames (uint8 [16,80,160,3]) from vae/data/rgb/{0..15}.png and
   real_seg_u8.npy      the matching segmentation class-id maps (uint8 [16,80,160,1], values 0..12).
 
@@ -167,6 +168,14 @@ def main():
         "ppo_agent": "models/pretrained_agent/checkpoints/model.ckpt-705.index",
     }
     variables = {k: parse_index(os.path.join(REF, p)) for k, p in ckpts.items()}
+    # the three shipped bundle INDEX files themselves (2.7 KB each; their .data shards are not part of the reference checkout):
+    # byte-level golden vectors for the table writer / reader of mi355/tf_bundle.py
+    import shutil
+    os.makedirs(os.path.join(OUT, "ref_index"), exist_ok=True)
+    for k, p in ckpts.items():
+        dst = os.path.join(OUT, "ref_index", k + ".index")
+        shutil.copyfile(os.path.join(REF, p), dst)
+        os.chmod(dst, 0o644)
     meta = {"_source": ckpts, "_generator": "tests/golden/make_golden.py"}
     with open(os.path.join(OUT, "ref_variables.json"), "w") as f:
         json.dump({**meta, **variables}, f, indent=1, sort_keys=True)

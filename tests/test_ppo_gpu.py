@@ -117,7 +117,9 @@ def test_partial_minibatch_and_predict_shapes(tmp_path):
     assert m.get_episode_idx() == 1
 
 
-def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir):
+@pytest.mark.parametrize("fmt", ["npz", "tf"])
+def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir, fmt, monkeypatch):
+    monkeypatch.setenv("MI355_CKPT_FORMAT", fmt)
     ref = json.load(open(os.path.join(golden_dir, "ref_variables.json")))["ppo_agent"]
     ref = {k: v for k, v in ref.items() if not k.startswith("vae/")}       # the agent checkpoint also carries the VAE graph
     o, m = make_pair(tmp_path / "a")
@@ -130,6 +132,12 @@ def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir):
     sd = m.state_dict()
     assert {k: list(np.shape(v)) for k, v in sd.items()} == {k: v["shape"] for k, v in ref.items()}
     m.save()
+    if fmt == "tf":
+        from mi355 import tf_bundle as tb
+        ours, _ = tb.read_index(os.path.join(m.checkpoint_dir, "model.ckpt-1.index"))
+        theirs, _ = tb.read_index(os.path.join(golden_dir, "ref_index", "ppo_agent.index"))
+        theirs = {k: e for k, e in theirs.items() if not k.startswith("vae/")}
+        assert {k: (e["dtype"], e["shape"], e["size"]) for k, e in ours.items()} == {k: (e["dtype"], e["shape"], e["size"]) for k, e in theirs.items()}
     m2 = PPO(np.array([67]), po.ActionSpace(), model_dir=str(tmp_path / "a"), learning_rate=1e-4, lr_decay=1.0, value_scale=1.0, initial_std=1.0)
     m2.init_session(init_logging=False)
     assert m2.load_latest_checkpoint() is True and m2.get_episode_idx() == 1 and m2.get_train_step_idx() == 1

@@ -168,7 +168,11 @@ def test_config1_epoch_evaluate_then_train_fp32(tmp_path):
     assert gt[0] < gv[0]
 
 
-def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir):
+@pytest.mark.parametrize("fmt", ["npz", "tf"])
+def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir, fmt, monkeypatch):
+    """fmt = tf: the files are the reference's own format (tf.train.Saver bundle, mi355/tf_bundle.py): same variable names, shapes AND
+    dtypes as the reference's shipped model.ckpt-232.index, restored through the same load_latest_checkpoint()."""
+    monkeypatch.setenv("MI355_CKPT_FORMAT", fmt)
     ref = json.load(open(os.path.join(golden_dir, "ref_variables.json")))["vae_rgb"]
     m = make(tmp_path / "a", "fp32", params=trained_like_params(1))
     frames = synth_frames(4)
@@ -179,6 +183,12 @@ def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir):
     assert {k: list(np.shape(v)) for k, v in sd.items()} == {k: v["shape"] for k, v in ref.items()}   # every TF global variable
     m.save()
     assert os.path.exists(os.path.join(m.checkpoint_dir, "checkpoint"))
+    if fmt == "tf":
+        from mi355 import tf_bundle as tb
+        assert sorted(os.listdir(m.checkpoint_dir)) == ["checkpoint", "model.ckpt-7.data-00000-of-00001", "model.ckpt-7.index"]
+        ours, _ = tb.read_index(os.path.join(m.checkpoint_dir, "model.ckpt-7.index"))
+        theirs, _ = tb.read_index(os.path.join(golden_dir, "ref_index", "vae_rgb.index"))
+        assert {k: (e["dtype"], e["shape"], e["size"]) for k, e in ours.items()} == {k: (e["dtype"], e["shape"], e["size"]) for k, e in theirs.items()}
     m2 = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "a"), precision="fp32")
     m2.init_session(init_logging=False)
     assert m2.load_latest_checkpoint() is True and m2.get_step_idx() == 7
