@@ -47,6 +47,25 @@ def vae_variables(z_dim, source_shape, target_shape):
     return v
 
 
+def mlp_vae_variables(z_dim, source_shape, target_shape, encoder_sizes=(512, 256), decoder_sizes=(256, 512)):
+    """name -> shape for the trainable MlpVAE variables, TF creation order (reference vae/models.py:287-297: tf.layers.dense default
+    names inside variable_scope("encoder") / ("decoder"): dense, dense_1, ...)."""
+    v = OrderedDict()
+    cin = int(np.prod(source_shape))
+    for i, h in enumerate(encoder_sizes):
+        name = "vae/encoder/dense" + ("_%d" % i if i else "")
+        v[name + "/kernel"], v[name + "/bias"] = (cin, int(h)), (int(h),)
+        cin = int(h)
+    for head in ("mean", "logstd_sqare"):
+        v["vae/%s/kernel" % head], v["vae/%s/bias" % head] = (cin, int(z_dim)), (int(z_dim),)
+    cin = int(z_dim)
+    for i, h in enumerate(list(decoder_sizes) + [int(np.prod(target_shape))]):
+        name = "vae/decoder/dense" + ("_%d" % i if i else "")
+        v[name + "/kernel"], v[name + "/bias"] = (cin, int(h)), (int(h),)
+        cin = int(h)
+    return v
+
+
 def ppo_variables(input_dim, num_actions, hidden=(500, 300), scope="policy"):
     """name -> shape for the 13 trainable policy variables, TF creation order (ppo.py:42-55)."""
     h1, h2 = hidden
@@ -87,6 +106,12 @@ def init_vae(seed, z_dim, source_shape, target_shape):
     rng = np.random.RandomState(seed)
     return OrderedDict((n, glorot_uniform(rng, s) if n.endswith("kernel") else np.zeros(s, np.float32))
                        for n, s in vae_variables(z_dim, source_shape, target_shape).items())
+
+
+def init_mlp_vae(seed, z_dim, source_shape, target_shape, encoder_sizes=(512, 256), decoder_sizes=(256, 512)):
+    rng = np.random.RandomState(seed)
+    return OrderedDict((n, glorot_uniform(rng, s) if n.endswith("kernel") else np.zeros(s, np.float32))
+                       for n, s in mlp_vae_variables(z_dim, source_shape, target_shape, encoder_sizes, decoder_sizes).items())
 
 
 def init_ppo(seed, input_dim, num_actions, initial_std, initial_mean_factor=0.1, hidden=(500, 300)):

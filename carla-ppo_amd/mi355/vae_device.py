@@ -153,9 +153,13 @@ class VaeDevice:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def sync_shadow(self):
+        """Refresh the derived weight copies (bf16 shadow, K-contiguous kernels) after self.params was written from outside."""
+        self.L.mi_vae_sync_shadow(self.handle, self.stream())
+
     def load_params(self, named):
         self.params.copy_(torch.from_numpy(self._to_flat(named)))
-        self.L.mi_vae_sync_shadow(self.handle, self.stream())
+        self.sync_shadow()
 
     def load_slots(self, m_named, v_named):
         self.adam_m.copy_(torch.from_numpy(self._to_flat(m_named)))

@@ -72,7 +72,7 @@ class VAE():
         if self.precision not in ("bf16", "fp32", "f32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.seed = seed
-        self._variables = vae_variables(int(z_dim), tuple(int(s) for s in source_shape), tuple(int(s) for s in target_shape))
+        self._variables = self._variable_table()
         self._init_values = None
         self.step_idx = 0                              # vae/step_idx: epoch counter (vae/models.py:116-117)
         self.beta1_power, self.beta2_power = np.float32(ADAM_BETA1), np.float32(ADAM_BETA2)
@@ -95,19 +95,29 @@ class VAE():
     def init_session(self, sess=None, init_logging=True):
         """Reference: tf.Session() + global_variables_initializer (+ FileWriters).  Here: create the device engine,
         initialise the variables (Glorot-uniform kernels, zero biases) and upload them.  Raises without a GPU."""
-        from mi355.vae_device import VaeDevice
         self.sess = sess if sess is not None else self
-        self.dev = VaeDevice(self.source_shape, self.target_shape, self.z_dim, self.beta, self.kl_tolerance, self.loss_name,
-                             self.precision, max_batch=128 if self.training else 16, with_optimizer=self.training)
-        values = self._init_values or init_vae(self.seed, int(self.z_dim), self.dev.source_shape, self.dev.target_shape)
+        self.dev = self._make_device(max_batch=128 if self.training else 16)
+        values = self._init_values or self._initial_values()
         self.dev.load_params(values)
         if midist.world_size() > 1:                    # replicas start identical: rank 0's values win
             midist.broadcast(self.dev.params, 0)
-            self.dev.L.mi_vae_sync_shadow(self.dev.handle, self.dev.stream())
+            self.dev.sync_shadow()
         if init_logging:
             from mi355.summary import SummaryWriter
             self.train_writer = SummaryWriter(os.path.join(self.log_dir, "train"))
             self.val_writer = SummaryWriter(os.path.join(self.log_dir, "val"))
+
+    # architecture hooks (ConvVAE: the native engine; MlpVAE overrides all three)
+    def _variable_table(self):
+        return vae_variables(int(self.z_dim), tuple(int(s) for s in self.source_shape), tuple(int(s) for s in self.target_shape))
+
+    def _make_device(self, max_batch):
+        from mi355.vae_device import VaeDevice
+        return VaeDevice(self.source_shape, self.target_shape, self.z_dim, self.beta, self.kl_tolerance, self.loss_name,
+                         self.precision, max_batch=max_batch, with_optimizer=self.training)
+
+    def _initial_values(self):
+        return init_vae(self.seed, int(self.z_dim), self.dev.source_shape, self.dev.target_shape)
 
     def _need_dev(self):
         if self.dev is None:
@@ -347,8 +357,28 @@ class ConvVAE(VAE):
 
 
 class MlpVAE(VAE):
-    """Multi-layer perceptron VAE (reference vae/models.py:271-299).  Not on the MI355X hot path yet
-    ("next"): constructing one raises instead of silently running something else."""
+    """Multi-layer perceptron VAE (reference vae/models.py:271-299): flatten -> dense + ReLU per encoder size -> mean / logstd_sqare heads
+    -> sample -> dense + ReLU per decoder size -> dense(prod(target_shape)) logits.  Same class surface and training path as ConvVAE; the
+    device side (mi355/mlp_vae_device.py) sequences the dense-layer kernels of the C ABI."""
 
     def __init__(self, source_shape, target_shape=None, encoder_sizes=(512, 256), decoder_sizes=(256, 512), **kwargs):
-        raise NotImplementedError("MlpVAE has no MI355X kernels yet (scope: SURVEY.md 8f item 2); use ConvVAE")
+        target_shape = source_shape if target_shape is None else target_shape
+        self.encoder_sizes = tuple(int(h) for h in encoder_sizes)
+        self.decoder_sizes = tuple(int(h) for h in decoder_sizes)
+        kwargs.pop("build_encoder_fn", None)
+        kwargs.pop("build_decoder_fn", None)
+        super().__init__(source_shape, target_shape, None, None, **kwargs)
+
+    def _variable_table(self):
+        from mi355.init import mlp_vae_variables
+        return mlp_vae_variables(int(self.z_dim), tuple(int(s) for s in self.source_shape), tuple(int(s) for s in self.target_shape),
+                                 self.encoder_sizes, self.decoder_sizes)
+
+    def _make_device(self, max_batch):
+        from mi355.mlp_vae_device import MlpVaeDevice
+        return MlpVaeDevice(self.source_shape, self.target_shape, self.z_dim, self.beta, self.kl_tolerance, self.loss_name, self.precision,
+                            encoder_sizes=self.encoder_sizes, decoder_sizes=self.decoder_sizes, max_batch=max_batch, with_optimizer=self.training)
+
+    def _initial_values(self):
+        from mi355.init import init_mlp_vae
+        return init_mlp_vae(self.seed, int(self.z_dim), self.dev.source_shape, self.dev.target_shape, self.encoder_sizes, self.decoder_sizes)

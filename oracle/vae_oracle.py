@@ -13,6 +13,7 @@ Restates (all citations relative to /root/reference):
   vae/models.py:140-142 AdamOptimizer(lr const).minimize -> AdamTF
   vae/models.py:188-231 generate_from_latent / reconstruct / encode / train_one_epoch / evaluate -> OracleVAE
   vae/models.py:249-266 ConvVAE.build_encoder / build_decoder -> vae_forward()
+  vae/models.py:271-299 MlpVAE build_mlp / build_encoder / build_decoder -> mlp_vae_variable_specs(), mlp_vae_forward()
 
 Layouts are TensorFlow's: conv kernels HWIO [kh,kw,in,out]; transposed-conv kernels [kh,kw,out,in];
 dense kernels [in,out]; activations NHWC; flatten order (H,W,C).
@@ -154,6 +155,70 @@ def vae_forward(params, src, eps=None, sample=True, dtype=torch.float32, storage
     logits = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)                        # [B, H*W*C_t]
     out["logits"] = logits
     return out
+
+
+def mlp_vae_variable_specs(z_dim=64, source_shape=(80, 160, 3), target_shape=None, encoder_sizes=(512, 256), decoder_sizes=(256, 512)):
+    """Trainable variables of MlpVAE in TF creation order (tf.layers.dense default names inside variable_scope("encoder") /
+    ("decoder"): dense, dense_1, ...; vae/models.py:287-297)."""
+    target_shape = source_shape if target_shape is None else target_shape
+    specs = OrderedDict()
+    cin = int(np.prod(source_shape))
+    for i, h in enumerate(encoder_sizes):
+        name = "vae/encoder/dense" + ("_%d" % i if i else "")
+        specs[name + "/kernel"], specs[name + "/bias"] = (cin, int(h)), (int(h),)
+        cin = int(h)
+    for head in ("mean", "logstd_sqare"):
+        specs["vae/%s/kernel" % head], specs["vae/%s/bias" % head] = (cin, z_dim), (z_dim,)
+    cin = z_dim
+    for i, h in enumerate(list(decoder_sizes) + [int(np.prod(target_shape))]):
+        name = "vae/decoder/dense" + ("_%d" % i if i else "")
+        specs[name + "/kernel"], specs[name + "/bias"] = (cin, int(h)), (int(h),)
+        cin = int(h)
+    return specs
+
+
+def init_mlp_vae_params(seed=0, **kw):
+    rng = np.random.RandomState(seed)
+    return OrderedDict((n, glorot_uniform(rng, s) if n.endswith("kernel") else np.zeros(s, np.float32)) for n, s in mlp_vae_variable_specs(**kw).items())
+
+
+def mlp_vae_forward(params, src, eps=None, sample=True, dtype=torch.float32, storage="fp32", z_override=None):
+    """MlpVAE (vae/models.py:287-297): flatten -> dense+ReLU per encoder size (the LAST one too: output_activation=relu) -> heads -> z ->
+    dense+ReLU per decoder size -> dense(prod(target_shape)) without activation = logits."""
+    enc = sorted((k for k in params if k.startswith("vae/encoder/") and k.endswith("kernel")), key=lambda k: (len(k), k))
+    dec = sorted((k for k in params if k.startswith("vae/decoder/") and k.endswith("kernel")), key=lambda k: (len(k), k))
+    out = {}
+    if z_override is None:
+        x = _q(_t(src, dtype).reshape(len(src), -1), storage)
+        for k in enc:
+            x = _q(F.relu(x @ _qw(params[k], storage) + params[k[:-6] + "bias"]), storage)
+        mean = x @ _qw(params["vae/mean/kernel"], storage) + params["vae/mean/bias"]
+        logvar = x @ _qw(params["vae/logstd_sqare/kernel"], storage) + params["vae/logstd_sqare/bias"]
+        out.update(mean=mean, logvar=logvar)
+        if sample:
+            assert eps is not None, "training-mode forward needs injected noise"
+            z = mean + torch.exp(0.5 * logvar) * _t(eps, dtype)
+        else:
+            z = mean
+    else:
+        z = _t(z_override, dtype)
+    out["z"] = z
+    x = _q(z, storage)
+    for i, k in enumerate(dec):
+        x = x @ _qw(params[k], storage) + params[k[:-6] + "bias"]
+        if i + 1 < len(dec):
+            x = _q(F.relu(x), storage)
+    out["logits"] = x
+    return out
+
+
+def mlp_vae_loss_and_grads(params_np, src, tgt, eps, beta=1.0, kl_tolerance=0.0, loss_fn="bce", dtype=torch.float32, storage="fp32"):
+    params = OrderedDict((k, _t(v, dtype).clone().requires_grad_(True)) for k, v in params_np.items())
+    fw = mlp_vae_forward(params, src, eps, sample=True, dtype=dtype, storage=storage)
+    recon, kl, loss = vae_losses(fw, tgt, beta, kl_tolerance, loss_fn, dtype=dtype)
+    loss.backward()
+    grads = OrderedDict((k, (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()) for k, p in params.items())
+    return (float(recon.detach()), float(kl.detach()), float(loss.detach())), grads, {k: v.detach() for k, v in fw.items()}
 
 
 def vae_losses(fw, tgt, beta=1.0, kl_tolerance=0.0, loss_fn="bce", z_dim=None, dtype=torch.float32):

@@ -92,8 +92,15 @@ def test_class_surface_matches_reference_signatures(tmp_path):
     assert tuple(v.encoded_shape) == (3, 8, 256)
     with pytest.raises(AssertionError):
         vm.ConvVAE(np.array([81, 160, 3]), z_dim=64, model_dir=str(tmp_path / "x"))         # decoder yields 80 rows, not 81 (vae/models.py:265)
-    with pytest.raises(NotImplementedError):
-        vm.MlpVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "y"))
+    # MlpVAE (vae/models.py:271-299): same surface; variables in TF creation order with tf.layers.dense default names
+    mv = vm.MlpVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "y"))
+    assert isinstance(mv, vm.VAE) and mv.encoder_sizes == (512, 256) and mv.decoder_sizes == (256, 512)
+    assert list(mv._variables.items())[:4] == [("vae/encoder/dense/kernel", (38400, 512)), ("vae/encoder/dense/bias", (512,)),
+                                                ("vae/encoder/dense_1/kernel", (512, 256)), ("vae/encoder/dense_1/bias", (256,))]
+    assert list(mv._variables)[4:8] == ["vae/mean/kernel", "vae/mean/bias", "vae/logstd_sqare/kernel", "vae/logstd_sqare/bias"]
+    assert list(mv._variables.items())[-2:] == [("vae/decoder/dense_2/kernel", (512, 38400)), ("vae/decoder/dense_2/bias", (38400,))]
+    from oracle import vae_oracle as vo
+    assert dict(mv._variables) == dict(vo.mlp_vae_variable_specs(64, (80, 160, 3)))
 
     class Box:
         low, high, shape = np.array([-1, 0], np.float32), np.array([1, 1], np.float32), (2,)
