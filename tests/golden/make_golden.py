@@ -12,6 +12,7 @@ Outputs (all small, committed):
   ref_event_scalars.json  first/last/min scalar values logged by the reference's own VAE training runs
                        (parsed from the TensorBoard event files). Coarse known-answers: the untrained
                        validation reconstruction loss must be ~= n_pixels*ln2.
+  ref_events_head.bin  the first small records of the reference's rgb VAE training event file, verbatim (golden bytes for mi355/summary.py)
   ref_index/*.index    the three shipped TF bundle index files, verbatim (golden bytes for mi355/tf_bundle.py)
   real_frames_u8.npy   16 real CARLA frames (uint8 [16,80,160,3]) from vae/data/rgb/{0..15}.png and
   real_seg_u8.npy      the matching segmentation class-id maps (uint8 [16,80,160,1], values 0..12).
@@ -193,6 +194,17 @@ def main():
         scal[k] = {"_source": os.path.join(os.path.relpath(d, REF), fn), **summarize(parse_events(os.path.join(d, fn)))}
     with open(os.path.join(OUT, "ref_event_scalars.json"), "w") as f:
         json.dump(scal, f, indent=1, sort_keys=True)
+    # the first small TFRecord records of the rgb VAE training log, verbatim (file_version + the first scalar events; the graph_def
+    # record between them is skipped -- every record carries its own length and checksums): golden bytes for mi355/summary.py
+    d = os.path.join(REF, events["vae_rgb/train"])
+    data = open(os.path.join(d, sorted(os.listdir(d))[0]), "rb").read()
+    pos, recs = 0, []
+    while pos + 12 <= len(data) and len(recs) < 12:
+        ln = struct.unpack("<Q", data[pos:pos + 8])[0]
+        recs.append(data[pos:pos + 16 + ln])
+        pos += 16 + ln
+    with open(os.path.join(OUT, "ref_events_head.bin"), "wb") as f:
+        f.write(b"".join([r for r in recs if len(r) < 400][:7]))
 
     rgb = np.stack([np.asarray(Image.open(os.path.join(REF, "vae/data/rgb/%d.png" % i)))[:, :, :3] for i in range(16)])
     seg = np.stack([np.asarray(Image.open(os.path.join(REF, "vae/data/segmentation/%d.png" % i)))[:, :, :1] for i in range(16)])

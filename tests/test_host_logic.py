@@ -231,6 +231,38 @@ def test_tf_bundle_roundtrip_and_checkpoint_dir_in_reference_format(tmp_path):
     assert sd["vae/mean/kernel"][0, 0] == 6 and int(sd["vae/step_idx"]) == 6 and sd["vae/step_idx"].shape == ()
 
 
+def test_tensorboard_event_files_match_the_reference_framing(golden_dir, tmp_path):
+    """mi355/summary.py writes tf.summary.FileWriter files: the reference's own event file (first records, verbatim) passes our reader with
+    both CRCs of every record checked, its first scalars are the ones in ref_event_scalars.json, and a file written here starts with the
+    same file_version record (identical bytes apart from the wall-clock field and the two checksums that cover it) and reads back."""
+    import glob
+    import struct
+    from mi355 import summary as sm
+    ref_path = os.path.join(golden_dir, "ref_events_head.bin")
+    ver, series = sm.read_events(ref_path, verify=True)
+    scal = json.load(open(os.path.join(golden_dir, "ref_event_scalars.json")))["vae_rgb/train"]
+    assert ver == "brain.Event:2" and set(series) == {"vae/kl_loss", "vae/reconstruction_loss", "vae/learning_rate"}
+    for tag, pts in series.items():
+        assert pts[0][0] == scal[tag]["first_step"] and pts[0][2] == pytest.approx(scal[tag]["first"], rel=1e-6)
+    w = sm.SummaryWriter(str(tmp_path / "logs"))
+    for i in range(4):
+        w.add_scalar("vae/kl_loss", 44.5 - i, i)
+        w.add_scalar("vae/reconstruction_loss", 25000.0 / (i + 1), i)
+    w.add_text("hyperparameters", {"learning_rate": 1e-4, "z_dim": 64}, 0)
+    w.close()
+    (path,) = glob.glob(str(tmp_path / "logs" / "events.out.tfevents.*"))
+    ver2, s2 = sm.read_events(path, verify=True)
+    assert ver2 == "brain.Event:2" and [p[0] for p in s2["vae/kl_loss"]] == [0, 1, 2, 3] and [p[2] for p in s2["vae/kl_loss"]] == [44.5, 43.5, 42.5, 41.5]
+    assert s2["vae/reconstruction_loss"][3][2] == pytest.approx(6250.0)
+    a, b = open(ref_path, "rb").read()[:40], open(path, "rb").read()[:40]
+    assert a[:12] == b[:12] and a[12:13] == b[12:13] and a[21:36] == b[21:36]           # length, its crc, field tags, "brain.Event:2"
+    raw = bytearray(open(path, "rb").read())
+    raw[50] ^= 1
+    open(path, "wb").write(raw)
+    with pytest.raises(ValueError, match="checksum"):
+        sm.read_events(path)
+
+
 def test_fastdiv_constants_are_exact():
     """Python mirror of make_fastdiv()/FastDiv::div (csrc/common.hpp): q = (n * mul) >> shift must equal n // d for n < 2^31."""
     rng = np.random.RandomState(0)
