@@ -365,3 +365,33 @@ def test_mlp_vae_bf16_trains_and_checkpoints(tmp_path):
     m2.init_session(init_logging=False)
     assert m2.load_latest_checkpoint() is True and m2.get_step_idx() == 3
     assert m.train_step(src, src, eps=eps) == pytest.approx(m2.train_step(src, src, eps=eps), rel=1e-6)
+
+
+def test_data_parallel_two_ranks_on_the_gpu(tmp_path):
+    """The product's data-parallel path end to end with world_size 2 (two ranks sharing this GPU over gloo, tests/dp_gpu_worker.py): the
+    all-reduced gradients of a global minibatch equal the single-process gradients of the same minibatch, the epoch metrics agree, both
+    ranks end with identical parameters, and those equal the single-process result up to Adam's sensitivity where |g| ~ 1e-8."""
+    import subprocess
+    import sys
+    import dp_gpu_worker as W
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dp")
+    os.makedirs(out)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r0, r1 = np.load(os.path.join(out, "rank0.npz")), np.load(os.path.join(out, "rank1.npz"))
+    assert int(r0["world"]) == 2
+    frames, eps = W.dataset()
+    m = W.build(str(tmp_path / "single"), trained_like_params(2))
+    grads, losses, params = W.run(m, frames, eps)
+    for k, g in grads.items():
+        key = "g|" + k.replace("/", "|")
+        assert np.array_equal(r0[key], r1[key]), k                                   # the same reduced buffer on both ranks
+        assert rel_err(r0[key], g) < 2e-5, (k, rel_err(r0[key], g))
+    assert np.allclose(r0["losses"], losses, rtol=1e-5) and np.array_equal(r0["losses"], r1["losses"])
+    for k, v in params.items():
+        key = "p|" + k.replace("/", "|")
+        assert np.array_equal(r0[key], r1[key]), k                                   # replicas stay bit-identical
+        assert rel_err(r0[key], v) < 2e-2, (k, rel_err(r0[key], v))
