@@ -339,8 +339,9 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
 }
 
 // Backward of the last mi_vae_forward(want_grad=1) into the flat fp32 gradient buffer (which must be zero on entry;
-// mi_vae_apply_adam clears it again).  part: 0 = everything, 1 = decoder half (deconv4..dense1 + dz), 2 = encoder half.
-// The two halves exist so the data-parallel host can all-reduce the decoder gradients while the encoder half runs.
+// mi_vae_apply_adam clears it again).  part: 0 = everything, 1 = decoder half (deconv4..dense1 + dz), 2 = encoder half = 3 (heads + conv4:
+// 88 % of the encoder's parameters) followed by 4 (conv3..conv1).  The parts exist so the data-parallel host can all-reduce the gradient
+// bucket of a finished part while the next part runs; every separately called part ends with the stream join that completes its bucket.
 int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part) {
     VaeEngine* e = (VaeEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
@@ -385,7 +386,9 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
         if (part == 1) join();                               // a full backward joins once, at its end: nothing below reads a filter gradient
     }
-    if (part == 0 || part == 2) {
+    if (part < 0 || part > 4) return mi_fail(MI_ERR_SHAPE, "mi_vae_backward: part must be 0..4");
+    const bool upper = part == 0 || part == 2 || part == 3, lower = part == 0 || part == 2 || part == 4;
+    if (upper) {
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
         TOP(e, st, OP_REPARAM_BWD, mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
@@ -393,7 +396,10 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
         TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
         TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
+    }
+    if (upper || lower) {
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
+            if (i == NCONV - 1 ? !upper : !lower) continue;
             const void* gy = e->at(W.gact[i + 1]);
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
             // conv1 has no input gradient, so the caller's stream would idle while the (longer) filter-gradient stream drains: its

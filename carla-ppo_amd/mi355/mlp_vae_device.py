@@ -59,6 +59,7 @@ class MlpVaeDevice:
             self.layout[name + "/kernel"], off = (off, k * n), off + k * n
             self.layout[name + "/bias"], off = (off, n), off + n
         self.n_flat = off
+        self.grad_buckets = [(1, self.decoder_offset, self.n_flat), (2, 0, self.decoder_offset)]   # (backward part, lo, hi), see VaeDevice
         z = lambda dt=torch.float32: torch.zeros(self.n_flat, device=self.device, dtype=dt)   # noqa: E731
         self.params = z()
         self.grads = z() if with_optimizer else None

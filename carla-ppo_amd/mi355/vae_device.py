@@ -75,6 +75,11 @@ class VaeDevice:
         self.weights_t = z(torch.bfloat16 if self.dtype == milib.MI_BF16 else torch.float32)     # K-contiguous kernel copies
         self.metrics = torch.zeros(3, device=self.device)
         self.decoder_offset = self.layout["vae/decoder/dense1/kernel"][0]   # grads[decoder_offset:] are ready first in backward
+        # data-parallel gradient buckets in the order backward completes them: (engine part, first float, one past the last float).
+        # decoder (43 % of the parameters) | heads + conv4 (51 %) | conv3..conv1 (6 %): only the last, small bucket is reduced with
+        # nothing left to overlap it.
+        c4 = self.layout["vae/encoder/conv4/kernel"][0]
+        self.grad_buckets = [(1, self.decoder_offset, self.n_flat), (3, c4, self.decoder_offset), (4, 0, c4)]
 
     def _create(self, max_batch):
         if self.handle is not None:

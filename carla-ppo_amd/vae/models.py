@@ -256,17 +256,17 @@ class VAE():
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
 
     def _train_minibatch(self, src, tgt, idx, n_local, inv_batch, eps):
-        """One SGD step on rows idx of the resident tables: forward, backward (decoder half first so its gradient
-        all-reduce overlaps the encoder half), gradient all-reduce, fused Adam."""
+        """One SGD step on rows idx of the resident tables: forward, backward in the device's bucket order (decoder first, then heads + conv4,
+        then conv3..conv1: each bucket's gradient all-reduce overlaps the next part), fused Adam."""
         dev = self.dev
         dev.forward(src, tgt, idx, n_local, inv_batch, eps, 1, 1)
         if midist.world_size() > 1:
-            dev.backward(src, idx, eps, inv_batch, part=1)
-            w1 = midist.all_reduce_sum(dev.grads[dev.decoder_offset:], async_op=True)
-            dev.backward(src, idx, eps, inv_batch, part=2)
-            w2 = midist.all_reduce_sum(dev.grads[:dev.decoder_offset], async_op=True)
-            w1.wait()
-            w2.wait()
+            pending = []
+            for part, lo, hi in dev.grad_buckets:      # each bucket's all-reduce runs under the next part of backward
+                dev.backward(src, idx, eps, inv_batch, part=part)
+                pending.append(midist.all_reduce_sum(dev.grads[lo:hi], async_op=True))
+            for w in pending:
+                w.wait()
         else:
             dev.backward(src, idx, eps, inv_batch, part=0)
         self._adam_step()

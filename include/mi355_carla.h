@@ -155,7 +155,8 @@ int mi_vae_sync_shadow(void* h, void* stream);
 void* mi_vae_buffer(void* h, int which);
 /* forward + ELBO terms: the per-minibatch sess.run of VAE.evaluate (vae/models.py:226-229) / forward half of train_step (:213-216) */
 int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
-/* gradients of loss = recon + beta*kl wrt all 22 variables (optimizer.minimize, vae/models.py:142); part 0 all, 1 decoder, 2 encoder */
+/* gradients of loss = recon + beta*kl wrt all 22 variables (optimizer.minimize, vae/models.py:142); part 0 all, 1 decoder half,
+ * 2 encoder half = 3 (heads + conv4) then 4 (conv3..conv1): the data-parallel host all-reduces a finished part's bucket under the next part */
 int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part);
 int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
 /* VAE.encode / generate_from_latent (= north_star "decode") / reconstruct — vae/models.py:188-202 */

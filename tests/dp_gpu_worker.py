@@ -42,11 +42,13 @@ def run(m, frames, eps):
     e = m._eps(hi - lo, eps[0][lo:hi])
     dev.forward(src, src, idx, hi - lo, 1.0 / B, e, 1, 1, accumulate_metrics=False)
     if midist.world_size() > 1:
-        dev.backward(src, idx, e, 1.0 / B, part=1)
-        w1 = midist.all_reduce_sum(dev.grads[dev.decoder_offset:], async_op=True)
-        dev.backward(src, idx, e, 1.0 / B, part=2)
-        w2 = midist.all_reduce_sum(dev.grads[:dev.decoder_offset], async_op=True)
-        w1.wait(); w2.wait()
+        pending = []
+        for part, lo_f, hi_f in dev.grad_buckets:       # the same bucket loop as VAE._train_minibatch
+            dev.backward(src, idx, e, 1.0 / B, part=part)
+            pending.append(midist.all_reduce_sum(dev.grads[lo_f:hi_f], async_op=True))
+        for w in pending:
+            w.wait()
+        assert sorted((lo_f, hi_f) for _, lo_f, hi_f in dev.grad_buckets)[0][0] == 0 and sum(hi_f - lo_f for _, lo_f, hi_f in dev.grad_buckets) == dev.n_flat
     else:
         dev.backward(src, idx, e, 1.0 / B, part=0)
     torch.cuda.synchronize()
