@@ -23,7 +23,7 @@ template <int CPR> __device__ __forceinline__ int gn_swz(int row) { return CPR =
 // C (input channels) * sizeof(T) must be 64 or 128 bytes: CPR = 4 | 8 sixteen-byte chunks per pixel
 // NOUT: output channels when known at compile time (3 rgb, 1 segmentation: packed dword stores), 0 = generic element stores
 template <typename T, int TAPS, int CPR, int NOUT>
-__global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p) {
+__global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_narrow_kernel(const TapParams p) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VE = 16 / ESZ;
     constexpr int PA = CPR * 16;
@@ -69,10 +69,7 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
         }
     }
 
-    // ---- this lane's output pixels (epilogue role: position lrow of the wave's 32, output-row parity lgrp) and, for the fused
-    // reconstruction loss, their label values: requested NOW so that the fp32 frame gather (HBM latency) runs under the tile DMA and
-    // the MFMAs -- loaded in the epilogue it sat between the logits store and the dlogits store and waited for the former's
-    // acknowledgement on top of its own latency ----
+    // ---- this lane's output pixels (epilogue role: position lrow of the wave's 32, output-row parity lgrp) ----
     const int P = P0 + wave * 32 + lrow;
     uint32_t g, gx, b, gy;
     p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
@@ -81,22 +78,6 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
     const int oy = 2 * (int)gy + ph, ox = 2 * (int)gx;
     const bool live = P < p.MP && oy < p.OH && ox < p.OW;
     const int npx = ox + 1 < p.OW ? 2 : 1;                // output pixels of this lane (pw = 0, 1)
-    constexpr int CNTL = NOUT > 0 ? 2 * NOUT : 2;
-    float yv[CNTL];
-#pragma unroll
-    for (int j = 0; j < CNTL; ++j) yv[j] = 0.f;
-    if constexpr (NOUT > 0) {
-        if (p.labels && live && npx == 2) {
-            const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
-            const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
-#pragma unroll
-            for (int d = 0; d < CNTL / 2; ++d) {
-                const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
-                yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
-            }
-        }
-    }
-
     // ---- weights: fragment (tap, kk) of lane (row ne = lrow, chunk 2 kk + lgrp) straight from global / L2 ----
     freg wf[NT][NKK];
     {
@@ -136,6 +117,24 @@ __global__ __launch_bounds__(GN_NT) void gather_narrow_kernel(const TapParams p)
         for (int kk = 0; kk < NKK; ++kk) {
             const freg af = *(const freg*)(lds + q * PA + (((2 * kk + lgrp) ^ sw) << 4));
             Frag<T>::mma(wf[tap][kk], af, acc);           // D[row = parity*N + channel][col = position]
+        }
+    }
+
+    // labels of the fused loss: requested here -- after the MFMAs (holding them through the main phase costs the registers that decide
+    // between 5 and 7 resident blocks per CU) but BEFORE the logits store (a load behind a store waits for the store's acknowledgement)
+    constexpr int CNTL = NOUT > 0 ? 2 * NOUT : 2;
+    float yv[CNTL];
+#pragma unroll
+    for (int j = 0; j < CNTL; ++j) yv[j] = 0.f;
+    if constexpr (NOUT > 0) {
+        if (p.labels && live && npx == 2) {
+            const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
+            const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
+#pragma unroll
+            for (int d = 0; d < CNTL / 2; ++d) {
+                const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
+                yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
+            }
         }
     }
 
@@ -453,7 +452,7 @@ struct NarrowConvParams {
 };
 
 template <typename T, typename TS>
-__global__ __launch_bounds__(256) void narrow_conv_kernel(const NarrowConvParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void narrow_conv_kernel(const NarrowConvParams p) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VE = 16 / ESZ;
     constexpr int OPITCH = 32 * ESZ + 16;                 // output transpose: 32 channels per pixel + 16 B pad
