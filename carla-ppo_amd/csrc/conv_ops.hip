@@ -47,7 +47,6 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
 // ---------------------------------------------------------------------------------------------------------------
 long long* g_trace = nullptr; int g_trace_cap = 0;
 int g_wgrad_skip = 0;
-int g_tap_stagger = 0;
 int g_gemm2_on = -1;
 int g_tap_min = -2;
 bool gemm2_enabled() {
@@ -165,7 +164,6 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     const int gy_t = (q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64);
     const bool auto_small = blocks >= 300 && blocks <= 1000 && gy_t <= 2;
     const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
-    q.stagger = (!small_tile && blocks >= 512) ? g_tap_stagger : 0;   // one block per CU and at least two rounds
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
     else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q, small_tile) : launch_tapconv<bf16_t, TC_GATHER>(st, q, small_tile);
@@ -584,7 +582,6 @@ int mi_set_tuning(int key, int value) {
     else if (key == 9) { prev = g_tapwgrad_blocks; g_tapwgrad_blocks = value < 16 ? 16 : value; }
     else if (key == 10) { prev = g_nw_waves; g_nw_waves = value; }
     else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
-    else if (key == 8) { prev = g_tap_stagger; g_tap_stagger = value < 0 ? 0 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

@@ -40,7 +40,6 @@ struct TapParams {
     void* out; const float* bias; const void* mask; int relu;
     int direct_epilogue;             // 1: registers -> 16-byte stores (half-wave swap), 0: LDS-staged coalesced stores
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
-    int stagger;                       // cycles the first-round blocks on odd CUs wait before starting (0 = off), see tapconv_kernel
     int dbg;                           // debug (mi_set_tuning key 2): 3 = direct epilogue without its stores, 4 = without the MFMA steps (wrong results)
     // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
     const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
@@ -88,16 +87,6 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     long long* const tr = p.trace ? p.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (tid >> 6)) * 32 : nullptr;   // 8 wave slots per block in the trace layout
     const bool tr_on = tr && ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
 #define TC_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    // Every block does the same work, so the 256 CUs run in lockstep: all load, all compute, all store -- the store burst of a round
-    // (256 x 64 KB) runs at the HBM write rate while no MFMA is busy, and vice versa.  Delaying the FIRST block of every second CU by
-    // about half a block period puts the two halves of the chip in anti-phase for the rest of the launch (all periods are equal).
-    if (p.stagger > 0 && blockIdx.y * gridDim.x + blockIdx.x < 256) {
-        const unsigned cu = __builtin_amdgcn_s_getreg((3 << 11) | (8 << 6) | 4);   // HW_ID.cu_id
-        if (cu & 1) {
-            const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-            while ((long long)__builtin_amdgcn_s_memtime() - t0 < p.stagger) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     TC_STAMP();
     const int P0 = xcd_remap(blockIdx.x, gridDim.x) * BMT;
     const int n0 = blockIdx.y * BNE;
@@ -129,8 +118,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     const int cchA = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
     uint32_t offA[NIA];                                   // byte offset of the slot's first pixel (G2_OOB: slot outside every image)
     uint32_t vmA[NIA];                                    // conv form: validity of the (ph,pw) sub-pixels, bit ph*2+pw
-#pragma unroll
-    for (int i = 0; i < NIA; ++i) {
+    auto slotA = [&](int i) {                              // slot -> pixel decode of this thread's row of DMA instruction i
         const int t = wave + NWAVE * i;
         const int P = P0 + 8 * t + r8;
         const bool ok = t < ninstrA && P < p.MP;
@@ -154,7 +142,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
             offA[i] = in ? (((b * p.IH + iy) * p.IW + ix) * p.C) * ESZ : G2_OOB;
             vmA[i] = 0;
         }
-    }
+    };
     // per channel slice: this thread's chunk -> byte offset inside the slot (+ which sub-pixel it belongs to, conv form)
     uint32_t sl_koff = 0, sl_bit = 0;
     auto sliceA = [&](int cc) {
@@ -178,6 +166,12 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(Abase + buf * ASTAGE + t * 1024), 16, (int)vo, 0, 0, 0);
         return 1;
     };
+
+    // slice 0 of the slot range goes out instruction by instruction as soon as its rows are decoded: the first loads are in flight ~2k
+    // cycles earlier than with "decode everything, then issue everything", under the rest of the set-up (weight roles, LDS addresses)
+    sliceA(0);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) { slotA(i); issueA(0, i); }
 
     // ---------------- B-tile DMA roles: wave fills rows 8 (wave*NJB + j) .. +7 ----------------
     int cchB[NJB];
@@ -243,9 +237,6 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
         for (int u = 0; u < TPS; ++u)
             if (ss * TPS + u < NT) issueB(ss * TPS + u, stage * BSTAGE + u * BTILE);
     };
-    sliceA(0);
-#pragma unroll
-    for (int i = 0; i < NIA; ++i) issueA(0, i);
     sliceB(0);
     issue_step_B(0, 0);
     TC_STAMP();

@@ -73,16 +73,6 @@ if name == "variants":                                     # timing only: big ti
             res.append("%s %.1f" % (label, us))
         print("%-14s %s" % (nm, "   ".join(res)))
     sys.exit(0)
-if name == "stagger":                                      # timing only: start stagger (mi_set_tuning key 8) sweep on the big-tile layers
-    for nm in ("deconv3.fwd", "conv2.dgrad", "conv2.fwd", "deconv2.fwd", "conv3.dgrad"):
-        res = []
-        for sg in (0, 3000, 6000, 9000, 12000, 16000):
-            prev = L.mi_set_tuning(8, sg)
-            us, _ = run(nm, False)
-            L.mi_set_tuning(8, prev)
-            res.append("%d: %.1f" % (sg, us))
-        print("%-14s %s" % (nm, "   ".join(res)))
-    sys.exit(0)
 if len(sys.argv) > 2:
     L.mi_set_tuning(5, int(sys.argv[2])); L.mi_set_tuning(1, 1)
 for nm in ([name] if name != "all" else list(LAYERS)):
