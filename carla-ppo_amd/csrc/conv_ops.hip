@@ -225,6 +225,16 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
                 q.pair_tap[q.npairs] = (unsigned char)tap; q.pair_nt[q.npairs] = (unsigned char)nt; q.pair_first[q.npairs] = first ? 1 : 0; ++q.npairs;
             }
         }
+    // the first pair of every output tile (the one that also accumulates the tile's bias gradient) goes to the front of the list: pairs
+    // 0 .. ntb-1 are slot 0 of waves 0 .. ntb-1, the only slot the kernel keeps a bias accumulator for
+    {
+        unsigned char t2[32], n2[32], f2[32];
+        int k = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < q.npairs; ++i)
+                if ((q.pair_first[i] != 0) == (pass == 0)) { t2[k] = q.pair_tap[i]; n2[k] = q.pair_nt[i]; f2[k] = q.pair_first[i]; ++k; }
+        for (int i = 0; i < q.npairs; ++i) { q.pair_tap[i] = t2[i]; q.pair_nt[i] = n2[i]; q.pair_first[i] = f2[i]; }
+    }
     q.dbias = dbias;
     int splits = g_tapwgrad_blocks / gy; if (splits < 1) splits = 1;
     long long pps = (MP + splits - 1) / splits; pps = (pps + TW_BP - 1) / TW_BP * TW_BP;

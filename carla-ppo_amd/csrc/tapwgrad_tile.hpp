@@ -254,14 +254,18 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 
     // fused bias gradient: column sums of the gradient tile = (all-ones rows) x D on the matrix core, one extra MFMA per
     // k-step in the first pair of every output tile of the kb == 0 blocks; row 0 of the result carries the sums
-    f32x16 accb[PPW];
+    // (pair layout: the first pair of an output tile is one of pairs 0 .. NTB-1, i.e. slot q = 0 of a wave; split layout: both tiles of a
+    //  tap-0 wave.  Accumulating ones x D for EVERY slot cost the 9-tap config 64 registers -- no room to pipeline the fragment reads --
+    //  and made its bias waves issue 12 MFMAs per k-step against 8 in the other four waves.)
+    constexpr int NBQ = SPLIT ? PPW : 1;
+    f32x16 accb[NBQ];
 #pragma unroll
-    for (int q = 0; q < PPW; ++q)
+    for (int q = 0; q < NBQ; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accb[q][r] = 0.f;
     bool any_bias = false;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) any_bias = any_bias || pr_bias[q];
+    for (int q = 0; q < NBQ; ++q) any_bias = any_bias || pr_bias[q];
     const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     constexpr int ND = SPLIT ? PPW : 1;
     constexpr int NU = SPLIT ? NKS : NKS * PPW;
     constexpr int NKI = NKS;                              // k16-steps that carry DMA issue (bunching them into the first half: measured 8 % slower)
-    constexpr bool PIPE = SPLIT || PPW <= 2;              // the 9-tap config (4 pairs + 4 bias accumulators per wave) has no registers left for it
+    constexpr bool PIPE = true;
     struct Frag { u16x8 d[ND]; u16x8 a[KT]; };
     auto tr_read = [&](uint32_t off, int pitch) -> u16x8 {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + off));
@@ -317,8 +321,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                 for (int j = 0; j < ND; ++j) {
                     const int q = SPLIT ? j : q0;
                     // no branch on pr_on: an unused pair slot recomputes pair 0 and is dropped
-                    if constexpr (BIAS)
-                        accb[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, f.d[j]), accb[q], 0, 0, 0);
+                    if constexpr (BIAS) {
+                        if (q < NBQ) accb[q < NBQ ? q : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, f.d[j]), accb[q < NBQ ? q : 0], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
                         // orientation: the 32 lanes of a register are 32 CONTIGUOUS elements of dW (coalesced 128-byte stores into the slabs):
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     TW_STAMP();
     const int lcol = lane & 31, lgrp = lane >> 5;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
+    for (int q = 0; q < NBQ; ++q) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
         if (!pr_bias[q] || lane >= 32) continue;
         const int ne = ne0 + pr_nt[q] * 32 + lane;
         if (ne >= p.NE) continue;
