@@ -225,7 +225,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     for (int q = 0; q < PPW; ++q) {
         if constexpr (SPLIT) {
             pr_on[q] = true; pr_tap[q] = wave >> 1; pr_nt[q] = q;
-            pr_bias[q] = p.dbias && kb == 0 && (wave >> 1) == 0;
+            pr_bias[q] = q == 0 && p.dbias && kb == 0 && (wave >> 1) < 2;      // split layout: the waves of taps 0 and 1 sum output tile 0 and 1 (one extra MFMA each)
         } else {
             const int pi = wave + 8 * q;
             pr_on[q] = pi < p.npairs;
@@ -254,10 +254,11 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 
     // fused bias gradient: column sums of the gradient tile = (all-ones rows) x D on the matrix core, one extra MFMA per
     // k-step in the first pair of every output tile of the kb == 0 blocks; row 0 of the result carries the sums
-    // (pair layout: the first pair of an output tile is one of pairs 0 .. NTB-1, i.e. slot q = 0 of a wave; split layout: both tiles of a
-    //  tap-0 wave.  Accumulating ones x D for EVERY slot cost the 9-tap config 64 registers -- no room to pipeline the fragment reads --
-    //  and made its bias waves issue 12 MFMAs per k-step against 8 in the other four waves.)
-    constexpr int NBQ = SPLIT ? PPW : 1;
+    // (pair layout: the first pair of an output tile is one of pairs 0 .. NTB-1, i.e. slot q = 0 of a wave; split layout: the waves of tap t < 2
+    //  take output tile t.  Accumulating ones x D for EVERY slot cost the 9-tap config 64 registers -- no room to pipeline the fragment
+    //  reads -- and made its bias waves issue 12 MFMAs per k-step against 8 in the other four waves.)
+    constexpr int NBQ = 1;
+    const int bias_nt = SPLIT ? (wave >> 1) & 1 : 0;     // split layout: which of the two gradient fragments of a k-step this wave sums
     f32x16 accb[NBQ];
 #pragma unroll
     for (int q = 0; q < NBQ; ++q)
@@ -322,7 +323,11 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                     const int q = SPLIT ? j : q0;
                     // no branch on pr_on: an unused pair slot recomputes pair 0 and is dropped
                     if constexpr (BIAS) {
-                        if (q < NBQ) accb[q < NBQ ? q : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, f.d[j]), accb[q < NBQ ? q : 0], 0, 0, 0);
+                        if (q == 0) {
+                            u16x8 dsel = f.d[j];
+                            if constexpr (SPLIT) dsel = bias_nt ? f.d[1] : f.d[0];
+                            accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, dsel), accb[0], 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
     for (int q = 0; q < NBQ; ++q) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
         if (!pr_bias[q] || lane >= 32) continue;
-        const int ne = ne0 + pr_nt[q] * 32 + lane;
+        const int ne = ne0 + (SPLIT ? bias_nt : pr_nt[q]) * 32 + lane;
         if (ne >= p.NE) continue;
         int n = ne;
         if constexpr (MODE == TC_GATHER) n = ne - (int)p.div_n.div((uint32_t)ne) * p.N;
