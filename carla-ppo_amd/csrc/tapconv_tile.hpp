@@ -80,6 +80,11 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int wm = wave / WN, wn = wave % WN;
+    // 32-output tile of accumulator column j of this wave.  k = 5 gather form with one parity class per tile (N = 32, four tiles): the classes
+    // reach 9 / 6 / 6 / 4 of the 3 x 3 taps (zero tiles are skipped), so the natural split {0,1} | {2,3} gives one wave column 15 tile-taps and
+    // the other 10; {0,3} | {1,2} gives 13 and 12.
+    const bool pair_classes = TAPS == 3 && MODE == TC_GATHER && TN == 2 && p.N == 32 && p.NE == 128;
+    auto tile_of = [&](int j) { const int t = wn * TN + j; return pair_classes ? ((0x9C >> (2 * t)) & 3) : t; };   // 0x9C: {0,3,1,2}
     const int lrow = lane & 31, lgrp = lane >> 5;
     const int r8 = lane >> 3;
 
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bias4[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int ne = n0 + (wn * TN + j) * 32 + 4 * lgrp + 8 * q;
+            const int ne = n0 + tile_of(j) * 32 + 4 * lgrp + 8 * q;
             if (p.bias && ne < p.NE) {
                 int nb = ne;
                 if constexpr (MODE == TC_GATHER) nb -= (int)p.div_n.div((uint32_t)ne) * p.N;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) boff[kk][j] = ((wn * TN + j) * 32 + lrow) * RB + (((kk * 2 + lgrp) ^ ((lrow >> 1) & 7)) << 4);
+        for (int j = 0; j < TN; ++j) boff[kk][j] = (tile_of(j) * 32 + lrow) * RB + (((kk * 2 + lgrp) ^ ((lrow >> 1) & 7)) << 4);
     int q0[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) q0[i] = (wm * TM + i) * 32 + lrow;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
                     if (p.N >= 32) {                      // a 32-wide tile lies inside one parity class
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const int cls = (int)p.div_n.div((uint32_t)(n0 + (wn * TN + j) * 32));
+                            const int cls = (int)p.div_n.div((uint32_t)(n0 + tile_of(j) * 32));
                             live[j] = !((ta == 0 && (cls >> 1) + 2 * p.HY >= p.KH) || (tb == 0 && (cls & 1) + 2 * p.HX >= p.KW));
                         }
                     }
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
             const bool vy0 = pin && oy0 < p.OH, vx0 = ox0 < p.OW, vy1 = pin && oy0 + 1 < p.OH, vx1 = ox0 + 1 < p.OW;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int ne0 = n0 + (wn * TN + j) * 32;  // wave-uniform; a 32-wide output tile never straddles a parity class
+                const int ne0 = n0 + tile_of(j) * 32;     // wave-uniform; a 32-wide output tile never straddles a parity class
                 int sub = ne0;                             // wave-uniform element offset of the tile inside the slot's pixels
                 bool ok = vy0 && vx0;
                 if constexpr (MODE == TC_GATHER) {
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cn = (wn * TN + j) * 32 + 4 * lgrp + 8 * q;       // output column inside the tile
+                const int cn = tile_of(j) * 32 + 4 * lgrp + 8 * q;          // output column inside the tile
                 float v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = acc[i][j][4 * q + t];
