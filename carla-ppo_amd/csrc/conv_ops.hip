@@ -171,6 +171,51 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Deferred split reductions.  The reduce that follows a tapwgrad launch is a small, bandwidth-trivial kernel, but on the filter-gradient
+// stream of the engine it shares the chip with a big input-gradient kernel and takes 15-30 us instead of 7.  In deferred mode the launch
+// is recorded instead (parameters by value; every layer then needs its OWN scratch region until the flush) and mi_tapwgrad_flush issues
+// all of them back to back.  Process-global like the tuning knobs; used by the VAE engine only.
+struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; };
+static PendingReduce g_pending[16];
+static int g_npending = 0, g_defer_reduces = 0;
+static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element: about 512 blocks in flight, at most ~16 slabs per thread
+    unsigned ry = 1;
+    while (((unsigned)(r.ngroups / 256 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4) ry *= 2;
+    return ry;
+}
+static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
+    const unsigned ry = reduce_ry(r);
+    const dim3 rg((unsigned)((r.ngroups + 255) / 256), ry, 1);
+    if (r.kind == 0) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
+    else if (r.kind == 1) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
+    else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
+}
+extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode drops whatever an aborted pass may have left in the list
+    const int prev = g_defer_reduces;
+    g_defer_reduces = on ? 1 : 0;
+    g_npending = 0;
+    return prev;
+}
+extern "C" int mi_tapwgrad_flush(void* stream) {
+    const int n = g_npending;
+    g_npending = 0;
+    if (n == 0) return MI_OK;
+    if (n == 1 || n > TW_MAX_FUSED) {
+        for (int i = 0; i < n; ++i) launch_tiled_reduce((hipStream_t)stream, g_pending[i]);
+        return mi_check_launch("reduce_tiled_kernel");
+    }
+    static FusedReduceParams f;                           // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
+    f.n = n; f.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const PendingReduce& r = g_pending[i];
+        f.q[i] = r.q; f.splits[i] = r.splits; f.ngroups[i] = r.ngroups; f.kind[i] = r.kind; f.ry[i] = (int)reduce_ry(r);
+        f.first[i + 1] = f.first[i] + ((r.ngroups + 255) / 256) * f.ry[i];
+    }
+    for (int i = n; i < TW_MAX_FUSED; ++i) f.first[i + 1] = f.first[n];
+    hipLaunchKernelGGL(reduce_fused_kernel, dim3((unsigned)f.first[n]), dim3(256), 0, (hipStream_t)stream, f);
+    return mi_check_launch("reduce_fused_kernel");
+}
+
 // tapwgrad (tapwgrad_tile.hpp): bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles.
 // mi_set_tuning key 3 / MI355_TAPWGRAD=0 disables it.
 // ---------------------------------------------------------------------------------------------------------------
@@ -265,14 +310,10 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     }
     int rc = mi_check_launch("tapwgrad_kernel");
     if (rc == MI_OK && q.slabs) {
-        const int ngroups = (int)(slab_floats / 4);
-        unsigned ry = 1;                                  // slabs per thread chain: keep about 512 blocks in flight
-        while ((unsigned)(ngroups / 256 + 1) * ry < 512 && (int)(ry * 2) <= splits / 4) ry *= 2;
-        const dim3 rg((unsigned)((ngroups + 255) / 256), ry, 1);
-        if (mode == TC_CONV) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, q, splits, ngroups);
-        else if (taps == 2) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, q, splits, ngroups);
-        else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, q, splits, ngroups);
-        rc = mi_check_launch("reduce_tiled_kernel");
+        PendingReduce r;
+        r.q = q; r.splits = splits; r.ngroups = (int)(slab_floats / 4); r.kind = mode == TC_CONV ? 0 : (taps == 2 ? 1 : 2);
+        if (g_defer_reduces && g_npending < 16) g_pending[g_npending++] = r;
+        else { launch_tiled_reduce(st, r); rc = mi_check_launch("reduce_tiled_kernel"); }
     }
     return rc == MI_OK ? 1 : rc;
 }

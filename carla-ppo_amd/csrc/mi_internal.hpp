@@ -7,3 +7,7 @@ enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_SHAPE = -2, MI_ERR_LAUNCH = -3, MI_ERR
 
 int mi_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK / MI_ERR_LAUNCH
+
+// deferred split reductions of the raw-staged filter-gradient kernel (conv_ops.hip; used by the VAE engine)
+extern "C" int mi_tapwgrad_defer(int on);        // returns the previous mode
+extern "C" int mi_tapwgrad_flush(void* stream);  // launches the recorded reduces on `stream`

@@ -76,6 +76,7 @@ enum {
     OP_REPARAM_BWD = 28, OP_HEADS_BIAS = 29, OP_HEADS_WGRAD = 30, OP_HEADS_DGRAD = 31, OP_CONV_BIAS = 32, OP_CONV_WGRAD = 36,
     OP_CONV_DGRAD = 40, OP_ADAM = 44, N_OPS = 45
 };
+constexpr int SCRATCH_REGIONS = 6;  // deconv3..1 and conv4..2 keep their partial-sum slabs until the deferred reduce (conv_ops.hip)
 const char* const OP_NAMES[N_OPS] = {
     "conv1.fwd", "conv2.fwd", "conv3.fwd", "conv4.fwd", "heads.fwd", "reparam_kl.fwd", "dense1.fwd",
     "deconv1.fwd", "deconv2.fwd", "deconv3.fwd", "deconv4.fwd", "recon_loss", "finalize_losses",
@@ -153,7 +154,7 @@ void make_workspace(VaeEngine& e) {
     e.partial_cap = (int)(B * 64 > B * e.nchunks ? B * 64 : B * e.nchunks);   // loss partial sums: per (frame, chunk) or per block of the fused decoder tail
     W.partial = add((long long)e.partial_cap * 4); W.bpart = add((long long)e.partial_cap * 16); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
-    W.scratch_bytes = d.dtype == MI_BF16 ? 64ll << 20 : 0;
+    W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
     W.total = o;
 }
@@ -366,15 +367,29 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
     auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
         if (fork) { hipEventRecord(e->ev_ready, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_ready, 0); }
     };
+    // In two-stream mode the split reductions of the filter gradients are deferred to the end of the side stream's work (they are tiny, but
+    // next to a big input-gradient kernel each takes 15-30 us instead of ~7): every layer writes its slabs into its own scratch region.
+    const bool defer = fork && W.scratch_bytes > 0;
+    const long long region = W.scratch_bytes / SCRATCH_REGIONS;
+    int next_region = 0;
+    auto scratch_of = [&]() -> void* {
+        void* ptr = (char*)e->at(W.scratch) + (defer ? (next_region % SCRATCH_REGIONS) * region : 0);
+        ++next_region;
+        return ptr;
+    };
+    const long long scratch_sz = defer ? region : W.scratch_bytes;
+    if (defer) mi_tapwgrad_defer(1);
     auto join = [&]() {
+        if (defer) mi_tapwgrad_flush(sw);
         if (fork) { hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent((hipStream_t)st, e->ev_done, 0); }
     };
+    struct DeferGuard { bool on; ~DeferGuard() { if (on) mi_tapwgrad_defer(0); } } guard{defer};
     if (part == 0 || part == 1) {
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             const void* gy = e->at(W.gdec[i + 1]);
             release();                                       // gy is complete on st (loss pass / previous input gradient)
             // BiasAddGrad is fused into the filter-gradient call
-            TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), e->at(W.scratch), W.scratch_bytes, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
+            TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), scratch_of(), scratch_sz, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
         }
@@ -407,7 +422,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
             void* sg = i == 0 ? st : sw;
             if (i > 0) release();
             TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
-                                                                   (i == 0 && fork) ? nullptr : e->at(W.scratch), (i == 0 && fork) ? 0 : W.scratch_bytes, e->gptr(2 * i + 1)));
+                                                                   (i == 0 && fork) ? nullptr : scratch_of(), (i == 0 && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), e->at(W.gact[i])));
