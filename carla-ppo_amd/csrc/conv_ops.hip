@@ -47,6 +47,7 @@ void fill_conv_geom(GemmParams& p, int B, int IH, int IW, int C, int OH, int OW,
 // ---------------------------------------------------------------------------------------------------------------
 long long* g_trace = nullptr; int g_trace_cap = 0;
 int g_wgrad_skip = 0;
+int g_tap_mask_prefetch = 1;                                // tapconv: touch the ReluGrad-mask lines in the last main-loop step; mi_set_tuning key 12
 int g_gemm2_on = -1;
 int g_tap_min = -2;
 bool gemm2_enabled() {
@@ -157,7 +158,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     q.direct_epilogue = (g_tap_direct && N % 32 == 0) ? 1 : 0;       // a 32-output tile is all valid or all out of range
-    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg = g_wgrad_skip;
+    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg = g_wgrad_skip; q.mask_prefetch = g_tap_mask_prefetch;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
     // measured (tools/trace_tapconv.py variants): the 128-position tile wins 5-12 % where the 256-position grid is only 1.3-3 rounds
     // of blocks (tile quantisation), loses a little on the 4-column grids and ties on the big grids
@@ -632,6 +633,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }
     else if (key == 9) { prev = g_tapwgrad_blocks; g_tapwgrad_blocks = value < 16 ? 16 : value; }
     else if (key == 10) { prev = g_nw_waves; g_nw_waves = value; }
+    else if (key == 12) { prev = g_tap_mask_prefetch; g_tap_mask_prefetch = value ? 1 : 0; }
     else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;

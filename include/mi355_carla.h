@@ -72,7 +72,8 @@ unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
  * key 6: tapconv epilogue (1 = registers -> 16-byte stores through a half-wave swap, 0 = LDS-staged coalesced stores);
  * key 7: tapwgrad wave layout for 2x2-tap layers (1 = wave per (tap, position half), 0 = wave per (tap, output tile));
  * key 9: tapwgrad target block count (position splits x block columns; default 256 = one block per CU); key 10: waves per block of
- * the narrow filter-gradient kernel (4 | 8 | 12); key 11: target block count of the dense filter gradients.  Returns the previous value. */
+ * the narrow filter-gradient kernel (4 | 8 | 12); key 11: target block count of the dense filter gradients;
+ * key 12: tapconv ReluGrad-mask prefetch in the last main-loop step on/off.  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);
