@@ -434,6 +434,7 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     const long long M = (long long)B * OH * OW;
     if (M >= (1ll << 30)) return 0;
+    if ((long long)OH * OW < 32) return 0;               // a wave's 32 pixels must not span more than two frames
     NarrowConvParams q = {};
     q.src = src; q.frame_idx = frame_idx; q.frame_stride = (long long)IH * IW * Cs; q.w = wt;
     q.B = B; q.IH = IH; q.IW = IW; q.Cs = Cs; q.OH = OH; q.OW = OW; q.KH = KH; q.KW = KW; q.M = (int)M;

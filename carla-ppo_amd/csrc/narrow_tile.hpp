@@ -474,7 +474,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t b, rem, y, x;
     p.div_ohw.divmod((uint32_t)(mok ? m : 0), b, rem);
     p.div_ow.divmod(rem, y, x);
-    const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+    // frame gather: the 32 pixels of a wave lie in at most two frames (the host requires OH x OW >= 32); their indices are two wave-uniform
+    // (scalar) loads instead of a per-lane load that every patch load then depends on
+    const uint32_t b0 = p.div_ohw.div((uint32_t)__builtin_amdgcn_readfirstlane(m0));
+    const uint32_t b1 = min(b0 + 1u, (uint32_t)(p.B - 1));
+    const long long fr0 = p.frame_idx ? (long long)p.frame_idx[b0] : (long long)b0, fr1 = p.frame_idx ? (long long)p.frame_idx[b1] : (long long)b1;
+    const long long fr = b == b0 ? fr0 : fr1;
     const TS* __restrict__ src = (const TS*)p.src;
     const TS* pix = src + fr * p.frame_stride + ((long long)(2 * y) * p.IW + 2 * x) * p.Cs;
 
