@@ -65,7 +65,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "conv2.fwd"
 if name == "variants":                                     # timing only: big tile vs small tile vs gemm2 for every layer
     for nm in LAYERS:
         res = []
-        for label, cfg in (("quad-epi", {5: 1, 1: 1, 6: 2}), ("direct-epi", {5: 1, 1: 1, 6: 1}), ("staged-epi", {5: 1, 1: 1, 6: 0}), ("small+quad", {5: 2, 1: 1, 6: 2}), ("gemm2", {1: -1})):
+        for label, cfg in (("direct-epi", {5: 1, 1: 1, 6: 1}), ("staged-epi", {5: 1, 1: 1, 6: 0}), ("small+direct", {5: 2, 1: 1, 6: 1}), ("gemm2", {1: -1})):
             prev = {k: L.mi_set_tuning(k, v) for k, v in cfg.items()}
             us, _ = run(nm, False)
             for k, v in prev.items():
