@@ -26,6 +26,7 @@ struct PpoEngine {
     // workspace offsets (bytes)
     long long s_pad, h1, h2, g1, g2, u, vraw, h1o, h2o, uo, du, dv, dh2, dh1, dg2, dg1, partial, losses, mean, low, high, ws_total;
     int last_M;
+    hipStream_t side; hipEvent_t ev_fork, ev_join; int side_ok;     // second stream of the forked minibatch step (0 = not tried, 1 = ok, -1 = unavailable)
     float* P(int t) const { return params + off[t]; }
     float* PO(int t) const { return params_old + off[t]; }
     float* G(int t) const { return grads + off[t]; }
@@ -83,17 +84,21 @@ __global__ void head_dgrad_kernel(const float* __restrict__ du, const float* __r
 
 #define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
 
-int trunk_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, bool value_branch, void* h1, void* h2, void* u, void* vraw) {
+int policy_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, void* h1, void* h2, void* u) {
     const MiPpoDesc& d = e->d;
     CK(mi_gemm_bias_act(st, MI_F32, e->at(e->s_pad), M, e->kin, prm + off[0], 0, d.h1, prm + off[1], 1, nullptr, h1, 1, 1));
     CK(mi_gemm_bias_act(st, MI_F32, h1, M, d.h1, prm + off[2], 0, d.h2, prm + off[3], 1, nullptr, h2, 1, 1));
-    CK(mi_gemm_bias_act(st, MI_F32, h2, M, d.h2, prm + off[4], 0, d.num_actions, prm + off[5], 0, nullptr, u, 1, 1));
-    if (value_branch) {
-        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->s_pad), M, e->kin, prm + off[7], 0, d.h1, prm + off[8], 1, nullptr, e->at(e->g1), 1, 1));
-        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->g1), M, d.h1, prm + off[9], 0, d.h2, prm + off[10], 1, nullptr, e->at(e->g2), 1, 1));
-        CK(mi_gemm_bias_act(st, MI_F32, e->at(e->g2), M, d.h2, prm + off[11], 0, 1, prm + off[12], 0, nullptr, vraw, 1, 1));
-    }
-    return MI_OK;
+    return mi_gemm_bias_act(st, MI_F32, h2, M, d.h2, prm + off[4], 0, d.num_actions, prm + off[5], 0, nullptr, u, 1, 1);
+}
+int value_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, void* vraw) {
+    const MiPpoDesc& d = e->d;
+    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->s_pad), M, e->kin, prm + off[7], 0, d.h1, prm + off[8], 1, nullptr, e->at(e->g1), 1, 1));
+    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->g1), M, d.h1, prm + off[9], 0, d.h2, prm + off[10], 1, nullptr, e->at(e->g2), 1, 1));
+    return mi_gemm_bias_act(st, MI_F32, e->at(e->g2), M, d.h2, prm + off[11], 0, 1, prm + off[12], 0, nullptr, vraw, 1, 1);
+}
+int trunk_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, bool value_branch, void* h1, void* h2, void* u, void* vraw) {
+    CK(policy_fwd(e, st, prm, off, M, h1, h2, u));
+    return value_branch ? value_fwd(e, st, prm, off, M, vraw) : MI_OK;
 }
 
 int stage_states(PpoEngine* e, void* st, const float* states, int M) {
@@ -146,7 +151,11 @@ void* mi_ppo_create(const MiPpoDesc* d, float* params, float* params_old, float*
     return e;
 }
 
-void mi_ppo_destroy(void* h) { free(h); }
+void mi_ppo_destroy(void* h) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_join); }
+    free(h);
+}
 
 // 0 losses[5] (policy, value, entropy, total, mean ratio)   1 action_mean [M,A] of the last predict
 void* mi_ppo_buffer(void* h, int which) {
@@ -186,35 +195,53 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     const MiPpoDesc& d = e->d;
     void* st = stream;
     const int A = d.num_actions;
+    // The step is ~28 launches of 5-9 us kernels that leave the chip almost empty, and the policy and value networks only meet in the loss:
+    // the value side (and the old policy's forward) runs on a second stream.  Forward: policy(theta) | value(theta) + policy(theta_old);
+    // backward: policy head + trunk | value head + trunk.  MI355_PPO_STREAMS=0 serialises everything again.
+    static int two_streams = -1;
+    if (two_streams < 0) { const char* ev = getenv("MI355_PPO_STREAMS"); two_streams = (ev && ev[0] == '0') ? 0 : 1; }
+    if (two_streams && !e->side_ok) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
+        else e->side_ok = -1;
+    }
+    const bool fork = two_streams && e->side_ok == 1;
+    void* sw = fork ? (void*)e->side : st;
+    auto release = [&]() { if (fork) { hipEventRecord(e->ev_fork, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_fork, 0); } };
+    auto join = [&]() { if (fork) { hipEventRecord(e->ev_join, e->side); hipStreamWaitEvent((hipStream_t)st, e->ev_join, 0); } };
     CK(stage_states(e, st, states, M));
-    CK(trunk_fwd(e, st, e->params, e->off, M, true, e->at(e->h1), e->at(e->h2), e->at(e->u), e->at(e->vraw)));
-    CK(trunk_fwd(e, st, e->params_old, e->off, M, false, e->at(e->h1o), e->at(e->h2o), e->at(e->uo), nullptr));
+    release();
+    CK(policy_fwd(e, st, e->params, e->off, M, e->at(e->h1), e->at(e->h2), e->at(e->u)));
+    CK(value_fwd(e, sw, e->params, e->off, M, e->at(e->vraw)));
+    CK(policy_fwd(e, sw, e->params_old, e->off, M, e->at(e->h1o), e->at(e->h2o), e->at(e->uo)));
+    join();
     CK(mi_ppo_loss_fwd_bwd(st, (const float*)e->at(e->u), (const float*)e->at(e->uo), e->P(6), e->PO(6), (const float*)e->at(e->vraw), actions, returns, advantage,
                            (const float*)e->at(e->low), (const float*)e->at(e->high), M, A, d.clip_eps, d.value_scale, d.entropy_scale, inv_m, grad_scale,
                            (float*)e->at(e->du), (float*)e->at(e->dv), (float*)e->at(e->partial), (float*)e->at(e->losses), e->G(6)));
-    // heads
-    CK(mi_colsum(st, MI_F32, e->at(e->du), M, A, e->G(5)));
-    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->h2), e->at(e->du), M, d.h2, A, e->G(4)));
-    CK(mi_colsum(st, MI_F32, e->at(e->dv), M, 1, e->G(12)));
-    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->g2), e->at(e->dv), M, d.h2, 1, e->G(11)));
-    {
+    {   // gradient through the two heads into both trunks (needs du and dv: before the fork)
         const int n = M * d.h2;
         hipLaunchKernelGGL(head_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)e->at(e->du), (const float*)e->at(e->dv), e->P(4), e->P(11),
                            (const float*)e->at(e->h2), (const float*)e->at(e->g2), M, d.h2, A, (float*)e->at(e->dh2), (float*)e->at(e->dg2));
         CK(mi_check_launch("head_dgrad"));
     }
-    // policy trunk
+    release();
+    // policy side (caller's stream): head, trunk
+    CK(mi_colsum(st, MI_F32, e->at(e->du), M, A, e->G(5)));
+    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->h2), e->at(e->du), M, d.h2, A, e->G(4)));
     CK(mi_colsum(st, MI_F32, e->at(e->dh2), M, d.h2, e->G(3)));
     CK(mi_gemm_wgrad(st, MI_F32, e->at(e->h1), e->at(e->dh2), M, d.h1, d.h2, e->G(2)));
     CK(mi_gemm_bias_act(st, MI_F32, e->at(e->dh2), M, d.h2, e->P(2), 1, d.h1, nullptr, 0, e->at(e->h1), e->at(e->dh1), 1, 1));
     CK(mi_colsum(st, MI_F32, e->at(e->dh1), M, d.h1, e->G(1)));
     CK(mi_gemm_wgrad(st, MI_F32, e->at(e->s_pad), e->at(e->dh1), M, e->kin, d.h1, e->G(0)));
-    // value trunk
-    CK(mi_colsum(st, MI_F32, e->at(e->dg2), M, d.h2, e->G(10)));
-    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->g1), e->at(e->dg2), M, d.h1, d.h2, e->G(9)));
-    CK(mi_gemm_bias_act(st, MI_F32, e->at(e->dg2), M, d.h2, e->P(9), 1, d.h1, nullptr, 0, e->at(e->g1), e->at(e->dg1), 1, 1));
-    CK(mi_colsum(st, MI_F32, e->at(e->dg1), M, d.h1, e->G(8)));
-    CK(mi_gemm_wgrad(st, MI_F32, e->at(e->s_pad), e->at(e->dg1), M, e->kin, d.h1, e->G(7)));
+    // value side (second stream): head, trunk
+    CK(mi_colsum(sw, MI_F32, e->at(e->dv), M, 1, e->G(12)));
+    CK(mi_gemm_wgrad(sw, MI_F32, e->at(e->g2), e->at(e->dv), M, d.h2, 1, e->G(11)));
+    CK(mi_colsum(sw, MI_F32, e->at(e->dg2), M, d.h2, e->G(10)));
+    CK(mi_gemm_wgrad(sw, MI_F32, e->at(e->g1), e->at(e->dg2), M, d.h1, d.h2, e->G(9)));
+    CK(mi_gemm_bias_act(sw, MI_F32, e->at(e->dg2), M, d.h2, e->P(9), 1, d.h1, nullptr, 0, e->at(e->g1), e->at(e->dg1), 1, 1));
+    CK(mi_colsum(sw, MI_F32, e->at(e->dg1), M, d.h1, e->G(8)));
+    CK(mi_gemm_wgrad(sw, MI_F32, e->at(e->s_pad), e->at(e->dg1), M, e->kin, d.h1, e->G(7)));
+    join();
     e->last_M = M;
     return MI_OK;
 }
