@@ -262,6 +262,27 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = f32_to_bf16(src[i]);
 }
 
+// raw camera bytes -> [0, 1] frames: float32(k) / float32(255), correctly rounded (the value the reference's host preprocessing
+// `frame.astype(np.float32) / 255.0` produces -- vae/train_vae.py:15-18); 16 bytes in, four 16-byte vectors out per thread step
+__global__ __launch_bounds__(256) void u8_to_unit_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x * 16;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v = *(const u32x4_t*)(src + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __fdiv_rn((float)((v[q] >> (8 * e)) & 0xffu), 255.0f);
+                *(f32x4*)(dst + i + 4 * q) = o;
+            }
+        } else {
+            for (long long j = i; j < n && j < i + 16; ++j) dst[j] = __fdiv_rn((float)src[j], 255.0f);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // column sums (BiasAddGrad): out[n] += sum_m x[m,n].  Two regimes: N <= 256 (flat, stride a multiple of N) and N > 256.
 // ---------------------------------------------------------------------------------------------------
@@ -448,6 +469,13 @@ int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad,
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     return mi_check_launch("cast_f32_bf16");
+}
+
+int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n) {
+    if (n < 0) return mi_fail(MI_ERR_ARG, "mi_u8_to_unit_f32: negative length");
+    if (n == 0) return MI_OK;
+    hipLaunchKernelGGL(u8_to_unit_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return mi_check_launch("u8_to_unit");
 }
 
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count) {

@@ -19,7 +19,7 @@ _CTYPES = {
     "float*": ctypes.c_void_p, "const float*": ctypes.c_void_p,
     "double*": ctypes.c_void_p, "const double*": ctypes.c_void_p,
     "int*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
-    "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p,
+    "char*": ctypes.c_char_p, "const char*": ctypes.c_char_p, "const unsigned char*": ctypes.c_void_p,
     "int": ctypes.c_int, "unsigned int": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
     "long long*": ctypes.c_void_p, "const long long*": ctypes.c_void_p, "void": None,
     "const MiVaeDesc*": ctypes.c_void_p, "const MiPpoDesc*": ctypes.c_void_p,

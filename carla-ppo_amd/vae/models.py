@@ -174,11 +174,13 @@ class VAE():
     # ------------------------------------------------------------------ data staging (plumbing)
     def _frames(self, arr, n_feat, what, cache=False):
         """HBM-resident fp32 copy [N, n_feat] of a host frame table; verify_range (vae/models.py:24-30,89-90) on upload.
+        uint8 tables (raw frames) are uploaded as bytes and normalised to [0, 1] on the device: in range by construction.
         cache=True (epoch loops only): the same host table is uploaded once and reused across epochs; a strided
         content fingerprint guards against the caller mutating it in place."""
         import torch
         dev = self._need_dev()
-        a = arr if isinstance(arr, np.ndarray) and arr.dtype == np.float32 else np.asarray(arr, dtype=np.float32)
+        u8 = isinstance(arr, np.ndarray) and arr.dtype == np.uint8     # raw camera frames: uploaded as bytes, divided by 255 on the device
+        a = arr if isinstance(arr, np.ndarray) and arr.dtype in (np.float32, np.uint8) else np.asarray(arr, dtype=np.float32)
         key = None
         if cache and a.size:
             flatv = a.reshape(-1)
@@ -190,7 +192,11 @@ class VAE():
         if a2.shape[1] != n_feat:
             raise ValueError("%s: expected %d values per frame, got shape %s" % (what, n_feat, a.shape))
         t = torch.from_numpy(a2).to(dev.device)
-        if not dev.range_ok(t):
+        if u8:                                                         # float32(k) / float32(255), correctly rounded: exactly the host preprocessing's values
+            tf = torch.empty(t.shape, device=dev.device, dtype=torch.float32)
+            dev.L.mi_u8_to_unit_f32(dev.stream(), t.data_ptr(), tf.data_ptr(), t.numel())
+            t = tf
+        elif not dev.range_ok(t):
             raise ValueError("verify_range: min= %r max= %r outside [0, 1] (%s)" % (float(a2.min()), float(a2.max()), what))
         if key is not None:
             if len(self._frames_cache) >= 4:

@@ -34,13 +34,27 @@ def preprocess_seg_frame(frame):
     return frame[:, :, :1].astype(np.float32) / 12.0                 # class id 0..12 -> [0,1] (:26-29)
 
 
-def load_images(dir_path, preprocess_fn):
+def rgb_frame_u8(frame):
+    return np.ascontiguousarray(frame[:, :, :3])                     # RGBA -> RGB, still uint8: /255 happens on the device (VAE._frames)
+
+
+def load_images(dir_path, preprocess_fn, workers=None):
+    """Same result as the reference loader (vae/train_vae.py:31-39): every *.png of dir_path in os.listdir order, preprocessed and stacked.
+    Decoding runs on a thread pool (PIL releases the GIL while it inflates); order is that of the directory listing, not of completion."""
+    from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
-    images = []
-    for filename in os.listdir(dir_path):                            # os.listdir order, like the reference (:31-39)
-        if os.path.splitext(filename)[1] == ".png":
-            images.append(preprocess_fn(np.asarray(Image.open(os.path.join(dir_path, filename)))))
-    return np.stack(images, axis=0)
+    names = [f for f in os.listdir(dir_path) if os.path.splitext(f)[1] == ".png"]
+    if not names:
+        raise FileNotFoundError("no .png frames in %s" % dir_path)
+
+    def one(name):
+        with Image.open(os.path.join(dir_path, name)) as im:
+            return preprocess_fn(np.asarray(im))
+    workers = workers if workers is not None else min(32, os.cpu_count() or 1)
+    if workers <= 1 or len(names) < 4:
+        return np.stack([one(n) for n in names], axis=0)
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return np.stack(list(pool.map(one, names)), axis=0)
 
 
 def train_val_split(images, val_portion=0.1):
@@ -63,13 +77,15 @@ def main(argv=None):
     parser.add_argument("--kl_tolerance", type=float, default=0.0)
     parser.add_argument("-restart", action="store_true")
     parser.add_argument("--max_epochs", type=int, default=0, help="(new) stop after this many epochs; 0 = early stopping only")
+    parser.add_argument("--host_float_frames", action="store_true", help="(new) convert the RGB frames to float32 / 255 on the host like the reference")
     args = parser.parse_args(argv)
 
     from mi355 import dist as midist
     world, rank, _ = midist.init_from_env()
     chief = rank == 0
 
-    rgb_images = load_images(os.path.join(args.dataset, "rgb"), preprocess_rgb_frame)
+    # RGB frames stay uint8 on the host (4x less memory and upload); the model normalises them on the device with the same float32 division
+    rgb_images = load_images(os.path.join(args.dataset, "rgb"), preprocess_rgb_frame if args.host_float_frames else rgb_frame_u8)
     seg_images = load_images(os.path.join(args.dataset, "segmentation"), preprocess_seg_frame) if args.use_segmentation_as_target else None
 
     np.random.seed(0)                                                # every rank: identical permutations

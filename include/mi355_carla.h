@@ -122,6 +122,8 @@ int mi_vae_finalize_losses_flat(void* stream, const float* partial, int n_partia
 /* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
+/* raw uint8 frames -> float32(k) / float32(255), correctly rounded: the reference's host preprocessing (vae/train_vae.py:15-18) done on the device */
+int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n);
 /* K-contiguous copies of the [K,N] kernels for the MFMA B operand: dst[off + n*K + k] = (T) src[off + k*N + n], count <= 16 tensors */
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count);
 /* BiasAddGrad */

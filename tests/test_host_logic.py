@@ -263,6 +263,33 @@ def test_tensorboard_event_files_match_the_reference_framing(golden_dir, tmp_pat
         sm.read_events(path)
 
 
+def test_dataset_loader_is_parallel_ordered_and_uint8(tmp_path):
+    """vae/train_vae.py load_images: the threaded decode returns exactly what the reference's serial loop returns -- every *.png in
+    os.listdir order -- and the uint8 variant of the RGB preprocessing is the float one before its division (normalised later on the device)."""
+    from PIL import Image
+    import vae.train_vae as tv
+    d = tmp_path / "rgb"
+    d.mkdir()
+    rng = np.random.RandomState(0)
+    frames = {}
+    for i in rng.permutation(23):
+        a = rng.randint(0, 256, (80, 160, 4), dtype=np.uint8)
+        Image.fromarray(a, "RGBA").save(str(d / ("%d.png" % i)))
+        frames["%d.png" % i] = a
+    (d / "notes.txt").write_text("not a frame")
+    order = [f for f in os.listdir(str(d)) if f.endswith(".png")]
+    serial = tv.load_images(str(d), tv.preprocess_rgb_frame, workers=1)
+    par = tv.load_images(str(d), tv.preprocess_rgb_frame, workers=8)
+    u8 = tv.load_images(str(d), tv.rgb_frame_u8, workers=8)
+    assert serial.shape == (23, 80, 160, 3) and serial.dtype == np.float32 and np.array_equal(serial, par)
+    assert u8.dtype == np.uint8 and np.array_equal(u8, np.stack([frames[f][:, :, :3] for f in order]))
+    assert np.array_equal(u8.astype(np.float32) / 255.0, serial)
+    tr, va = tv.train_val_split(u8, 0.1)
+    assert len(va) == 2 and len(tr) == 21 and np.array_equal(va, u8[:2])
+    with pytest.raises(FileNotFoundError):
+        tv.load_images(str(tmp_path), tv.rgb_frame_u8)
+
+
 def test_fastdiv_constants_are_exact():
     """Python mirror of make_fastdiv()/FastDiv::div (csrc/common.hpp): q = (n * mul) >> shift must equal n // d for n < 2^31."""
     rng = np.random.RandomState(0)

@@ -395,3 +395,19 @@ def test_data_parallel_two_ranks_on_the_gpu(tmp_path):
         key = "p|" + k.replace("/", "|")
         assert np.array_equal(r0[key], r1[key]), k                                   # replicas stay bit-identical
         assert rel_err(r0[key], v) < 2e-2, (k, rel_err(r0[key], v))
+
+
+def test_uint8_frame_tables_upload_bit_exact(tmp_path):
+    """Raw uint8 camera frames handed to the training surface are normalised on the device to exactly the float32 values the reference's
+    host preprocessing (frame / 255.0) produces: same resident table, same epoch metrics."""
+    m = make(tmp_path, "fp32", params=trained_like_params(3))
+    u8 = np.random.RandomState(9).randint(0, 256, (12, 80, 160, 3), dtype=np.uint8)
+    f32 = u8.astype(np.float32) / 255.0
+    a, b = m._frames(u8, 38400, "src"), m._frames(f32, 38400, "src")
+    assert a.dtype == torch.float32 and torch.equal(a, b)
+    eps = [np.random.RandomState(1).standard_normal((4, 64)).astype(np.float32) for _ in range(3)]
+    np.random.seed(3)                                   # the epoch loops draw the reference's legacy-numpy permutation
+    r1 = m.evaluate(u8, u8, 4, eps=eps)
+    np.random.seed(3)
+    r2 = m.evaluate(f32, f32, 4, eps=eps)
+    assert list(r1) == list(r2)
