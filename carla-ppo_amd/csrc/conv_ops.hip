@@ -266,6 +266,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
                 valid = (nt >> 1) + 2 * (q.HY - ta) < KH && (nt & 1) + 2 * (q.HX - tb) < KW;
             }
             if (valid) {
+                if (q.npairs >= 32) return 0;             // (k = 6 with every (tap, class) pair live: 36 pairs -- not a layer of this model)
                 bool first = true;
                 for (int k = 0; k < q.npairs; ++k) if (q.pair_nt[k] == nt) first = false;
                 q.pair_tap[q.npairs] = (unsigned char)tap; q.pair_nt[q.npairs] = (unsigned char)nt; q.pair_first[q.npairs] = first ? 1 : 0; ++q.npairs;
