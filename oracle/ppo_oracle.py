@@ -1,6 +1,10 @@
 """CPU oracle: PPO policy/value graph, clipped-surrogate loss, gradients, TF-Adam, GAE, minibatch schedule.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py) — parity unpinned by reference tests.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Parity: the reference has no tests and TF 1.13 cannot run here, but the policy /
+value forward pass, sampling + clipping, the three loss terms, all 13 gradients, update_old_policy and the Adam trajectory are pinned to
+the shipped agent's serialized graph (models/pretrained_agent `.meta` -> tests/golden/ref_graph_ppo.json.gz, executed by
+oracle/tf_graph.py; tests/test_ref_graph.py); GAE / advantage normalisation / minibatch schedule (Python in the reference) by
+oracle/gae_ref.c and the KATs in tests/.
 
 Restates (citations relative to /root/reference):
   utils.py:25-28        build_mlp                       -> _mlp()

@@ -1,7 +1,9 @@
 """CPU oracle: ConvVAE forward / ELBO / gradients / TF-Adam / epoch loops.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py) — parity unpinned by reference tests; pinned by the
-golden fixtures + analytic KATs + finite differences in tests/.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Parity: the reference has no tests and TF 1.13 cannot run here, but forward,
+losses, all 22 gradients and the Adam trajectory are pinned to the reference's serialized graphs (rgb and seg `.meta`
+MetaGraphDefs -> tests/golden/ref_graph_vae_*.json.gz, executed by oracle/tf_graph.py; tests/test_ref_graph.py, 1e-9 in float64);
+the epoch loops around them by the golden fixtures + analytic KATs + finite differences in tests/.
 
 Restates (all citations relative to /root/reference):
   vae/models.py:7-9     kl_divergence          -> kl_divergence()
