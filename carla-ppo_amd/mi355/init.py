@@ -86,14 +86,25 @@ def ppo_variables(input_dim, num_actions, hidden=(500, 300), scope="policy"):
     return v
 
 
-def glorot_uniform(rng, shape):
+def glorot_limit(shape):
+    """+-limit of tf.glorot_uniform_initializer: fans are the LAST two dims x the receptive field (also for [kh,kw,out,in] transposed-conv
+    kernels).  Equals the `Initializer/random_uniform/{min,max}` constants of the reference's graphs (tests/test_ref_graph.py)."""
     receptive = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
-    limit = np.sqrt(6.0 / ((shape[-2] + shape[-1]) * receptive))
+    return float(np.sqrt(6.0 / ((shape[-2] + shape[-1]) * receptive)))
+
+
+def glorot_uniform(rng, shape):
+    limit = glorot_limit(shape)
     return rng.uniform(-limit, limit, size=shape).astype(np.float32)
 
 
+def truncnormal_stddev(shape, scale):
+    """variance_scaling(scale, fan_in, truncated normal): the `Initializer/truncated_normal/stddev` constant of the reference's graph."""
+    return float(np.sqrt(scale / shape[0]) / 0.87962566103423978)      # TF's truncated-normal variance correction
+
+
 def variance_scaling_fan_in_truncnormal(rng, shape, scale):
-    stddev = np.sqrt(scale / shape[0]) / 0.87962566103423978      # TF's truncated-normal variance correction
+    stddev = truncnormal_stddev(shape, scale)
     x = rng.standard_normal(size=shape)
     out = np.abs(x) > 2.0
     while out.any():

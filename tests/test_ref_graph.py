@@ -77,6 +77,35 @@ def test_vae_graph_constants_match_the_product():
     assert vm.adam_alpha(1e-4, np.float32(0.9), np.float32(0.999)) == pytest.approx(1e-4 * np.sqrt(1 - 0.999) / (1 - 0.9), rel=2e-5)       # float32 (1 - beta2_power)
 
 
+def test_initializers_match_reference_graph_constants():
+    """tf.layers' default initializers leave their limits in the graph as constants: the product's and the oracle's samplers use the same."""
+    from mi355 import init as mi
+    for which in ("vae_rgb", "vae_seg", "ppo"):
+        g, _ = load_graph(which, np.float32)
+        seen = 0
+        for name in g.variables():
+            hi = name + "/Initializer/random_uniform/max"
+            if hi in g.nodes:
+                shape = g.variable_shape(name)
+                assert mi.glorot_limit(shape) == pytest.approx(float(g.const(hi)), rel=1e-6), name
+                assert float(g.const(name + "/Initializer/random_uniform/min")) == -float(g.const(hi))
+                draw, odraw = mi.glorot_uniform(np.random.RandomState(0), shape), vo.glorot_uniform(np.random.RandomState(0), shape)
+                assert np.abs(draw).max() <= float(g.const(hi)) * (1 + 1e-6) and np.abs(draw).max() > 0.9 * float(g.const(hi))
+                assert np.array_equal(draw, odraw)
+                seen += 1
+            elif name.endswith("/bias") and "Adam" not in name:
+                assert not np.any(g.run(name + "/Initializer/zeros"))
+        # 4 conv + 2 heads + dense1 + 4 deconv; the agent's graph holds the (inference) VAE too, + 5 + 5 dense kernels of policy / policy_old
+        assert seen == (11 if which != "ppo" else 21), (which, seen)
+    g, _ = load_graph("ppo", np.float32)
+    std = float(g.const("policy/action_mean/kernel/Initializer/truncated_normal/stddev"))
+    assert mi.truncnormal_stddev((300, 2), 0.1) == pytest.approx(std, rel=1e-6)
+    x = mi.variance_scaling_fan_in_truncnormal(np.random.RandomState(0), (300, 2), 0.1)
+    assert np.abs(x).max() <= 2 * std * (1 + 1e-6) and np.array_equal(x, po.variance_scaling_truncnormal(np.random.RandomState(0), (300, 2), 0.1))
+    assert g.const("policy/action_logstd/initial_value").tolist() == [0.0, 0.0]                   # log(initial_std = 1.0)
+    assert mi.init_ppo(0, 67, 2, 1.0)["policy/action_logstd"].tolist() == [0.0, 0.0]
+
+
 @pytest.mark.parametrize("which", ["vae_rgb", "vae_seg"])
 def test_vae_oracle_forward_losses_gradients_match_reference_graph(which):
     g, params, src, tgt, eps, feed = vae_case(which)
