@@ -136,6 +136,25 @@ def test_vae_inference_surface_matches_reference_graph():
         vo.verify_range(src + 1.0)
 
 
+def test_inference_mode_vae_inside_the_agent_graph():
+    """The shipped agent's graph holds the VAE as run_eval / train.py build it (training=False): the decoder is fed the MEAN, no sampling."""
+    g, _ = load_graph("ppo")
+    assert g.nodes["vae/decoder/dense1/MatMul"]["input"][0] == "vae/mean/BiasAdd"
+    assert not [n for n in g.order if n.startswith("vae/") and g.nodes[n]["op"] in ("RandomStandardNormal", "ApplyAdam")]
+    params = vo.init_vae_params(7, 64, (80, 160, 3), (80, 160, 1))                          # the shipped agent was trained on the seg VAE
+    init_variables(g, params)
+    src = (np.random.RandomState(8).randint(0, 256, (2, 80, 160, 3)) / 255.0).astype(np.float32)
+    feed = {"vae/source_state_placeholder": src}
+    o = vo.OracleVAE(target_shape=(80, 160, 1), params=params, training=False, dtype=torch.float64)
+    mean = g.run("vae/mean/BiasAdd", feed)
+    assert rel_err(mean, o.encode(src)) < 1e-6                                               # what train.py / run_eval.py feed the agent
+    rec = g.run("vae/reconstructed_states", feed)                                            # [2, 12800]: decoder of the mean
+    assert rel_err(rec, np.stack([np.asarray(r).reshape(-1) for r in o.generate_from_latent(mean)])) < 1e-6
+    z = np.random.RandomState(9).standard_normal((2, 64)).astype(np.float32)               # generate_from_latent: feed the sample tensor
+    got = g.run("vae/reconstructed_states", {"vae/mean/BiasAdd": z})
+    assert rel_err(got, np.stack([np.asarray(r).reshape(-1) for r in o.generate_from_latent(z)])) < 1e-6
+
+
 def test_vae_adam_trajectory_matches_reference_graph():
     g, params, src, tgt, eps, feed = vae_case("vae_rgb", seed=5, B=2)
     o = vo.OracleVAE(params=params, dtype=torch.float64)

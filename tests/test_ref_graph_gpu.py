@@ -74,6 +74,23 @@ def test_hip_vae_step_matches_reference_graph(tmp_path, which, target_c):
     assert m2.beta1_power == pytest.approx(float(g.vars["vae/beta1_power"]), rel=1e-6)
 
 
+def test_hip_inference_vae_matches_the_agent_graph(tmp_path):
+    """training=False, as run_eval / train.py build the VAE next to the agent: encode, mean-fed reconstruction, generate_from_latent."""
+    g, _ = load_graph("ppo")
+    params = vo.init_vae_params(7, 64, (80, 160, 3), (80, 160, 1))                          # the shipped agent was trained on the seg VAE
+    init_variables(g, params)
+    src = (np.random.RandomState(8).randint(0, 256, (2, 80, 160, 3)) / 255.0).astype(np.float32)
+    m = ConvVAE(np.array([80, 160, 3]), np.array([80, 160, 1]), z_dim=64, model_dir=str(tmp_path), precision="fp32", training=False)
+    m.set_weights(params)
+    m.init_session(init_logging=False)
+    feed = {"vae/source_state_placeholder": src}
+    mean = g.run("vae/mean/BiasAdd", feed)
+    assert rel_err(m.encode(src), mean) < 1e-4
+    assert rel_err(m.generate_from_latent(mean), g.run("vae/reconstructed_states", feed)) < 1e-4          # the graph decodes the mean
+    z = np.random.RandomState(9).standard_normal((2, 64)).astype(np.float32)
+    assert rel_err(m.generate_from_latent(z), g.run("vae/reconstructed_states", {"vae/mean/BiasAdd": z})) < 1e-4
+
+
 def test_hip_ppo_minibatch_matches_reference_graph(tmp_path):
     g, _ = load_graph("ppo")
     space = po.ActionSpace()
