@@ -247,6 +247,9 @@ class Graph:
     def op_Shape(self, node, x):
         return np.array(np.shape(x), dtype=self._np_dtype(self.attr(node, "out_type", "type", "int32")))
 
+    def op_Size(self, node, x):
+        return np.array(np.size(x), dtype=self._np_dtype(self.attr(node, "out_type", "type", "int32")))
+
     def op_ShapeN(self, node, *xs):
         return tuple(np.array(np.shape(x), dtype=np.int32) for x in xs)
 

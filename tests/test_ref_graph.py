@@ -159,16 +159,49 @@ def test_vae_adam_trajectory_matches_reference_graph():
     g, params, src, tgt, eps, feed = vae_case("vae_rgb", seed=5, B=2)
     o = vo.OracleVAE(params=params, dtype=torch.float64)
     for step in range(3):
-        g.run(["vae/Adam", "vae/Assign"], feed)                 # train_step + the step counter increment
+        g.run("vae/Adam", feed)                                  # sess.run(train_step)
         o.train_step(src, tgt, eps)
         for k in params:
             assert rel_err(g.vars[k], o.params[k]) < 2e-5, (step, k)
             assert rel_err(g.vars["vae/" + k + "/Adam"], o.adam.m[k]) < 2e-5 and rel_err(g.vars["vae/" + k + "/Adam_1"], o.adam.v[k]) < 2e-5, (step, k)
         assert float(g.vars["vae/beta1_power"]) == pytest.approx(float(o.adam.beta1_power), rel=1e-6)
         assert float(g.vars["vae/beta2_power"]) == pytest.approx(float(o.adam.beta2_power), rel=1e-6)
-    assert int(g.vars["vae/step_idx"]) == 3
     moved = max(rel_err(o.params[k], params[k]) for k in params if np.abs(params[k]).max() > 0)
     assert moved > 1e-3                                          # the 2e-5 above is small against what three steps change
+
+
+def test_vae_epoch_loops_and_metrics_replayed_on_the_reference_graph():
+    """train_one_epoch / evaluate (vae/models.py:207-231) replayed sess.run by sess.run on the reference graph -- legacy-numpy shuffle,
+    N // batch_size minibatches, tf.metrics.mean accumulators (local variables reset per epoch), inc_step_idx once per epoch."""
+    g, params, src, tgt, eps, feed = vae_case("vae_rgb", seed=13, B=5)
+    o = vo.OracleVAE(params=params, dtype=torch.float64)
+    noise = np.random.RandomState(14).standard_normal((8, 2, 64)).astype(np.float32)
+    local = [n for n in g.variables() if n.startswith(("vae/mean_3/", "vae/mean_4/"))]     # tf.local_variables_initializer()
+
+    def graph_epoch(train, bs, draws):
+        indices = np.arange(len(src))
+        np.random.shuffle(indices)
+        for n in local:
+            g.set_variable(n, 0.0)
+        ops = (["vae/Adam"] if train else []) + ["vae/mean_3/update_op", "vae/mean_4/update_op"]
+        for i in range(len(src) // bs):
+            mb = indices[i * bs:(i + 1) * bs]
+            g.run(ops, {"vae/source_state_placeholder": src[mb], "vae/target_state_placeholder": tgt[mb], VAE_EPS: draws[i][None]})
+        if train:
+            g.run("vae/Assign")                                  # inc_step_idx
+        return g.run(["vae/mean_4/value", "vae/mean_3/value"])   # [mean_reconstruction_loss, mean_kl_loss]
+
+    for epoch in range(2):
+        it = iter(noise[4 * epoch:])
+        np.random.seed(100 + epoch)
+        want_val = o.evaluate(src, tgt, 2, lambda n: next(it))
+        want_train = o.train_one_epoch(src, tgt, 2, lambda n: next(it))
+        np.random.seed(100 + epoch)
+        got_val = graph_epoch(False, 2, noise[4 * epoch:])
+        got_train = graph_epoch(True, 2, noise[4 * epoch + 2:])
+        assert got_val == pytest.approx(want_val, rel=1e-5) and got_train == pytest.approx(want_train, rel=1e-5), epoch
+    assert int(g.vars["vae/step_idx"]) == 2 == o.step_idx
+    assert int(g.vars["vae/mean_3/count"]) == 2                    # 5 // 2 minibatches, the remainder is dropped
 
 
 # ---------------------------------------------------------------------------------------------------- PPO
