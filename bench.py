@@ -258,6 +258,8 @@ def main():
                 out["ppo"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     midist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
