@@ -99,9 +99,31 @@ int tapconv_minblocks() {
 int g_tap_direct = 1;                                      // tapconv epilogue: 1 registers -> 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
 int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
 
+// tapconv grid (mi_set_tuning key 8, MI355_TAP_PERSIST): 0 one block per tile; 1 persistent blocks over tile ranges (tapconv_persist.hpp,
+// experimental), as many as are resident at once; N > 1: at most N persistent blocks per output column (tests: several tiles per block at small sizes)
+int g_tap_persist = -1;
+static int tap_persist() {
+    if (g_tap_persist < 0) { const char* e = getenv("MI355_TAP_PERSIST"); g_tap_persist = e ? atoi(e) : 0; if (g_tap_persist < 0) g_tap_persist = 0; }
+    return g_tap_persist;
+}
+
 template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
 int launch_tapconv_v(hipStream_t st, const TapParams& q) {
     const int gx = (q.MP + BMT - 1) / BMT;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (tap_persist() && q.direct_epilogue && !q.trace) {
+            // as many blocks as are resident at once (155 KB of LDS per 256-position block, 77 KB per 128-position block), each walking a
+            // contiguous range of tiles
+            const int gy = q.NE >= 128 ? (q.NE + 127) / 128 : (q.NE + 63) / 64;
+            int px = (256 * (BMT == 128 ? 2 : 1)) / gy;
+            if (px < 1) px = 1;
+            if (tap_persist() > 1 && px > tap_persist()) px = tap_persist();
+            if (px > gx) px = gx;
+            if (q.NE >= 128) hipLaunchKernelGGL((tapconv_persist_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), dim3(px, gy, 1), dim3(BMT * 2), 0, st, q);
+            else hipLaunchKernelGGL((tapconv_persist_kernel<T, MODE, 64, TAPS, BMT, MAXHALO>), dim3(px, gy, 1), dim3(BMT * 2), 0, st, q);
+            return mi_check_launch("tapconv_persist_kernel");
+        }
+    }
     if (q.NE >= 128) {
         dim3 g(gx, (q.NE + 127) / 128, 1);
         hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
@@ -630,6 +652,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
     else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
     else if (key == 6) { prev = g_tap_direct; g_tap_direct = value ? 1 : 0; }
+    else if (key == 8) { prev = tap_persist(); g_tap_persist = value < 0 ? 0 : value; }
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }

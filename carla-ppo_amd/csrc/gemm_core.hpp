@@ -18,6 +18,7 @@
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
 #include "tapconv_tile.hpp"
+#include "tapconv_persist.hpp"
 #include "wgrad_tile.hpp"
 #include "tapwgrad_tile.hpp"
 #include "narrow_tile.hpp"

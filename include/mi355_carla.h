@@ -71,6 +71,8 @@ unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
  * key 5: tapconv tile (0 auto, 1 = 256 positions / 1 block per CU, 2 = 128 positions / 2 blocks per CU);
  * key 6: tapconv epilogue (1 = registers -> 16-byte stores through a half-wave swap, 0 = LDS-staged coalesced stores);
  * key 7: tapwgrad wave layout for 2x2-tap layers (1 = wave per (tap, position half), 0 = wave per (tap, output tile));
+ * key 8: tapconv grid, EXPERIMENTAL (0 = one block per tile, 1 = persistent blocks walking contiguous tile ranges, N > 1 = at most N
+ * of them per output column; MI355_TAP_PERSIST);
  * key 9: tapwgrad target block count (position splits x block columns; default 256 = one block per CU); key 10: waves per block of
  * the narrow filter-gradient kernel (4 | 8 | 12); key 11: target block count of the dense filter gradients;
  * key 12: tapconv ReluGrad-mask prefetch in the last main-loop step on/off.  Returns the previous value. */
