@@ -5,6 +5,7 @@
 //                                              (deconv fwd, conv dgrad)
 //   gemm2_tile.hpp  gemm2_kernel               same contractions for the wide layers: LDS-DMA tiles, XOR-swizzled LDS, 128-B K stages
 //   tapconv_tile.hpp tapconv_kernel            stride-2 conv / transposed conv as a stride-1 tap conv on raw-staged slot tiles
+//   tapconv_persist.hpp tapconv_persist_kernel  the same with persistent blocks over tile ranges (experimental, off: mi_set_tuning key 8)
 //   wgrad_tile.hpp  wgrad_kernel               dW[kc,n] += sum_m im2col(big)[m,kc] * small[m,n]   (conv/deconv/dense wgrad)
 //
 //   tapwgrad_tile.hpp tapwgrad_kernel          bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles
