@@ -1,5 +1,5 @@
 """Debug: run one bf16 (or fp32) forward+backward of the ConvVAE at batch B on every kernel generation and report, per
-workspace tensor / gradient, the max abs difference against the first-generation kernels.  python tools/cmp_paths.py [B] [prec]"""
+workspace tensor / gradient, the max abs difference against the first-generation kernels.  (Under tests/: it uses the oracle's parameters.)  python tests/dbg_cmp_paths.py [B] [prec]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
