@@ -16,7 +16,6 @@ Extra objects on the same JSON line:
   ppo           PPO update throughput on z=64 latents (BASELINE configs[2]) — reported, not part of `value`.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys

@@ -236,7 +236,6 @@ def test_tensorboard_event_files_match_the_reference_framing(golden_dir, tmp_pat
     both CRCs of every record checked, its first scalars are the ones in ref_event_scalars.json, and a file written here starts with the
     same file_version record (identical bytes apart from the wall-clock field and the two checksums that cover it) and reads back."""
     import glob
-    import struct
     from mi355 import summary as sm
     ref_path = os.path.join(golden_dir, "ref_events_head.bin")
     ver, series = sm.read_events(ref_path, verify=True)
