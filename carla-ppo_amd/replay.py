@@ -1,0 +1,109 @@
+"""Synthetic replay (BASELINE configs[4], SURVEY 8c "C5"): many independent trajectories through the whole path at once --
+VAE encode of every frame, value estimates, GAE + per-trajectory advantage normalisation, PPO minibatch SGD -- device resident.
+
+It is the reference's per-horizon update (train.py:171-207: `encode_state` per step vae_common.py:45-59, `compute_gae`, returns /
+normalised advantages, `update_old_policy`, `num_epochs` x shuffled minibatches of `model.train`) applied to R recorded trajectories of
+T steps instead of one live rollout:
+
+    states[r, t]   = concat(vae.encode(frame[r, t]), measurements[r, t])         (vae_common.py:48,59; mean of the posterior)
+    values[r, t]   = V(states[r, t]),  t = 0..T  (the last one is the bootstrap value, train.py:172)
+    A[r, :]        = compute_gae(rewards[r], values[r, :T], values[r, T], dones[r], gamma, lam)        per row, fp64, bit-exact
+    returns[r, :]  = A + values ;  A <- (A - mean_r) / (std_r + 1e-8)                                   per row (train.py:176-177)
+    theta_old <- theta ; for each epoch: legacy-numpy shuffle of the R*T samples, minibatches of batch_size (last one partial)
+
+Data parallel: trajectories are independent, so each rank owns the rows [lo, hi) of shard_bounds(R); encode, values, GAE and
+the normalisation need no exchange; every minibatch step sums the flat gradient buffer over the ranks (PPO._step_resident), each rank
+contributing batch_size / world of ITS OWN samples (so the sample order differs from a single-process run of the same data: fp32
+parity across GPU counts is 1e-4 on the losses, not bit-exact).  No CPU fallback: needs the HIP library and a GPU.
+"""
+import numpy as np
+
+from mi355 import dist as midist
+
+
+def encode_resident(vae, frames, chunk=512):
+    """frames: uint8 or float [N, H, W, C] / [N, H*W*C] host array (uint8 is normalised on the device, bit-exact with /255) ->
+    device tensor [N, z_dim] of posterior means, encoded `chunk` frames per launch."""
+    import torch
+    dev = vae._need_dev()
+    n = len(frames)
+    feat = vae._src_feat()
+    out = torch.empty(n, int(vae.z_dim), device=dev.device)
+    for lo in range(0, n, chunk):
+        hi = min(lo + chunk, n)
+        src = vae._frames(frames[lo:hi], feat, "frames")
+        dev.encode(src, None, hi - lo, out[lo:hi])
+    return out
+
+
+def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma=0.99, lam=0.95, num_epochs=3, batch_size=32, encode_chunk=512,
+                  local_rows=False):
+    """One PPO update over R recorded trajectories (see the module docstring).
+
+    frames [R, T+1, H, W, C] (uint8 or float in [0,1]; the last frame of a row is the state after its last step), measurements [R, T+1, k],
+    actions [R, T, A] (the actions that were taken), rewards [R, T], dones [R, T].  batch_size is the GLOBAL minibatch size.
+    local_rows=True: the arrays already hold only this rank's trajectories (each rank loaded / generated its own shard; every rank must
+    hold the same number of them, so that all ranks run the same number of SGD steps).
+    Returns a dict: per-minibatch loss records (this rank's device scalars, read back once at the end), and this rank's returns /
+    advantages / values (fp64 / fp64 / fp32 numpy) for inspection."""
+    import torch
+    import utils
+
+    frames, measurements = np.asarray(frames), np.asarray(measurements, np.float32)
+    actions, rewards, dones = np.asarray(actions, np.float32), np.asarray(rewards, np.float64), np.asarray(dones, np.float64)
+    R, T = rewards.shape
+    if frames.shape[:2] != (R, T + 1) or measurements.shape[:2] != (R, T + 1) or actions.shape[:2] != (R, T) or dones.shape != (R, T):
+        raise ValueError("replay_update: frames / measurements [R, T+1, ...], actions [R, T, A], rewards / dones [R, T]")
+    world, rank = midist.world_size(), midist.rank()
+    if world > 1 and not local_rows and R % world != 0:
+        raise ValueError("replay_update: %d trajectories do not split evenly over %d ranks (every rank must run the same number of SGD steps)" % (R, world))
+    lo, hi = (0, R) if local_rows else midist.shard_bounds(R, rank, world)
+    r_loc = hi - lo
+    pdev = ppo._need_dev()
+    device = pdev.device
+
+    # 1. states of this rank's rows: encode every frame, append the measurements
+    z = encode_resident(vae, frames[lo:hi].reshape((r_loc * (T + 1),) + frames.shape[2:]), encode_chunk)
+    meas = torch.from_numpy(np.ascontiguousarray(measurements[lo:hi].reshape(r_loc * (T + 1), -1))).to(device)
+    states_all = torch.cat([z, meas], dim=1).contiguous()                       # [r_loc * (T+1), input_dim]
+    if states_all.shape[1] != ppo.input_dim:
+        raise ValueError("replay_update: z_dim + measurements = %d but the policy takes %d inputs" % (states_all.shape[1], ppo.input_dim))
+
+    # 2. value estimates of every state (greedy predict: no noise drawn; the action output is not used)
+    n_all = states_all.shape[0]
+    values_all = torch.empty(n_all, device=device)
+    scratch_act = torch.empty(min(n_all, 4096), ppo.num_actions, device=device)
+    for a in range(0, n_all, 4096):
+        b = min(a + 4096, n_all)
+        pdev.predict(states_all[a:b], b - a, None, True, scratch_act[:b - a], values_all[a:b])
+    values = values_all.view(r_loc, T + 1)
+
+    # 3. GAE + returns + per-row normalisation (fp64 on the device, bit-exact with numpy / scipy)
+    _, returns, adv = utils.compute_gae_batched(rewards[lo:hi], values.cpu().numpy(), dones[lo:hi], gamma, lam, normalize=True)
+
+    # 4. minibatch SGD on the flattened samples of this rank
+    s = states_all.view(r_loc, T + 1, -1)[:, :T].reshape(r_loc * T, -1).contiguous()
+    a = torch.from_numpy(np.ascontiguousarray(actions[lo:hi].reshape(r_loc * T, -1))).to(device)
+    ret = torch.from_numpy(np.ascontiguousarray(returns.reshape(-1).astype(np.float32))).to(device)      # f64 -> f32 at the feed (ppo.py:108-109)
+    adv_t = torch.from_numpy(np.ascontiguousarray(adv.reshape(-1).astype(np.float32))).to(device)
+    n_loc = r_loc * T
+    mb_lo, mb_hi = midist.shard_bounds(batch_size, rank, world)
+    mb_loc = mb_hi - mb_lo                                                       # this rank's share of a full global minibatch
+    ppo.update_old_policy()
+    records = []
+    for _ in range(num_epochs):
+        indices = np.arange(n_loc)
+        np.random.shuffle(indices)                                               # legacy numpy RNG, as train.py:194-195
+        perm = torch.from_numpy(indices).to(device)
+        n_steps = int(np.ceil(n_loc / mb_loc)) if mb_loc > 0 else 0
+        for i in range(n_steps):
+            mb = perm[i * mb_loc:(i + 1) * mb_loc]                               # the last one may be partial (train.py:199-201)
+            m_local = int(mb.numel())
+            m_global = m_local * world if world > 1 else m_local                 # ranks hold equal shares (R divisible by world is the C5 layout)
+            ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global)
+            ppo.train_step_counter += 1
+            records.append(pdev.losses.clone())
+    losses = torch.stack(records).cpu().numpy() if records else np.zeros((0, 5), np.float32)
+    keys = ("policy_loss", "value_loss", "entropy_loss", "loss", "prob_ratio")
+    return {"losses": [dict(zip(keys, (float(x) for x in row))) for row in losses], "returns": returns, "advantages": adv,
+            "values": values.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}

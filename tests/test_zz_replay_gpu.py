@@ -1,0 +1,79 @@
+"""BASELINE configs[4] / SURVEY 8c "C5" at parity-test size: the synthetic replay (replay.replay_update: VAE encode -> values -> GAE +
+per-trajectory normalisation -> PPO minibatch SGD, all device resident) against the same pipeline built from the oracle.
+
+Tolerances: encode / value outputs 1e-4 of the tensor's max (fp32 engine vs fp32 oracle); GAE, returns and normalised advantages
+bit-exact / 1e-12 against the oracle's fp64 statements on the SAME (device-produced) values; per-minibatch losses 2e-3 relative
+(the oracle runs on its own encodings, ~1e-5 away from the device's).
+
+Written after this round's GPU minutes were spent (it could only be collected here, not run), hence the non-strict xfail: a pass shows
+as XPASS, a problem in the test itself does not hide the rest of the suite.  File name: runs last."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU run of this test happens after authoring (no GPU minutes left in round 1)")]
+
+from oracle import ppo_oracle as po  # noqa: E402
+from oracle import vae_oracle as vo  # noqa: E402
+from ppo import PPO  # noqa: E402
+from vae.models import ConvVAE  # noqa: E402
+import replay  # noqa: E402
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_synthetic_replay_matches_oracle_pipeline(tmp_path):
+    R, T, gamma, lam = 4, 16, 0.99, 0.95
+    rng = np.random.RandomState(11)
+    frames = rng.randint(0, 256, (R, T + 1, 80, 160, 3), dtype=np.uint8)
+    meas = np.stack([rng.uniform(-1, 1, (R, T + 1)), rng.uniform(0, 1, (R, T + 1)), rng.uniform(0, 30, (R, T + 1))], axis=-1).astype(np.float32)
+    actions = np.stack([rng.uniform(-1, 1, (R, T)), rng.uniform(0, 1, (R, T))], axis=-1).astype(np.float32)
+    rewards = rng.uniform(0, 1, (R, T))
+    dones = np.zeros((R, T)); dones[1, -1] = 1
+
+    vparams = vo.init_vae_params(3)
+    vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "vae"), precision="fp32", training=False)
+    vae.set_weights(vparams)
+    vae.init_session(init_logging=False)
+    space = po.ActionSpace()
+    hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
+    o = po.OraclePPO([67], space, seed=2, **hp)
+    m = PPO(np.array([67]), space, model_dir=str(tmp_path / "ppo"), seed=2, **hp)
+    m.set_weights(o.params)
+    m.init_session(init_logging=False)
+
+    np.random.seed(5)
+    out = replay.replay_update(vae, m, frames, meas, actions, rewards, dones, gamma, lam, num_epochs=2, batch_size=24)
+    assert out["rows"] == (0, R) and out["samples_per_rank"] == R * T and len(out["losses"]) == 2 * 3          # 64 samples: 24 + 24 + 16 per epoch
+
+    # the same pipeline from the oracle's pieces
+    f32 = frames.reshape(-1, 80, 160, 3).astype(np.float32) / 255.0
+    ovae = vo.OracleVAE(params=vparams, training=False)
+    z = ovae.encode(f32)
+    states = np.concatenate([z, meas.reshape(-1, 3)], axis=1).astype(np.float32).reshape(R, T + 1, 67)
+    _, v_o = o.predict(states.reshape(-1, 67), greedy=True)
+    assert rel_err(out["values"], v_o.reshape(R, T + 1)) < 1e-4
+
+    # GAE / returns / normalisation: fp64, on the device-produced values -> bit-exact with the reference's numpy / scipy statements
+    vals = out["values"]
+    for r in range(R):
+        ref = po.compute_gae(list(rewards[r]), list(vals[r, :T]), vals[r, T], list(dones[r].astype(bool)), gamma, lam)
+        rr, aa = po.returns_and_normalized_advantages(ref.copy(), vals[r, :T].astype(np.float64))
+        assert np.array_equal(out["returns"][r], rr)
+        assert np.allclose(out["advantages"][r], aa, rtol=1e-12, atol=1e-12)
+
+    # minibatch SGD: same legacy-numpy permutations, same minibatch boundaries (last one partial)
+    s_flat, a_flat = states[:, :T].reshape(R * T, 67), actions.reshape(R * T, 2)
+    ret_flat, adv_flat = out["returns"].reshape(-1), out["advantages"].reshape(-1)
+    np.random.seed(5)
+    o.update_old_policy()
+    logs = [o.train(s_flat[mb], a_flat[mb], ret_flat[mb], adv_flat[mb]) for mb in po.minibatch_schedule(R * T, 24, 2)]
+    assert len(logs) == len(out["losses"])
+    for i, (want, got) in enumerate(zip(logs, out["losses"])):
+        assert got["loss"] == pytest.approx(want["loss"], rel=2e-3, abs=1e-4), i
+        assert got["value_loss"] == pytest.approx(want["value_loss"], rel=2e-3, abs=1e-4), i
+        assert got["policy_loss"] == pytest.approx(want["policy_loss"], rel=5e-3, abs=2e-4), i
+    assert out["losses"][0]["prob_ratio"] == pytest.approx(1.0, abs=1e-5)              # theta_old == theta at the first step
+    assert m.get_train_step_idx() == 6
