@@ -72,7 +72,7 @@ class Graph:
         x = np.asarray(x)
         return x.astype(self.fd) if x.dtype.kind == "f" else x
 
-    def variables(self, trainable_like=None):
+    def variables(self):
         return [n for n in self.order if self.nodes[n]["op"] == "VariableV2"]
 
     def variable_shape(self, name):
