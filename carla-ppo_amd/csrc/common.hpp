@@ -30,6 +30,21 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// ---- raw camera bytes -> [0, 1] (the reference's host preprocessing `frame.astype(np.float32) / 255.0`, vae/train_vae.py:15-18) ----
+// exact: q = k * fl(1/255), one Newton correction with two FMAs gives the correctly rounded float32(k) / float32(255) for every k in 0..255
+// (checked exhaustively, tests/test_oracle_golden.py); for bf16 storage the plain product already rounds to the same bf16 value.
+constexpr float U8_RCP255 = 0.003921568859368563f;
+__host__ __device__ __forceinline__ float u8_to_unit_exact(float k) {
+    const float q = k * U8_RCP255;
+    const float r = __builtin_fmaf(-q, 255.0f, k);
+    return __builtin_fmaf(r, U8_RCP255, q);
+}
+// source element -> float for the narrow-layer loaders: float / bf16 bits / uint8 camera byte (bf16-exact form, see above)
+template <typename TS> __device__ __forceinline__ float src_to_f32(TS v);
+template <> __device__ __forceinline__ float src_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float src_to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <> __device__ __forceinline__ float src_to_f32<unsigned char>(unsigned char v) { return (float)v * U8_RCP255; }
+
 // N consecutive elements moved as one naturally aligned vector access
 template <typename TT, int N> struct alignas(sizeof(TT) * N) PackN { TT v[N]; };
 

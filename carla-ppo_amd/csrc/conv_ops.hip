@@ -360,6 +360,7 @@ bool narrow_enabled() {
 
 struct NarrowLoss {                                       // optional fused reconstruction loss of gather_narrow_kernel
     const float* labels; const int* idx; long long stride; int kind; float inv_b; void* dlogits; float* lpart; float* bpart; int cap; int nblocks;
+    int labels_u8;                                        // labels are raw camera bytes (value k / 255), stride in bytes
 };
 
 int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
@@ -368,6 +369,7 @@ int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, i
     const int esz = dtype == MI_F32 ? 4 : 2;
     const int pa = C * esz;
     if ((pa != 64 && pa != 128) || (((uintptr_t)a) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)out) & 3) || (2 * N * esz) % 4 != 0) return 0;
+    if (!out && !loss) return 0;                          // out == nullptr is the fused-loss form (loss partials / dlogits only)
     TapParams q = {};
     q.TH = q.TW = (KH + 1) / 2; q.HY = q.HX = q.TH - 1;
     q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX; q.KC = C; q.NE = 4 * N;
@@ -380,9 +382,11 @@ int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, i
     q.out = out; q.bias = bias; q.mask = nullptr; q.relu = relu;
     if (loss) {
         const int nblk = (int)((MP + GN_BMT - 1) / GN_BMT);
-        if ((N != 1 && N != 3) || (OW & 1) || nblk > loss->cap || (((uintptr_t)loss->labels) & 7) || (loss->stride * 4) % 8 != 0 ||
+        const bool lab_ok = loss->labels_u8 ? ((((uintptr_t)loss->labels) & 1) == 0 && loss->stride % 2 == 0)
+                                            : ((((uintptr_t)loss->labels) & 7) == 0 && (loss->stride * 4) % 8 == 0);
+        if ((N != 1 && N != 3) || (OW & 1) || nblk > loss->cap || !lab_ok ||
             (loss->dlogits && (((uintptr_t)loss->dlogits) & 3))) return 0;
-        q.labels = loss->labels; q.lab_idx = loss->idx; q.lab_stride = loss->stride; q.loss_kind = loss->kind; q.inv_b = loss->inv_b;
+        q.labels = loss->labels; q.lab_idx = loss->idx; q.lab_stride = loss->stride; q.loss_kind = loss->kind; q.inv_b = loss->inv_b; q.lab_u8 = loss->labels_u8;
         q.dlogits = loss->dlogits; q.lpart = loss->lpart; q.bpart = loss->bpart;
         loss->nblocks = nblk;
     }
@@ -403,8 +407,9 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     if (!narrow_enabled() || dtype != MI_BF16) return 0;
     const int run = KW * Cs;
     if (Nwide != 32 || KH > 4 || run > 12 || run % 4 != 0 || KH * run > 64 || (((uintptr_t)wide) & 15)) return 0;
-    if ((((uintptr_t)narrow) & (narrow_f32 ? 7 : 3)) || ((long long)IW * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0) return 0;
-    if ((2 * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0 || ((long long)IH * IW * Cs * (narrow_f32 ? 4 : 2)) % (narrow_f32 ? 8 : 4) != 0) return 0;
+    const int nsz = narrow_f32 == 2 ? 1 : (narrow_f32 ? 4 : 2);       // narrow_f32: 0 = bf16, 1 = fp32, 2 = uint8 camera bytes (value k / 255)
+    if ((((uintptr_t)narrow) & (2 * nsz - 1)) || ((long long)IW * Cs * nsz) % (2 * nsz) != 0) return 0;
+    if ((2 * Cs * nsz) % (2 * nsz) != 0 || ((long long)IH * IW * Cs * nsz) % (2 * nsz) != 0) return 0;
     const long long M = (long long)B * OH * OW, s_bytes = M * 32 * 2;
     if (M >= (1ll << 26) || !fits_desc(s_bytes)) return 0;
     NarrowWgradParams q = {};
@@ -418,7 +423,7 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     if ((long long)OH * OW < NW_BP) return 0;
     if (ppw > 2ll * OH * OW) ppw = 2ll * OH * OW / NW_BP * NW_BP;   // a wave's range touches at most 3 frames (their indices are looked up once)
     nwave = (M + ppw - 1) / ppw;
-    const int nwv = g_nw_waves >= 12 ? 12 : g_nw_waves >= 8 ? 8 : 4;
+    const int nwv = (narrow_f32 == 2 || g_nw_waves >= 12) ? 12 : g_nw_waves >= 8 ? 8 : 4;
     const int blocks = (int)((nwave + nwv - 1) / nwv);
     q.pix_per_block = (int)ppw;
     q.div_ohw = make_fastdiv(OH * OW); q.div_ow = make_fastdiv(OW);
@@ -431,7 +436,8 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
         if (g3 && q.dbias) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 1, NWV_>), g, t, 0, st, q); \
         else if (g3) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 0, NWV_>), g, t, 0, st, q); \
         else hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 0, -1, NWV_>), g, t, 0, st, q); } while (0)
-    if (narrow_f32) { if (g_nw_waves >= 12) NW_LAUNCH(float, 12); else if (g_nw_waves >= 8) NW_LAUNCH(float, 8); else NW_LAUNCH(float, 4); }
+    if (narrow_f32 == 2) NW_LAUNCH(unsigned char, 12);
+    else if (narrow_f32) { if (g_nw_waves >= 12) NW_LAUNCH(float, 12); else if (g_nw_waves >= 8) NW_LAUNCH(float, 8); else NW_LAUNCH(float, 4); }
     else { if (g_nw_waves >= 12) NW_LAUNCH(bf16_t, 12); else if (g_nw_waves >= 8) NW_LAUNCH(bf16_t, 8); else NW_LAUNCH(bf16_t, 4); }
 #undef NW_LAUNCH
     int rc = mi_check_launch("narrow_wgrad_kernel");
@@ -450,8 +456,8 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     if (!narrow_enabled() || Cout != 32 || KH != KW || KH > 4) return 0;
     const int run = KW * Cs, K = KH * run;
     if (run % 4 != 0 || K > 48) return 0;
-    const int ssz = src_f32 ? 4 : 2, esz = dtype == MI_F32 ? 4 : 2;
-    if (dtype == MI_F32 && !src_f32) return 0;
+    const int ssz = src_f32 == 2 ? 1 : (src_f32 ? 4 : 2), esz = dtype == MI_F32 ? 4 : 2;   // src_f32: 0 = bf16, 1 = fp32, 2 = uint8 camera bytes
+    if (dtype == MI_F32 && src_f32 != 1) return 0;
     if ((((uintptr_t)src) & (2 * ssz - 1)) || ((long long)IW * Cs * ssz) % (2 * ssz) != 0 || (2 * Cs * ssz) % (2 * ssz) != 0 || ((long long)IH * IW * Cs * ssz) % (2 * ssz) != 0) return 0;
     if ((((uintptr_t)wt) & 15) || (K * esz) % 16 != 0 || (((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15)) || (bias && (((uintptr_t)bias) & 15))) return 0;
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
@@ -465,6 +471,7 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     q.bias = bias; q.relu = relu; q.mask = mask; q.out = out;
     dim3 g((unsigned)((M + 127) / 128));
     if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
+    else if (src_f32 == 2) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
     else if (src_f32) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
     else hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, q);
     const int rc = mi_check_launch("narrow_conv_kernel");
@@ -672,9 +679,10 @@ int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_
                        int relu, void* out) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     if (w_transposed) {
-        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 || dtype == MI_F32, frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out);
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out);
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
+    if (x_is_f32 == 2) return mi_fail(MI_ERR_ARG, "mi_conv2d_nhwc_fwd: uint8 frames are only read by the narrow-layer kernel (bf16 mode, 1..3 channels -> 32, K-contiguous weights)");
     GemmParams p = {};
     p.a = x; p.a_frame_idx = frame_idx;
     fill_conv_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
@@ -706,9 +714,10 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
                             float* dbias) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     {
-        const int r4 = try_narrow_wgrad((hipStream_t)stream, dtype, x, x_is_f32 || dtype == MI_F32, frame_idx, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, dbias, nullptr, 0);   // atomics measured faster than slabs here (92 vs 119 us)
+        const int r4 = try_narrow_wgrad((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, dbias, nullptr, 0);   // atomics measured faster than slabs here (92 vs 119 us)
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
+    if (x_is_f32 == 2) return mi_fail(MI_ERR_ARG, "mi_conv2d_nhwc_wgrad: uint8 frames are only read by the narrow-layer kernel (bf16 mode)");
     if (!frame_idx && !x_is_f32) {
         const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
@@ -738,11 +747,19 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
 int mi_deconv2d_nhwc_fwd_bce(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout,
                              void* logits, const float* labels, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits,
                              float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial) {
+    return mi_deconv2d_nhwc_fwd_bce_u8(stream, dtype, x, B, IH, IW, Cin, w, bias, KH, KW, Cout, logits, labels, 0, frame_idx, label_stride, loss_kind, inv_batch, dlogits,
+                                       loss_partial, bias_partial, partial_capacity, n_partial);
+}
+
+int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout,
+                                void* logits, const void* labels_any, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits,
+                                float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial) {
+    const float* labels = (const float*)labels_any;
     if (!n_partial || !labels || !loss_partial || !bias_partial) return mi_fail(MI_ERR_ARG, "mi_deconv2d_nhwc_fwd_bce: missing buffers");
     *n_partial = 0;
     if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_deconv2d_nhwc_fwd_bce: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
     const int OH = (IH - 1) * 2 + KH, OW = (IW - 1) * 2 + KW;
-    NarrowLoss L = {labels, frame_idx, label_stride, loss_kind, inv_batch, dlogits, loss_partial, bias_partial, partial_capacity, 0};
+    NarrowLoss L = {labels, frame_idx, label_stride, loss_kind, inv_batch, dlogits, loss_partial, bias_partial, partial_capacity, 0, labels_u8 ? 1 : 0};
     const int r = try_gather_narrow((hipStream_t)stream, dtype, x, w, B, IH, IW, Cin, OH, OW, Cout, KH, KW, logits, bias, nullptr, 0, &L);
     if (r < 0) return r;
     if (r > 0) *n_partial = L.nblocks;

@@ -15,31 +15,86 @@ namespace {
 //   heads : [nsplit][B][2Z] fp32 split-K partial sums of flat*[W_mean | W_logvar]
 //   mean/logvar = sum_s heads + bias ; z = mean + exp(.5 logvar) * eps (sample) or mean ; kl_b = -.5 sum(1+lv-mu^2-e^lv)
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// Counter-based N(0,1) source for the reparameterisation noise and the exploration noise (the reference draws both from TensorFlow's
+// unseeded stateful RNG through tfp Normal.sample, vae/models.py:101-105, ppo.py:58-60: the stream itself cannot be reproduced, only its
+// distribution).  Philox4x32-10 (Salmon et al. 2011; known-answer vectors in tests/test_oracle_golden.py) keyed by the seed, counter =
+// running element index; Box-Muller on the first two words.  Element i of a stream depends on (seed, offset + i) only: any launch
+// geometry, any number of ranks, and a hipGraph replay (the offset lives in device memory) give the same numbers.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long index) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u1 = ((float)(r[0] >> 8) + 1.0f) * 5.9604644775390625e-08f;       // (0, 1]: 24 random bits
+    const float u2 = (float)(r[1] >> 8) * 5.9604644775390625e-08f;                // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+// rng (device, 4 x uint64): [0] seed, [1] element offset of the next draw, [2] block ticket, [3] unused.  When eps == nullptr and sample != 0
+// the kernel draws eps itself (and stores it in eps_out for the backward pass); the LAST block to finish advances the offset by B * Z, after
+// every block has read it (each block takes its ticket after its reads), so the next launch -- or the next replay of a captured graph --
+// continues the stream.
 template <typename T>
 __global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int nsplit, const float* __restrict__ bias_mean,
                                       const float* __restrict__ bias_lv, const float* __restrict__ eps, int sample,
                                       int B, int Z, float* __restrict__ mean, float* __restrict__ logvar,
-                                      T* __restrict__ z, float* __restrict__ kl_row) {
+                                      T* __restrict__ z, float* __restrict__ kl_row,
+                                      unsigned long long* rng, float* __restrict__ eps_out) {
     const int row = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     const int lane = threadIdx.x & 63;
-    if (row >= B) return;
-    float klacc = 0.f;
-    for (int j = lane; j < Z; j += WAVE) {
-        float mu = bias_mean[j], lv = bias_lv[j];
-        for (int s = 0; s < nsplit; ++s) {
-            const float* h = heads + ((long long)s * B + row) * (2 * Z);
-            mu += h[j];
-            lv += h[Z + j];
+    const bool draw = sample && !eps && rng;
+    unsigned long long seed = 0, off = 0;
+    if (draw) { seed = rng[0]; off = __hip_atomic_load(&rng[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (row < B) {
+        float klacc = 0.f;
+        for (int j = lane; j < Z; j += WAVE) {
+            float mu = bias_mean[j], lv = bias_lv[j];
+            for (int s = 0; s < nsplit; ++s) {
+                const float* h = heads + ((long long)s * B + row) * (2 * Z);
+                mu += h[j];
+                lv += h[Z + j];
+            }
+            mean[(long long)row * Z + j] = mu;
+            logvar[(long long)row * Z + j] = lv;
+            float zz = mu;
+            if (sample) {
+                float e;
+                if (draw) { e = philox_normal(seed, off + (unsigned long long)row * Z + j); eps_out[(long long)row * Z + j] = e; }
+                else e = eps[(long long)row * Z + j];
+                zz = mu + expf(0.5f * lv) * e;
+            }
+            z[(long long)row * Z + j] = Elem<T>::from_f32(zz);
+            klacc += 1.0f + lv - mu * mu - expf(lv);
         }
-        mean[(long long)row * Z + j] = mu;
-        logvar[(long long)row * Z + j] = lv;
-        float zz = mu;
-        if (sample) zz = mu + expf(0.5f * lv) * eps[(long long)row * Z + j];
-        z[(long long)row * Z + j] = Elem<T>::from_f32(zz);
-        klacc += 1.0f + lv - mu * mu - expf(lv);
+        klacc = wave_sum(klacc);
+        if (lane == 0) kl_row[row] = -0.5f * klacc;
     }
-    klacc = wave_sum(klacc);
-    if (lane == 0) kl_row[row] = -0.5f * klacc;
+    if (draw) {
+        __syncthreads();                                  // every wave of this block has read the offset
+        if (threadIdx.x == 0) {
+            const unsigned long long t = atomicAdd(&rng[2], 1ull);
+            if (t + 1 == gridDim.x) {                     // last block: nobody reads the offset of this launch any more
+                __hip_atomic_store(&rng[1], off + (unsigned long long)B * Z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&rng[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// standalone draw (PPO exploration noise, tests): out[i] = N(0,1) element (offset + i) of stream `seed`
+__global__ __launch_bounds__(256) void normal_philox_kernel(unsigned long long seed, unsigned long long offset, float* __restrict__ out, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = philox_normal(seed, offset + (unsigned long long)i);
 }
 
 // reparam + KL backward: dz = sum_s dzs ; dmu = dz + beta*mu*inv_b*act ; dlv = dz*eps*.5*exp(.5lv) + beta*.5*(e^lv-1)*inv_b*act
@@ -226,8 +281,9 @@ __global__ __launch_bounds__(FIN_NT) void finalize_losses_kernel(const float* __
 // MFMA kernels read and clears the gradient for the next step's atomics (saves a memset + a cast pass).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                      float* __restrict__ g, long long n, float alpha, float omb1,
+                                                      float* __restrict__ g, long long n, float alpha_arg, const float* __restrict__ alpha_dev, float omb1,
                                                       float omb2, float epsilon, bf16_t* __restrict__ shadow, int clear_grad) {
+    const float alpha = alpha_dev ? alpha_dev[0] : alpha_arg;      // device-resident step size: a captured step is replayed with a new value
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -408,11 +464,26 @@ extern "C" {
 
 int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv,
                           const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row) {
-    if (sample && !eps) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd: sampling needs eps");
+    return mi_vae_reparam_kl_fwd_rng(stream, dtype, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, z, kl_row, nullptr, nullptr);
+}
+
+// same; eps == NULL with sample != 0: the kernel draws the noise from the Philox stream in rng_state (4 x uint64 on the device: seed, next
+// element offset, 2 words of kernel bookkeeping -- zero them once) and stores what it drew in eps_out [B,Z] for the backward pass
+int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv,
+                              const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row,
+                              unsigned long long* rng_state, float* eps_out) {
+    if (sample && !eps && !(rng_state && eps_out)) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd: sampling needs eps or a generator state + eps_out");
     dim3 g((B + 3) / 4), b(256);
-    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (float*)z, kl_row);
-    else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (bf16_t*)z, kl_row);
+    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (float*)z, kl_row, rng_state, eps_out);
+    else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (bf16_t*)z, kl_row, rng_state, eps_out);
     return mi_check_launch("reparam_kl_fwd");
+}
+
+int mi_normal_philox(void* stream, unsigned long long seed, unsigned long long offset, float* out, long long n) {
+    if (n < 0 || (n > 0 && !out)) return mi_fail(MI_ERR_ARG, "mi_normal_philox: bad buffer");
+    if (n == 0) return MI_OK;
+    hipLaunchKernelGGL(normal_philox_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, seed, offset, out, n);
+    return mi_check_launch("normal_philox");
 }
 
 int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar,
@@ -459,9 +530,15 @@ int mi_vae_finalize_losses_flat(void* stream, const float* partial, int n_partia
 
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2,
                     float epsilon, void* bf16_shadow, int clear_grad) {
+    return mi_adam_tf_flat_dev(stream, param, m, v, grad, n, alpha, nullptr, beta1, beta2, epsilon, bf16_shadow, clear_grad);
+}
+
+// same; alpha_dev != NULL: the step size is read from device memory at run time (one float) instead of the argument
+int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2,
+                        float epsilon, void* bf16_shadow, int clear_grad) {
     if ((((uintptr_t)param) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad)) & 15) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: buffers must be 16-byte aligned");
     if (bf16_shadow && (((uintptr_t)bf16_shadow) & 7)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: bf16 shadow must be 8-byte aligned");
-    hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, n, alpha,
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, n, alpha, alpha_dev,
                        1.0f - beta1, 1.0f - beta2, epsilon, (bf16_t*)bf16_shadow, clear_grad);
     return mi_check_launch("adam_tf");
 }

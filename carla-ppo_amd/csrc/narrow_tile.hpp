@@ -129,11 +129,20 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
     if constexpr (NOUT > 0) {
         if (p.labels && live && npx == 2) {
             const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
-            const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
+            if (p.lab_u8) {                                // raw camera bytes: 2 NOUT consecutive bytes at an even offset; exact k / 255 in registers
+                const unsigned char* y = (const unsigned char*)p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
 #pragma unroll
-            for (int d = 0; d < CNTL / 2; ++d) {
-                const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
-                yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
+                for (int d = 0; d < CNTL / 2; ++d) {
+                    const PackU<unsigned char, 2, 2> t = *(const PackU<unsigned char, 2, 2>*)(y + 2 * d);
+                    yv[2 * d] = u8_to_unit_exact((float)t.v[0]); yv[2 * d + 1] = u8_to_unit_exact((float)t.v[1]);
+                }
+            } else {
+                const float* y = p.labels + fr * p.lab_stride + ((long long)oy * p.OW + ox) * NOUT;
+#pragma unroll
+                for (int d = 0; d < CNTL / 2; ++d) {
+                    const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4> t = *(const PackU<float, 2, (NOUT * 8) % 8 == 0 ? 8 : 4>*)(y + 2 * d);
+                    yv[2 * d] = t.v[0]; yv[2 * d + 1] = t.v[1];
+                }
             }
         }
     }
@@ -170,9 +179,11 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
 #pragma unroll
                 for (int d = 0; d < ND; ++d) w[d] = __builtin_bit_cast(uint32_t, v[d]);
             }
-            uint32_t* o32 = (uint32_t*)out;
+            if (p.out) {                                   // out == nullptr (fused loss only): the logits never go to HBM
+                uint32_t* o32 = (uint32_t*)out;
 #pragma unroll
-            for (int d = 0; d < ND; ++d) o32[d] = w[d];
+                for (int d = 0; d < ND; ++d) o32[d] = w[d];
+            }
             if (p.labels) {
                 // reconstruction loss on the STORED logits (vae/models.py:11-22,123-128; same math as recon_loss_kernel)
                 // (labels yv[]: requested at the top of the kernel)
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
             done = true;
         }
     }
-    if (!done) {                                          // generic path (odd OW edge, other N): element stores, no fused loss
+    if (!done && p.out) {                                 // generic path (odd OW edge, other N): element stores, no fused loss
         const int cnt = npx * p.N;
         for (int j = 0; j < cnt; ++j) {
             const int n = j >= p.N ? j - p.N : j;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(NWV * 64) void narrow_wgrad_kernel(const NarrowWgra
     // next two steps stay in flight while this step is consumed): 12 source values + one 16-byte piece of the wide rows per lane.
     // (the loaded vectors are kept RAW: converting or zero-filling them at load time would be a use of the load result inside the same
     //  iteration, i.e. a wait for it before the back edge -- the validity flags travel with them and are applied in store_step)
-    typedef PackU<TS, 4, (int)sizeof(TS) * 2> SrcVec;
+    typedef PackU<TS, 4, (int)sizeof(TS) * 2> SrcVec;   // uint8 camera frames: 4 bytes at 2-byte alignment (pixel offsets are multiples of 6 bytes)
     struct StepRegs { SrcVec raw[3]; f32x4 s; bool ok; bool sok; };
     auto load_step = [&](int step, StepRegs& R) {
         const int m = mbeg + step * NW_BP + tp;
@@ -336,8 +347,7 @@ __global__ __launch_bounds__(NWV * 64) void narrow_wgrad_kernel(const NarrowWgra
             float f4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float f;
-                if constexpr (sizeof(TS) == 4) f = (float)R.raw[g].v[e]; else f = bf16_to_f32((bf16_t)R.raw[g].v[e]);
+                const float f = src_to_f32<TS>(R.raw[g].v[e]);
                 f4[e] = R.ok ? f : 0.f;
             }
             *(PackN<bf16_t, 4>*)(wl + tp * PA + ((((col >> 3) ^ sw)) << 4) + (col & 7) * 2) = pack4<bf16_t>(f4);
@@ -509,8 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const PackU<TS, 4, (int)sizeof(TS) * 2> t = *(const PackU<TS, 4, (int)sizeof(TS) * 2>*)(ok ? pix + (long long)kh * p.IW * p.Cs + qr * 4 : src);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float f;
-                if constexpr (sizeof(TS) == 4) f = (float)t.v[e]; else f = bf16_to_f32((bf16_t)t.v[e]);
+                const float f = src_to_f32<TS>(t.v[e]);
                 pv[4 * gi + e] = ok ? f : 0.f;
             }
         }

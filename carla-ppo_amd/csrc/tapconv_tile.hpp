@@ -43,7 +43,8 @@ struct TapParams {
     int dbg;                           // debug (mi_set_tuning key 2): 3 = direct epilogue without its stores
     int mask_prefetch;                 // touch the ReluGrad-mask lines in the last main-loop step (mi_set_tuning key 12)
     // gather_narrow_kernel only: reconstruction loss fused into the epilogue (labels == nullptr: plain transposed conv)
-    const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32, optional gather
+    const float* labels; const int* lab_idx; long long lab_stride;   // target frames [*, OH*OW*N] fp32 (or uint8 bytes, lab_u8), optional gather
+    int lab_u8;
     int loss_kind; float inv_b;
     void* dlogits;                     // d loss / d logits * inv_b, same layout as out (nullptr: loss only)
     float* lpart; float* bpart;        // per block: loss partial sum; 4 floats of per-channel dlogits sums

@@ -66,6 +66,7 @@ struct Workspace {
     long long z, dheads;               // T
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
+    long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
     long long total;
 };
 
@@ -112,6 +113,12 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int rng_ready;                      // generator state in the workspace has been initialised (mi_vae_set_seed)
+    const float* last_eps;              // the noise the last sampling forward used (caller's buffer or the engine's own draw)
+    int last_u8;                        // frame-table format of the last forward (backward reads the same source table)
+    // one captured SGD step (mi_vae_train_step with use_graph): replayed while the call's pointer arguments stay the same
+    hipGraphExec_t gexec;
+    struct GraphKey { const void *src, *tgt, *eps, *metrics, *stream; int u8, has_idx, B; float inv_batch, b1, b2, epsilon, mw; } gkey;
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
     const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
     const float* bptr(int t) const { return params + L.off[t]; }
@@ -156,6 +163,7 @@ void make_workspace(VaeEngine& e) {
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
     W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
+    W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256); W.idx_stage = add(B * 4); W.scalars = add(256);
     W.total = o;
 }
 
@@ -192,18 +200,23 @@ int check_batch(const VaeEngine* e, int B) {
 }
 
 // encoder: frames (fp32, optional gather) -> act[1..4] -> heads slabs -> mean/logvar/z/kl
-int run_encoder(VaeEngine* e, void* st, const float* frames, const int* idx, int B, const float* eps, int sample) {
+int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const int* idx, int B, const float* eps, int sample) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    if (frames_u8 && d.dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "vae engine: uint8 frame tables are read by the bf16 engine only (fp32 mode takes float frames)");
     for (int i = 0; i < NCONV; ++i) {
-        const void* x = i == 0 ? (const void*)frames : e->at(e->W.act[i]);
-        TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i],
+        const void* x = i == 0 ? frames : e->at(e->W.act[i]);
+        TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (frames_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i],
                               e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
     }
     TOP(e, st, OP_HEADS_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wtptr(8), 1, 2 * d.z_dim, nullptr, 0, nullptr,
                         e->at(e->W.heads_slab), 1, e->ns_heads));
     // split-K slabs are laid out [ns][B][2Z] with the CURRENT batch as the middle dimension
-    TOP(e, st, OP_REPARAM_FWD, mi_vae_reparam_kl_fwd(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
-                             B, d.z_dim, (float*)e->at(e->W.mean), (float*)e->at(e->W.logvar), e->at(e->W.z), (float*)e->at(e->W.kl_row)));
+    if (sample && !eps && !e->rng_ready)
+        return mi_fail(MI_ERR_STATE, "vae engine: sampling without injected noise needs mi_vae_set_seed() first");
+    TOP(e, st, OP_REPARAM_FWD, mi_vae_reparam_kl_fwd_rng(st, d.dtype, (const float*)e->at(e->W.heads_slab), e->ns_heads, e->bptr(9), e->bptr(9) + d.z_dim, eps, sample,
+                             B, d.z_dim, (float*)e->at(e->W.mean), (float*)e->at(e->W.logvar), e->at(e->W.z), (float*)e->at(e->W.kl_row),
+                             (unsigned long long*)e->at(e->W.rng), (float*)e->at(e->W.eps_buf)));
+    if (sample) e->last_eps = eps ? eps : (const float*)e->at(e->W.eps_buf);
     return MI_OK;
 }
 
@@ -274,6 +287,7 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
 
 void mi_vae_destroy(void* h) {
     VaeEngine* e = (VaeEngine*)h;
+    if (e && e->gexec) hipGraphExecDestroy(e->gexec);
     if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
     free(h);
 }
@@ -305,12 +319,13 @@ void* mi_vae_buffer(void* h, int which) {
 // Forward pass + ELBO terms of one minibatch: VAE.evaluate's per-batch sess.run (vae/models.py:226-229) and the
 // forward half of train_step (:213-216).  src/tgt: fp32 frame tables [n_frames, ...] on the device; idx: int32 [B] or null.
 // inv_batch = 1/B_global (data parallel: each rank passes its local rows).  want_grad: also write dlogits for backward.
-int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch,
+int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch,
                    const float* eps, int sample, int want_grad, float* metrics3, float metric_weight) {
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
-    CK(run_encoder(e, stream, src, idx, B, eps, sample));
+    CK(run_encoder(e, stream, src, frames_u8, idx, B, eps, sample));
+    e->last_u8 = frames_u8 ? 1 : 0;
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
     const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
     // the BiasAddGrad of deconv4 (sum of dlogits per target channel) rides on the loss pass when the gradient is wanted
@@ -322,15 +337,17 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
     // decoder tail: deconv4 with the reconstruction loss fused into its epilogue where the narrow kernel is eligible (logits are still written)
     CK(run_decoder(e, stream, B, 3));
     int nblk = 0;
-    TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
-                                            e->at(e->W.dec[4]), tgt, idx, (long long)P, d.loss_kind, inv_batch, want_grad ? e->at(e->W.gdec[4]) : nullptr,
+    // (the fused form never stores the logits: only the loss partial sums and dlogits leave the kernel)
+    TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce_u8(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
+                                            nullptr, tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, want_grad ? e->at(e->W.gdec[4]) : nullptr,
                                             (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk));
     if (nblk > 0) {
         TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses_flat(stream, (const float*)e->at(e->W.partial), nblk, (const float*)e->at(e->W.kl_row), kl_floor, B, inv_batch,
                                        (float*)e->at(e->W.out2), metrics3, metric_weight, (const float*)e->at(e->W.bpart), nblk, d.ct, fuse_b4 ? e->gptr(19) : nullptr));
     } else {
+        if (frames_u8) return mi_fail(MI_ERR_ARG, "vae engine: uint8 target frames need the fused decoder-tail loss kernel (1- or 3-channel target, narrow kernels enabled)");
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4], 0, e->at(e->W.dec[4])));
-        TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd_bias(stream, d.dtype, e->at(e->W.dec[4]), tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
+        TOP(e, stream, OP_RECON_LOSS, mi_bce_logits_fwd_bwd_bias(stream, d.dtype, e->at(e->W.dec[4]), (const float*)tgt, idx, (long long)P, B, P, d.loss_kind, inv_batch,
                                  want_grad ? e->at(e->W.gdec[4]) : nullptr, (float*)e->at(e->W.partial), d.ct, fuse_b4 ? e->gptr(19) : nullptr));
         TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses(stream, (const float*)e->at(e->W.partial), e->nchunks, (const float*)e->at(e->W.kl_row), kl_floor, B,
                                   inv_batch, (float*)e->at(e->W.out2), metrics3, metric_weight));
@@ -343,9 +360,11 @@ int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, co
 // mi_vae_apply_adam clears it again).  part: 0 = everything, 1 = decoder half (deconv4..dense1 + dz), 2 = encoder half = 3 (heads + conv4:
 // 88 % of the encoder's parameters) followed by 4 (conv3..conv1).  The parts exist so the data-parallel host can all-reduce the gradient
 // bucket of a finished part while the next part runs; every separately called part ends with the stream join that completes its bucket.
-int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part) {
+int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, const float* eps, float inv_batch, int part) {
     VaeEngine* e = (VaeEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    if (!eps) eps = e->last_eps;                          // the noise the forward pass drew itself (or was given)
+    if (!eps) return mi_fail(MI_ERR_STATE, "mi_vae_backward: no sampling forward pass recorded");
     const int B = e->last_B;
     if (B < 1) return mi_fail(MI_ERR_STATE, "mi_vae_backward: no forward pass recorded");
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_vae_backward: engine created without a gradient buffer");
@@ -421,7 +440,7 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
             // filter gradient runs there instead -- without the shared split scratch, which the side stream may still be using
             void* sg = i == 0 ? st : sw;
             if (i > 0) release();
-            TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? 1 : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
+            TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
                                                                    (i == 0 && fork) ? nullptr : scratch_of(), (i == 0 && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
@@ -433,20 +452,88 @@ int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, con
 }
 
 // tf.train.AdamOptimizer step over all 22 reference variables at once; alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
-int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon) {
-    VaeEngine* e = (VaeEngine*)h;
-    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon) {
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_vae_apply_adam: engine created without optimiser buffers");
-    TOP(e, stream, OP_ADAM, mi_adam_tf_flat(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, beta1, beta2, epsilon,
-                                            e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1));
+    TOP(e, stream, OP_ADAM, mi_adam_tf_flat_dev(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, alpha_dev, beta1, beta2, epsilon,
+                                                e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1));
     return refresh_transposed(e, stream);
 }
 
-// VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32
-int mi_vae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out) {
+int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
+}
+
+// Seeds the engine's own noise source (Philox stream `seed`, element 0 next): used whenever a sampling pass is given eps == NULL.
+int mi_vae_set_seed(void* h, unsigned long long seed) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
+    const unsigned long long st[4] = {seed, 0ull, 0ull, 0ull};
+    if (hipMemcpy(e->at(e->W.rng), st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_set_seed: copy failed");
+    e->rng_ready = 1;
+    return MI_OK;
+}
+
+namespace {
+// the per-step values of a (captured) step travel through device memory: this rank's rows of the minibatch and Adam's step size
+__global__ void stage_step_kernel(const int* __restrict__ idx, int B, int* __restrict__ idx_stage, float alpha, float* __restrict__ scalars) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx && i < B) idx_stage[i] = idx[i];
+    if (i == 0) scalars[0] = alpha;
+}
+}  // namespace
+
+// One whole SGD step (the reference's sess.run([train_step, ...]), vae/models.py:213-216): forward + ELBO, backward, TF-Adam, on ONE call.
+// use_graph != 0: the launch sequence (38 dispatches on two streams) is captured into a hipGraph the first time and replayed while the
+// pointer arguments, batch size and hyper-parameters stay the same; what changes every step -- the minibatch rows and Adam's bias-corrected
+// step size -- is staged into the workspace by one small kernel in front of the replay, and the noise stream continues from its device-side
+// offset.  Single-rank path: the data-parallel host drives mi_vae_forward / _backward(parts) / _apply_adam around its bucket all-reduces.
+int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps,
+                      float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight, int use_graph) {
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
-    CK(run_encoder(e, stream, src, idx, B, nullptr, 0));
+    hipStream_t st = (hipStream_t)stream;
+    int* idx_stage = (int*)e->at(e->W.idx_stage);
+    float* scalars = (float*)e->at(e->W.scalars);
+    hipLaunchKernelGGL(stage_step_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, idx_stage, alpha, scalars);
+    CK(mi_check_launch("stage_step"));
+    const int* idx_in = idx ? idx_stage : nullptr;
+    auto body = [&]() -> int {
+        CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx_in, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+        CK(mi_vae_backward(h, stream, src, idx_in, eps, inv_batch, 0));
+        return apply_adam(e, stream, 0.f, scalars, beta1, beta2, epsilon);
+    };
+    if (!use_graph || e->tm.mode) return body();          // per-op timing brackets single launches with events: eager
+    const VaeEngine::GraphKey key = {src, tgt, eps, metrics3, stream, frames_u8 ? 1 : 0, idx ? 1 : 0, B, inv_batch, beta1, beta2, epsilon, metric_weight};
+    if (!e->gexec || memcmp(&key, &e->gkey, sizeof(key)) != 0) {
+        if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (!e->side_ok) {                                // the second stream and its events are created outside the capture
+            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
+            else e->side_ok = -1;
+        }
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipStreamBeginCapture failed");
+        const int rc = body();
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc != MI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess || !graph) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipStreamEndCapture failed");
+        const hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ie != hipSuccess) { e->gexec = nullptr; return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipGraphInstantiate failed"); }
+        memset(&e->gkey, 0, sizeof(e->gkey));
+        e->gkey = key;
+    }
+    if (hipGraphLaunch(e->gexec, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_vae_train_step: hipGraphLaunch failed");
+    return MI_OK;
+}
+
+// VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32
+int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    CK(run_encoder(e, stream, src, frames_u8, idx, B, nullptr, 0));
     if (mean_out && hipMemcpyAsync(mean_out, e->at(e->W.mean), (size_t)B * e->d.z_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
         return mi_fail(MI_ERR_LAUNCH, "mi_vae_encode: copy failed");
     return MI_OK;
@@ -469,10 +556,10 @@ int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out
 }
 
 // VAE.reconstruct (vae/models.py:193-197): frames -> sigmoid(logits); samples z when sample=1 (training graph)
-int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out) {
+int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out) {
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
-    CK(run_encoder(e, stream, src, idx, B, eps, sample));
+    CK(run_encoder(e, stream, src, frames_u8, idx, B, eps, sample));
     CK(run_decoder(e, stream, B));
     const Geom& g = e->g;
     return mi_sigmoid(stream, e->d.dtype, e->at(e->W.dec[4]), recon_out, (long long)B * g.dh[4] * g.dw[4] * g.dc[4]);

@@ -138,3 +138,13 @@ def init_ppo(seed, input_dim, num_actions, initial_std, initial_mean_factor=0.1,
         else:
             out[n] = np.zeros(s, np.float32)
     return out
+
+
+def seed_from_numpy_state():
+    """Default model seed when the caller passes none: a hash of numpy's GLOBAL legacy RNG state, read WITHOUT advancing it.  The reference's
+    train.py seeds TensorFlow and numpy from the same --seed (train.py:50-53) and TensorFlow's graph seed then drives initialisation and
+    sampling; here `np.random.seed(seed)` is the only one of the two that still exists, so it drives both -- and because the state is only
+    peeked, the minibatch permutations the reference draws from that generator (vae/models.py:209, train.py:195) stay bit-identical."""
+    import zlib
+    st = np.random.get_state()
+    return int(zlib.crc32(np.asarray(st[1], np.uint32).tobytes() + int(st[2]).to_bytes(4, "little")) & 0x7FFFFFFF)

@@ -23,7 +23,7 @@ import numpy as np
 TABLE_MAGIC = 0xdb4775248b80fb57
 _DT_TO_NP = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 10: np.bool_, 4: np.uint8, 6: np.int8, 5: np.int16}
 _NP_TO_DT = {np.dtype(v): k for k, v in _DT_TO_NP.items()}
-BLOCK_SIZE = 4096
+BLOCK_SIZE = 262144                                      # tensorflow/core/lib/io/table_options.h: Options::block_size default (the bundle writer keeps it)
 RESTART_INTERVAL = 16
 
 

@@ -95,6 +95,9 @@ class VaeDevice:
             raise milib.MiError("mi_vae_create: " + self.L.cdll.mi_last_error().decode())
         self.max_batch = int(max_batch)
         self.losses = self._view(0, 2)
+        if getattr(self, "_seed", None) is not None:        # a re-created engine (larger workspace) moves on to a fresh noise stream
+            self._seed += 0x9E3779B97F4A7C15
+            self.L.mi_vae_set_seed(self.handle, int(self._seed) & 0xFFFFFFFFFFFFFFFF)
 
     def ensure_batch(self, b):
         if b > self.max_batch:
@@ -180,10 +183,29 @@ class VaeDevice:
         return self._from_flat(self.grads.cpu().numpy())
 
     # ---- steps (all asynchronous on the current torch stream) ----
+    # Frame tables are float32 [N, feat] in [0, 1] or -- bf16 engine only -- raw uint8 camera frames [N, feat] (normalised to k / 255 inside
+    # the kernels that read them: 4x less HBM traffic in conv1 forward / filter gradient and the loss); source and target share the format.
+    @property
+    def accepts_u8(self):
+        return self.dtype == milib.MI_BF16
+
+    @staticmethod
+    def _u8(src, tgt=None):
+        u8 = src.dtype == torch.uint8
+        if tgt is not None and (tgt.dtype == torch.uint8) != u8:
+            raise ValueError("source and target frame tables must share their format (both uint8 or both float32)")
+        return 1 if u8 else 0
+
+    def set_seed(self, seed):
+        """Seed of the engine's own N(0,1) stream (used whenever a sampling pass gets eps=None)."""
+        torch.cuda.synchronize(self.device)
+        self.L.mi_vae_set_seed(self.handle, int(seed) & 0xFFFFFFFFFFFFFFFF)
+        self._seed = int(seed)
+
     def forward(self, src, tgt, idx, B, inv_batch, eps, sample, want_grad, accumulate_metrics=True):
         self.ensure_batch(B)
         p = milib.ptr
-        self.L.mi_vae_forward(self.handle, self.stream(), p(src), p(tgt), p(idx), int(B), float(inv_batch), p(eps), int(sample),
+        self.L.mi_vae_forward(self.handle, self.stream(), p(src), p(tgt), self._u8(src, tgt), p(idx), int(B), float(inv_batch), p(eps), int(sample),
                               int(want_grad), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def backward(self, src, idx, eps, inv_batch, part=0):
@@ -193,9 +215,16 @@ class VaeDevice:
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.L.mi_vae_apply_adam(self.handle, self.stream(), float(alpha), float(beta1), float(beta2), float(epsilon))
 
+    def train_step(self, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, graph=True, accumulate_metrics=True):
+        """One whole SGD step in one C call; graph=True replays the captured hipGraph of the step (single-rank path)."""
+        self.ensure_batch(B)
+        p = milib.ptr
+        self.L.mi_vae_train_step(self.handle, self.stream(), p(src), p(tgt), self._u8(src, tgt), p(idx), int(B), float(inv_batch), p(eps), float(alpha),
+                                 float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch), 1 if graph else 0)
+
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)
-        self.L.mi_vae_encode(self.handle, self.stream(), milib.ptr(src), milib.ptr(idx), int(B), milib.ptr(out))
+        self.L.mi_vae_encode(self.handle, self.stream(), milib.ptr(src), self._u8(src), milib.ptr(idx), int(B), milib.ptr(out))
 
     def decode(self, z, B, out):
         self.ensure_batch(B)
@@ -203,7 +232,7 @@ class VaeDevice:
 
     def reconstruct(self, src, idx, B, eps, sample, out):
         self.ensure_batch(B)
-        self.L.mi_vae_reconstruct(self.handle, self.stream(), milib.ptr(src), milib.ptr(idx), int(B), milib.ptr(eps), int(sample), milib.ptr(out))
+        self.L.mi_vae_reconstruct(self.handle, self.stream(), milib.ptr(src), self._u8(src), milib.ptr(idx), int(B), milib.ptr(eps), int(sample), milib.ptr(out))
 
     def range_ok(self, t):
         flag = torch.zeros(1, device=self.device, dtype=torch.int32)

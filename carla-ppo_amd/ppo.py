@@ -31,7 +31,7 @@ class PPO():
     def __init__(self, input_shape, action_space,
                  learning_rate=3e-4, lr_decay=0.998, epsilon=0.2,
                  value_scale=0.5, entropy_scale=0.01, initial_std=0.4,
-                 model_dir="./", seed=0):
+                 model_dir="./", seed=None):
         self.input_dim = int(np.asarray(input_shape).reshape(-1)[0])
         self.num_actions = int(action_space.shape[0])
         self.action_low = np.asarray(action_space.low, np.float32).reshape(-1)
@@ -66,6 +66,9 @@ class PPO():
     def init_session(self, sess=None, init_logging=True):
         from mi355.ppo_device import PpoDevice
         self.sess = sess if sess is not None else self
+        if self.seed is None:                                  # train.py's np.random.seed(--seed) drives initialisation and sampling (mi355.init.seed_from_numpy_state)
+            from mi355.init import seed_from_numpy_state
+            self.seed = seed_from_numpy_state()
         self.dev = PpoDevice(self.input_dim, self.num_actions, self.action_low, self.action_high,
                              self.epsilon, self.value_scale, self.entropy_scale)
         values = self._init_values or init_ppo(self.seed, self.input_dim, self.num_actions, self.initial_std)
@@ -161,9 +164,12 @@ class PPO():
         a = self._to_dev(taken_actions, (m, self.num_actions))
         r = self._to_dev(returns, (m,))
         adv = self._to_dev(advantage, (m,))
-        self._step_resident(s, a, r, adv, m, m)
+        # data parallel (torch.distributed initialised): every rank passes ITS rows of the global minibatch, equal counts on all ranks;
+        # gradients are those of sum_local / M_global and the state-independent entropy term is shared through grad_scale = 1 / world,
+        # so that the all-reduced buffer is the gradient of the global mean (mi355/dist.py).  Single process: m_global = m.
+        self._step_resident(s, a, r, adv, m, m * midist.world_size())
         if self.train_writer is not None:                      # episodic means (ppo.py:150-163); never on a timed path
-            L = dev.losses.cpu().numpy()
+            L = self._global_losses()
             for k, v in zip(("train_loss/policy", "train_loss/value", "train_loss/entropy", "train_loss/loss", "train/prob_ratio"), L):
                 self._metric_sums[k] = self._metric_sums.get(k, 0.0) + float(v)
             self._metric_sums["train/returns"] = self._metric_sums.get("train/returns", 0.0) + float(np.mean(returns))
@@ -172,12 +178,24 @@ class PPO():
             self._metric_n += 1
         self.train_step_counter += 1
 
+    def _global_losses(self):
+        """The five loss scalars of the last step as numpy.  Data parallel: the device holds this rank's share of the batch means (sums over
+        its rows / M_global) for the policy / value terms and the probability ratio; they are summed over the ranks here, the
+        state-independent entropy term is already the global value."""
+        L = self.dev.losses.clone()
+        if midist.world_size() > 1:
+            ent = L[2].clone()
+            midist.all_reduce_sum(L)
+            L[2] = ent
+            L[3] = -L[0] + L[1] - L[2]
+        return L.cpu().numpy()
+
     learn = train                                              # north-star alias
 
     def train_step(self, input_states, taken_actions, returns, advantage):
         """train() that also returns the five loss scalars {policy, value, entropy, loss, prob_ratio} (for parity tests/benchmarks)."""
         self.train(input_states, taken_actions, returns, advantage)
-        L = self.dev.losses.cpu().numpy()
+        L = self._global_losses()
         return dict(policy_loss=float(L[0]), value_loss=float(L[1]), entropy_loss=float(L[2]), loss=float(L[3]), prob_ratio=float(L[4]))
 
     def update_old_policy(self):
@@ -200,7 +218,7 @@ class PPO():
             else:
                 if self._noise_gen is None:
                     self._noise_gen = torch.Generator(device=dev.device)
-                    self._noise_gen.manual_seed(0xAC7 + midist.rank())
+                    self._noise_gen.manual_seed(0xAC7 + 1000003 * int(self.seed or 0) + midist.rank())
                 nz = torch.randn(m, self.num_actions, device=dev.device, generator=self._noise_gen)
         action = torch.empty(m, self.num_actions, device=dev.device)
         value = torch.empty(m, device=dev.device)

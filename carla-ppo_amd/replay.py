@@ -31,7 +31,7 @@ def encode_resident(vae, frames, chunk=512):
     out = torch.empty(n, int(vae.z_dim), device=dev.device)
     for lo in range(0, n, chunk):
         hi = min(lo + chunk, n)
-        src = vae._frames(frames[lo:hi], feat, "frames")
+        src = vae._frames(frames[lo:hi], feat, "frames", keep_u8_ok=True)      # uint8 stays uint8 in HBM on the bf16 engine (conv1 normalises in registers)
         dev.encode(src, None, hi - lo, out[lo:hi])
     return out
 
@@ -57,6 +57,9 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     world, rank = midist.world_size(), midist.rank()
     if world > 1 and not local_rows and R % world != 0:
         raise ValueError("replay_update: %d trajectories do not split evenly over %d ranks (every rank must run the same number of SGD steps)" % (R, world))
+    if world > 1 and (batch_size < world or batch_size % world != 0):
+        # unequal shares would give the ranks different numbers of SGD steps (= different numbers of gradient all-reduces: a hang)
+        raise ValueError("replay_update: the global minibatch size %d must be a positive multiple of the %d ranks" % (batch_size, world))
     lo, hi = (0, R) if local_rows else midist.shard_bounds(R, rank, world)
     r_loc = hi - lo
     pdev = ppo._need_dev()
@@ -106,4 +109,4 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     losses = torch.stack(records).cpu().numpy() if records else np.zeros((0, 5), np.float32)
     keys = ("policy_loss", "value_loss", "entropy_loss", "loss", "prob_ratio")
     return {"losses": [dict(zip(keys, (float(x) for x in row))) for row in losses], "returns": returns, "advantages": adv,
-            "values": values.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}
+            "values": values.cpu().numpy(), "z": z.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}

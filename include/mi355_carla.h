@@ -81,7 +81,8 @@ int mi_set_tuning(int key, int value);
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);
 
 /* ---- convolution family (implicit-GEMM on MFMA, LDS-staged tiles) ---- */
-/* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be fp32 frames gathered through frame_idx. */
+/* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be frames gathered through frame_idx: x_is_f32 = 1 fp32
+ * frames, 2 = raw uint8 camera frames (value k / 255, the host preprocessing of vae/train_vae.py:15-18 done in registers; bf16 narrow-layer kernel only). */
 int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout, int relu, void* out);
 /* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
@@ -97,6 +98,8 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
  * partial per block into loss_partial[] and 4 floats of per-channel dlogits sums per block into bias_partial[].  *n_partial = number of
  * blocks written, or 0 when the layer is not eligible for the fused kernel (nothing was launched: call the two ops separately). */
 int mi_deconv2d_nhwc_fwd_bce(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, void* logits, const float* labels, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial);
+/* same; labels_u8 != 0: labels are raw uint8 frames (label_stride in bytes), normalised to exactly float32(k) / float32(255) in registers; logits == NULL: the logits are not stored */
+int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, void* logits, const void* labels_any, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
@@ -111,6 +114,11 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
 /* ---- VAE elementwise / reduction kernels ---- */
 /* Normal(mean, exp(.5 lv)).sample + kl_divergence — vae/models.py:7-9,101-105 (eps injected; TF RNG is unseeded) */
 int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row);
+/* same with the engine-side noise source: eps == NULL and sample != 0 draws N(0,1) from the Philox4x32-10 stream in rng_state (device, 4 x uint64:
+ * seed, next element offset, 2 words of kernel bookkeeping) and stores the draw in eps_out [B,Z] for the backward pass — tfp Normal.sample, vae/models.py:101-105 */
+int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row, unsigned long long* rng_state, float* eps_out);
+/* out[i] = N(0,1) element (offset + i) of Philox stream `seed` (exploration noise of ppo.py:58-60, tests) */
+int mi_normal_philox(void* stream, unsigned long long seed, unsigned long long offset, float* out, long long n);
 int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar, const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads);
 /* bce_loss / bce_loss_v2 / mse_loss + reduce_sum(axis=1) + gradient — vae/models.py:11-22,123-128 */
 int mi_recon_loss_chunks(int P);
@@ -123,6 +131,8 @@ int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, cons
 int mi_vae_finalize_losses_flat(void* stream, const float* partial, int n_partial, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight, const float* bias_partial, int n_bias_partial, int channels, float* dbias);
 /* tf.train.AdamOptimizer ApplyAdam x N fused over one flat buffer — vae/models.py:141-142, ppo.py:143-144 */
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
+/* same; alpha_dev != NULL: the step size is read from device memory (a captured step is replayed with a new value) */
+int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
 /* raw uint8 frames -> float32(k) / float32(255), correctly rounded: the reference's host preprocessing (vae/train_vae.py:15-18) done on the device */
 int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n);
@@ -159,15 +169,20 @@ void mi_vae_destroy(void* h);
 int mi_vae_sync_shadow(void* h, void* stream);
 void* mi_vae_buffer(void* h, int which);
 /* forward + ELBO terms: the per-minibatch sess.run of VAE.evaluate (vae/models.py:226-229) / forward half of train_step (:213-216) */
-int mi_vae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
+/* frames_u8 != 0: src / tgt are raw uint8 frame tables (bf16 engine, rgb target == source format); eps == NULL with sample != 0: the engine draws the noise (mi_vae_set_seed) */
+int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
 /* gradients of loss = recon + beta*kl wrt all 22 variables (optimizer.minimize, vae/models.py:142); part 0 all, 1 decoder half,
  * 2 encoder half = 3 (heads + conv4) then 4 (conv3..conv1): the data-parallel host all-reduces a finished part's bucket under the next part */
-int mi_vae_backward(void* h, void* stream, const float* src, const int* idx, const float* eps, float inv_batch, int part);
+int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, const float* eps, float inv_batch, int part);
 int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
+/* seed of the engine's own N(0,1) source (TF's graph-level seed, train.py:50-51) */
+int mi_vae_set_seed(void* h, unsigned long long seed);
+/* one whole SGD step = the reference's sess.run([train_step, ...]) (vae/models.py:213-216) in ONE call; use_graph != 0: captured once as a hipGraph and replayed */
+int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight, int use_graph);
 /* VAE.encode / generate_from_latent (= north_star "decode") / reconstruct — vae/models.py:188-202 */
-int mi_vae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out);
+int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
-int mi_vae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out);
+int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
 /* per-op timing with HIP events recorded on the launch stream (bench.py's live roofline numbers) */
 int mi_vae_op_count(void);

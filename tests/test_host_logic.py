@@ -20,7 +20,7 @@ def test_shared_library_exports_every_declared_symbol():
     L = milib.get()                                   # raises if the .so is missing or lacks a declared symbol
     for name in protos:
         assert hasattr(L.cdll, name), name
-    assert L.mi_abi_version() == 1
+    assert L.mi_abi_version() == 2
     assert L.mi_vae_desc_size() == ctypes.sizeof(milib.MiVaeDesc) and L.mi_ppo_desc_size() == ctypes.sizeof(milib.MiPpoDesc)
     # every public entry point cites the reference op it replaces
     text = open(milib.HEADER).read()
@@ -338,3 +338,27 @@ def test_data_parallel_two_ranks_gloo_equals_single_process(tmp_path):
     assert res["max_param_rel_err_vs_single"] < 2e-2, res
     assert abs(res["metric_recon_dp"] / res["metric_recon_single"] - 1) < 1e-6
     assert res["ppo_max_grad_rel_err"] < 2e-5, res
+
+
+def test_vae_common_call_chain_is_pinned_to_the_reference(golden_dir):
+    """SURVEY 8 row a22.  tests/golden/vae_common_calls.json is what the reference's own vae_common.py (load_vae :6-27, encode_state :45-61) does
+    to the `vae.models` classes -- recorded by running /root/reference/vae_common.py against a recording stand-in.  The restatement the GPU
+    test drives the drop-in with (tests/ref_call_chain.py) must produce the identical trace; where the reference checkout exists, the
+    fixture is re-derived from it."""
+    import ref_call_chain as rc
+    golden = json.load(open(os.path.join(golden_dir, "vae_common_calls.json")))
+    assert sorted(golden) == sorted(rc.MODEL_DIRS)
+    for d in rc.MODEL_DIRS:
+        assert rc.trace_restatement(d) == golden[d], d
+        if os.path.exists(os.path.join(rc.REFERENCE, "vae_common.py")):
+            assert rc.trace_reference(d) == golden[d], d
+    t = golden[rc.MODEL_DIRS[0]]
+    assert [c["call"] for c in t["calls"]] == ["ConvVAE", "init_session", "load_latest_checkpoint", "encode"]
+    assert t["calls"][0]["kwargs"]["training"] is False and t["calls"][0]["kwargs"]["models_dir"] == "vae"
+    assert t["calls"][0]["kwargs"]["target_shape"]["ndarray"] == [80, 160, 1]                # "seg_" in the directory name
+    assert t["state"] == {"shape": [67], "dtype": "float64", "head": [0.0, 1.0, 2.0], "tail": [-0.25, 0.5, 12.5]}
+    # the drop-in's constructors accept exactly these keywords (models_dir is swallowed by **kwargs as in the reference, vae/models.py:41)
+    from vae.models import ConvVAE, MlpVAE
+    for cls in (ConvVAE, MlpVAE):
+        sig = inspect.signature(cls.__init__)
+        assert any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())

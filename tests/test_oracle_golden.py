@@ -291,3 +291,38 @@ def test_oracle_vae_epoch_loop_semantics():
     assert m.encode(frames[:3]).shape == (3, 64)
     assert len(m.reconstruct(frames[:2], eps=np.zeros((2, 64), np.float32))) == 2
     assert m.generate_from_latent(np.zeros((2, 64))).shape == (2, 38400)
+
+
+def test_philox4x32_10_known_answers_and_normal_moments():
+    """Known-answer vectors of Philox4x32-10 (Random123 kat_vectors) for the restatement the GPU noise test compares the device stream with;
+    the Box-Muller output of that stream has the moments of N(0,1)."""
+    import philox_ref as pr
+    z4, z2 = np.zeros((1, 4), np.uint32), np.zeros((1, 2), np.uint32)
+    assert [hex(int(v)) for v in pr.philox4x32_10(z4, z2)[0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f4, f2 = np.full((1, 4), 0xFFFFFFFF, np.uint32), np.full((1, 2), 0xFFFFFFFF, np.uint32)
+    assert [hex(int(v)) for v in pr.philox4x32_10(f4, f2)[0]] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    pi4 = np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32)
+    pi2 = np.array([[0xa4093822, 0x299f31d0]], np.uint32)
+    assert [hex(int(v)) for v in pr.philox4x32_10(pi4, pi2)[0]] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    x = pr.normal(0x5EED, 0, 1 << 16).astype(np.float64)
+    assert abs(x.mean()) < 0.02 and abs(x.std() - 1.0) < 0.02 and abs((x ** 3).mean()) < 0.05 and abs((x ** 4).mean() - 3.0) < 0.15
+    assert np.array_equal(pr.normal(7, 100, 50), pr.normal(7, 0, 150)[100:])                # element i depends on (seed, offset + i) only
+
+
+def test_uint8_normalisation_formulas_are_exact():
+    """The in-register forms of the host preprocessing `frame.astype(np.float32) / 255.0` (vae/train_vae.py:15-18) used by the kernels that read
+    uint8 frame tables: fp32: q = k * fl(1/255), r = fma(-q, 255, k), y = fma(r, fl(1/255), q) equals the correctly rounded division for every
+    byte; bf16 storage: the plain product already rounds to the same bf16 value as the exact quotient."""
+    k = np.arange(256, dtype=np.float32)
+    ref = (k / np.float32(255.0)).astype(np.float32)
+    c = np.float32(0.003921568859368563)
+    assert c == np.float32(1.0) / np.float32(255.0)
+    q = (k * c).astype(np.float32)
+    r = (k.astype(np.float64) - q.astype(np.float64) * 255.0).astype(np.float32)            # fma(-q, 255, k): the product is exact in double
+    y = (q.astype(np.float64) + r.astype(np.float64) * np.float64(c)).astype(np.float32)     # fma(r, c, q)
+    assert np.array_equal(y, ref)
+
+    def bf16(x):
+        u = x.view(np.uint32)
+        return ((u + (((u >> 16) & 1) + 0x7FFF)) >> 16).astype(np.uint16)
+    assert np.array_equal(bf16(q), bf16(ref))

@@ -36,7 +36,7 @@ class FakeVae:
     def _src_feat(self):
         return self.feat
 
-    def _frames(self, arr, feat, what):
+    def _frames(self, arr, feat, what, keep_u8_ok=False):
         assert arr.dtype == np.uint8
         return torch.from_numpy(arr.reshape(len(arr), -1).astype(np.float32) / np.float32(255.0))
 
