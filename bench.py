@@ -5,15 +5,23 @@
 
 A "step" is one ConvVAE SGD step (forward, ELBO, backward, gradient all-reduce when N>1, fused TF-Adam) on one minibatch
 of 512 synthetic 160x80x3 frames PER GPU in bf16 (BASELINE configs[1]; global batch 512*N -> configs[3] at N=8), frames
-already resident in HBM (a pool of synthetic uint8-grid frames, minibatches gathered inside the conv1 / loss kernels).
+already resident in HBM (a pool of synthetic uint8 camera frames -- the reference's own frame format, normalised to k/255
+inside the kernels that read them; minibatches are gathered inside the conv1 / loss kernels; the reparameterisation noise is
+drawn inside the reparameterisation kernel).  Nothing runs on the timed path but the library's own kernels.
 `value` = frames/s of the whole job = N*512*K / max-over-ranks(time of exactly K steps).
 
 Extra objects on the same JSON line:
   roofline      the dominant kernel of the step (picked from a per-op HIP-event profile during warm-up), timed with HIP
-                events on the launch stream over the K timed steps; achieved = algorithmic FLOPs (or bytes) / avg duration.
+                events on the launch stream over the K timed steps; achieved = algorithmic FLOPs (or bytes) / avg duration;
+                `bound` = whichever of the two floors (algorithmic bytes / 8 TB/s, algorithmic FLOPs / MFMA peak) is higher.
   cpu_baseline  the CPU oracle (a port of the reference's TF graph; the reference itself needs TensorFlow 1.13) timed on
-                this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                this box's host cores: >= 3 warm-up + >= 10 timed steps of the same minibatch shape (rank 0, N=1 only);
+                `ppo` inside it: the oracle's PPO update (configs[2]) timed the same way.
+  parity        measured in THIS run: the benchmarked engine (and the fp32 engine) against the oracle on the cpu_baseline's
+                batch-512 inputs: relative deviation of the two losses and of encode() (max-normalised).
+  fp32          throughput of the exact-fp32 mode (the mode that meets the 1e-4 tolerance) on the same workload.
   ppo           PPO update throughput on z=64 latents (BASELINE configs[2]) — reported, not part of `value`.
+  replay        BASELINE configs[4] on this GPU: VAE encode + GAE + PPO minibatch SGD over 1024 trajectories x 128 steps.
 """
 import argparse
 import json
@@ -37,37 +45,66 @@ ENC = [(80, 160, 3, 32), (39, 79, 32, 64), (18, 38, 64, 128), (8, 18, 128, 256)]
 DEC = [(3, 8, 256, 128, 4), (8, 18, 128, 64, 4), (18, 38, 64, 32, 5), (39, 79, 32, 3, 4)]  # IH, IW, Cin, Cout, k
 
 
-def op_work(name, B, esz, n_params):
-    """Algorithmic work of one launch of op `name` at batch B: (flops, bytes, bound). SURVEY.md 8(d) per-frame figures x B."""
+def op_work(name, B, esz, n_params, frame_bytes=4):
+    """Algorithmic work of one launch of op `name` at batch B: (flops, bytes). SURVEY.md 8(d) per-frame figures x B; bytes = every operand
+    read once + the result written once (+ the ReLU-grad mask tensor for input gradients), weights included.  frame_bytes: 4 = fp32 frame
+    tables, 1 = uint8 tables."""
     layer, _, kind = name.partition(".")
-    # conv1 / deconv4 (K = 48 / N = 3): skinny streams, HBM bound per SURVEY 8(d): frame fp32 153 600 B, 39x79x32 map, 80x160x3 map
-    if layer in ("conv1", "deconv4") and kind in ("fwd", "dgrad", "wgrad"):
-        big = 38400.0 * (4 if layer == "conv1" else esz)            # frames are fp32, logits / dlogits are T
-        mid = 39 * 79 * 32.0 * esz
-        nbytes = {"fwd": big + mid, "wgrad": big + mid, "dgrad": big + 2 * mid}[kind]   # dgrad also reads the ReLU mask
-        return None, nbytes * B, "hbm"
     if layer.startswith("conv") and kind in ("fwd", "dgrad", "wgrad"):
         ih, iw, ci, co = ENC[int(layer[4]) - 1]
         oh, ow = (ih - 4) // 2 + 1, (iw - 4) // 2 + 1
-        return 2.0 * oh * ow * co * 16 * ci * B, None, "mfma"
+        flops = 2.0 * oh * ow * co * 16 * ci * B
+        xin = ih * iw * ci * (frame_bytes if layer == "conv1" else esz) * B
+        yout = oh * ow * co * esz * B
+        w = 16 * ci * co * (esz if kind != "wgrad" else 4)
+        nbytes = {"fwd": xin + yout + w, "dgrad": yout + 2 * xin + w, "wgrad": xin + yout + w}[kind]     # dgrad: dy in, mask in, dx out
+        return flops, float(nbytes)
     if layer.startswith("deconv") and kind in ("fwd", "dgrad", "wgrad"):
         ih, iw, ci, co, k = DEC[int(layer[6]) - 1]
-        return 2.0 * ih * iw * ci * k * k * co * B, None, "mfma"
+        oh, ow = (ih - 1) * 2 + k, (iw - 1) * 2 + k
+        flops = 2.0 * ih * iw * ci * k * k * co * B
+        xin, yout = ih * iw * ci * esz * B, oh * ow * co * esz * B
+        w = k * k * ci * co * (esz if kind != "wgrad" else 4)
+        if layer == "deconv4" and kind == "fwd":         # fused with the reconstruction loss: labels in, dlogits out, the logits stay on chip
+            return flops, float(xin + oh * ow * co * frame_bytes * B + yout + w)
+        nbytes = {"fwd": xin + yout + w, "dgrad": yout + 2 * xin + w, "wgrad": xin + yout + w}[kind]
+        return flops, float(nbytes)
     if layer in ("heads", "dense1") and kind in ("fwd", "dgrad", "wgrad"):
-        return 2.0 * 6144 * (128 if layer == "heads" else 64) * B, None, "mfma"
+        n = 128 if layer == "heads" else 64
+        return 2.0 * 6144 * n * B, float((6144 + n) * esz * B + 6144 * n * (esz if kind != "wgrad" else 4))
     if name == "recon_loss":
-        return None, 38400.0 * (2 * esz + 4) * B, "hbm"
+        return None, 38400.0 * (2 * esz + frame_bytes) * B
     if name == "adam":
-        return None, n_params * (28.0 + (2 if esz == 2 else 0)), "hbm"
+        return None, n_params * (28.0 + (2 if esz == 2 else 0))
     if kind == "bias_grad":
         if layer.startswith("conv"):
             ih, iw, ci, co = ENC[int(layer[4]) - 1]
-            return None, float(((ih - 4) // 2 + 1) * ((iw - 4) // 2 + 1) * co * esz * B), "hbm"
+            return None, float(((ih - 4) // 2 + 1) * ((iw - 4) // 2 + 1) * co * esz * B)
         if layer.startswith("deconv"):
             ih, iw, ci, co, k = DEC[int(layer[6]) - 1]
-            return None, float(((ih - 1) * 2 + k) * ((iw - 1) * 2 + k) * co * esz * B), "hbm"
-        return None, float((6144 if layer == "dense1" else 128) * esz * B), "hbm"
-    return None, float(64 * 6 * 4 * B), "hbm"           # reparam / finalize: tiny
+            return None, float(((ih - 1) * 2 + k) * ((iw - 1) * 2 + k) * co * esz * B)
+        return None, float((6144 if layer == "dense1" else 128) * esz * B)
+    return None, float(64 * 6 * 4 * B)                  # reparam / finalize: tiny
+
+
+def roofline_of(name, avg_s, B, esz, n_params, precision, frame_bytes):
+    """Roofline object of one op: the bound is decided by comparing the arithmetic intensity with the ridge point."""
+    flops, nbytes = op_work(name, B, esz, n_params, frame_bytes)
+    peak_f = PEAK["mfma_bf16" if precision == "bf16" else "mfma_f32"]
+    t_hbm = nbytes / PEAK["hbm"]
+    t_mfma = (flops or 0.0) / peak_f
+    out = {"kernel": name, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+           "arithmetic_intensity_flop_per_byte": (flops / nbytes) if flops else None, "ridge_flop_per_byte": peak_f / PEAK["hbm"],
+           "floor_ms": {"hbm": t_hbm * 1e3, "mfma": t_mfma * 1e3}, "traffic": None}
+    if t_mfma > t_hbm:
+        ach = flops / avg_s
+        out.update({"bound": "mfma", "achieved": ach / 1e12, "peak": peak_f / 1e12, "unit": "TFLOP/s", "frac": ach / peak_f})
+    else:
+        ach = nbytes / avg_s
+        out.update({"bound": "hbm", "achieved": ach / 1e9, "peak": PEAK["hbm"] / 1e9, "unit": "GB/s", "frac": ach / PEAK["hbm"]})
+        if flops:
+            out["mfma_frac_for_reference"] = flops / avg_s / peak_f
+    return out
 
 
 def collect_timing(dev, n_ops):
@@ -77,33 +114,89 @@ def collect_timing(dev, n_ops):
     return ms, cnt
 
 
-def cpu_baseline(batch, seed=0):
-    """Oracle (port of the reference graph) SGD steps on the host cores: 1 warm-up + 3 timed steps of the same minibatch shape."""
+def cpu_inputs(batch):
+    frames = np.random.RandomState(1234).randint(0, 256, (batch, 80, 160, 3), dtype=np.uint8)
+    eps = np.random.RandomState(4321).standard_normal((batch, 64)).astype(np.float32)
+    return frames, eps
+
+
+def cpu_baseline(batch, seed=0, warm=3, timed=10):
+    """Oracle (port of the reference graph) SGD steps on the host cores (>= 3 warm-up + >= 10 timed steps of the same
+    minibatch shape) + the oracle's PPO update (configs[2]); also returns what the parity object needs (oracle losses / encodings)."""
+    from oracle import ppo_oracle as po
     from oracle import vae_oracle as vo
     # 16 threads measured fastest for this graph on the GPU box's 2x EPYC 9575F (16: 515, 32: 474, 64: 273, 128: 151 frames/s)
     cores = min(int(os.environ.get("MI355_CPU_BASELINE_THREADS", "16")), os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    o = vo.OracleVAE(seed=seed)
-    rng = np.random.RandomState(1234)
-    frames = rng.randint(0, 256, (batch, 80, 160, 3), dtype=np.uint8).astype(np.float32) / 255.0
-    eps = np.random.RandomState(4321).standard_normal((batch, 64)).astype(np.float32)
-    o.train_step(frames, frames, eps)
-    n, t0 = 3, time.perf_counter()
-    for _ in range(n):
+    u8, eps = cpu_inputs(batch)
+    frames = u8.astype(np.float32) / 255.0
+    params = vo.init_vae_params(seed)
+    (recon, kl, _), _, fw = vo.vae_loss_and_grads(params, frames, frames, eps)           # step-0 losses / posterior means for the parity object
+    ref = {"params": params, "recon": recon, "kl": kl, "mean": fw["mean"].numpy()}
+    o = vo.OracleVAE(params={k: v.copy() for k, v in params.items()})
+    for _ in range(warm):
+        o.train_step(frames, frames, eps)
+    t0 = time.perf_counter()
+    for _ in range(timed):
         o.train_step(frames, frames, eps)
     dt = time.perf_counter() - t0
-    return {"value": batch * n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d ConvVAE fp32 SGD steps at batch %d (torch-CPU oracle of the reference TF graph; TF 1.13 itself is not runnable)" % (n, batch)}
+    out = {"value": batch * timed / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d warm-up + %d timed ConvVAE fp32 SGD steps at batch %d (torch-CPU oracle of the reference TF graph; TF 1.13 itself is not runnable)" % (warm, timed, batch)}
+    # PPO update on the same cores: horizon 128, 4 epochs x 4 minibatches of 32 (configs[2])
+    hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
+    m = po.OraclePPO([67], po.ActionSpace(), seed=1, **hp)
+    rng = np.random.RandomState(7)
+    T = 128
+    s = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    R, A = rng.randn(T).astype(np.float32), rng.randn(T).astype(np.float32)
+
+    def update():
+        m.update_old_policy()
+        for mb in po.minibatch_schedule(T, 32, 4):
+            m.train(s[mb], a[mb], R[mb], A[mb])
+    for _ in range(3):
+        update()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        update()
+    dtp = (time.perf_counter() - t0) / 10
+    out["ppo"] = {"samples_per_s": T / dtp, "ms_per_update": dtp * 1e3, "sample": "3 warm-up + 10 timed PPO updates (horizon 128, 4 epochs x 4 minibatches of 32), torch-CPU oracle, same cores"}
+    return out, ref
 
 
-def ppo_extra(tmp, steps=3):
+def parity_object(tmp, ref, batch):
+    """The HIP engines against the oracle on the cpu_baseline's inputs, measured in this run (forward losses + encode of one batch-512 pass)."""
+    from vae.models import ConvVAE
+    u8, eps = cpu_inputs(batch)
+    frames = u8.astype(np.float32) / 255.0
+    out = {"inputs": "batch %d, seeds 1234 / 4321 / 0 (SURVEY 8d), oracle = torch-CPU fp32 port of the reference graph" % batch}
+    for prec in ("bf16", "fp32"):
+        m = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=os.path.join(tmp, "parity_" + prec), precision=prec, seed=0)
+        m.set_weights(ref["params"])
+        m.init_session(init_logging=False)
+        src = m._frames(frames, 38400, "src")
+        e = m._eps(batch, eps)
+        m.dev.forward(src, src, None, batch, 1.0 / batch, e, 1, 0)
+        got = m.dev.losses.cpu().numpy()
+        mean = m.dev._view(1, batch * 64).cpu().numpy().reshape(batch, 64)
+        out[prec] = {"recon_loss_rel": float(abs(got[0] / ref["recon"] - 1)), "kl_loss_rel": float(abs(got[1] / ref["kl"] - 1)),
+                     "encode_rel_of_max": float(np.abs(mean - ref["mean"]).max() / np.abs(ref["mean"]).max())}
+        m.dev.close()
+    out["note"] = ("fp32 = exact-fp32 MFMA engine (the drop-in's default; north_star's 1e-4); bf16 = the benchmarked throughput mode (bf16 storage, fp32 "
+                   "accumulate): its deviation is bf16 rounding of activations / weights, stated here instead of claimed away; TF's own fp32 kernel "
+                   "rounding is unpinned (TF 1.13 not runnable): the oracle is pinned to the reference's serialized graphs at 1e-9 in float64")
+    return out
+
+
+def ppo_extra(tmp, steps=5):
     """BASELINE configs[2]: PPO update on z=64 latents, horizon 128, 4 minibatch epochs of 32 -> samples/s (reported only)."""
     from ppo import PPO
 
     class Box:
         low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
     m = PPO(np.array([67]), Box(), learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0,
-            model_dir=os.path.join(tmp, "ppo"))
+            model_dir=os.path.join(tmp, "ppo"), seed=0)
     m.init_session(init_logging=False)
     rng = np.random.RandomState(7)
     T = 128
@@ -131,16 +224,85 @@ def ppo_extra(tmp, steps=3):
             "ms_per_sgd_step": dt * 1e3 / 16}
 
 
+def fp32_extra(tmp, B, pool_u8, idx, steps=40, warm=5):
+    """The same workload on the exact-fp32 engine (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): the mode that meets north_star's 1e-4."""
+    from vae.models import ConvVAE
+    m = ConvVAE(np.array([80, 160, 3]), z_dim=64, beta=1.0, learning_rate=1e-4, model_dir=os.path.join(tmp, "vae32"), precision="fp32", seed=0)
+    m.init_session(init_logging=False)
+    m.dev.ensure_batch(B)
+    n = min(pool_u8.shape[0], 1024)
+    pool = torch.empty(n, 38400, device=pool_u8.device)
+    m.dev.L.mi_u8_to_unit_f32(m.dev.stream(), pool_u8.data_ptr(), pool.data_ptr(), pool.numel())
+    sel = (idx.to(torch.int64) % n).to(torch.int32).contiguous()
+    for i in range(warm):
+        m._train_minibatch(pool, pool, sel[i], B, 1.0 / B, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m._train_minibatch(pool, pool, sel[(warm + i) % sel.shape[0]], B, 1.0 / B, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fl = 776494080.0 * B * steps / dt
+    m.dev.close()
+    return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "frac_of_157TF": fl / PEAK["mfma_f32"],
+            "storage": "fp32 activations / weights, exact-fp32 MFMA; fp32 frame table"}
+
+
+def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
+    """BASELINE configs[4] on ONE GPU: encode 1024 x 129 uint8 frames, values, GAE, PPO minibatch SGD (global minibatch 2048)."""
+    import replay
+    from ppo import PPO
+    from vae.models import ConvVAE
+
+    class Box:
+        low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
+    vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=os.path.join(tmp, "rvae"), precision="bf16", training=False, seed=0)
+    vae.init_session(init_logging=False)
+    ppo = PPO(np.array([67]), Box(), learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0,
+              model_dir=os.path.join(tmp, "rppo"), seed=0)
+    ppo.init_session(init_logging=False)
+    rng = np.random.default_rng(1234)
+    frames = rng.integers(0, 256, (rows, T + 1, 80, 160, 3), dtype=np.uint8)
+    meas = np.stack([rng.uniform(-1, 1, (rows, T + 1)), rng.uniform(0, 1, (rows, T + 1)), rng.uniform(0, 30, (rows, T + 1))], axis=-1).astype(np.float32)
+    actions = np.stack([rng.uniform(-1, 1, (rows, T)), rng.uniform(0, 1, (rows, T))], axis=-1).astype(np.float32)
+    rewards, dones = rng.uniform(0, 1, (rows, T)), np.zeros((rows, T))
+    stages = {}
+    replay.replay_update(vae, ppo, frames[:8], meas[:8], actions[:8], rewards[:8], dones[:8], 0.99, 0.95, 1, batch)      # warm-up: engines sized
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = replay.replay_update(vae, ppo, frames, meas, actions, rewards, dones, 0.99, 0.95, epochs, batch, stage_times=stages)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = rows * T
+    res = {"config": "synthetic replay (BASELINE configs[4] on 1 GPU): %d trajectories x %d steps, bf16 VAE encode of %d uint8 frames, values, GAE + per-row "
+                     "normalisation, PPO SGD %d epochs x minibatch %d (fp32)" % (rows, T, rows * (T + 1), epochs, batch),
+           "seconds": dt, "samples_per_s": n / dt, "sgd_steps": len(out["losses"]), "includes": "host->device upload of the uint8 frames (PCIe)",
+           "last_loss": out["losses"][-1]["loss"] if out["losses"] else None}
+    for k, v in stages.items():
+        res[k + "_s"] = v
+    if "encode" in stages:
+        res["encode_frames_per_s"] = rows * (T + 1) / stages["encode"]
+    if "sgd" in stages:
+        res["ppo_sgd_samples_per_s"] = n * epochs / stages["sgd"]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step (BASELINE configs[1])")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--pool", type=int, default=2048, help="synthetic frames resident in HBM per GPU")
+    ap.add_argument("--frames", default="u8", choices=["u8", "f32"], help="format of the HBM-resident frame pool (bf16 engine: uint8 camera bytes by default)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("MI355_BENCH_GRAPH", "0")),
+                    help="1: the timed steps replay the captured hipGraph of the step (the dominant kernel is then timed in an eager pass after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true")
+    ap.add_argument("--no-replay", action="store_true")
+    ap.add_argument("--replay-rows", type=int, default=1024)
     args = ap.parse_args()
 
     from mi355 import dist as midist
@@ -152,27 +314,36 @@ def main():
 
     tmp = tempfile.mkdtemp(prefix="mi355_bench_")
     B = args.batch
+    os.environ["MI355_GRAPH"] = "1" if args.graph else "0"
     model = ConvVAE(np.array([80, 160, 3]), z_dim=64, beta=1.0, learning_rate=1e-4, model_dir=os.path.join(tmp, "vae"), precision=args.precision, seed=0)
     model.init_session(init_logging=False)
     dev = model.dev
     dev.ensure_batch(B)
     device = dev.device
+    u8_pool = args.frames == "u8" and args.precision == "bf16"
 
-    # synthetic uint8-grid frames, HBM resident (randint(0,256)/255), generated on the device
+    # synthetic uint8 camera frames, HBM resident (randint(0,256) [/255]), generated on the device
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
-    pool = (torch.randint(0, 256, (args.pool, 38400), device=device, generator=g, dtype=torch.int32).to(torch.float32) / 255.0).contiguous()
+    pool_u8 = torch.randint(0, 256, (args.pool, 38400), device=device, generator=g, dtype=torch.int32).to(torch.uint8).contiguous()
+    if u8_pool:
+        pool = pool_u8
+    else:
+        pool = torch.empty(args.pool, 38400, device=device)
+        dev.L.mi_u8_to_unit_f32(dev.stream(), pool_u8.data_ptr(), pool.data_ptr(), pool.numel())
     total = args.warmup + args.steps
-    idx = torch.stack([torch.randperm(args.pool, device=device, generator=g)[:B] for _ in range(total + 2)]).to(torch.int32).contiguous()
+    n_idx = min(total + 2, 64)                            # 64 different minibatches of the pool, cycled
+    idx = torch.stack([torch.randperm(args.pool, device=device, generator=g)[:B] for _ in range(n_idx)]).to(torch.int32).contiguous()
     inv_b = 1.0 / (B * world)
     n_ops = dev.L.mi_vae_op_count()
     names = [dev.L.mi_vae_op_name(i).decode() for i in range(n_ops)]
     esz = 2 if args.precision == "bf16" else 4
+    frame_bytes = 1 if u8_pool else 4
 
     def step(i):
-        model._train_minibatch(pool, pool, idx[i], B, inv_b, model._eps(B))
+        model._train_minibatch(pool, pool, idx[i % n_idx], B, inv_b, None)     # eps=None: drawn inside the reparameterisation kernel
 
-    # ---- warm-up (untimed); the last warm-up steps run with every op bracketed by HIP events to find the dominant kernel ----
+    # ---- warm-up (untimed); two of the warm-up steps run with every op bracketed by HIP events to find the dominant kernel ----
     for i in range(max(args.warmup - 2, 0)):
         step(i)
     torch.cuda.synchronize()
@@ -185,9 +356,14 @@ def main():
     ms_all, cnt_all = collect_timing(dev, n_ops)
     per_op = {names[i]: float(ms_all[i] / cnt_all[i]) for i in range(n_ops) if cnt_all[i] > 0}
     dominant = max(per_op, key=per_op.get) if per_op else None
+    if args.graph and world == 1:                         # capture + first replays belong to the warm-up
+        for i in range(3):
+            step(total + i)
+        torch.cuda.synchronize()
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides; the dominant op keeps its two HIP events ----
-    if dominant is not None:
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides; (eager mode) the dominant op keeps its two HIP events ----
+    events_live = dominant is not None and not (args.graph and world == 1)
+    if events_live:
         dev.L.mi_vae_timing_begin(dev.handle, 2, names.index(dominant), args.steps + 4)
     midist.barrier()
     torch.cuda.synchronize()
@@ -195,39 +371,61 @@ def main():
     for i in range(args.warmup, total):
         step(i)
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
     midist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed, t_local], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    losses = dev.losses.cpu().numpy()
     roofline = None
     if dominant is not None:
+        how = "HIP events on the launch stream around every launch of this op inside the timed region"
+        if not events_live:                               # graph replays cannot carry per-launch events: a short eager pass right after the timed region
+            dev.L.mi_vae_timing_begin(dev.handle, 2, names.index(dominant), 64)
+            for i in range(min(args.steps, 50)):
+                step(i)
+            torch.cuda.synchronize()
+            how = "HIP events around every launch of this op in an eager pass of %d steps right after the graph-replayed timed region" % min(args.steps, 50)
         ms_d, cnt_d = collect_timing(dev, n_ops)
         di = names.index(dominant)
         avg_s = float(ms_d[di] / max(cnt_d[di], 1)) * 1e-3
-        flops, nbytes, bound = op_work(dominant, B, esz, dev.n_flat)
-        if bound == "mfma":
-            peak = PEAK["mfma_bf16" if args.precision == "bf16" else "mfma_f32"]
-            ach = flops / avg_s
-            roofline = {"kernel": dominant, "bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                        "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches_timed": int(cnt_d[di]), "algorithmic_flops_per_launch": flops}
-        else:
-            ach = nbytes / avg_s
-            roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach / 1e9, "peak": PEAK["hbm"] / 1e9, "unit": "GB/s", "frac": ach / PEAK["hbm"],
-                        "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches_timed": int(cnt_d[di]), "algorithmic_bytes_per_launch": nbytes}
-    # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction),
-    # measured offline on this same workload and committed under profiles/ (PMC counters cannot be read from inside the bench)
-    if roofline is not None:
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            for op, rec in tj["ops"].items():
-                if dominant in [x.strip().split(" ")[0] for x in op.split("/")]:
-                    roofline["traffic"] = rec["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json: " + tj["provenance"]
-        except Exception:
-            pass
-    losses = dev.losses.cpu().numpy()
+        roofline = roofline_of(dominant, avg_s, B, esz, dev.n_flat, args.precision, frame_bytes)
+        roofline["launches_timed"] = int(cnt_d[di])
+        roofline["timing"] = how
+        # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction),
+        # measured offline on this same workload and committed under profiles/ (PMC counters cannot be read from inside the bench)
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                for op, rec in tj["ops"].items():
+                    if dominant in [x.strip().split(" ")[0] for x in op.split("/")]:
+                        roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                        roofline["traffic_source"] = "profiles/%s: %s" % (fn, tj["provenance"])
+                if roofline["traffic"] is not None:
+                    break
+            except Exception:
+                pass
+
+    # data parallel: what one rank spends per step, and how much of it is gradient all-reduce that nothing overlaps
+    dp = None
+    if world > 1:
+        per_rank = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
+        torch.distributed.all_gather(per_rank, torch.tensor([t_local / args.steps * 1e3, 0.0], device=device, dtype=torch.float64))
+        # exposed all-reduce: the same steps with the collectives skipped (gradients then differ per rank: parameters are re-broadcast afterwards)
+        os.environ["MI355_DP_SKIP_ALLREDUCE"] = "1"
+        torch.cuda.synchronize(); midist.barrier()
+        t1 = time.perf_counter()
+        for i in range(min(args.steps, 50)):
+            step(i)
+        torch.cuda.synchronize()
+        t_nocomm = (time.perf_counter() - t1) / min(args.steps, 50) * 1e3
+        os.environ.pop("MI355_DP_SKIP_ALLREDUCE")
+        midist.barrier()
+        midist.broadcast(dev.params, 0); dev.sync_shadow()
+        dp = {"ms_per_step_by_rank": [float(x[0].item()) for x in per_rank], "ms_per_step_without_allreduce_rank0": t_nocomm,
+              "exposed_allreduce_ms_rank0": max(t_local / args.steps * 1e3 - t_nocomm, 0.0), "gradient_bytes_per_step": int(dev.n_flat) * 4, "buckets": 3}
 
     if rank == 0:
         frames_per_s = B * world * args.steps / elapsed
@@ -238,6 +436,9 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "ConvVAE SGD step (fwd+ELBO+bwd+TF-Adam), batch=%d per GPU, 160x80x3 frames, z_dim=64, rgb target (BASELINE configs[1]; global batch %d)" % (B, B * world),
                        "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single", "frames_resident_in_hbm": args.pool,
+                       "frame_table": "uint8 camera bytes, k/255 in registers" if u8_pool else "float32 in [0,1]",
+                       "noise": "N(0,1) drawn inside the reparameterisation kernel (Philox4x32-10)",
+                       "launch": "hipGraph replay of the captured step" if (args.graph and world == 1) else "eager launches",
                        "storage": "bf16 activations/weights, fp32 accumulate, fp32 master weights+Adam" if args.precision == "bf16" else "fp32"},
             "roofline": roofline,
             "step_model_flops_utilisation": {"algorithmic_tflops_per_step": step_flops / 1e12,
@@ -245,16 +446,30 @@ def main():
                                              "frac_of_mfma_peak": step_flops * args.steps / elapsed / PEAK["mfma_bf16" if args.precision == "bf16" else "mfma_f32"]},
             "per_op_ms": {k: round(v, 4) for k, v in sorted(per_op.items(), key=lambda kv: -kv[1])},
             "final_losses": {"reconstruction": float(losses[0]), "kl": float(losses[1])},
+            "data_parallel": dp,
         }
+        out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B)
-        else:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"], ref = cpu_baseline(B)
+            try:
+                out["parity"] = parity_object(tmp, ref, B)
+            except Exception as e:
+                out["parity"] = {"error": repr(e)}
+        if world == 1 and not args.no_fp32 and args.precision == "bf16":
+            try:
+                out["fp32"] = fp32_extra(tmp, B, pool_u8, idx)
+            except Exception as e:
+                out["fp32"] = {"error": repr(e)}
         if world == 1 and not args.no_ppo:
             try:
                 out["ppo"] = ppo_extra(tmp)
             except Exception as e:      # the headline metric must still print
                 out["ppo"] = {"error": repr(e)}
+        if world == 1 and not args.no_replay:
+            try:
+                out["replay"] = replay_extra(tmp, args.replay_rows)
+            except Exception as e:
+                out["replay"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     midist.barrier()
     if world > 1:

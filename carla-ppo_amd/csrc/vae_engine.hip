@@ -118,6 +118,7 @@ struct VaeEngine {
     int last_u8;                        // frame-table format of the last forward (backward reads the same source table)
     // one captured SGD step (mi_vae_train_step with use_graph): replayed while the call's pointer arguments stay the same
     hipGraphExec_t gexec;
+    hipStream_t cap; int cap_ok;        // engine-owned stream the step is recorded on
     struct GraphKey { const void *src, *tgt, *eps, *metrics, *stream; int u8, has_idx, B; float inv_batch, b1, b2, epsilon, mw; } gkey;
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
     const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
@@ -288,6 +289,7 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
 void mi_vae_destroy(void* h) {
     VaeEngine* e = (VaeEngine*)h;
     if (e && e->gexec) hipGraphExecDestroy(e->gexec);
+    if (e && e->cap_ok == 1) hipStreamDestroy(e->cap);
     if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
     free(h);
 }
@@ -499,24 +501,34 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
     hipLaunchKernelGGL(stage_step_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, idx_stage, alpha, scalars);
     CK(mi_check_launch("stage_step"));
     const int* idx_in = idx ? idx_stage : nullptr;
-    auto body = [&]() -> int {
-        CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx_in, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
-        CK(mi_vae_backward(h, stream, src, idx_in, eps, inv_batch, 0));
-        return apply_adam(e, stream, 0.f, scalars, beta1, beta2, epsilon);
+    auto body = [&](void* s) -> int {
+        CK(mi_vae_forward(h, s, src, tgt, frames_u8, idx_in, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+        CK(mi_vae_backward(h, s, src, idx_in, eps, inv_batch, 0));
+        return apply_adam(e, s, 0.f, scalars, beta1, beta2, epsilon);
     };
-    if (!use_graph || e->tm.mode) return body();          // per-op timing brackets single launches with events: eager
+    // eager: on request; while per-op timing brackets single launches with events; and with injected noise (a parity-run pattern: the caller's
+    // eps buffer usually changes every step, which would mean a new capture every step)
+    if (!use_graph || e->tm.mode || eps) return body(stream);
     const VaeEngine::GraphKey key = {src, tgt, eps, metrics3, stream, frames_u8 ? 1 : 0, idx ? 1 : 0, B, inv_batch, beta1, beta2, epsilon, metric_weight};
     if (!e->gexec || memcmp(&key, &e->gkey, sizeof(key)) != 0) {
-        if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->gexec) {                                   // the previous graph may still be running on the caller's stream
+            if (hipStreamSynchronize(st) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: stream synchronisation failed");
+            hipGraphExecDestroy(e->gexec); e->gexec = nullptr;
+        }
         if (!e->side_ok) {                                // the second stream and its events are created outside the capture
             if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
             else e->side_ok = -1;
         }
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipStreamBeginCapture failed");
-        const int rc = body();
+        // the caller's stream may be the legacy null stream, which cannot be captured: the launch sequence is recorded on a stream of the
+        // engine's own and the instantiated graph is then launched on the caller's stream
+        if (!e->cap_ok) e->cap_ok = hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking) == hipSuccess ? 1 : -1;
+        if (e->cap_ok != 1) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: could not create the capture stream");
+        const hipError_t be = hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal);
+        if (be != hipSuccess) { (void)hipGetLastError(); return mi_fail(MI_ERR_STATE, hipGetErrorString(be)); }
+        const int rc = body((void*)e->cap);
         hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        const hipError_t ce = hipStreamEndCapture(e->cap, &graph);
         if (rc != MI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
         if (ce != hipSuccess || !graph) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipStreamEndCapture failed");
         const hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);

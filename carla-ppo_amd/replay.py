@@ -37,13 +37,15 @@ def encode_resident(vae, frames, chunk=512):
 
 
 def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma=0.99, lam=0.95, num_epochs=3, batch_size=32, encode_chunk=512,
-                  local_rows=False):
+                  local_rows=False, stage_times=None):
     """One PPO update over R recorded trajectories (see the module docstring).
 
     frames [R, T+1, H, W, C] (uint8 or float in [0,1]; the last frame of a row is the state after its last step), measurements [R, T+1, k],
     actions [R, T, A] (the actions that were taken), rewards [R, T], dones [R, T].  batch_size is the GLOBAL minibatch size.
     local_rows=True: the arrays already hold only this rank's trajectories (each rank loaded / generated its own shard; every rank must
     hold the same number of them, so that all ranks run the same number of SGD steps).
+    stage_times: optional dict that receives the wall time (seconds, device synchronised at the stage boundaries) of "encode" (upload + VAE
+    encode), "values", "gae" and "sgd".
     Returns a dict: per-minibatch loss records (this rank's device scalars, read back once at the end), and this rank's returns /
     advantages / values (fp64 / fp64 / fp32 numpy) for inspection."""
     import torch
@@ -65,6 +67,14 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     pdev = ppo._need_dev()
     device = pdev.device
 
+    import time
+
+    def mark(name, t0):
+        if stage_times is not None:
+            torch.cuda.synchronize(device)
+            stage_times[name] = stage_times.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+    t_stage = time.perf_counter()
     # 1. states of this rank's rows: encode every frame, append the measurements
     z = encode_resident(vae, frames[lo:hi].reshape((r_loc * (T + 1),) + frames.shape[2:]), encode_chunk)
     meas = torch.from_numpy(np.ascontiguousarray(measurements[lo:hi].reshape(r_loc * (T + 1), -1))).to(device)
@@ -72,6 +82,7 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     if states_all.shape[1] != ppo.input_dim:
         raise ValueError("replay_update: z_dim + measurements = %d but the policy takes %d inputs" % (states_all.shape[1], ppo.input_dim))
 
+    t_stage = mark("encode", t_stage)
     # 2. value estimates of every state (greedy predict: no noise drawn; the action output is not used)
     n_all = states_all.shape[0]
     values_all = torch.empty(n_all, device=device)
@@ -81,9 +92,11 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
         pdev.predict(states_all[a:b], b - a, None, True, scratch_act[:b - a], values_all[a:b])
     values = values_all.view(r_loc, T + 1)
 
+    t_stage = mark("values", t_stage)
     # 3. GAE + returns + per-row normalisation (fp64 on the device, bit-exact with numpy / scipy)
     _, returns, adv = utils.compute_gae_batched(rewards[lo:hi], values.cpu().numpy(), dones[lo:hi], gamma, lam, normalize=True)
 
+    t_stage = mark("gae", t_stage)
     # 4. minibatch SGD on the flattened samples of this rank
     s = states_all.view(r_loc, T + 1, -1)[:, :T].reshape(r_loc * T, -1).contiguous()
     a = torch.from_numpy(np.ascontiguousarray(actions[lo:hi].reshape(r_loc * T, -1))).to(device)
@@ -107,6 +120,7 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
             ppo.train_step_counter += 1
             records.append(pdev.losses.clone())
     losses = torch.stack(records).cpu().numpy() if records else np.zeros((0, 5), np.float32)
+    mark("sgd", t_stage)
     keys = ("policy_loss", "value_loss", "entropy_loss", "loss", "prob_ratio")
     return {"losses": [dict(zip(keys, (float(x) for x in row))) for row in losses], "returns": returns, "advantages": adv,
             "values": values.cpu().numpy(), "z": z.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}

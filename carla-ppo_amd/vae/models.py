@@ -291,9 +291,11 @@ class VAE():
         then conv3..conv1: each bucket's gradient all-reduce overlaps the next part), fused Adam."""
         dev = self.dev
         if midist.world_size() == 1 and hasattr(dev, "train_step"):
-            # single rank: the whole step is one C call; by default the captured hipGraph of the step is replayed (MI355_GRAPH=0: eager launches)
+            # single rank: the whole step is one C call.  MI355_GRAPH=1 replays the captured hipGraph of the step instead of launching eagerly:
+            # measured SLOWER on ROCm 7.2 (1.26 vs 1.19 ms per step at batch 512: the graph loses the overlap of the two backward streams and
+            # gains nothing at same-stream kernel boundaries, profiles/r02_*), so eager launches are the default
             dev.train_step(src, tgt, idx, n_local, inv_batch, eps, adam_alpha(self.learning_rate_value, self.beta1_power, self.beta2_power),
-                           ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON, graph=os.environ.get("MI355_GRAPH", "1") != "0")
+                           ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON, graph=os.environ.get("MI355_GRAPH", "0") == "1")
             self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
             self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
             return
@@ -302,6 +304,8 @@ class VAE():
             pending = []
             for part, lo, hi in dev.grad_buckets:      # each bucket's all-reduce runs under the next part of backward
                 dev.backward(src, idx, eps, inv_batch, part=part)
+                if os.environ.get("MI355_DP_SKIP_ALLREDUCE") == "1":      # bench.py only: the step without its collectives (exposed all-reduce time)
+                    continue
                 pending.append(midist.all_reduce_sum(dev.grads[lo:hi], async_op=True))
             for w in pending:
                 w.wait()
