@@ -585,6 +585,10 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     if (!p.out_f32) {
+        const int r5 = mi_try_rwconv_gather(st, dtype, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, p.out, p.bias, p.mask, p.relu);
+        if (r5 != 0) return r5 > 0 ? MI_OK : r5;
+    }
+    if (!p.out_f32) {
         const int r3 = try_tapconv(st, dtype, TC_GATHER, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, 0, p.out, p.bias, p.mask, p.relu);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
@@ -647,6 +651,8 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 
 }  // namespace
 
+void mi_get_trace(long long** buf, int* cap) { *buf = g_trace; *cap = g_trace_cap; }
+
 extern "C" {
 
 // debug: device buffer of int64 stamps, 32 per wave of every tapconv block (see tools/trace_tapconv.py); nullptr switches it off
@@ -667,6 +673,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 10) { prev = g_nw_waves; g_nw_waves = value; }
     else if (key == 12) { prev = g_tap_mask_prefetch; g_tap_mask_prefetch = value ? 1 : 0; }
     else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
+    else if (key == 13) { prev = mi_rwconv_mode(value < 0 ? 0 : value); }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

@@ -203,7 +203,7 @@ struct DenseSmallParams {
     int M, N, K, relu;
 };
 
-__global__ __launch_bounds__(256) void dense_smallm_kernel(const DenseSmallParams p) {
+static __global__ __launch_bounds__(256) void dense_smallm_kernel(const DenseSmallParams p) {
     __shared__ float red[3][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lgrp = lane >> 5;

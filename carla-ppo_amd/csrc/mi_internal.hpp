@@ -11,3 +11,9 @@ int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK /
 // deferred split reductions of the raw-staged filter-gradient kernel (conv_ops.hip; used by the VAE engine)
 extern "C" int mi_tapwgrad_defer(int on);        // returns the previous mode
 extern "C" int mi_tapwgrad_flush(void* stream);  // launches the recorded reduces on `stream`
+
+// register-weight kernel of the thin gather-form layers (rwconv.hip): 1 launched, 0 not eligible, < 0 error
+int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
+                         int KH, int KW, void* out, const float* bias, const void* mask, int relu);
+int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
+void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace

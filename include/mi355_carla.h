@@ -75,7 +75,9 @@ unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
  * of them per output column; MI355_TAP_PERSIST);
  * key 9: tapwgrad target block count (position splits x block columns; default 256 = one block per CU); key 10: waves per block of
  * the narrow filter-gradient kernel (4 | 8 | 12); key 11: target block count of the dense filter gradients;
- * key 12: tapconv ReluGrad-mask prefetch in the last main-loop step on/off.  Returns the previous value. */
+ * key 12: tapconv ReluGrad-mask prefetch in the last main-loop step on/off;
+ * key 13: register-weight kernel of the thin gather-form layers (rwconv.hip: deconv3 fwd, conv2 dgrad): 0 off, 1 auto (grids that fill the
+ * chip), 2 whenever the layer is eligible (MI355_RWCONV).  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);

@@ -22,7 +22,9 @@ DECONVS = [  # IH, IW, Cin, Cout, k
 # other two pin the dispatch through mi_set_tuning so that EVERY generation meets the same float64 reference on every geometry.
 # `persist` = `newest` with the experimental persistent tapconv blocks (mi_set_tuning key 8; capped at 3 blocks per output column so that
 # every block walks SEVERAL tiles at these small sizes; bf16 only -- the fp32 path has no persistent form)
-GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1}, "persist": {0: 1, 1: 1, 3: 1, 4: 1, 8: 3}}
+# `rwconv` = `newest` with the register-weight kernel forced for the thin gather-form layers (key 13 = 2; auto takes it only on chip-filling grids)
+GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0}, "persist": {0: 1, 1: 1, 3: 1, 4: 1, 8: 3, 13: 0},
+               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2}}
 
 
 @pytest.fixture(params=list(GENERATIONS))
@@ -49,8 +51,8 @@ def _nhwc(a):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("geom", CONVS)
 def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
-    if kernels == "persist" and dt != "bf16":
-        pytest.skip("persistent tapconv is bf16 only")
+    if kernels in ("persist", "rwconv") and dt != "bf16":
+        pytest.skip("persistent tapconv / register-weight kernel are bf16 only")
     L = milib.get()
     code, td = DT[dt]
     IH, IW, Ci, Co, k = geom
@@ -111,8 +113,8 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("geom", DECONVS)
 def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
-    if kernels == "persist" and dt != "bf16":
-        pytest.skip("persistent tapconv is bf16 only")
+    if kernels in ("persist", "rwconv") and dt != "bf16":
+        pytest.skip("persistent tapconv / register-weight kernel are bf16 only")
     L = milib.get()
     code, td = DT[dt]
     IH, IW, Ci, Co, k = geom
