@@ -35,26 +35,87 @@ __device__ __forceinline__ uint32_t pk_positive_mask(uint32_t m, uint32_t ones, 
     return r;
 }
 
-constexpr int RW_BMT = 256;          // positions per block
-constexpr int RW_MAXHALO = 96;
-constexpr int RW_MAXSLOT = RW_BMT + RW_MAXHALO;
+// LDS fragment reads issued and waited for BY HAND: hipcc's scheduler sinks ds_reads next to their MFMA (one read in flight: every MFMA then
+// waits a full LDS latency), whatever distance the source puts between them.  asm volatile keeps the issue order; the wait names the fragment
+// it releases as an in/out operand, so the MFMAs that consume it cannot be scheduled above the wait.  LDS returns in order: lgkmcnt(N) = all
+// but the N most recent reads have landed (an outstanding scalar load can only make the wait stricter).
+__device__ __forceinline__ void lds_read_b128_pair(u16x8& a, u16x8& b, uint32_t addr) {      // rows q and q + 32 (the next 32-position tile)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(a), "=&v"(b) : "v"(addr));
+}
+template <int N> __device__ __forceinline__ void lds_wait_pair(u16x8& a, u16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// A block is PERSISTENT: it keeps its weights in registers and walks chunks of NTILE x 32 positions; the slot range of the next chunk is
+// staged (LDS-DMA, second buffer) while the current one is computed.  One block barrier per chunk: "my DMA of this chunk has landed and
+// everybody is done with the previous chunk", after which the buffer of the previous chunk is refilled.
+// Block shapes.  k = 4 (equal work per class): 4 waves, 128 positions per chunk, 3 blocks per CU.  k = 5: the classes reach 9 / 6 / 6 / 4
+// taps, so a 4-wave block leaves the MFMA pipes of three SIMDs waiting for the fourth; there the block has 8 waves = two halves of four, each
+// half walks its own 128 positions of a 256-position chunk and the second half takes the classes in REVERSE order: waves w and w + 4 share
+// a SIMD (the dispatcher places a workgroup's waves on the SIMDs cyclically), which pairs the classes {0,3} and {1,2}: 13 and 12 tap-units
+// per SIMD instead of 9 | 6 | 6 | 4.  (The pairing is a performance assumption only: every wave computes its own class whatever its SIMD.)
+template <int TAPS> struct RwCfg {
+    static constexpr int NW = TAPS == 2 ? 4 : 8;                      // waves per block
+    static constexpr int NTILE = 4;                                   // 32-position tiles per wave and chunk
+    static constexpr int BMT = 32 * NTILE * (NW / 4);                 // positions per chunk
+    static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;               // largest (TAPS-1) * GW + TAPS - 1 the buffers are sized for
+    static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 352 rows of 128 B
+    static constexpr int BUF = MAXSLOT * 128;                         // 22 | 44 KB per buffer, two buffers: 3 blocks | 1 block per CU
+    static constexpr int NIA = (MAXSLOT / 8 + NW - 1) / NW;           // DMA instructions per wave and chunk (upper bound)
+};
+
+// stage the slot range [P0, P0 + BMT + halo) into `buf`: instruction t = wave + 4 i fills rows 8 t .. 8 t + 7 (lane: row 8 t + lane / 8,
+// physical 16-byte chunk lane % 8, fetching the logical chunk (lane % 8) ^ ((row >> 1) & 7): the swizzle of tapconv_tile.hpp)
+template <int TAPS>
+__device__ __forceinline__ void rw_stage(const TapParams& p, const __amdgpu_buffer_rsrc_t rsA, unsigned char* buf, int P0, int wave, int lane, int ninstr) {
+    constexpr int NW = RwCfg<TAPS>::NW;
+    const int r8 = lane >> 3;
+    // slot -> (frame, gy, gx) once per chunk; the following instructions of this wave are 8 NW slots further each (GW > 32 on this path: at
+    // most NW / 4 row wraps per step)
+    uint32_t g, gx, b, gy;
+    const int Pf = P0 + 8 * wave + r8;
+    p.div_gw.divmod((uint32_t)Pf, g, gx);
+    p.div_g.divmod(g, b, gy);
+#pragma unroll
+    for (int i = 0; i < RwCfg<TAPS>::NIA; ++i) {
+        const int t = wave + NW * i;
+        if (t >= ninstr) break;                           // wave-uniform
+        const int q = 8 * t + r8;
+        const int c = (lane & 7) ^ ((q >> 1) & 7);
+        const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
+        const bool in = P0 + q < p.MP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const uint32_t vo = in ? (((b * p.IH + iy) * p.IW + ix) * 64u + c * 8u) * 2u : G2_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(buf + t * 1024), 16, (int)vo, 0, 0, 0);
+        gx += 8 * NW;
+#pragma unroll
+        for (int r = 0; r < NW / 4; ++r)
+            if ((int)gx >= p.GW) { gx -= p.GW; ++gy; if ((int)gy >= p.GH) { gy = 0; ++b; } }
+    }
+}
 
 // One wave = one output parity class CLS (ph = CLS >> 1, pw = CLS & 1).  TAPS taps per axis, KH kernel size (compile time: which
 // (tap, class) pairs exist), C = 64 input channels (one 128-byte row per slot), N = 32 output channels per class.
-template <int TAPS, int KH, int CLS, bool RELU, bool MASK>
-__device__ __forceinline__ void rw_class(const TapParams& p, const unsigned char* lds, const float* bias_lds, int P0, int lane, long long* tr, int tr_n) {
-    constexpr int RB = 128, NT = TAPS * TAPS, NTILE = RW_BMT / 32;
+template <int TAPS, int KH, int CLS, bool RELU, bool MASK, int DBG = 0>
+__device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds, const float* bias_lds, const __amdgpu_buffer_rsrc_t rsA,
+                                         int chunk, const int cstride, const int cend, int wave, int half, int lane, long long* tr, int tr_n) {
+    typedef RwCfg<TAPS> Cfg;
+    constexpr int RB = 128, NT = TAPS * TAPS, NTILE = Cfg::NTILE;
     constexpr int PH = CLS >> 1, PW = CLS & 1, H = TAPS - 1;
     typedef u16x8 freg;
     const int lrow = lane & 31, lgrp = lane >> 5;
+    const int halo = (TAPS - 1) * p.GW + TAPS - 1;
+    const int ninstr = (Cfg::BMT + halo + 7) >> 3;
 
-    // ---- weights: fragment (tap, kk) = 8 consecutive input channels (kk*16 + lgrp*8) of output channel lrow, straight from L2 ----
+    rw_stage<TAPS>(p, rsA, lds, chunk * Cfg::BMT, wave, lane, ninstr);           // first chunk -> buffer 0
+#define RW_STAMP() do { if (tr && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    RW_STAMP();                                           // 1: first slot range requested
+
+    // ---- weights: fragment (tap, kk) = 8 consecutive input channels (kk*16 + lgrp*8) of output channel lrow, straight from L2, ONCE ----
     freg wf[NT][4];
     {
         const bf16_t* __restrict__ W = (const bf16_t*)p.b;
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
-            constexpr int dummy = 0; (void)dummy;
             const int ta = tap / TAPS, tb = tap % TAPS;
             const int kh = PH + 2 * (H - ta), kw = PW + 2 * (H - tb);
             if (kh >= KH || kw >= KH) continue;           // literal after unrolling: this class does not reach that kernel row / column
@@ -63,148 +124,187 @@ __device__ __forceinline__ void rw_class(const TapParams& p, const unsigned char
             for (int kk = 0; kk < 4; ++kk) wf[tap][kk] = *(const freg*)(wrow + kk * 16);
         }
     }
+    RW_STAMP();                                           // 2: weights requested
 
     // ---- LDS read addresses: row q = lrow + delta_tap (+ 32 per tile, which leaves the swizzle term alone); rows are 128 B, bits 4..6 are
     //      the (swizzled) 16-byte chunk, so the four k-steps of a tap are v_tap ^ (kk << 5) ----
-    uint32_t vtap[NT];
+    uint32_t vtap0[NT];
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
         const int q = lrow + (tap / TAPS) * p.GW + (tap % TAPS);
-        vtap[tap] = (uint32_t)(q * RB + ((lgrp ^ ((q >> 1) & 7)) << 4));
+        vtap0[tap] = (uint32_t)(q * RB + ((lgrp ^ ((q >> 1) & 7)) << 4));
     }
-
-#define RW_STAMP() do { if (tr && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    RW_STAMP();                                           // 2: weights requested
     const bf16_t* __restrict__ maskp = (const bf16_t*)p.mask;
-    // the slot range (LDS-DMA issued at the top of the kernel) and the bias row have landed; the weight fragments requested above are
-    // waited for here as well (vmcnt(0)), so that no wait on them remains inside the tile loop.  Every wave executes exactly one s_barrier.
-    __syncthreads();
-    RW_STAMP();                                           // 3: slot range + weights landed
 
+    // output stores go through a buffer descriptor: lanes without a valid pixel get an out-of-range offset (dropped by the hardware) instead
+    // of a branch around the store, so every tile issues EXACTLY two store instructions -- which is what lets the chunk barrier wait for the
+    // staged slot range with s_waitcnt vmcnt(4) ("all but the 4 newest VMEM operations", i.e. not for the last stores' acknowledgements:
+    // those cost ~2.3k cycles per chunk with the compiler's vmcnt(0) in front of __syncthreads())
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.b_bytes, 0x00020000);    // (b_bytes carries the OUTPUT size in bytes here)
+
+    // the first slot range, the bias row and this wave's weight fragments have landed; after the barrier so has everybody's share
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
 #pragma unroll 1
-    for (int tile = 0; tile < NTILE; ++tile) {
-        // ---- this lane's output pixel of the tile, store offsets, ReluGrad-mask request (all before the MFMAs) ----
-        const int P = P0 + tile * 32 + lrow;
-        const bool pin = P < p.MP;
-        uint32_t g, gx, b, gy;
-        p.div_gw.divmod((uint32_t)(pin ? P : 0), g, gx);
-        p.div_g.divmod(g, b, gy);
-        const int oy = 2 * (int)gy + PH, ox = 2 * (int)gx + PW;
-        const bool ok = pin && oy < p.OH && ox < p.OW;
-        const uint32_t e0 = ok ? ((b * p.OH + oy) * p.OW + ox) * 32u + 8u * lgrp : 0u;      // element offset of unit 0 (unit 1: + 16)
-        PackN<uint32_t, 4> umk[2];
-        if constexpr (MASK) {
-            umk[0] = *(const PackN<uint32_t, 4>*)(maskp + e0);                               // offset 0 is always readable
-            umk[1] = *(const PackN<uint32_t, 4>*)(maskp + e0 + 16);
-        }
-        // ---- accumulators start at the bias of their channel: register r = channel 8 (r >> 2) + 4 lgrp + (r & 3) ----
-        f32x16 acc;
+    for (; chunk < cend; chunk += cstride, cur ^= 1) {
+        RW_STAMP();                                       // 3 + 2 i: chunk i landed, buffers handed over
+        if (chunk + cstride < cend) rw_stage<TAPS>(p, rsA, lds + (cur ^ 1) * Cfg::BUF, (chunk + cstride) * Cfg::BMT, wave, lane, ninstr);
+        const int P0 = chunk * Cfg::BMT + half * 32 * NTILE;                                  // this wave's half of the chunk
+        const uint32_t bufoff = (uint32_t)(cur * Cfg::BUF + half * 32 * NTILE * RB);
+        // two 32-position tiles at a time: two independent accumulator chains, and the fragment reads run RW_AHEAD (tap, k-step) pairs ahead
+        // of the MFMAs that consume them (hipcc's own schedule kept a single read in flight: every MFMA then waits one LDS latency)
+#pragma unroll 1
+        for (int tile = 0; tile < NTILE; tile += 2) {
+            // ---- this lane's two output pixels, store offsets, ReluGrad-mask requests (all before the MFMAs) ----
+            uint32_t e0[2]; bool ok[2];
+            PackN<uint32_t, 4> umk[2][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *(const f32x4*)(bias_lds + 8 * q + 4 * lgrp);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[4 * q + t] = b4[t];
-        }
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            const int ta = tap / TAPS, tb = tap % TAPS;
-            if (PH + 2 * (H - ta) >= KH || PW + 2 * (H - tb) >= KH) continue;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const freg af = *(const freg*)(lds + (vtap[tap] ^ (uint32_t)(kk << 5)));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[tap][kk]), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const int P = P0 + (tile + h) * 32 + lrow;
+                const bool pin = P < p.MP;
+                uint32_t g, gx, b, gy;
+                p.div_gw.divmod((uint32_t)(pin ? P : 0), g, gx);
+                p.div_g.divmod(g, b, gy);
+                const int oy = 2 * (int)gy + PH, ox = 2 * (int)gx + PW;
+                ok[h] = pin && oy < p.OH && ox < p.OW;
+                e0[h] = ok[h] ? ((b * p.OH + oy) * p.OW + ox) * 32u + 8u * lgrp : 0u;       // element offset of unit 0 (unit 1: + 16)
+                if constexpr (MASK) {
+                    umk[h][0] = *(const PackN<uint32_t, 4>*)(maskp + e0[h]);                 // offset 0 is always readable
+                    umk[h][1] = *(const PackN<uint32_t, 4>*)(maskp + e0[h] + 16);
+                }
             }
-        }
+            // ---- accumulators start at the bias of their channel: register r = channel 8 (r >> 2) + 4 lgrp + (r & 3) ----
+            f32x16 acc[2];
 #pragma unroll
-        for (int tap = 0; tap < NT; ++tap) vtap[tap] += 32 * RB;                              // next tile: 32 rows further
-        RW_STAMP();                                       // 4 + 2 tile: MFMAs issued
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(bias_lds + 8 * q + 4 * lgrp);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = b4[t]; acc[1][4 * q + t] = b4[t]; }
+            }
+            const uint32_t toff = bufoff + (uint32_t)(tile * 32 * RB);                       // wave-uniform
+            // live (tap, k-step) steps of this class in issue order (compile time)
+            struct Steps { int n; int id[NT * 4]; };
+            constexpr Steps ST = [] {
+                Steps r = {0, {}};
+                for (int tap = 0; tap < NT; ++tap) {
+                    const int ta = tap / TAPS, tb = tap % TAPS;
+                    if (PH + 2 * (H - ta) >= KH || PW + 2 * (H - tb) >= KH) continue;
+                    for (int kk = 0; kk < 4; ++kk) r.id[r.n++] = tap * 4 + kk;
+                }
+                return r;
+            }();
+            constexpr int AH = 3;                         // steps (pairs of reads) in flight ahead of the MFMAs
+            freg ring[AH + 1][2];
+            auto fetch = [&](int k) {                     // k-th live step -> ring slot k % (AH + 1)
+                const int sid = ST.id[k];
+                const uint32_t vt = (vtap0[sid >> 2] + toff) ^ (uint32_t)((sid & 3) << 5);
+                if constexpr (DBG == 2) { if (k < AH + 1) lds_read_b128_pair(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt); }   // debug: no LDS traffic beyond the first reads
+                else lds_read_b128_pair(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
+            };
+#pragma unroll
+            for (int k = 0; k < AH && k < ST.n; ++k) fetch(k);
+#pragma unroll
+            for (int k = 0; k < ST.n; ++k) {
+                if (k + AH < ST.n) fetch(k + AH);
+                freg (&cur_)[2] = ring[k % (AH + 1)];
+                const int after = (ST.n - 1 - k) < AH ? (ST.n - 1 - k) : AH;                 // steps requested after this one
+                if (DBG == 2) lds_wait_pair<0>(cur_[0], cur_[1]);
+                else if (after == 3) lds_wait_pair<6>(cur_[0], cur_[1]);
+                else if (after == 2) lds_wait_pair<4>(cur_[0], cur_[1]);
+                else if (after == 1) lds_wait_pair<2>(cur_[0], cur_[1]);
+                else lds_wait_pair<0>(cur_[0], cur_[1]);
+                const int sid = ST.id[k];
+                if constexpr (DBG == 3) {                 // debug: no MFMAs (the fragments are still consumed)
+                    acc[0][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[0][0] | ((uint32_t)wf[sid >> 2][sid & 3][0] << 16));
+                    acc[1][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[1][0] | ((uint32_t)wf[sid >> 2][sid & 3][1] << 16));
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid >> 2][sid & 3]), __builtin_bit_cast(bf16x8, cur_[0]), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid >> 2][sid & 3]), __builtin_bit_cast(bf16x8, cur_[1]), acc[1], 0, 0, 0);
+                }
+            }
 
-        // ---- epilogue: ReLU, bf16, pair the 4-channel groups of the two half-waves, mask, two 16-byte stores ----
-        uint32_t w[4][2];
+            // ---- epilogue: bf16 (hardware rounding), ReLU, pair the 4-channel groups of the two half-waves, mask, two 16-byte stores ----
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const float v[4] = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
-            const PackN<bf16_t, 4> pk = pack4<bf16_t>(v);                                     // hardware round-to-nearest-even
-            w[gq][0] = (uint32_t)pk.v[0] | ((uint32_t)pk.v[1] << 16); w[gq][1] = (uint32_t)pk.v[2] | ((uint32_t)pk.v[3] << 16);
-            if constexpr (RELU) { w[gq][0] = pk_relu_bf16(w[gq][0]); w[gq][1] = pk_relu_bf16(w[gq][1]); }   // ReLU on the rounded value: same result, 8 instead of 16 ops
-        }
+            for (int h = 0; h < 2; ++h) {
+                uint32_t w[4][2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float v[4] = {acc[h][4 * gq], acc[h][4 * gq + 1], acc[h][4 * gq + 2], acc[h][4 * gq + 3]};
+                    const PackN<bf16_t, 4> pk = pack4<bf16_t>(v);
+                    w[gq][0] = (uint32_t)pk.v[0] | ((uint32_t)pk.v[1] << 16); w[gq][1] = (uint32_t)pk.v[2] | ((uint32_t)pk.v[3] << 16);
+                    if constexpr (RELU) { w[gq][0] = pk_relu_bf16(w[gq][0]); w[gq][1] = pk_relu_bf16(w[gq][1]); }   // ReLU on the rounded value: same result, 8 instead of 16 ops
+                }
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
-                w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
+                        w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
+                    }
+                if constexpr (MASK) {                     // ReluGrad: keep where the mask tensor (the forward activation) is > 0
+                    const uint32_t ones = 0x00010001u, ffff = 0xffffffffu;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) w[gq][d] &= pk_positive_mask(umk[h][gq >> 1].v[2 * (gq & 1) + d], ones, ffff);
+                }
+                {
+                    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                    const bool st_ok = ok[h] && (DBG != 1 || w[0][0] == 0x12345678u);       // debug 1: (practically) nothing stored
+                    const uint32_t bo = st_ok ? e0[h] * 2u : G2_OOB;                         // byte offset; out of range = dropped
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, 0);
+                }
             }
-        if constexpr (MASK) {                             // ReluGrad: keep where the mask tensor (the forward activation) is > 0
-            const uint32_t ones = 0x00010001u, ffff = 0xffffffffu;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) w[gq][d] &= pk_positive_mask(umk[gq >> 1].v[2 * (gq & 1) + d], ones, ffff);
         }
-        if (ok) {
-            bf16_t* __restrict__ out = (bf16_t*)p.out;
-            *(PackN<uint32_t, 4>*)(out + e0) = PackN<uint32_t, 4>{{w[0][0], w[0][1], w[1][0], w[1][1]}};
-            *(PackN<uint32_t, 4>*)(out + e0 + 16) = PackN<uint32_t, 4>{{w[2][0], w[2][1], w[3][0], w[3][1]}};
-        }
-        RW_STAMP();                                       // 5 + 2 tile: epilogue issued
+        RW_STAMP();                                       // 4 + 2 i: chunk i computed
+        // next chunk's slot range (requested at the top of this iteration, before 8 | 16 newer VMEM operations) has landed: everything but
+        // the last tile pair's 4 stores is complete; after the barrier every wave is also done reading this chunk's buffer
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    if (tr && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID: wave / simd / cu / se / xcc placement
 #undef RW_STAMP
 }
 
-template <int TAPS, int KH, bool RELU, bool MASK>
-__global__ __launch_bounds__(256, TAPS == 2 ? 3 : 2) void rwconv_gather_kernel(const TapParams p) {
-    constexpr int RB = 128;
-    constexpr int NIA = (RW_MAXSLOT / 8 + 3) / 4;         // A-tile DMA instructions per wave (upper bound)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[RW_MAXSLOT * RB + 128];
-    float* const bias_lds = (float*)(lds + RW_MAXSLOT * RB);
+template <int TAPS, int KH, bool RELU, bool MASK, int DBG = 0>
+__global__ __launch_bounds__(RwCfg<TAPS>::NW * 64, TAPS == 2 ? 3 : 2) void rwconv_gather_kernel(const TapParams p, const int nchunks) {
+    typedef RwCfg<TAPS> Cfg;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 128];
+    float* const bias_lds = (float*)(lds + 2 * Cfg::BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P0 = xcd_remap(blockIdx.x, gridDim.x) * RW_BMT;
+    const int half = wave >> 2, cls = half ? 3 - (wave & 3) : (wave & 3);
+    // chunk schedule: XCD x (= blockIdx % 8: the dispatcher's round-robin) owns a contiguous range of chunks; at any time its blocks work on
+    // neighbouring chunks (shared halo rows stay in that XCD's L2)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;                 // the host launches a multiple of 8 blocks
+    const int q8 = nchunks >> 3, r8 = nchunks & 7;
+    const int cbeg = xcd * q8 + (xcd < r8 ? xcd : r8), cend = cbeg + q8 + (xcd < r8 ? 1 : 0);
     // debug (mi_debug_set_trace): s_memtime stamps of lane 0 of every wave, 32 per wave, 8 wave slots per block
     long long* tr = nullptr; int tr_n = 0;
     if (p.trace && ((long long)blockIdx.x * 8 + 8) * 32 <= p.trace_cap && lane == 0) tr = p.trace + ((long long)blockIdx.x * 8 + wave) * 32;
     if (tr) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime();       // 0: start
-    const int halo = (TAPS - 1) * p.GW + TAPS - 1;
-    const int ninstr = (RW_BMT + halo + 7) >> 3;          // 8-slot DMA instructions covering the staged range
-
-    // ---- stage the slot range: instruction t = wave + 4 i fills slots 8 t .. 8 t + 7 (lane: slot 8 t + lane / 8, physical chunk lane % 8) ----
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
-    {
-        const int r8 = lane >> 3;
-#pragma unroll
-        for (int i = 0; i < NIA; ++i) {
-            const int t = wave + 4 * i;
-            if (t >= ninstr) break;                       // wave-uniform
-            const int q = 8 * t + r8;
-            const int P = P0 + q;
-            const int c = (lane & 7) ^ ((q >> 1) & 7);    // logical chunk this lane fetches (source-side swizzle)
-            uint32_t g, gx, b, gy;
-            p.div_gw.divmod((uint32_t)(P < p.MP ? P : 0), g, gx);
-            p.div_g.divmod(g, b, gy);
-            const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
-            const bool in = P < p.MP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-            const uint32_t vo = in ? (((b * p.IH + iy) * p.IW + ix) * 64u + c * 8u) * 2u : G2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + t * 1024), 16, (int)vo, 0, 0, 0);
-        }
-    }
     if (tid < 32) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
-    if (tr) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime();       // 1: slot-range DMA issued
-    // each wave: request its class's weight fragments, ONE block barrier (inside rw_class), then its 8 tiles on its own
-    if (wave == 0) rw_class<TAPS, KH, 0, RELU, MASK>(p, lds, bias_lds, P0, lane, tr, tr_n);
-    else if (wave == 1) rw_class<TAPS, KH, 1, RELU, MASK>(p, lds, bias_lds, P0, lane, tr, tr_n);
-    else if (wave == 2) rw_class<TAPS, KH, 2, RELU, MASK>(p, lds, bias_lds, P0, lane, tr, tr_n);
-    else rw_class<TAPS, KH, 3, RELU, MASK>(p, lds, bias_lds, P0, lane, tr, tr_n);
+    if (cbeg + j >= cend) return;                         // block-uniform: more blocks than chunks on this XCD
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    // each wave: stage its share of the first chunk, request its class's weight fragments, then the chunk loop (one block barrier per chunk)
+    if (cls == 0) rw_class<TAPS, KH, 0, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else if (cls == 1) rw_class<TAPS, KH, 1, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else if (cls == 2) rw_class<TAPS, KH, 2, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else rw_class<TAPS, KH, 3, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    if (tr) tr[31] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID of this wave (wave / SIMD / CU placement)
 }
 
 }  // namespace mi
 
 using namespace mi;
 
+int g_rwconv_dbg = 0;
+int g_rwconv_blocks = 0;                                 // debug (MI355_RWCONV_BLOCKS): persistent blocks per XCD, 0 = as many as stay resident
 int g_rwconv_mode = -1;                                  // mi_set_tuning key 13 / MI355_RWCONV: 0 off, 1 auto, 2 whenever the layer is eligible
 int mi_rwconv_mode(int set) {                            // set < 0: query
+    if (g_rwconv_mode < 0) { const char* b = getenv("MI355_RWCONV_BLOCKS"); g_rwconv_blocks = b ? atoi(b) : 0; const char* d = getenv("MI355_RWCONV_DBG"); g_rwconv_dbg = d ? atoi(d) : 0; }
     if (g_rwconv_mode < 0) { const char* e = getenv("MI355_RWCONV"); g_rwconv_mode = e ? atoi(e) : 1; if (g_rwconv_mode < 0 || g_rwconv_mode > 2) g_rwconv_mode = 1; }
     const int prev = g_rwconv_mode;
     if (set >= 0) g_rwconv_mode = set > 2 ? 2 : set;
@@ -222,23 +322,38 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     TapParams q = {};
     q.TH = q.TW = (KH + 1) / 2; q.HY = q.HX = q.TH - 1;
     q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX;
-    if ((q.TH - 1) * q.GW + q.TW - 1 > RW_MAXHALO) return 0;
+    const int halo = (q.TH - 1) * q.GW + q.TW - 1;
+    if (halo > (q.TH == 2 ? RwCfg<2>::MAXHALO : RwCfg<3>::MAXHALO) || q.GW <= 32) return 0;     // (GW > 32: the staging loop's incremental slot decode)
     const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * 2;
     if (MP >= (1ll << 30) || a_bytes <= 0 || a_bytes >= (long long)G2_OOB) return 0;
-    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.b = w; q.b_bytes = 0;
+    const long long o_bytes = (long long)B * OH * OW * N * 2;
+    if (o_bytes >= (long long)G2_OOB) return 0;
+    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.b = w; q.b_bytes = (uint32_t)o_bytes;      // b_bytes: size of the OUTPUT tensor (its buffer descriptor)
     q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
     q.KC = C; q.NE = 4 * N;
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     mi_get_trace(&q.trace, &q.trace_cap);
-    const dim3 g((unsigned)((MP + RW_BMT - 1) / RW_BMT));
-    if (g_rwconv_mode == 0 || (g_rwconv_mode == 1 && g.x < 300)) return 0;      // auto: only where the grid fills the chip (as tapconv)
+    const int bmt = KH == 4 ? RwCfg<2>::BMT : RwCfg<3>::BMT;
+    const int nchunks = (int)((MP + bmt - 1) / bmt);
+    if (g_rwconv_mode == 0 || (g_rwconv_mode == 1 && MP < 75000)) return 0;      // auto: only where the grid fills the chip (as tapconv)
+    // persistent grid: as many blocks as stay resident (3 per CU for k = 4, 2 for k = 5), a multiple of 8 (one share per XCD)
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    int per_xcd = (n_cu / 8) * (KH == 4 ? 3 : 1);
+    if (g_rwconv_blocks > 0) per_xcd = g_rwconv_blocks;
+    if (per_xcd > (nchunks + 7) / 8) per_xcd = (nchunks + 7) / 8;
+    const dim3 g((unsigned)(8 * per_xcd));
 #define RW_LAUNCH(TAPS_, KH_) do { \
-        if (relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, true>), g, dim3(256), 0, st, q); \
-        else if (relu) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, false>), g, dim3(256), 0, st, q); \
-        else if (mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, true>), g, dim3(256), 0, st, q); \
-        else hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, false>), g, dim3(256), 0, st, q); } while (0)
-    if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
+        if (relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, true>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
+        else if (relu) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, false>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
+        else if (mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, true>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
+        else hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, false>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); } while (0)
+    if (KH == 5 && relu && !mask && g_rwconv_dbg > 0) {  // debug variants of the deconv3-forward instantiation (MI355_RWCONV_DBG: 1 no stores, 2 no LDS reads, 3 no MFMAs)
+        if (g_rwconv_dbg == 1) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 1>), g, dim3(512), 0, st, q, nchunks);
+        else if (g_rwconv_dbg == 2) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 2>), g, dim3(512), 0, st, q, nchunks);
+        else hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 3>), g, dim3(512), 0, st, q, nchunks);
+    } else if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
 #undef RW_LAUNCH
     const int rc = mi_check_launch("rwconv_gather_kernel");
     return rc == MI_OK ? 1 : rc;

@@ -39,23 +39,27 @@ buf = torch.zeros(cap, dtype=torch.int64, device="cuda")
 L.mi_debug_set_trace(buf.data_ptr(), cap)
 f(); torch.cuda.synchronize()
 L.mi_debug_set_trace(None, 0)
-t = buf.cpu().numpy().reshape(-1, 8, 32)[:, :4, :]
-t = t[t[:, 0, 0] != 0].astype(np.float64)
+raw = buf.cpu().numpy().reshape(-1, 8, 32)
+raw = raw[raw[:, 0, 0] != 0]
+hw = raw[:, :, 31].copy()
+t = raw.astype(np.float64); t[:, :, 31] = 0
 nb = t.shape[0]
-t0 = t[:, :, 0].min()
-print("%s: %.1f us / launch alone; %d blocks traced; kernel span %.0f ticks (s_memtime: 100 MHz)" % (name, us, nb, t[:, :, :20].max() - t0))
-ntile = 8
-for c in range(4):
-    w_ = t[:, c, :]
-    life = w_[:, 3 + 2 * ntile] - w_[:, 0]
-    mf = np.array([w_[:, 4 + 2 * i] - (w_[:, 3] if i == 0 else w_[:, 3 + 2 * i]) for i in range(ntile)])
-    ep = np.array([w_[:, 5 + 2 * i] - w_[:, 4 + 2 * i] for i in range(ntile)])
-    print("class %d: dma-issue %.0f  weights-req %.0f  wait-landed %.0f | mfma/tile %s | epi/tile %s | life %.0f" % (
+nw = int((t[0, :, 0] != 0).sum())
+print("%s: %.1f us / launch alone; %d blocks traced, %d waves per block" % (name, us, nb, nw))
+for c in range(nw):
+    w_ = t[:, c, :31]
+    n = (w_ > 0).sum(axis=1)                       # stamps per wave: 3 + 2 chunks
+    nch = ((n - 3) // 2).astype(int)
+    k = max(int(nch.min()), 1)
+    comp = np.array([w_[:, 4 + 2 * i] - w_[:, 3 + 2 * i] for i in range(k)])
+    wait = np.array([w_[:, 5 + 2 * i] - w_[:, 4 + 2 * i] for i in range(k - 1)]) if k > 1 else np.zeros((1, 1))
+    simd = (hw[:, c] >> 4) & 3
+    print("wave %d: stage-req %.0f weights-req %.0f first-landed %.0f | compute per chunk %s | barrier wait %s | simd histogram %s" % (
         c, (w_[:, 1] - w_[:, 0]).mean(), (w_[:, 2] - w_[:, 1]).mean(), (w_[:, 3] - w_[:, 2]).mean(),
-        " ".join("%.0f" % v for v in mf.mean(axis=1)), " ".join("%.0f" % v for v in ep.mean(axis=1)), life.mean()))
-# residency: HW_ID word (stamp index 4 + 2*ntile): bits [11:8] CU id, [15:13] SE (gfx9 layout); count blocks alive over time per (xcc, se, cu)
-hw = t[:, 0, 4 + 2 * ntile].astype(np.int64)
-start, end = t[:, :, 0].min(axis=1), t[:, :, 3 + 2 * ntile].max(axis=1)
-span = end.max() - start.min()
-print("sum of block lifetimes / (kernel span x 256 CUs) = %.2f blocks resident per CU on average" % ((end - start).sum() / (span * 256)))
-print("HW_ID samples:", [hex(int(v)) for v in hw[:6]])
+        " ".join("%.0f" % v for v in comp.mean(axis=1)), " ".join("%.0f" % v for v in wait.mean(axis=1)), np.bincount(simd, minlength=4).tolist()))
+same = 0
+for b in range(nb):
+    sd = (hw[b, :nw] >> 4) & 3
+    if nw == 8 and all(sd[i] == sd[i + 4] for i in range(4)) and len(set(sd[:4].tolist())) == 4:
+        same += 1
+print("blocks whose waves w and w+4 share a SIMD (and waves 0-3 cover all four): %d of %d" % (same, nb))
