@@ -452,7 +452,7 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
 
 // conv k x k, s2 from a 1..3-channel tensor into exactly 32 channels (narrow_tile.hpp): conv1 fwd, deconv4 dgrad
 int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, const int* frame_idx, const void* wt, int B, int IH, int IW, int Cs,
-                    int KH, int KW, int Cout, const float* bias, int relu, const void* mask, void* out) {
+                    int KH, int KW, int Cout, const float* bias, int relu, const void* mask, void* out, void* bits_out = nullptr, const void* mask_bits = nullptr) {
     if (!narrow_enabled() || Cout != 32 || KH != KW || KH > 4) return 0;
     const int run = KW * Cs, K = KH * run;
     if (run % 4 != 0 || K > 48) return 0;
@@ -469,6 +469,8 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     q.B = B; q.IH = IH; q.IW = IW; q.Cs = Cs; q.OH = OH; q.OW = OW; q.KH = KH; q.KW = KW; q.M = (int)M;
     q.div_ohw = make_fastdiv(OH * OW); q.div_ow = make_fastdiv(OW); q.div_g3 = make_fastdiv(run / 4);
     q.bias = bias; q.relu = relu; q.mask = mask; q.out = out;
+    q.bits_out = (dtype == MI_BF16 && relu) ? (uint32_t*)bits_out : nullptr; q.mask_bits = dtype == MI_BF16 ? (const uint32_t*)mask_bits : nullptr;
+    if (bits_out && !q.bits_out) return 0;                // the caller asked for ReLU bits this kernel cannot write
     dim3 g((unsigned)((M + 127) / 128));
     if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
     else if (src_f32 == 2) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
@@ -585,7 +587,7 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     if (!p.out_f32) {
-        const int r5 = mi_try_rwconv_gather(st, dtype, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, p.out, p.bias, p.mask, p.relu);
+        const int r5 = mi_try_rwconv_gather(st, dtype, p.a, p.b, B, IH, IW, C, OH, OW, N, KH, KW, p.out, p.bias, p.mask, p.relu, nullptr, nullptr);
         if (r5 != 0) return r5 > 0 ? MI_OK : r5;
     }
     if (!p.out_f32) {
@@ -684,9 +686,20 @@ int mi_set_tuning(int key, int value) {
 int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
                        int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout,
                        int relu, void* out) {
+    return mi_conv2d_nhwc_fwd_bits(stream, dtype, x, frame_idx, x_is_f32, B, IH, IW, Cin, w, w_transposed, bias, KH, KW, Cout, relu, out, nullptr, nullptr);
+}
+
+// same; relu_bits != NULL: the kernel also writes the ReLU bit words of its output (2 x uint32 per pixel and 32 channels, see the header)
+// where it can -- *wrote_bits tells -- so that the input gradient of the NEXT layer reads 8 bytes per pixel instead of the 64-byte row
+int mi_conv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32,
+                            int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout,
+                            int relu, void* out, void* relu_bits, int* wrote_bits) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
+    if (wrote_bits) *wrote_bits = 0;
     if (w_transposed) {
-        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out);
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out,
+                                       (dtype == MI_BF16 && relu && Cout == 32) ? relu_bits : nullptr);
+        if (r4 > 0 && wrote_bits && relu_bits && dtype == MI_BF16 && relu && Cout == 32) *wrote_bits = 1;
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     if (x_is_f32 == 2) return mi_fail(MI_ERR_ARG, "mi_conv2d_nhwc_fwd: uint8 frames are only read by the narrow-layer kernel (bf16 mode, 1..3 channels -> 32, K-contiguous weights)");
@@ -703,6 +716,17 @@ int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_
 // (TF Conv2DBackpropInput; the HWIO conv kernel read as a [kh,kw,out=ci,in=co] transposed-conv kernel)
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                          const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx) {
+    return mi_conv2d_nhwc_dgrad_bits(stream, dtype, dy, B, OH, OW, Cout, w, KH, KW, Cin, IH, IW, mask, nullptr, dx);
+}
+
+// same; mask_bits != NULL: the ReLU bit words of the mask tensor (written by mi_conv2d_nhwc_fwd_bits) are read instead of the tensor itself
+// by the kernels that can (the register-weight kernel); the others still read `mask`
+int mi_conv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                              const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, const void* mask_bits, void* dx) {
+    if (mask_bits) {
+        const int r5 = mi_try_rwconv_gather((hipStream_t)stream, dtype, dy, w, B, OH, OW, Cout, IH, IW, Cin, KH, KW, dx, nullptr, mask, 0, mask_bits, nullptr);
+        if (r5 != 0) return r5 > 0 ? MI_OK : r5;
+    }
     GemmParams p = {};
     p.a = dy; p.b = w; p.ldb = 0; p.b_vec = 1;
     p.out = dx; p.bias = nullptr; p.mask = mask; p.relu = 0; p.out_f32 = 0;
@@ -743,6 +767,18 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
 // conv2d_transpose NHWC stride-2 VALID forward, kernel [kh,kw,co,ci] (reference vae/models.py:261-264)
 int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin,
                          const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out) {
+    return mi_deconv2d_nhwc_fwd_bits(stream, dtype, x, B, IH, IW, Cin, w, bias, KH, KW, Cout, relu, out, nullptr, nullptr);
+}
+
+// same; relu_bits != NULL: also writes the ReLU bit words of the output where the kernel can (*wrote_bits tells)
+int mi_deconv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin,
+                              const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out, void* relu_bits, int* wrote_bits) {
+    if (wrote_bits) *wrote_bits = 0;
+    if (relu_bits && relu) {
+        const int r5 = mi_try_rwconv_gather((hipStream_t)stream, dtype, x, w, B, IH, IW, Cin, (IH - 1) * 2 + KH, (IW - 1) * 2 + KW, Cout, KH, KW, out, bias, nullptr, relu, nullptr, relu_bits);
+        if (r5 > 0 && wrote_bits) *wrote_bits = 1;
+        if (r5 != 0) return r5 > 0 ? MI_OK : r5;
+    }
     const int OH = (IH - 1) * 2 + KH, OW = (IW - 1) * 2 + KW;
     GemmParams p = {};
     p.a = x; p.b = w; p.ldb = 0; p.b_vec = 1;
@@ -777,9 +813,14 @@ int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, i
 // w_transposed = 1: w holds the kernel as [Cin][KH*KW*Cout]
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
                            const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx) {
+    return mi_deconv2d_nhwc_dgrad_bits(stream, dtype, dy, B, OH, OW, Cout, w, w_transposed, KH, KW, Cin, mask, nullptr, dx);
+}
+
+int mi_deconv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,
+                                const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, const void* mask_bits, void* dx) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     if (w_transposed) {
-        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, dy, dtype == MI_F32, nullptr, w, B, OH, OW, Cout, KH, KW, Cin, nullptr, 0, mask, dx);
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, dy, dtype == MI_F32, nullptr, w, B, OH, OW, Cout, KH, KW, Cin, nullptr, 0, mask, dx, nullptr, mask_bits);
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     GemmParams p = {};

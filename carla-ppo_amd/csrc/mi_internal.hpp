@@ -14,6 +14,6 @@ extern "C" int mi_tapwgrad_flush(void* stream);  // launches the recorded reduce
 
 // register-weight kernel of the thin gather-form layers (rwconv.hip): 1 launched, 0 not eligible, < 0 error
 int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
-                         int KH, int KW, void* out, const float* bias, const void* mask, int relu);
+                         int KH, int KW, void* out, const float* bias, const void* mask, int relu, const void* mask_bits, void* bits_out);
 int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace

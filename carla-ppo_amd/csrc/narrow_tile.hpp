@@ -459,6 +459,9 @@ struct NarrowConvParams {
     int B, IH, IW, Cs, OH, OW, KH, KW, M;
     FastDiv div_ohw, div_ow, div_g3;
     const float* bias; int relu; const void* mask; void* out;         // out / mask [B,OH,OW,32], T
+    // ReLU bit words (bf16 only; 2 x uint32 per pixel: word j = channels 16 j .. 16 j + 15, bit i = channel 16 j + 2 i > 0, bit 16 + i = channel
+    // 16 j + 2 i + 1 > 0): bits_out = written from the stored (post-ReLU) values; mask_bits = read INSTEAD of the 64-byte mask row
+    uint32_t* bits_out; const uint32_t* mask_bits;
 };
 
 template <typename T, typename TS>
@@ -562,7 +565,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const T* __restrict__ maskp = (const T*)p.mask;
     constexpr int NK = 32 * CPP / 64;
     PackN<T, VE> mk[NK];                                  // every mask vector is requested before the first store (a load behind a store
-    if (maskp) {                                          //  waits for the store's acknowledgement: vmcnt counts both)
+    uint32_t mword[NK];                                   //  waits for the store's acknowledgement: vmcnt counts both)
+    const bool use_bits = sizeof(T) == 2 && p.mask_bits != nullptr;
+    if (use_bits) {                                       // 4 bytes per lane instead of 16: word (c16 >> 1) of the pixel
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
+            mword[k] = p.mask_bits[m0 + px < p.M ? (long long)(m0 + px) * 2 + (c16 >> 1) : 0];
+        }
+    } else if (maskp) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
@@ -572,10 +583,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         const int id = lane + 64 * k, px = id / CPP, c16 = id % CPP;
-        if (m0 + px >= p.M) continue;
+        const bool pok = m0 + px < p.M;
         PackN<T, VE> o = *(const PackN<T, VE>*)(ot + px * OPITCH + c16 * 16);
         const long long off = (long long)(m0 + px) * 32 + c16 * VE;
-        if (maskp) {
+        if constexpr (sizeof(T) == 2) {
+            if (use_bits) {                               // pair d of this lane's 8 channels is pair 4 (c16 & 1) + d of the word
+                PackN<uint32_t, 4> ow = __builtin_bit_cast(PackN<uint32_t, 4>, o);
+                const uint32_t sh = mword[k] >> (4 * (c16 & 1));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) ow.v[d] &= ((sh >> d) & 0x00010001u) * 0xffffu;
+                o = __builtin_bit_cast(PackN<T, VE>, ow);
+            }
+            if (p.bits_out) {                             // ReLU bits of the values being stored (post-ReLU: never negative)
+                const PackN<uint32_t, 4> ow = __builtin_bit_cast(PackN<uint32_t, 4>, o);
+                uint32_t part = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {             // min(x, 1) per 16-bit half = "non-zero" (one packed op), shifted into place
+                    uint32_t nz;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(ow.v[d]), "v"(0x00010001u));
+                    part |= nz << d;
+                }
+                part <<= 4 * (c16 & 1);
+                part |= __shfl_xor(part, 1, 64);          // the neighbouring lane holds the other 8 channels of the same word
+                if (pok && (c16 & 1) == 0) p.bits_out[(long long)(m0 + px) * 2 + (c16 >> 1)] = part;
+            }
+        }
+        if (!pok) continue;
+        if (!use_bits && maskp) {
 #pragma unroll
             for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[k].v[t]) > 0.f ? o.v[t] : (T)0;
         }

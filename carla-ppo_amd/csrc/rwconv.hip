@@ -95,7 +95,7 @@ __device__ __forceinline__ void rw_stage(const TapParams& p, const __amdgpu_buff
 
 // One wave = one output parity class CLS (ph = CLS >> 1, pw = CLS & 1).  TAPS taps per axis, KH kernel size (compile time: which
 // (tap, class) pairs exist), C = 64 input channels (one 128-byte row per slot), N = 32 output channels per class.
-template <int TAPS, int KH, int CLS, bool RELU, bool MASK, int DBG = 0>
+template <int TAPS, int KH, int CLS, bool RELU, int MASK, bool BITS, int DBG = 0>
 __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds, const float* bias_lds, const __amdgpu_buffer_rsrc_t rsA,
                                          int chunk, const int cstride, const int cend, int wave, int half, int lane, long long* tr, int tr_n) {
     typedef RwCfg<TAPS> Cfg;
@@ -138,9 +138,10 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
 
     // output stores go through a buffer descriptor: lanes without a valid pixel get an out-of-range offset (dropped by the hardware) instead
     // of a branch around the store, so every tile issues EXACTLY two store instructions -- which is what lets the chunk barrier wait for the
-    // staged slot range with s_waitcnt vmcnt(4) ("all but the 4 newest VMEM operations", i.e. not for the last stores' acknowledgements:
+    // staged slot range with s_waitcnt vmcnt(4 | 6) ("all but the newest VMEM operations", i.e. not for the last stores' acknowledgements:
     // those cost ~2.3k cycles per chunk with the compiler's vmcnt(0) in front of __syncthreads())
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.b_bytes, 0x00020000);    // (b_bytes carries the OUTPUT size in bytes here)
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(BITS ? (void*)p.bits_out : p.out, 0, (int)(p.b_bytes >> 3), 0x00020000);   // bit words: 8 of every 64 bytes
 
     // the first slot range, the bias row and this wave's weight fragments have landed; after the barrier so has everybody's share
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -169,9 +170,12 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
                 const int oy = 2 * (int)gy + PH, ox = 2 * (int)gx + PW;
                 ok[h] = pin && oy < p.OH && ox < p.OW;
                 e0[h] = ok[h] ? ((b * p.OH + oy) * p.OW + ox) * 32u + 8u * lgrp : 0u;       // element offset of unit 0 (unit 1: + 16)
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
                     umk[h][0] = *(const PackN<uint32_t, 4>*)(maskp + e0[h]);                 // offset 0 is always readable
                     umk[h][1] = *(const PackN<uint32_t, 4>*)(maskp + e0[h] + 16);
+                } else if constexpr (MASK == 2) {         // ReLU bit words: 8 bytes per pixel instead of 64 (both half-waves read the same two words)
+                    const PackN<uint32_t, 2> mw = *(const PackN<uint32_t, 2>*)(p.mask_bits + (e0[h] >> 5) * 2);
+                    umk[h][0].v[0] = mw.v[0] >> (4 * lgrp); umk[h][0].v[1] = mw.v[1] >> (4 * lgrp);
                 }
             }
             // ---- accumulators start at the bias of their channel: register r = channel 8 (r >> 2) + 4 lgrp + (r & 3) ----
@@ -242,12 +246,33 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
                         auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
                         w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
                     }
-                if constexpr (MASK) {                     // ReluGrad: keep where the mask tensor (the forward activation) is > 0
+                if constexpr (MASK == 1) {                // ReluGrad: keep where the mask tensor (the forward activation) is > 0
                     const uint32_t ones = 0x00010001u, ffff = 0xffffffffu;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                         for (int d = 0; d < 2; ++d) w[gq][d] &= pk_positive_mask(umk[h][gq >> 1].v[2 * (gq & 1) + d], ones, ffff);
+                } else if constexpr (MASK == 2) {         // unit x = word x; its dwords are the pairs 4 lgrp + {0,1,2,3}: bits d and 16 + d of the shifted word
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) w[gq][d] &= ((umk[h][0].v[gq >> 1] >> (2 * (gq & 1) + d)) & 0x00010001u) * 0xffffu;
+                }
+                if constexpr (BITS) {                     // ReLU bit words of the values being stored (post-ReLU: never negative)
+                    uint32_t pw_[2] = {0u, 0u};
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            uint32_t nz;
+                            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(w[gq][d]), "v"(0x00010001u));
+                            pw_[gq >> 1] |= nz << (4 * lgrp + 2 * (gq & 1) + d);
+                        }
+                    auto r = __builtin_amdgcn_permlane32_swap(pw_[0], pw_[1], false, false);  // lower half: both parts of word 0, upper half: of word 1
+                    const uint32_t word = r[0] | r[1];
+                    const bool st_ok = ok[h];
+                    const uint32_t bo = st_ok ? ((e0[h] >> 5) * 2u + (uint32_t)lgrp) * 4u : G2_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(word, rsB, (int)bo, 0, 0);
                 }
                 {
                     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -261,13 +286,14 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
         RW_STAMP();                                       // 4 + 2 i: chunk i computed
         // next chunk's slot range (requested at the top of this iteration, before 8 | 16 newer VMEM operations) has landed: everything but
         // the last tile pair's 4 stores is complete; after the barrier every wave is also done reading this chunk's buffer
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (BITS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  // (+ one bit-word store per tile)
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 #undef RW_STAMP
 }
 
-template <int TAPS, int KH, bool RELU, bool MASK, int DBG = 0>
+template <int TAPS, int KH, bool RELU, int MASK, bool BITS, int DBG = 0>
 __global__ __launch_bounds__(RwCfg<TAPS>::NW * 64, TAPS == 2 ? 3 : 2) void rwconv_gather_kernel(const TapParams p, const int nchunks) {
     typedef RwCfg<TAPS> Cfg;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 128];
@@ -289,10 +315,10 @@ __global__ __launch_bounds__(RwCfg<TAPS>::NW * 64, TAPS == 2 ? 3 : 2) void rwcon
     if (cbeg + j >= cend) return;                         // block-uniform: more blocks than chunks on this XCD
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     // each wave: stage its share of the first chunk, request its class's weight fragments, then the chunk loop (one block barrier per chunk)
-    if (cls == 0) rw_class<TAPS, KH, 0, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else if (cls == 1) rw_class<TAPS, KH, 1, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else if (cls == 2) rw_class<TAPS, KH, 2, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else rw_class<TAPS, KH, 3, RELU, MASK, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    if (cls == 0) rw_class<TAPS, KH, 0, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else if (cls == 1) rw_class<TAPS, KH, 1, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else if (cls == 2) rw_class<TAPS, KH, 2, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    else rw_class<TAPS, KH, 3, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
     if (tr) tr[31] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID of this wave (wave / SIMD / CU placement)
 }
 
@@ -314,7 +340,7 @@ int mi_rwconv_mode(int set) {                            // set < 0: query
 // gather-form transposed conv / conv input gradient on the register-weight kernel.  Same contract as try_tapconv (conv_ops.hip):
 // returns 1 launched, 0 not eligible, < 0 error.  x [B,IH,IW,64] bf16, w [KH][KW][32][64] bf16, out / mask [B,OH,OW,32] bf16.
 int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
-                         int KH, int KW, void* out, const float* bias, const void* mask, int relu) {
+                         int KH, int KW, void* out, const float* bias, const void* mask, int relu, const void* mask_bits, void* bits_out) {
     mi_rwconv_mode(-1);
     if (dtype != MI_BF16 || C != 64 || N != 32 || KH != KW || (KH != 4 && KH != 5)) return 0;
     if ((((uintptr_t)a) | ((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)mask)) & 15) return 0;
@@ -333,6 +359,8 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     q.KC = C; q.NE = 4 * N;
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
+    q.mask_bits = mask ? (const uint32_t*)mask_bits : nullptr; q.bits_out = relu ? (uint32_t*)bits_out : nullptr;
+    if ((bits_out && !q.bits_out) || ((((uintptr_t)mask_bits) | ((uintptr_t)bits_out)) & 7)) return 0;
     mi_get_trace(&q.trace, &q.trace_cap);
     const int bmt = KH == 4 ? RwCfg<2>::BMT : RwCfg<3>::BMT;
     const int nchunks = (int)((MP + bmt - 1) / bmt);
@@ -345,14 +373,18 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     if (per_xcd > (nchunks + 7) / 8) per_xcd = (nchunks + 7) / 8;
     const dim3 g((unsigned)(8 * per_xcd));
 #define RW_LAUNCH(TAPS_, KH_) do { \
-        if (relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, true>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
-        else if (relu) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, false>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
-        else if (mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, true>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); \
-        else hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, false>), g, dim3(TAPS_ == 2 ? 256 : 512), 0, st, q, nchunks); } while (0)
-    if (KH == 5 && relu && !mask && g_rwconv_dbg > 0) {  // debug variants of the deconv3-forward instantiation (MI355_RWCONV_DBG: 1 no stores, 2 no LDS reads, 3 no MFMAs)
-        if (g_rwconv_dbg == 1) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 1>), g, dim3(512), 0, st, q, nchunks);
-        else if (g_rwconv_dbg == 2) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 2>), g, dim3(512), 0, st, q, nchunks);
-        else hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, false, 3>), g, dim3(512), 0, st, q, nchunks);
+        const dim3 t_(TAPS_ == 2 ? 256 : 512); \
+        if (relu && q.bits_out && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 0, true>), g, t_, 0, st, q, nchunks); \
+        else if (bits_out) return 0; \
+        else if (relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 1, false>), g, t_, 0, st, q, nchunks); \
+        else if (relu) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 0, false>), g, t_, 0, st, q, nchunks); \
+        else if (q.mask_bits) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 2, false>), g, t_, 0, st, q, nchunks); \
+        else if (mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 1, false>), g, t_, 0, st, q, nchunks); \
+        else hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 0, false>), g, t_, 0, st, q, nchunks); } while (0)
+    if (KH == 5 && relu && !mask && !bits_out && g_rwconv_dbg > 0) {  // debug variants of the deconv3-forward instantiation (MI355_RWCONV_DBG: 1 no stores, 2 no LDS reads, 3 no MFMAs)
+        if (g_rwconv_dbg == 1) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 1>), g, dim3(512), 0, st, q, nchunks);
+        else if (g_rwconv_dbg == 2) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 2>), g, dim3(512), 0, st, q, nchunks);
+        else hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 3>), g, dim3(512), 0, st, q, nchunks);
     } else if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
 #undef RW_LAUNCH
     const int rc = mi_check_launch("rwconv_gather_kernel");

@@ -38,6 +38,7 @@ struct TapParams {
     int ldb;                         // conv form: row pitch (elements) of the K-contiguous weight copy [N][KH*KW*C]
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     void* out; const float* bias; const void* mask; int relu;
+    const uint32_t* mask_bits; uint32_t* bits_out;    // rwconv.hip only: ReLU bit words read instead of `mask` / written next to `out` (mi355_carla.h)
     int direct_epilogue;             // 1: registers -> 16-byte stores (half-wave swap), 0: LDS-staged coalesced stores
     long long* trace; int trace_cap;   // debug: per-wave s_memtime stamps (mi_debug_set_trace), nullptr in production
     int dbg;                           // debug (mi_set_tuning key 2): 3 = direct epilogue without its stores

@@ -66,6 +66,7 @@ struct Workspace {
     long long z, dheads;               // T
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
+    long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
     long long total;
 };
@@ -113,6 +114,7 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int bits1_ok, bits3_ok;             // the last forward pass wrote the ReLU bit words of act1 / dec3
     int rng_ready;                      // generator state in the workspace has been initialised (mi_vae_set_seed)
     const float* last_eps;              // the noise the last sampling forward used (caller's buffer or the engine's own draw)
     int last_u8;                        // frame-table format of the last forward (backward reads the same source table)
@@ -164,6 +166,7 @@ void make_workspace(VaeEngine& e) {
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
     W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
+    W.bits_act1 = add(B * g.ih[1] * g.iw[1] * (g.c[1] / 16) * 4); W.bits_dec3 = add(B * g.dh[3] * g.dw[3] * (g.dc[3] / 16) * 4);
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256); W.idx_stage = add(B * 4); W.scalars = add(256);
     W.total = o;
 }
@@ -200,14 +203,23 @@ int check_batch(const VaeEngine* e, int B) {
     return MI_OK;
 }
 
+bool relu_bits_enabled() {                             // MI355_RELU_BITS=0: the input gradients read the activation tensors as ReluGrad masks (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* ev = getenv("MI355_RELU_BITS"); on = (ev && ev[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
 // encoder: frames (fp32, optional gather) -> act[1..4] -> heads slabs -> mean/logvar/z/kl
-int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const int* idx, int B, const float* eps, int sample) {
+int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const int* idx, int B, const float* eps, int sample, int want_bits = 0) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
     if (frames_u8 && d.dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "vae engine: uint8 frame tables are read by the bf16 engine only (fp32 mode takes float frames)");
+    e->bits1_ok = 0;
     for (int i = 0; i < NCONV; ++i) {
         const void* x = i == 0 ? frames : e->at(e->W.act[i]);
-        TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (frames_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i],
-                              e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1])));
+        // conv1 (training pass, bf16): also writes the ReLU bit words conv2's input gradient reads instead of the 101 MB activation tensor
+        const bool bits = i == 0 && want_bits && relu_bits_enabled() && d.dtype == MI_BF16 && g.c[1] == 32;
+        TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd_bits(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (frames_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i],
+                              e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1]), bits ? e->at(e->W.bits_act1) : nullptr, bits ? &e->bits1_ok : nullptr));
     }
     TOP(e, st, OP_HEADS_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.act[4]), B, g.flat, e->wtptr(8), 1, 2 * d.z_dim, nullptr, 0, nullptr,
                         e->at(e->W.heads_slab), 1, e->ns_heads));
@@ -222,12 +234,15 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
 }
 
 // decoder: z (T) -> dense1 -> deconv1..4 -> logits
-int run_decoder(VaeEngine* e, void* st, int B, int last = 4) {
+int run_decoder(VaeEngine* e, void* st, int B, int last = 4, int want_bits = 0) {
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    e->bits3_ok = 0;
     TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wtptr(10), 1, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
-    for (int i = 0; i < last; ++i)
-        TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
-                                DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1])));
+    for (int i = 0; i < last; ++i) {
+        const bool bits = i == 2 && want_bits && relu_bits_enabled() && d.dtype == MI_BF16 && g.dc[3] == 32;   // deconv3: ReLU bit words for deconv4's input gradient
+        TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd_bits(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
+                                DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1]), bits ? e->at(e->W.bits_dec3) : nullptr, bits ? &e->bits3_ok : nullptr));
+    }
     return MI_OK;
 }
 
@@ -326,7 +341,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
-    CK(run_encoder(e, stream, src, frames_u8, idx, B, eps, sample));
+    CK(run_encoder(e, stream, src, frames_u8, idx, B, eps, sample, want_grad));
     e->last_u8 = frames_u8 ? 1 : 0;
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
     const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
@@ -337,7 +352,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
                                      "(its deconv4 bias gradient is already in the gradient buffer)");
     e->b4_fused = fuse_b4 ? 1 : 0;
     // decoder tail: deconv4 with the reconstruction loss fused into its epilogue where the narrow kernel is eligible (logits are still written)
-    CK(run_decoder(e, stream, B, 3));
+    CK(run_decoder(e, stream, B, 3, want_grad));
     int nblk = 0;
     // (the fused form never stores the logits: only the loss partial sums and dlogits leave the kernel)
     TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce_u8(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
@@ -411,8 +426,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             release();                                       // gy is complete on st (loss pass / previous input gradient)
             // BiasAddGrad is fused into the filter-gradient call
             TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), scratch_of(), scratch_sz, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
-            TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
-                                      i > 0 ? e->at(W.dec[i]) : nullptr, e->at(W.gdec[i])));
+            TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
+                                      i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
         }
         e->b4_fused = 0;
         // dense1: h = z W1 + b1
@@ -445,8 +460,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
                                                                    (i == 0 && fork) ? nullptr : scratch_of(), (i == 0 && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
-                TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
-                                        e->at(W.act[i]), e->at(W.gact[i])));
+                TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
+                                        e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
         }
         join();
     }

@@ -86,6 +86,13 @@ int mi_debug_set_trace(void* dev_ptr, int capacity_entries);
 /* tf.layers.conv2d k x k, s2, VALID + BiasAdd + Relu — vae/models.py:250-253.  x may be frames gathered through frame_idx: x_is_f32 = 1 fp32
  * frames, 2 = raw uint8 camera frames (value k / 255, the host preprocessing of vae/train_vae.py:15-18 done in registers; bf16 narrow-layer kernel only). */
 int mi_conv2d_nhwc_fwd(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout, int relu, void* out);
+/* ReLU bit words (bf16 engine): a forward kernel can also write, per output pixel and group of 16 channels, one uint32 whose bit i (i < 8) says
+ * "channel 16 j + 2 i > 0" and bit 16 + i "channel 16 j + 2 i + 1 > 0"; the ReluGrad of the next layer's input gradient then reads those words
+ * (1/16 of the bytes) instead of the activation tensor.  relu_bits: [B*OH*OW][Cout/16] uint32, *wrote_bits = 1 when the kernel produced them. */
+int mi_conv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* w, int w_transposed, const float* bias, int KH, int KW, int Cout, int relu, void* out, void* relu_bits, int* wrote_bits);
+int mi_conv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, const void* mask_bits, void* dx);
+int mi_deconv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, int relu, void* out, void* relu_bits, int* wrote_bits);
+int mi_deconv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, const void* mask_bits, void* dx);
 /* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
 /* Conv2DBackpropFilter: dw += im2col(x)^T dy (fp32 atomics) */

@@ -491,3 +491,73 @@ def test_gae_scan_bit_exact_and_normalize():
         rr, aa = po.returns_and_normalized_advantages(got[r].copy(), val[r, :T])
         assert np.array_equal(r2[r], rr)
         assert np.allclose(a2[r], aa, rtol=1e-12, atol=1e-12)
+
+
+def _relu_bit_words(act):
+    """Reference packing of the ReLU bit words (mi355_carla.h): act [.., C] -> uint32 [.., C // 16]; bit i = channel 16 j + 2 i > 0,
+    bit 16 + i = channel 16 j + 2 i + 1 > 0."""
+    a = (np.asarray(act) > 0).astype(np.uint32)
+    a = a.reshape(a.shape[:-1] + (a.shape[-1] // 16, 8, 2))
+    sh = np.arange(8, dtype=np.uint32)
+    return ((a[..., 0] << sh).sum(-1) | ((a[..., 1] << sh).sum(-1) << np.uint32(16))).astype(np.uint32)
+
+
+def test_relu_bit_words_producers_and_consumers():
+    """bf16 engine: conv1 forward (narrow kernel) and deconv3 forward (register-weight kernel) also write the ReLU bit words of their output;
+    conv2's input gradient (register-weight kernel) and deconv4's (narrow kernel) read those 8 bytes per pixel instead of the 64-byte
+    activation row.  Words equal the reference packing of (stored output > 0); gradients equal the full-mask results bit for bit."""
+    L = milib.get()
+    prev = L.mi_set_tuning(13, 2)
+    try:
+        code, td = DT["bf16"]
+        rng = np.random.RandomState(3)
+        B = 3
+        # --- producer 1: conv1 forward 80x160x3 -> 39x79x32
+        x = rng.rand(B, 80, 160, 3).astype(np.float32)
+        w = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)
+        b = (0.1 * rng.randn(32)).astype(np.float32)
+        wt = torch.from_numpy(w).permute(3, 0, 1, 2).reshape(32, -1).contiguous()
+        out = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        bits = torch.zeros(B * 39 * 79 * 2, device="cuda", dtype=torch.int32)
+        wrote = np.zeros(1, np.int32)
+        L.mi_conv2d_nhwc_fwd_bits(stream(), code, P(dev(x)), None, 1, B, 80, 160, 3, P(dev(wt, td)), 1, P(dev(b)), 4, 4, 32, 1, out.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
+        assert wrote[0] == 1
+        act1 = host(out)
+        assert np.array_equal(bits.cpu().numpy().view(np.uint32).reshape(B, 39, 79, 2), _relu_bit_words(act1))
+        assert 0.2 < (act1 > 0).mean() < 0.8
+        # --- consumer 1: conv2 input gradient with those words == with the full mask
+        dy = rng.randn(B, 18, 38, 64).astype(np.float32)
+        w2 = (rng.randn(4, 4, 32, 64) / np.sqrt(512)).astype(np.float32)
+        dx_full = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        dx_bits = torch.empty_like(dx_full)
+        dyd, w2d = dev(dy, td), dev(w2, td)
+        L.mi_conv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, 18, 38, 64, w2d.data_ptr(), 4, 4, 32, 39, 79, out.data_ptr(), dx_full.data_ptr())
+        L.mi_conv2d_nhwc_dgrad_bits(stream(), code, dyd.data_ptr(), B, 18, 38, 64, w2d.data_ptr(), 4, 4, 32, 39, 79, out.data_ptr(), bits.data_ptr(), dx_bits.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(dx_full, dx_bits) and float(dx_full.float().abs().max()) > 0
+        # --- producer 2: deconv3 forward 18x38x64 -> 39x79x32 (k5)
+        x3 = np.maximum(rng.randn(B, 18, 38, 64), 0).astype(np.float32)
+        w3 = (rng.randn(5, 5, 32, 64) / np.sqrt(25 * 64 / 4)).astype(np.float32)
+        o3 = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        o3_ref = torch.empty_like(o3)
+        bits3 = torch.zeros(B * 39 * 79 * 2, device="cuda", dtype=torch.int32)
+        x3d, w3d, b3d = dev(x3, td), dev(w3, td), dev(b)
+        wrote[0] = 0
+        L.mi_deconv2d_nhwc_fwd_bits(stream(), code, x3d.data_ptr(), B, 18, 38, 64, w3d.data_ptr(), b3d.data_ptr(), 5, 5, 32, 1, o3.data_ptr(), bits3.data_ptr(), wrote.ctypes.data)
+        L.mi_deconv2d_nhwc_fwd(stream(), code, x3d.data_ptr(), B, 18, 38, 64, w3d.data_ptr(), b3d.data_ptr(), 5, 5, 32, 1, o3_ref.data_ptr())
+        torch.cuda.synchronize()
+        assert wrote[0] == 1 and torch.equal(o3, o3_ref)
+        assert np.array_equal(bits3.cpu().numpy().view(np.uint32).reshape(B, 39, 79, 2), _relu_bit_words(host(o3)))
+        # --- consumer 2: deconv4 input gradient (80x160x3 logits gradient -> 39x79x32)
+        dl = rng.randn(B, 80, 160, 3).astype(np.float32)
+        w4 = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)                      # [kh,kw,co=3,ci=32]
+        w4t = torch.from_numpy(w4).permute(3, 0, 1, 2).reshape(32, -1).contiguous()          # [Cin][kh*kw*co]
+        g_full = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        g_bits = torch.empty_like(g_full)
+        dld, w4d = dev(dl, td), dev(w4t, td)
+        L.mi_deconv2d_nhwc_dgrad(stream(), code, dld.data_ptr(), B, 80, 160, 3, w4d.data_ptr(), 1, 4, 4, 32, o3.data_ptr(), g_full.data_ptr())
+        L.mi_deconv2d_nhwc_dgrad_bits(stream(), code, dld.data_ptr(), B, 80, 160, 3, w4d.data_ptr(), 1, 4, 4, 32, o3.data_ptr(), bits3.data_ptr(), g_bits.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(g_full, g_bits) and float(g_full.float().abs().max()) > 0
+    finally:
+        L.mi_set_tuning(13, prev)
