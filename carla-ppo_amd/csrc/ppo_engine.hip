@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "mi_internal.hpp"
 #include "mi355_carla.h"
+#include "ppo_fused.hpp"
 
 using namespace mi;
 
@@ -25,6 +26,7 @@ struct PpoEngine {
     char* ws;
     // workspace offsets (bytes)
     long long s_pad, h1, h2, g1, g2, u, vraw, h1o, h2o, uo, du, dv, dh2, dh1, dg2, dg1, partial, losses, mean, low, high, ws_total;
+    long long f_h1, f_h2, f_dh1, f_dh2, f_part;   // fused step (ppo_fused.hip): [3][M][H1], [3][M][H2], [2][M][H1], [2][M][H2], loss-block partials
     int last_M;
     hipStream_t side; hipEvent_t ev_fork, ev_join; int side_ok;     // second stream of the forked minibatch step (0 = not tried, 1 = ok, -1 = unavailable)
     float* P(int t) const { return params + off[t]; }
@@ -53,6 +55,8 @@ void layout(PpoEngine& e) {
     e.dh2 = wa(M * d.h2 * 4); e.dh1 = wa(M * d.h1 * 4); e.dg2 = wa(M * d.h2 * 4); e.dg1 = wa(M * d.h1 * 4);
     e.partial = wa((long long)mi_ppo_loss_partial_floats((int)M) * 4);
     e.losses = wa(256); e.mean = wa(M * d.num_actions * 4); e.low = wa(256); e.high = wa(256);
+    e.f_h1 = wa(3 * M * d.h1 * 4); e.f_h2 = wa(3 * M * d.h2 * 4); e.f_dh1 = wa(2 * M * d.h1 * 4); e.f_dh2 = wa(2 * M * d.h2 * 4);
+    e.f_part = wa((long long)mi_ppo_fused_partial_floats((int)M) * 4);
     e.ws_total = w;
 }
 
@@ -83,6 +87,26 @@ __global__ void head_dgrad_kernel(const float* __restrict__ du, const float* __r
 }
 
 #define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
+
+bool fused_enabled() {                                   // MI355_PPO_FUSED=0: the first-generation step (one launch per layer op), for A/B runs
+    static int on = -1;
+    if (on < 0) { const char* ev = getenv("MI355_PPO_FUSED"); on = (ev && ev[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+void fill_fused(const PpoEngine* e, PpoFusedParams& q, const float* states, int M) {
+    const MiPpoDesc& d = e->d;
+    q = PpoFusedParams{};
+    q.theta = e->params; q.theta_old = e->params_old; q.adam_m = e->m; q.adam_v = e->v; q.grads = e->grads;
+    for (int i = 0; i < 13; ++i) q.off[i] = e->off[i];
+    q.kin = e->kin; q.din = d.input_dim; q.H1 = d.h1; q.H2 = d.h2; q.A = d.num_actions; q.M = M;
+    q.states = states; q.low = (const float*)e->at(e->low); q.high = (const float*)e->at(e->high);
+    q.h1 = (float*)e->at(e->f_h1); q.h2 = (float*)e->at(e->f_h2); q.dh1 = (float*)e->at(e->f_dh1); q.dh2 = (float*)e->at(e->f_dh2);
+    q.du = (float*)e->at(e->du); q.dv = (float*)e->at(e->dv); q.partial = (float*)e->at(e->f_part); q.losses = (float*)e->at(e->losses);
+    q.mean_out = (float*)e->at(e->mean);
+    q.n_nets = 3;
+    q.clip_eps = d.clip_eps; q.value_scale = d.value_scale; q.entropy_scale = d.entropy_scale;
+}
 
 int policy_fwd(PpoEngine* e, void* st, const float* prm, const long long* off, int M, void* h1, void* h2, void* u) {
     const MiPpoDesc& d = e->d;
@@ -178,6 +202,11 @@ int mi_ppo_predict(void* h, void* stream, const float* states, int M, const floa
     PpoEngine* e = (PpoEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_predict: batch outside [1, max_batch]");
+    if (!greedy && !noise) return mi_fail(MI_ERR_ARG, "mi_ppo_predict: sampling needs noise");
+    if (fused_enabled()) {                                // 3 launches: layer 1, layer 2 (policy + value), heads
+        PpoFusedParams q; fill_fused(e, q, states, M);
+        return mi_ppo_fused_predict((hipStream_t)stream, q, noise, greedy, action, value);
+    }
     CK(stage_states(e, stream, states, M));
     CK(trunk_fwd(e, stream, e->params, e->off, M, true, e->at(e->h1), e->at(e->h2), e->at(e->u), value));
     return mi_policy_head(stream, (const float*)e->at(e->u), e->P(6), noise, (const float*)e->at(e->low), (const float*)e->at(e->high),
@@ -192,6 +221,12 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_forward_backward: batch outside [1, max_batch]");
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_ppo_forward_backward: engine created without a gradient buffer");
+    if (fused_enabled() && M <= 256) {                    // 5 launches; gradients written (not accumulated) into the flat buffer
+        PpoFusedParams q; fill_fused(e, q, states, M);
+        q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
+        e->last_M = M;
+        return mi_ppo_fused_step((hipStream_t)stream, q, 0);
+    }
     const MiPpoDesc& d = e->d;
     void* st = stream;
     const int A = d.num_actions;
@@ -246,6 +281,40 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     join();
     e->last_M = M;
     return MI_OK;
+}
+
+// The whole of PPO.train's device work (ppo.py:218-229) in one call, single rank: forward of policy / value / old policy, losses, backward
+// and tf.train.AdamOptimizer, as five launches (ppo_fused.hip); the optimiser update is applied by the blocks that produce each gradient
+// tile, so no gradient buffer is involved.  logp_old != NULL: log pi_old(a|s) of these samples, computed once per horizon batch with
+// mi_ppo_logp_old (theta_old is constant between two update_old_policy() calls): the old policy's forward pass is skipped.
+int mi_ppo_train_step(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old,
+                      int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step: batch outside [1, max_batch]");
+    if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step: engine created without optimiser buffers");
+    if (M > 256) {
+        // large minibatches (the synthetic replay: 2048 rows per GPU): the fused kernels sum over the minibatch rows inside a few blocks, which
+        // is right for the reference's 32 rows and wrong here -- the tiled fp32 MFMA kernels (one launch per layer op) fill the chip instead
+        CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale));
+        return mi_ppo_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
+    }
+    PpoFusedParams q; fill_fused(e, q, states, M);
+    q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
+    q.logp_old = logp_old; q.n_nets = logp_old ? 2 : 3;
+    q.alpha = alpha; q.omb1 = 1.0f - beta1; q.omb2 = 1.0f - beta2; q.epsilon = epsilon;
+    e->last_M = M;
+    return mi_ppo_fused_step((hipStream_t)stream, q, 1);
+}
+
+// log pi_old(a | s) of M samples under theta_old -> out [M] (the per-horizon cache for mi_ppo_train_step)
+int mi_ppo_logp_old(void* h, void* stream, const float* states, const float* actions, int M, float* out) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_logp_old: batch outside [1, max_batch]");
+    PpoFusedParams q; fill_fused(e, q, states, M);
+    q.actions = actions;
+    return mi_ppo_fused_logp_old((hipStream_t)stream, q, out);
 }
 
 // tf.train.AdamOptimizer over the 13 policy/ variables (ppo.py:143-144); alpha folds lr*lr_decay^episode and the bias correction

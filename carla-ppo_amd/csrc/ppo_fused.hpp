@@ -1,0 +1,30 @@
+// ppo_fused.hpp — parameter block and host entry points of the fused PPO kernels (ppo_fused.hip), shared with ppo_engine.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi {
+
+struct PpoFusedParams {
+    // flat parameter buffers (engine layout, offsets in floats) and optimiser state
+    float *theta, *adam_m, *adam_v, *grads; const float* theta_old;
+    long long off[13];
+    int kin, din, H1, H2, A, M;
+    // activations (workspace): [net][M][H] with net 0 = policy, 1 = value, 2 = old policy
+    const float *states, *actions, *returns, *adv, *low, *high;
+    float *h1, *h2, *dh1, *dh2;                           // h1/h2: 3 nets; dh1/dh2: 2 nets
+    float *du, *dv, *partial, *losses, *mean_out;
+    const float* logp_old;                                // cached log pi_old(a|s) per sample (nullptr: recomputed from net 2)
+    float* logp_out;                                      // when set: the loss kernel also stores log pi(a|s) (used to fill the cache)
+    int n_nets;                                           // 3, or 2 with the cache
+    float clip_eps, value_scale, entropy_scale, inv_m, grad_scale;
+    float alpha, omb1, omb2, epsilon;                     // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); omb = 1 - beta
+    int n_loss_blocks;
+};
+
+}  // namespace mi
+
+int mi_ppo_fused_partial_floats(int M);
+int mi_ppo_fused_trunks(hipStream_t st, const mi::PpoFusedParams& q);
+int mi_ppo_fused_step(hipStream_t st, mi::PpoFusedParams& q, int fuse_adam);
+int mi_ppo_fused_predict(hipStream_t st, mi::PpoFusedParams& q, const float* noise, int greedy, float* action, float* value);
+int mi_ppo_fused_logp_old(hipStream_t st, mi::PpoFusedParams& q, float* out);

@@ -57,7 +57,11 @@ class PpoDevice:
         self.max_batch = int(max_batch)
         addr = self.L.mi_ppo_buffer(self.handle, 0)
         o = addr - self.workspace.data_ptr()
-        self.losses = self.workspace[o:o + 20].view(torch.float32)
+        # [policy, value, entropy, total, mean prob ratio, mean action_mean[A], std[A]] of the last minibatch step
+        self.losses = self.workspace[o:o + 4 * (5 + 2 * self.num_actions)].view(torch.float32)
+        addr = self.L.mi_ppo_buffer(self.handle, 1)
+        o = addr - self.workspace.data_ptr()
+        self.action_mean = self.workspace[o:o + 4 * int(max_batch) * self.num_actions].view(torch.float32).view(int(max_batch), self.num_actions)
 
     def ensure_batch(self, m):
         if m > self.max_batch:
@@ -137,6 +141,19 @@ class PpoDevice:
         self.ensure_batch(M)
         p = milib.ptr
         self.L.mi_ppo_forward_backward(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), int(M), float(inv_m), float(grad_scale))
+
+    def train_step(self, states, actions, returns, advantage, M, inv_m, grad_scale, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, logp_old=None):
+        """The whole minibatch step in one C call (single rank): fused forward / losses / backward / Adam (csrc/ppo_fused.hip)."""
+        self.ensure_batch(M)
+        p = milib.ptr
+        self.L.mi_ppo_train_step(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), int(M), float(inv_m), float(grad_scale),
+                                 float(alpha), float(beta1), float(beta2), float(epsilon))
+
+    def logp_old(self, states, actions, M, out):
+        """log pi_old(a | s) of M samples under theta_old (computed once per horizon batch; theta_old only changes in update_old())."""
+        self.ensure_batch(M)
+        p = milib.ptr
+        self.L.mi_ppo_logp_old(self.handle, self.stream(), p(states), p(actions), int(M), p(out))
 
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.L.mi_ppo_apply_adam(self.handle, self.stream(), float(alpha), float(beta1), float(beta2), float(epsilon))

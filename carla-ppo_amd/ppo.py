@@ -146,13 +146,18 @@ class PPO():
         a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))      # f64 -> f32 at the feed (ppo.py:108-109)
         return torch.from_numpy(a).to(self.dev.device)
 
-    def _step_resident(self, s, a, r, adv, m_local, m_global):
-        """One SGD step on device-resident minibatch tensors: grads, (all-reduce), Adam."""
+    def _step_resident(self, s, a, r, adv, m_local, m_global, logp_old=None):
+        """One SGD step on device-resident minibatch tensors.  Single rank: one C call (fused forward / losses / backward / Adam, five launches);
+        data parallel: gradients, all-reduce, Adam.  logp_old: cached log pi_old(a|s) of these samples (PpoDevice.logp_old), optional."""
         dev = self.dev
-        dev.forward_backward(s, a, r, adv, m_local, 1.0 / m_global, m_local / float(m_global))
-        if midist.world_size() > 1:
-            midist.all_reduce_sum(dev.grads)
-        dev.apply_adam(_adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power), ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+        alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
+        if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0":
+            dev.train_step(s, a, r, adv, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON, logp_old=logp_old)
+        else:
+            dev.forward_backward(s, a, r, adv, m_local, 1.0 / m_global, m_local / float(m_global))
+            if midist.world_size() > 1:
+                midist.all_reduce_sum(dev.grads)
+            dev.apply_adam(alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
         self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
 
@@ -172,6 +177,11 @@ class PPO():
             L = self._global_losses()
             for k, v in zip(("train_loss/policy", "train_loss/value", "train_loss/entropy", "train_loss/loss", "train/prob_ratio"), L):
                 self._metric_sums[k] = self._metric_sums.get(k, 0.0) + float(v)
+            ta = np.asarray(taken_actions, np.float64).reshape(m, self.num_actions)
+            for i in range(self.num_actions):                  # ppo.py:155-158: minibatch means of the taken action, the policy mean and its std
+                for tag, val in (("taken_actions", ta[:, i].mean()), ("mean", L[5 + i]), ("std", L[5 + self.num_actions + i])):
+                    k = "train_actor/action_{}/{}".format(i, tag)
+                    self._metric_sums[k] = self._metric_sums.get(k, 0.0) + float(val)
             self._metric_sums["train/returns"] = self._metric_sums.get("train/returns", 0.0) + float(np.mean(returns))
             self._metric_sums["train/advantage"] = self._metric_sums.get("train/advantage", 0.0) + float(np.mean(advantage))
             self._metric_sums["train/learning_rate"] = self._metric_sums.get("train/learning_rate", 0.0) + float(self.current_learning_rate())
@@ -225,9 +235,14 @@ class PPO():
         dev.predict(s, m, nz, greedy, action, value)
         sampled_action, value = action.cpu().numpy(), value.cpu().numpy()
         if write_to_summary:
-            if self.train_writer is not None:
+            if self.train_writer is not None:                  # ppo.py:175-180: sampled action, policy mean and std of the FIRST state of the batch
+                mean0 = dev.action_mean[0].cpu().numpy()
+                o, n = dev.layout["policy/action_logstd"]
+                std = np.exp(dev.params[o:o + n].cpu().numpy())
                 for i in range(self.num_actions):
                     self.train_writer.add_scalar("predict_actor/action_{}/sampled_action".format(i), sampled_action[0, i], self.predict_step_counter)
+                    self.train_writer.add_scalar("predict_actor/action_{}/mean".format(i), float(mean0[i]), self.predict_step_counter)
+                    self.train_writer.add_scalar("predict_actor/action_{}/std".format(i), float(std[i]), self.predict_step_counter)
             self.predict_step_counter += 1
         if len(input_states) == 1:
             return sampled_action[0], value[0]
@@ -248,8 +263,8 @@ class PPO():
             self.train_writer.add_scalar(summary_name, value, step)
 
     def write_dict_to_summary(self, summary_name, params, step):
-        if self.train_writer is not None:
-            self.train_writer.add_text(summary_name, {k: str(v) for k, v in params.items()}, step)
+        if self.train_writer is not None:                      # the reference adds this summary WITHOUT a global step (ppo.py:269): event step 0
+            self.train_writer.add_text(summary_name, {k: str(v) for k, v in params.items()}, 0)
 
     def write_episodic_summaries(self):
         """Writes the episodic means, then increments episode_counter and resets the accumulators (ppo.py:271-273)."""

@@ -106,6 +106,14 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     mb_lo, mb_hi = midist.shard_bounds(batch_size, rank, world)
     mb_loc = mb_hi - mb_lo                                                       # this rank's share of a full global minibatch
     ppo.update_old_policy()
+    # theta_old is now fixed for the whole update: log pi_old(a | s) of every sample is computed ONCE (the reference's graph recomputes the old
+    # policy's forward pass in every minibatch step, ppo.py:112-121 -- same numbers)
+    logp_old = None
+    if world == 1 and hasattr(pdev, "logp_old"):
+        logp_old = torch.empty(n_loc, device=device)
+        for lo_ in range(0, n_loc, 4096):
+            hi_ = min(lo_ + 4096, n_loc)
+            pdev.logp_old(s[lo_:hi_], a[lo_:hi_], hi_ - lo_, logp_old[lo_:hi_])
     records = []
     for _ in range(num_epochs):
         indices = np.arange(n_loc)
@@ -116,7 +124,10 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
             mb = perm[i * mb_loc:(i + 1) * mb_loc]                               # the last one may be partial (train.py:199-201)
             m_local = int(mb.numel())
             m_global = m_local * world if world > 1 else m_local                 # ranks hold equal shares (R divisible by world is the C5 layout)
-            ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global)
+            if logp_old is not None:
+                ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global, logp_old=logp_old[mb].contiguous())
+            else:
+                ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global)
             ppo.train_step_counter += 1
             records.append(pdev.losses.clone())
     losses = torch.stack(records).cpu().numpy() if records else np.zeros((0, 5), np.float32)

@@ -210,11 +210,16 @@ void mi_ppo_destroy(void* h);
 void* mi_ppo_buffer(void* h, int which);
 /* PPO.update_old_policy — ppo.py:275-276 */
 int mi_ppo_update_old(void* h, void* stream);
-/* PPO.predict — ppo.py:231-251 */
+/* PPO.predict — ppo.py:231-251.  mi_ppo_buffer(h, 0): losses of the last step: [policy, value, entropy, total, mean ratio, mean action_mean[A], std[A]] (the
+ * scalars of ppo.py:150-163); mi_ppo_buffer(h, 1): action_mean [M,A] of the last predict / train step */
 int mi_ppo_predict(void* h, void* stream, const float* states, int M, const float* noise, int greedy, float* action, float* value);
 /* gradient half + optimiser half of PPO.train (= north_star "learn") — ppo.py:218-229 */
 int mi_ppo_forward_backward(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, int M, float inv_m, float grad_scale);
 int mi_ppo_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
+/* PPO.train's device work in ONE call (single rank): fused forward / losses / backward / Adam, five launches — ppo.py:218-229; logp_old (optional):
+ * log pi_old(a|s) of the samples from mi_ppo_logp_old, computed once per horizon batch (theta_old is constant between update_old_policy() calls) */
+int mi_ppo_train_step(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
+int mi_ppo_logp_old(void* h, void* stream, const float* states, const float* actions, int M, float* out);
 
 #ifdef __cplusplus
 }

@@ -158,3 +158,61 @@ def test_gae_batched_rows_bit_exact_and_normalised(tmp_path):
         rr, aa = po.returns_and_normalized_advantages(ref.copy(), val[r, :T].astype(np.float64))
         assert np.array_equal(ret[r], rr) and np.allclose(adv[r], aa, rtol=1e-12, atol=1e-12)
     assert utils.compute_gae([], [], 0.0, [], 0.99, 0.95).shape == (0,)
+
+
+@pytest.mark.parametrize("M", [32, 77, 256, 2048])
+def test_fused_step_gradients_update_and_cache_match_oracle(tmp_path, M):
+    """The PPO minibatch step at the reference's minibatch (32), at a ragged size, at the largest fused size (256) and at the synthetic
+    replay's per-GPU minibatch (2048: above 256 rows the tiled fp32 MFMA kernels run instead of the fused ones).  Against the oracle:
+    (1) the gradient form (data-parallel path: gradients written, then all-reduce + Adam): five loss scalars 1e-4, all 13 gradients 2e-4 of
+    the tensor max; (2) the single-rank form (one C call, Adam applied by the blocks that produce each gradient tile): parameters after the
+    step equal the oracle's TF-Adam update on ITS gradients wherever the gradient is not at the 1e-8 epsilon scale; (3) with the cached
+    log pi_old (mi_ppo_logp_old, the old policy's forward pass skipped) the step is identical to (2)."""
+    o, m = make_pair(tmp_path)
+    rng = np.random.RandomState(5 + M)
+    for k in o.params:                                   # theta != theta_old: ratio != 1, some samples clipped
+        o.params[k] = o.params[k] + (0.02 * rng.standard_normal(o.params[k].shape)).astype(np.float32)
+    m.dev.load_params(o.params)                          # theta only; theta_old stays the initial copy (as after update_old_policy + some steps)
+    s = (0.5 * rng.standard_normal((M, 67))).astype(np.float32)
+    a = np.stack([rng.uniform(-1, 1, M), rng.uniform(0, 1, M)], axis=1).astype(np.float32)
+    R, A = rng.randn(M).astype(np.float32), rng.randn(M).astype(np.float32)
+    scal, grads = o.loss_and_grads(s, a, R, A)
+    d = m.dev
+    sd, ad, Rd, Ad = m._to_dev(s, (M, 67)), m._to_dev(a, (M, 2)), m._to_dev(R, (M,)), m._to_dev(A, (M,))
+    d.forward_backward(sd, ad, Rd, Ad, M, 1.0 / M, 1.0)
+    L = d.losses.cpu().numpy()
+    for got, key in zip(L, ("policy_loss", "value_loss", "entropy_loss", "loss", "ratio_mean")):
+        assert got == pytest.approx(scal[key], rel=1e-4, abs=1e-6), (key, got, scal[key])
+    g = d.export_grads()
+    bad = {k: rel_err(g[k], grads[k]) for k in grads if rel_err(g[k], grads[k]) > 2e-4}
+    assert not bad, bad
+    d.grads.zero_()
+    # (2) one-call step vs the oracle's Adam on its own gradients
+    from oracle import vae_oracle as vo
+    before = {k: v.copy() for k, v in o.params.items()}
+    want = {k: v.copy() for k, v in before.items()}
+    adam = vo.AdamTF({k: v.shape for k, v in before.items()})
+    adam.step(want, grads, 1e-4)
+    from ppo import _adam_alpha
+    alpha = _adam_alpha(1e-4, 0.9, 0.999)
+    d.train_step(sd, ad, Rd, Ad, M, 1.0 / M, 1.0, alpha)
+    got = d.export_params()
+    for k in want:
+        sig = np.abs(grads[k]) > 1e-6                     # where Adam's first step is +-lr regardless of rounding
+        assert np.allclose(got[k][sig], want[k][sig], rtol=0, atol=2e-6), k
+        assert np.abs(got[k] - before[k]).max() <= 1.01e-4 + 1e-9
+    if M <= 256:
+        L2 = d.losses.cpu().numpy()
+        assert np.allclose(L2[:5], L[:5], rtol=1e-6, atol=1e-7)
+        assert np.allclose(L2[5:7], d.action_mean[:M].cpu().numpy().mean(0), rtol=1e-5)                                  # mean over the minibatch of action_mean
+        assert np.allclose(L2[7:9], np.exp(before["policy/action_logstd"]), rtol=1e-6)                                     # std = exp(logstd) before the step
+        # (3) cached log pi_old: same update from the same starting point
+        import torch
+        d.load_params(before)
+        d.adam_m.zero_(); d.adam_v.zero_()
+        lp = torch.empty(M, device=d.device)
+        d.logp_old(sd, ad, M, lp)
+        d.train_step(sd, ad, Rd, Ad, M, 1.0 / M, 1.0, alpha, logp_old=lp)
+        got2 = d.export_params()
+        for k in got:
+            assert np.allclose(got2[k], got[k], rtol=0, atol=1e-7), k
