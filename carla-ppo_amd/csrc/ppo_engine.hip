@@ -133,6 +133,13 @@ int stage_states(PpoEngine* e, void* st, const float* states, int M) {
 
 }  // namespace
 
+int mi_ppo_internal_fill(void* h, PpoFusedParams* q, const float* states, int M) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e || M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "ppo engine: bad handle or batch");
+    fill_fused(e, *q, states, M);
+    return MI_OK;
+}
+
 extern "C" {
 
 int mi_ppo_desc_size(void) { return (int)sizeof(MiPpoDesc); }

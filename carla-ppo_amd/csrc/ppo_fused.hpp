@@ -19,6 +19,9 @@ struct PpoFusedParams {
     float clip_eps, value_scale, entropy_scale, inv_m, grad_scale;
     float alpha, omb1, omb2, epsilon;                     // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); omb = 1 - beta
     int n_loss_blocks;
+    // rollout step (M = 1): the state is assembled on load: element k < st_split = states[k] + st_bias[k] (raw encoder mean + its bias), the rest
+    // comes from st_tail (the measurements); z_out receives the first st_split elements
+    const float* st_bias; const float* st_tail; int st_split; float* z_out;
 };
 
 }  // namespace mi
@@ -28,3 +31,7 @@ int mi_ppo_fused_trunks(hipStream_t st, const mi::PpoFusedParams& q);
 int mi_ppo_fused_step(hipStream_t st, mi::PpoFusedParams& q, int fuse_adam);
 int mi_ppo_fused_predict(hipStream_t st, mi::PpoFusedParams& q, const float* noise, int greedy, float* action, float* value);
 int mi_ppo_fused_logp_old(hipStream_t st, mi::PpoFusedParams& q, float* out);
+// internal accessors of the two engines for the rollout step (rollout path only)
+int mi_ppo_internal_fill(void* ppo_handle, mi::PpoFusedParams* q, const float* states, int M);
+int mi_rollout_conv(hipStream_t st, const float* x, const float* x_bias, int IH, int IW, int C, const float* w, int ldw, int N, int KH, int KW, float* out_raw, int flat_k);
+int mi_rollout_conv1(hipStream_t st, const unsigned char* frame, const float* w, const float* bias, float* out, int IH, int IW, int Cs, int KH, int KW, int N);

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "mi_internal.hpp"
 #include "mi355_carla.h"
+#include "ppo_fused.hpp"
 
 namespace {
 
@@ -67,6 +68,7 @@ struct Workspace {
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
+    long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
     long long total;
 };
@@ -167,6 +169,12 @@ void make_workspace(VaeEngine& e) {
     W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
     W.bits_act1 = add(B * g.ih[1] * g.iw[1] * (g.c[1] / 16) * 4); W.bits_dec3 = add(B * g.dh[3] * g.dw[3] * (g.dc[3] / 16) * 4);
+    {
+        long long n = 0;
+        for (int i = 1; i <= NCONV; ++i) n += (long long)g.ih[i] * g.iw[i] * g.c[i];
+        W.roll_bytes = (n + d.z_dim + 64) * 4;
+        W.roll = add(W.roll_bytes);
+    }
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256); W.idx_stage = add(B * 4); W.scalars = add(256);
     W.total = o;
 }
@@ -554,6 +562,35 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
     }
     if (hipGraphLaunch(e->gexec, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_vae_train_step: hipGraphLaunch failed");
     return MI_OK;
+}
+
+// One environment step of the rollout loop in ONE call (callers vae_common.py:45-61, train.py:142, run_eval.py:54):
+//   frame_u8 [IH,IW,3] raw camera bytes (device) -> /255 -> conv x 4 -> mean z -> state = [z, measurements] -> PPO.predict
+//   out (device, num_actions + 1 + z_dim floats) = [action | value | z]; noise [num_actions] (device) for sampling, NULL with greedy.
+// Exact fp32 on the fp32 master weights whatever the engine's storage type; 9 launches (rollout.hip), no host synchronisation inside.
+int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char* frame_u8, const float* measurements, int n_meas, const float* noise, int greedy, float* out) {
+    VaeEngine* e = (VaeEngine*)vae_h;
+    if (!e || !ppo_h) return mi_fail(MI_ERR_STATE, "mi_rollout_step: null handle");
+    if (!frame_u8 || !out || (n_meas > 0 && !measurements) || (!greedy && !noise)) return mi_fail(MI_ERR_ARG, "mi_rollout_step: missing buffers");
+    const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    hipStream_t st = (hipStream_t)stream;
+    float* roll = (float*)e->at(e->W.roll);
+    float* act[NCONV + 1]; act[0] = nullptr;
+    long long o = 0;
+    for (int i = 1; i <= NCONV; ++i) { act[i] = roll + o; o += (long long)g.ih[i] * g.iw[i] * g.c[i]; }
+    float* mean_raw = roll + o;
+    // raw-sum buffers of the split-K layers start at zero (conv1 writes its output directly)
+    if (hipMemsetAsync(act[2], 0, (size_t)((mean_raw + d.z_dim) - act[2]) * 4, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_rollout_step: memset failed");
+    CK(mi_rollout_conv1(st, frame_u8, e->params + e->L.off[0], e->bptr(1), act[1], g.ih[0], g.iw[0], g.c[0], 4, 4, g.c[1]));
+    for (int i = 1; i < NCONV; ++i)                      // conv(i+1): input act[i] (conv2 reads conv1's finished output, the others raw sums + bias + ReLU on load)
+        CK(mi_rollout_conv(st, act[i], i == 1 ? nullptr : e->bptr(2 * (i - 1) + 1), g.ih[i], g.iw[i], g.c[i], e->params + e->L.off[2 * i], g.c[i + 1], g.c[i + 1], 4, 4, act[i + 1], 0));
+    // mean head: the first z_dim columns of the fused [flat, 2 z] kernel; input = relu(conv4 raw + bias) flattened in (H, W, C) order
+    CK(mi_rollout_conv(st, act[NCONV], e->bptr(2 * (NCONV - 1) + 1), 1, 1, g.c[NCONV], e->params + e->L.off[8], 2 * d.z_dim, d.z_dim, 1, 1, mean_raw, g.flat));
+    mi::PpoFusedParams q;
+    CK(mi_ppo_internal_fill(ppo_h, &q, mean_raw, 1));
+    if (q.din != d.z_dim + n_meas) return mi_fail(MI_ERR_SHAPE, "mi_rollout_step: z_dim + measurements must equal the policy's input size");
+    q.st_bias = e->bptr(9); q.st_tail = measurements; q.st_split = d.z_dim; q.z_out = out + q.A + 1;
+    return mi_ppo_fused_predict(st, q, noise, greedy, out, out + q.A);
 }
 
 // VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32

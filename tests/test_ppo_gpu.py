@@ -216,3 +216,41 @@ def test_fused_step_gradients_update_and_cache_match_oracle(tmp_path, M):
         got2 = d.export_params()
         for k in got:
             assert np.allclose(got2[k], got[k], rtol=0, atol=1e-7), k
+
+
+def test_rollout_step_one_call_matches_encode_then_predict(tmp_path):
+    """mi_rollout_step (raw uint8 frame + measurements -> action, value, z in one call) against the oracle's
+    encode([frame / 255])[0] -> np.append(z, measurements) -> predict(state), fp32, 1e-4; sampled and greedy; and against the drop-in's own
+    two-call path (VAE.encode + PPO.predict)."""
+    from oracle import vae_oracle as vo
+    from rollout import RolloutStep
+    from vae.models import ConvVAE
+    rng = np.random.RandomState(21)
+    vparams = vo.init_vae_params(3)
+    for k in vparams:
+        if k.endswith("bias"):
+            vparams[k] = (0.05 * rng.standard_normal(vparams[k].shape)).astype(np.float32)
+    for precision in ("fp32", "bf16"):                    # the rollout path computes in exact fp32 on the master weights either way
+        vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / ("vae_" + precision)), precision=precision, training=False)
+        vae.set_weights(vparams)
+        vae.init_session(init_logging=False)
+        o, m = make_pair(tmp_path / ("ppo_" + precision))
+        ovae = vo.OracleVAE(params=vparams, training=False)
+        step = RolloutStep(vae, m)
+        for i in range(3):
+            frame = rng.randint(0, 256, (80, 160, 3), dtype=np.uint8)
+            meas = [float(rng.uniform(-1, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 30))]
+            noise = rng.standard_normal(2).astype(np.float32)
+            z_o = ovae.encode([frame.astype(np.float32) / 255.0])[0]
+            state_o = np.append(z_o, meas)
+            for greedy in (False, True):
+                a_o, v_o = o.predict(state_o, greedy=greedy, noise=None if greedy else noise[None])
+                a, v, state = step(frame, meas, greedy=greedy, noise=noise)
+                assert state.shape == (67,) and state.dtype == np.float64 and np.array_equal(state[64:], np.asarray(meas))
+                assert rel_err(state[:64], z_o) < 1e-4, (precision, i, rel_err(state[:64], z_o))
+                assert np.allclose(a, np.asarray(a_o).reshape(-1), rtol=1e-4, atol=1e-5) and v == pytest.approx(float(np.asarray(v_o).reshape(-1)[0]), rel=1e-4, abs=1e-5)
+        if precision == "fp32":                           # the two-call surface of the same engines
+            z2 = vae.encode([frame.astype(np.float32) / 255.0])[0]
+            a2, v2 = m.predict(np.append(z2, meas), greedy=True)
+            a, v, state = step(frame, meas, greedy=True)
+            assert rel_err(state[:64], z2) < 1e-5 and np.allclose(a, a2, atol=1e-5) and v == pytest.approx(float(v2), rel=1e-5, abs=1e-6)

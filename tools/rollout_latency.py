@@ -30,3 +30,13 @@ t_enc = []
 for i in range(200):
     t0 = time.perf_counter(); vae.encode([frames[i % 64]]); t_enc.append(time.perf_counter() - t0)
 print("encode + predict at batch 1: median %.0f us, p90 %.0f us (encode alone: median %.0f us)" % (np.median(ts), np.percentile(ts, 90), np.median(np.array(t_enc) * 1e6)))
+# the one-call form: raw uint8 frame + measurements -> action, value, state
+from rollout import RolloutStep
+step = RolloutStep(vae, agent)
+u8 = rng.randint(0, 256, (64, 80, 160, 3), dtype=np.uint8)
+for i in range(20): step(u8[i % 64], meas[i % 64])
+ts = []
+for i in range(500):
+    t0 = time.perf_counter(); step(u8[i % 64], meas[i % 64]); ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e6
+print("RolloutStep (one call, uint8 frame in, action / value / state out): median %.1f us, p90 %.1f us, min %.1f us" % (np.median(ts), np.percentile(ts, 90), ts.min()))
