@@ -89,8 +89,7 @@ __global__ __launch_bounds__(256) void ppo_l1_kernel(const PpoFusedParams q) {
 #pragma unroll
                       for (int e = 0; e < 4; ++e) {
                           const int ke = k + e;
-                          if (q.st_bias) a[e] = (mok && ke < q.din) ? (ke < q.st_split ? srow[ke] + q.st_bias[ke] : q.st_tail[ke - q.st_split]) : 0.f;
-                          else a[e] = (mok && ke < q.din) ? srow[ke] : 0.f;
+                          a[e] = (mok && ke < q.din) ? srow[ke] : 0.f;
                       }
                       return a; },
         [&](int s_) { const int k = s_ * 8 + lgrp * 4; f32x4 b;
@@ -492,7 +491,6 @@ __global__ __launch_bounds__(256) void ppo_predict_head_kernel(const PpoFusedPar
 #pragma unroll
         for (int a = 0; a < NA; ++a) au[a] += __shfl_xor(au[a], o, 64);
     }
-    if (q.z_out && blockIdx.x == 0 && tid < q.st_split) q.z_out[tid] = q.states[tid] + q.st_bias[tid];      // rollout step: the encoder mean
     if (part != 0 || m >= q.M) return;
     float lp = 0.f;
     _Pragma("unroll") for (int a = 0; a < NA; ++a) if (a < A) {

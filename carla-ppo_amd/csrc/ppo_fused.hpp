@@ -19,9 +19,6 @@ struct PpoFusedParams {
     float clip_eps, value_scale, entropy_scale, inv_m, grad_scale;
     float alpha, omb1, omb2, epsilon;                     // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); omb = 1 - beta
     int n_loss_blocks;
-    // rollout step (M = 1): the state is assembled on load: element k < st_split = states[k] + st_bias[k] (raw encoder mean + its bias), the rest
-    // comes from st_tail (the measurements); z_out receives the first st_split elements
-    const float* st_bias; const float* st_tail; int st_split; float* z_out;
 };
 
 }  // namespace mi
@@ -33,5 +30,7 @@ int mi_ppo_fused_predict(hipStream_t st, mi::PpoFusedParams& q, const float* noi
 int mi_ppo_fused_logp_old(hipStream_t st, mi::PpoFusedParams& q, float* out);
 // internal accessors of the two engines for the rollout step (rollout path only)
 int mi_ppo_internal_fill(void* ppo_handle, mi::PpoFusedParams* q, const float* states, int M);
+struct MiZeroList { float* p[3]; long long n[3]; };     // raw-sum buffers conv1's launch clears for the split-K layers behind it
 int mi_rollout_conv(hipStream_t st, const float* x, const float* x_bias, int IH, int IW, int C, const float* w, int ldw, int N, int KH, int KW, float* out_raw, int flat_k);
-int mi_rollout_conv1(hipStream_t st, const unsigned char* frame, const float* w, const float* bias, float* out, int IH, int IW, int Cs, int KH, int KW, int N);
+int mi_rollout_conv1(hipStream_t st, const unsigned char* frame, const float* w, const float* bias, float* out, int IH, int IW, int Cs, int KH, int KW, int N, const MiZeroList* zero);
+int mi_rollout_policy(hipStream_t st, const mi::PpoFusedParams& q, const float* mean_raw, const float* mean_bias, int z_dim, const float* measurements, const float* noise, int greedy, float* out);

@@ -567,7 +567,8 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
 // One environment step of the rollout loop in ONE call (callers vae_common.py:45-61, train.py:142, run_eval.py:54):
 //   frame_u8 [IH,IW,3] raw camera bytes (device) -> /255 -> conv x 4 -> mean z -> state = [z, measurements] -> PPO.predict
 //   out (device, num_actions + 1 + z_dim floats) = [action | value | z]; noise [num_actions] (device) for sampling, NULL with greedy.
-// Exact fp32 on the fp32 master weights whatever the engine's storage type; 9 launches (rollout.hip), no host synchronisation inside.
+// Exact fp32 on the fp32 master weights whatever the engine's storage type; 8 launches (rollout.hip), no host synchronisation inside.
+// `out` may be device memory or pinned (device-mapped) host memory: the head kernel stores its 67 floats straight into it.
 int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char* frame_u8, const float* measurements, int n_meas, const float* noise, int greedy, float* out) {
     VaeEngine* e = (VaeEngine*)vae_h;
     if (!e || !ppo_h) return mi_fail(MI_ERR_STATE, "mi_rollout_step: null handle");
@@ -579,18 +580,23 @@ int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char*
     long long o = 0;
     for (int i = 1; i <= NCONV; ++i) { act[i] = roll + o; o += (long long)g.ih[i] * g.iw[i] * g.c[i]; }
     float* mean_raw = roll + o;
-    // raw-sum buffers of the split-K layers start at zero (conv1 writes its output directly)
-    if (hipMemsetAsync(act[2], 0, (size_t)((mean_raw + d.z_dim) - act[2]) * 4, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_rollout_step: memset failed");
-    CK(mi_rollout_conv1(st, frame_u8, e->params + e->L.off[0], e->bptr(1), act[1], g.ih[0], g.iw[0], g.c[0], 4, 4, g.c[1]));
-    for (int i = 1; i < NCONV; ++i)                      // conv(i+1): input act[i] (conv2 reads conv1's finished output, the others raw sums + bias + ReLU on load)
-        CK(mi_rollout_conv(st, act[i], i == 1 ? nullptr : e->bptr(2 * (i - 1) + 1), g.ih[i], g.iw[i], g.c[i], e->params + e->L.off[2 * i], g.c[i + 1], g.c[i + 1], 4, 4, act[i + 1], 0));
-    // mean head: the first z_dim columns of the fused [flat, 2 z] kernel; input = relu(conv4 raw + bias) flattened in (H, W, C) order
-    CK(mi_rollout_conv(st, act[NCONV], e->bptr(2 * (NCONV - 1) + 1), 1, 1, g.c[NCONV], e->params + e->L.off[8], 2 * d.z_dim, d.z_dim, 1, 1, mean_raw, g.flat));
     mi::PpoFusedParams q;
     CK(mi_ppo_internal_fill(ppo_h, &q, mean_raw, 1));
     if (q.din != d.z_dim + n_meas) return mi_fail(MI_ERR_SHAPE, "mi_rollout_step: z_dim + measurements must equal the policy's input size");
-    q.st_bias = e->bptr(9); q.st_tail = measurements; q.st_split = d.z_dim; q.z_out = out + q.A + 1;
-    return mi_ppo_fused_predict(st, q, noise, greedy, out, out + q.A);
+    // the raw-sum buffers of the split-K layers start at zero: conv1 (which writes its own output directly) clears them in the same launch
+    MiZeroList zl = {};
+    zl.p[0] = act[2]; zl.n[0] = (mean_raw + d.z_dim) - act[2];
+    zl.p[1] = q.h1; zl.n[1] = 2LL * q.H1;
+    zl.p[2] = q.h2; zl.n[2] = 2LL * q.H2;
+    struct MiRolloutConv { const float* x; const float* x_bias; int IH, IW, C; const float* w; int ldw, N, KH, KW; float* out_raw; int flat_k; } cv[4];
+    for (int i = 1; i < NCONV; ++i)                      // conv(i+1): input act[i] (conv2 reads conv1's finished output, the others raw sums + bias + ReLU on load)
+        cv[i - 1] = MiRolloutConv{act[i], i == 1 ? nullptr : e->bptr(2 * (i - 1) + 1), g.ih[i], g.iw[i], g.c[i], e->params + e->L.off[2 * i], g.c[i + 1], g.c[i + 1], 4, 4, act[i + 1], 0};
+    // mean head: the first z_dim columns of the fused [flat, 2 z] kernel; input = relu(conv4 raw + bias) flattened in (H, W, C) order
+    cv[3] = MiRolloutConv{act[NCONV], e->bptr(2 * (NCONV - 1) + 1), 1, 1, g.c[NCONV], e->params + e->L.off[8], 2 * d.z_dim, d.z_dim, 1, 1, mean_raw, g.flat};
+    CK(mi_rollout_conv1(st, frame_u8, e->params + e->L.off[0], e->bptr(1), act[1], g.ih[0], g.iw[0], g.c[0], 4, 4, g.c[1], &zl));
+    for (int i = 0; i < 4; ++i)
+        CK(mi_rollout_conv(st, cv[i].x, cv[i].x_bias, cv[i].IH, cv[i].IW, cv[i].C, cv[i].w, cv[i].ldw, cv[i].N, cv[i].KH, cv[i].KW, cv[i].out_raw, cv[i].flat_k));
+    return mi_rollout_policy(st, q, mean_raw, e->bptr(9), d.z_dim, measurements, noise, greedy, out);
 }
 
 // VAE.encode (vae/models.py:199-202): frames -> mean [B,Z] fp32

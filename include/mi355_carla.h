@@ -194,7 +194,8 @@ int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out
 int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
 /* one environment step of the rollout loop in one call — vae_common.py:45-61 (encode_state) + ppo.py:231-251 (predict): raw uint8 frame [IH,IW,3] and
- * measurements (device) -> out [num_actions + 1 + z_dim] = action | value | z (device); noise [num_actions] for sampling or NULL with greedy.  Exact fp32. */
+ * measurements -> out [num_actions + 1 + z_dim] = action | value | z; noise [num_actions] for sampling or NULL with greedy.  Exact fp32.
+ * Every buffer may be HBM or pinned (device-mapped) host memory: with pinned buffers the step needs no copy in either direction. */
 int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char* frame_u8, const float* measurements, int n_meas, const float* noise, int greedy, float* out);
 
 /* per-op timing with HIP events recorded on the launch stream (bench.py's live roofline numbers) */

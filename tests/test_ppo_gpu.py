@@ -236,8 +236,8 @@ def test_rollout_step_one_call_matches_encode_then_predict(tmp_path):
         vae.init_session(init_logging=False)
         o, m = make_pair(tmp_path / ("ppo_" + precision))
         ovae = vo.OracleVAE(params=vparams, training=False)
-        step = RolloutStep(vae, m)
         for i in range(3):
+            step = RolloutStep(vae, m, io="device" if i == 1 else "pinned")
             frame = rng.randint(0, 256, (80, 160, 3), dtype=np.uint8)
             meas = [float(rng.uniform(-1, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 30))]
             noise = rng.standard_normal(2).astype(np.float32)

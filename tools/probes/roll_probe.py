@@ -1,0 +1,75 @@
+import os, sys, time, ctypes
+import numpy as np
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "carla-ppo_amd"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from vae.models import ConvVAE
+from ppo import PPO
+from rollout import RolloutStep
+import tempfile
+d = tempfile.mkdtemp()
+vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=d + "/v", training=False); vae.init_session(init_logging=False)
+class Box:
+    low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
+agent = PPO(np.array([67]), Box(), model_dir=d + "/p"); agent.init_session(init_logging=False)
+step = RolloutStep(vae, agent)
+rng = np.random.RandomState(0)
+u8 = rng.randint(0, 256, (64, 80, 160, 3), dtype=np.uint8)
+meas = rng.rand(64, 3)
+for i in range(50): step(u8[i % 64], meas[i % 64])
+st = torch.cuda.current_stream()
+L = step.L
+T = np.zeros((500, 5))
+for i in range(500):
+    t0 = time.perf_counter()
+    step._in_np[:step.frame_bytes] = u8[i % 64].reshape(-1); step._f_np[:3] = meas[i % 64]; step._f_np[3:] = 0.1
+    t1 = time.perf_counter()
+    step.d_in.copy_(step.h_in, non_blocking=True)
+    t2 = time.perf_counter()
+    base = step.d_in.data_ptr(); fptr = base + step._noise_off
+    L.mi_rollout_step(vae.dev.handle, agent.dev.handle, st.cuda_stream, base, fptr, 3, fptr + 12, 0, step.h_out.data_ptr())
+    t3 = time.perf_counter()
+    st.synchronize()
+    t4 = time.perf_counter()
+    o = step._out_np[:3].copy()
+    t5 = time.perf_counter()
+    T[i] = [t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4]
+print("host pack %.1f | copy_ enqueue %.1f | rollout call %.1f | synchronize %.1f | unpack %.1f  (us, medians)" % tuple(np.median(T, 0) * 1e6))
+# variants: hipMemcpyAsync through ctypes, stream.query() spin
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+hip.hipStreamQuery.argtypes = [ctypes.c_void_p]
+hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+n = step.h_in.numel(); hp = step.h_in.data_ptr(); dp = step.d_in.data_ptr(); sp = st.cuda_stream
+for mode in ("sync", "query"):
+    ts = []
+    for i in range(500):
+        t0 = time.perf_counter()
+        step._in_np[:step.frame_bytes] = u8[i % 64].reshape(-1); step._f_np[:3] = meas[i % 64]; step._f_np[3:] = 0.1
+        hip.hipMemcpyAsync(dp, hp, n, 1, sp)
+        L.mi_rollout_step(vae.dev.handle, agent.dev.handle, sp, dp, dp + step._noise_off, 3, dp + step._noise_off + 12, 0, step.h_out.data_ptr())
+        if mode == "sync": hip.hipStreamSynchronize(sp)
+        else:
+            while hip.hipStreamQuery(sp) != 0: pass
+        o = step._out_np[:3].copy()
+        ts.append(time.perf_counter() - t0)
+    print("ctypes hipMemcpyAsync + %s: median %.1f us, min %.1f" % (mode, np.median(ts) * 1e6, np.min(ts) * 1e6))
+# zero-copy: the kernels read the packed pinned host buffer directly (frame bytes, measurements, noise)
+ts = []
+for i in range(500):
+    t0 = time.perf_counter()
+    step._in_np[:step.frame_bytes] = u8[i % 64].reshape(-1); step._f_np[:3] = meas[i % 64]; step._f_np[3:] = 0.1
+    L.mi_rollout_step(vae.dev.handle, agent.dev.handle, sp, hp, hp + step._noise_off, 3, hp + step._noise_off + 12, 0, step.h_out.data_ptr())
+    hip.hipStreamSynchronize(sp)
+    o = step._out_np[:3].copy()
+    ts.append(time.perf_counter() - t0)
+print("zero-copy in and out + sync: median %.1f us, min %.1f" % (np.median(ts) * 1e6, np.min(ts) * 1e6))
+a0 = step(u8[5], meas[5], greedy=True)
+step._in_np[:step.frame_bytes] = u8[5].reshape(-1); step._f_np[:3] = meas[5]
+L.mi_rollout_step(vae.dev.handle, agent.dev.handle, sp, hp, hp + step._noise_off, 3, None, 1, step.h_out.data_ptr()); hip.hipStreamSynchronize(sp)
+print("same result:", np.array_equal(a0[0], step._out_np[:2]), a0[1] == step._out_np[2])
+
+for i in range(300):
+    step._in_np[:step.frame_bytes] = u8[i % 64].reshape(-1); step._f_np[:3] = meas[i % 64]
+    L.mi_rollout_step(vae.dev.handle, agent.dev.handle, sp, hp, hp + step._noise_off, 3, hp + step._noise_off + 12, 0, step.h_out.data_ptr())
+    hip.hipStreamSynchronize(sp)

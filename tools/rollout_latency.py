@@ -39,4 +39,4 @@ ts = []
 for i in range(500):
     t0 = time.perf_counter(); step(u8[i % 64], meas[i % 64]); ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e6
-print("RolloutStep (one call, uint8 frame in, action / value / state out): median %.1f us, p90 %.1f us, min %.1f us" % (np.median(ts), np.percentile(ts, 90), ts.min()))
+print("RolloutStep (one call, uint8 frame in, action / value / state out; io=%s): median %.1f us, p90 %.1f us, min %.1f us" % (step.io, np.median(ts), np.percentile(ts, 90), ts.min()))
