@@ -425,7 +425,8 @@ def main():
         midist.barrier()
         midist.broadcast(dev.params, 0); dev.sync_shadow()
         dp = {"ms_per_step_by_rank": [float(x[0].item()) for x in per_rank], "ms_per_step_without_allreduce_rank0": t_nocomm,
-              "exposed_allreduce_ms_rank0": max(t_local / args.steps * 1e3 - t_nocomm, 0.0), "gradient_bytes_per_step": int(dev.n_flat) * 4, "buckets": 3}
+              "exposed_allreduce_ms_rank0": max(t_local / args.steps * 1e3 - t_nocomm, 0.0), "gradient_bytes_per_step": int(dev.n_flat) * 4, "buckets": 3,
+              "transport": midist.comm_note}
 
     if rank == 0:
         frames_per_s = B * world * args.steps / elapsed

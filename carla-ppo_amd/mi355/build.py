@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
                 print("[mi355.build] compiled", os.path.basename(done), flush=True)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
     if force or jobs or not os.path.exists(LIB):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
         if verbose:

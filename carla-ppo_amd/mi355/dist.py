@@ -1,6 +1,13 @@
-"""Data parallelism: one process per GPU, gradients all-reduced with torch.distributed (backend "nccl" = RCCL over
-xGMI on ROCm; "gloo" in the CPU tests).  The reference has no distributed code at all — this is the new
-component BASELINE configs 4-5 ask for.
+"""Data parallelism: one process per GPU; gradients are summed across ranks by RCCL over xGMI.  The reference has no distributed code at
+all — this is the new component BASELINE configs 4-5 ask for.
+
+Two transports behind the same four functions (all_reduce_sum, broadcast, barrier, world_size):
+  * the library's own communicator (csrc/comm.hip: mi_comm_init / mi_allreduce_sum_f32[_async] / mi_comm_wait / mi_broadcast), which calls RCCL
+    directly on the engine's stream — used for fp32 device tensors whenever the process group's backend is "nccl" (MI355_COMM=torch turns it
+    off).  torch.distributed is then only the rendezvous: it carries the 128-byte RCCL id from rank 0 to the others and reduces host-side
+    scalars.  Before it is trusted the communicator sums a known vector and every rank checks the result; any failure (library missing,
+    init error, wrong sum) falls back, on all ranks together, to
+  * torch.distributed collectives (backend "nccl" = the same RCCL; "gloo" in the CPU tests, where there is no device buffer to reduce).
 
 Scheme: every rank draws the SAME host permutation (same legacy-numpy seed), takes rows
 [r*B/W, (r+1)*B/W) of each global minibatch, computes gradients of  sum_local(loss_i) / B_global,  and the flat fp32
@@ -33,6 +40,97 @@ def init_from_env(backend=None):
     return world, rank, local
 
 
+class _MiComm:
+    """The C-ABI communicator of this process (include/mi355_carla.h, collectives section)."""
+
+    def __init__(self, handle, L):
+        self.handle, self.L = handle, L
+
+    def usable(self, t):
+        return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
+    def all_reduce(self, t, async_op=False):
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        if async_op:
+            self.L.mi_allreduce_sum_f32_async(self.handle, st, t.data_ptr(), t.numel())
+            return self
+        self.L.mi_allreduce_sum_f32(self.handle, st, t.data_ptr(), t.numel())
+        return None
+
+    def wait(self):                                    # joins every bucket queued so far (device-side; later handles find nothing pending)
+        self.L.mi_comm_wait(self.handle, torch.cuda.current_stream().cuda_stream)
+
+    def broadcast(self, t, src):
+        self.L.mi_broadcast(self.handle, torch.cuda.current_stream(t.device).cuda_stream, t.data_ptr(), t.numel() * t.element_size(), src)
+
+
+_mi_comm = None
+_mi_comm_tried = False
+comm_note = "single process"                          # which transport carries the gradient all-reduce (bench.py reports it)
+
+
+def _all_agree(ok, device):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def mi_comm():
+    """The library communicator, created on first use from the default process group (backend nccl only); None when torch carries the traffic."""
+    global _mi_comm, _mi_comm_tried, comm_note
+    if _mi_comm_tried or world_size() == 1:
+        return _mi_comm
+    _mi_comm_tried = True
+    backend = dist.get_backend()
+    comm_note = "torch.distributed (%s)" % backend
+    if backend != "nccl" or os.environ.get("MI355_COMM", "rccl") == "torch" or not torch.cuda.is_available():
+        return None
+    import ctypes
+    from mi355 import lib as milib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    W, r = dist.get_world_size(), dist.get_rank()
+    # 1. everything that can fail locally, agreed on before the collective init (a rank that cannot load RCCL must not leave the others waiting)
+    L, nbytes, ok = None, 128, True
+    try:
+        L = milib.get()
+        nbytes = L.mi_comm_id_bytes()
+    except Exception:
+        ok = False
+    idt = torch.zeros(nbytes, dtype=torch.uint8)
+    if ok and r == 0:
+        try:
+            L.mi_comm_unique_id(idt.data_ptr())
+        except Exception:
+            ok = False
+    if not _all_agree(ok, dev):
+        return None
+    idd = idt.to(dev)
+    dist.broadcast(idd, src=0)                          # the rendezvous: 128 bytes over the channel the process group already has
+    idt = idd.cpu()
+    # 2. collective init, then a known sum checked on every rank
+    handle = ctypes.c_void_p()
+    try:
+        L.mi_comm_init(ctypes.addressof(handle), r, W, idt.data_ptr())
+        c = _MiComm(handle, L)
+        probe = torch.full((4096,), float(r + 1), dtype=torch.float32, device=dev)
+        c.all_reduce(probe)
+        c.all_reduce(probe[:1024], async_op=True).wait()
+        torch.cuda.synchronize(dev)
+        want = W * (W + 1) / 2.0
+        ok = bool((probe[1024:] == want).all().item()) and bool((probe[:1024] == want * W).all().item())
+        b = torch.full((256,), float(r), dtype=torch.float32, device=dev)
+        c.broadcast(b, 0)
+        torch.cuda.synchronize(dev)
+        ok = ok and bool((b == 0).all().item())
+    except Exception:
+        ok, c = False, None
+    if not _all_agree(ok, dev):
+        return None
+    _mi_comm = c
+    comm_note = "mi_comm (RCCL through the C ABI, on the engine's stream)"
+    return _mi_comm
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -59,12 +157,19 @@ def all_reduce_sum(t, async_op=False):
     """In-place sum over ranks of a flat tensor (gradient bucket / metric accumulators)."""
     if world_size() == 1:
         return None
+    c = mi_comm()
+    if c is not None and c.usable(t):
+        return c.all_reduce(t, async_op)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 def broadcast(t, src=0):
     if world_size() > 1:
-        dist.broadcast(t, src=src)
+        c = mi_comm()
+        if c is not None and c.usable(t):
+            c.broadcast(t, src)
+        else:
+            dist.broadcast(t, src=src)
 
 
 def barrier():

@@ -198,6 +198,23 @@ int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, co
  * Every buffer may be HBM or pinned (device-mapped) host memory: with pinned buffers the step needs no copy in either direction. */
 int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char* frame_u8, const float* measurements, int n_meas, const float* noise, int greedy, float* out);
 
+/* ---- collectives of the data-parallel path (no reference counterpart: the reference is single-process) ----
+ * RCCL over xGMI, one communicator per process = per GPU; librccl.so.1 is bound at mi_comm_init (a single-GPU process never loads it).
+ * Rendezvous: rank 0 calls mi_comm_unique_id, the mi_comm_id_bytes() = 128 bytes travel to the other ranks by any out-of-band channel, every
+ * rank calls mi_comm_init (collective).  All calls below enqueue on HIP streams and never synchronise the host.
+ *   mi_allreduce_sum_f32        buf <- sum over ranks, in stream order on `stream` (gradient buffer / metric accumulators)
+ *   mi_allreduce_sum_f32_async  the same on the communicator's own stream, after what `stream` holds so far: a gradient bucket's all-reduce
+ *                               runs under the next part of the backward pass; mi_comm_wait(comm, stream) joins before the optimiser step
+ *   mi_broadcast                rank `root`'s bytes to every rank (the initial parameter replica, vae/models.py / ppo.py init_session) */
+int mi_comm_id_bytes(void);
+int mi_comm_unique_id(unsigned char* id_out);
+int mi_comm_init(void** comm_out, int rank, int world, const unsigned char* id);
+int mi_comm_destroy(void* comm);
+int mi_allreduce_sum_f32(void* comm, void* stream, float* buf, long long n);
+int mi_allreduce_sum_f32_async(void* comm, void* stream, float* buf, long long n);
+int mi_comm_wait(void* comm, void* stream);
+int mi_broadcast(void* comm, void* stream, void* buf, long long bytes, int root);
+
 /* per-op timing with HIP events recorded on the launch stream (bench.py's live roofline numbers) */
 int mi_vae_op_count(void);
 const char* mi_vae_op_name(int op);

@@ -61,16 +61,40 @@ def run(m, frames, eps):
     return grads, np.asarray(losses, np.float64), m.dev.export_params()
 
 
-def main(out):
-    world, rank, _ = midist.init_from_env("gloo")
-    torch.cuda.set_device(0)
+def ppo_batch():
+    rng = np.random.RandomState(5)
+    return (rng.standard_normal((32, 67)), np.stack([rng.uniform(-1, 1, 32), rng.uniform(0, 1, 32)], 1), rng.standard_normal(32), rng.standard_normal(32))
+
+
+def run_ppo(model_dir):
+    """PPO.train on a global minibatch of 32: every rank passes ITS 16 rows (ppo.py's data-parallel contract); 3 steps; losses and parameters."""
+    from ppo import PPO
+
+    class Box:
+        low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
+    m = PPO(np.array([67]), Box(), model_dir=model_dir, seed=3)
+    m.init_session(init_logging=False)
+    s, a, r, adv = ppo_batch()
+    lo, hi = midist.shard_bounds(32)
+    out = []
+    for _ in range(3):
+        L = m.train_step(s[lo:hi], a[lo:hi], r[lo:hi], adv[lo:hi])
+        out.append([L["policy_loss"], L["value_loss"], L["entropy_loss"], L["loss"], L["prob_ratio"]])
+    torch.cuda.synchronize()
+    return np.asarray(out, np.float64), m.dev.params.cpu().numpy().copy()
+
+
+def main(out, backend="gloo"):
+    world, rank, local = midist.init_from_env(backend)
+    torch.cuda.set_device(local if backend == "nccl" else 0)     # nccl: one device per rank (RCCL over xGMI); gloo: both ranks share cuda:0
     import test_vae_gpu as T
     frames, eps = dataset()
     m = build(os.path.join(out, "model_rank%d" % rank), T.trained_like_params(2))
     grads, losses, params = run(m, frames, eps)
-    np.savez(os.path.join(out, "rank%d.npz" % rank), losses=losses, world=world,
+    ppo_losses, ppo_params = run_ppo(os.path.join(out, "ppo_rank%d" % rank))
+    np.savez(os.path.join(out, "rank%d.npz" % rank), losses=losses, world=world, comm=np.array(midist.comm_note), ppo_losses=ppo_losses, ppo_params=ppo_params,
              **{"g|" + k.replace("/", "|"): v for k, v in grads.items()}, **{"p|" + k.replace("/", "|"): v for k, v in params.items()})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "gloo")

@@ -442,22 +442,64 @@ def test_mlp_vae_bf16_trains_and_checkpoints(tmp_path):
     assert m.train_step(src, src, eps=eps) == pytest.approx(m2.train_step(src, src, eps=eps), rel=1e-6)
 
 
-def test_data_parallel_two_ranks_on_the_gpu(tmp_path):
-    """The product's data-parallel path end to end with world_size 2 (two ranks sharing this GPU over gloo, tests/dp_gpu_worker.py): the
-    all-reduced gradients of a global minibatch equal the single-process gradients of the same minibatch, the epoch metrics agree, both
-    ranks end with identical parameters, and those equal the single-process result up to Adam's sensitivity where |g| ~ 1e-8."""
+def test_comm_c_abi_one_rank_world():
+    """The collective half of the C ABI against the real RCCL on this box, world size 1 (what one GPU allows): rendezvous id, communicator,
+    in-stream and side-stream all-reduce (identity at one rank), the join, broadcast, destroy.  librccl.so.1 is bound at run time."""
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    assert L.mi_comm_id_bytes() == 128
+    idb = np.zeros(128, np.uint8)
+    L.mi_comm_unique_id(idb.ctypes.data)
+    assert idb.any()
+    h = ctypes.c_void_p()
+    L.mi_comm_init(ctypes.addressof(h), 0, 1, idb.ctypes.data)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.randn(100003, device="cuda")
+        ref = x.clone()
+        L.mi_allreduce_sum_f32(h, st, x.data_ptr(), x.numel())
+        y = x * 2                                           # work queued behind the bucket on the caller's stream
+        L.mi_allreduce_sum_f32_async(h, st, x.data_ptr(), 4096)
+        L.mi_allreduce_sum_f32_async(h, st, x.data_ptr() + 4 * 4096, x.numel() - 4096)
+        L.mi_comm_wait(h, st)
+        L.mi_comm_wait(h, st)                               # nothing pending: no-op
+        L.mi_broadcast(h, st, x.data_ptr(), x.numel() * 4, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref) and torch.equal(y, ref * 2)
+        with pytest.raises(milib.MiError):
+            L.mi_broadcast(h, st, x.data_ptr(), 16, 3)      # root outside the communicator
+    finally:
+        L.mi_comm_destroy(h)
+
+
+def _run_two_ranks(tmp_path, backend, port):
     import subprocess
     import sys
-    import dp_gpu_worker as W
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "dp")
     os.makedirs(out)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+                        "--master-port", port, os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out, backend], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    r0, r1 = np.load(os.path.join(out, "rank0.npz")), np.load(os.path.join(out, "rank1.npz"))
+    return np.load(os.path.join(out, "rank0.npz")), np.load(os.path.join(out, "rank1.npz"))
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_data_parallel_two_ranks_on_the_gpu(tmp_path, backend):
+    """The product's data-parallel path end to end with world_size 2 (tests/dp_gpu_worker.py): the all-reduced gradients of a global minibatch
+    equal the single-process gradients of the same minibatch, the epoch metrics agree, both ranks end with identical parameters, and those
+    equal the single-process result up to Adam's sensitivity where |g| ~ 1e-8.
+    gloo: two ranks share this GPU (RCCL refuses two ranks on one device; gloo reduces device tensors through the host).
+    nccl: one device per rank, gradients summed by the library's own communicator (mi_comm, RCCL through the C ABI); needs two devices."""
+    import dp_gpu_worker as W
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL run needs two devices; this box has %d" % torch.cuda.device_count())
+    r0, r1 = _run_two_ranks(tmp_path, backend, "29541" if backend == "gloo" else "29543")
     assert int(r0["world"]) == 2
+    if backend == "nccl":
+        assert str(r0["comm"]).startswith("mi_comm"), str(r0["comm"])
     frames, eps = W.dataset()
     m = W.build(str(tmp_path / "single"), trained_like_params(2))
     grads, losses, params = W.run(m, frames, eps)
@@ -470,6 +512,11 @@ def test_data_parallel_two_ranks_on_the_gpu(tmp_path):
         key = "p|" + k.replace("/", "|")
         assert np.array_equal(r0[key], r1[key]), k                                   # replicas stay bit-identical
         assert rel_err(r0[key], v) < 2e-2, (k, rel_err(r0[key], v))
+    # PPO.train under data parallelism (each rank passes its 16 of 32 rows): the global loss scalars and the replicas against one process on all 32
+    pl, pp = W.run_ppo(str(tmp_path / "ppo_single"))
+    assert np.array_equal(r0["ppo_params"], r1["ppo_params"]) and np.array_equal(r0["ppo_losses"], r1["ppo_losses"])
+    assert np.allclose(r0["ppo_losses"], pl, rtol=2e-4, atol=1e-6), (r0["ppo_losses"], pl)
+    assert rel_err(r0["ppo_params"], pp) < 1e-4, rel_err(r0["ppo_params"], pp)
 
 
 def test_uint8_frame_tables_upload_bit_exact(tmp_path):
