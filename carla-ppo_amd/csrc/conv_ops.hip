@@ -99,31 +99,9 @@ int tapconv_minblocks() {
 int g_tap_direct = 1;                                      // tapconv epilogue: 1 registers -> 16-byte stores, 0 LDS-staged; mi_set_tuning key 6
 int g_tap_variant = 0;                                    // 0 auto, 1 big tile (256 x 96), 2 small tile (128 x 48); mi_set_tuning key 5
 
-// tapconv grid (mi_set_tuning key 8, MI355_TAP_PERSIST): 0 one block per tile; 1 persistent blocks over tile ranges (tapconv_persist.hpp,
-// experimental), as many as are resident at once; N > 1: at most N persistent blocks per output column (tests: several tiles per block at small sizes)
-int g_tap_persist = -1;
-static int tap_persist() {
-    if (g_tap_persist < 0) { const char* e = getenv("MI355_TAP_PERSIST"); g_tap_persist = e ? atoi(e) : 0; if (g_tap_persist < 0) g_tap_persist = 0; }
-    return g_tap_persist;
-}
-
 template <typename T, int MODE, int TAPS, int BMT, int MAXHALO>
 int launch_tapconv_v(hipStream_t st, const TapParams& q) {
     const int gx = (q.MP + BMT - 1) / BMT;
-    if constexpr (std::is_same<T, bf16_t>::value) {
-        if (tap_persist() && q.direct_epilogue && !q.trace) {
-            // as many blocks as are resident at once (155 KB of LDS per 256-position block, 77 KB per 128-position block), each walking a
-            // contiguous range of tiles
-            const int gy = q.NE >= 128 ? (q.NE + 127) / 128 : (q.NE + 63) / 64;
-            int px = (256 * (BMT == 128 ? 2 : 1)) / gy;
-            if (px < 1) px = 1;
-            if (tap_persist() > 1 && px > tap_persist()) px = tap_persist();
-            if (px > gx) px = gx;
-            if (q.NE >= 128) hipLaunchKernelGGL((tapconv_persist_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), dim3(px, gy, 1), dim3(BMT * 2), 0, st, q);
-            else hipLaunchKernelGGL((tapconv_persist_kernel<T, MODE, 64, TAPS, BMT, MAXHALO>), dim3(px, gy, 1), dim3(BMT * 2), 0, st, q);
-            return mi_check_launch("tapconv_persist_kernel");
-        }
-    }
     if (q.NE >= 128) {
         dim3 g(gx, (q.NE + 127) / 128, 1);
         hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
@@ -342,11 +320,18 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     return rc == MI_OK ? 1 : rc;
 }
 
+static bool narrow_lean_enabled() {                       // MI355_NARROW_LEAN=0: the first-generation narrow-layer kernels (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_NARROW_LEAN"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
 // gather-form transposed conv into a narrow output (narrow_tile.hpp): 4N <= 32 output columns, 64- or 128-byte input pixels
 template <typename T, int TAPS, int CPR>
 int launch_gather_narrow(hipStream_t st, const TapParams& q) {
     dim3 g((q.MP + GN_BMT - 1) / GN_BMT);
-    if (q.N == 3) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3>), g, dim3(GN_NT), 0, st, q);
+    if (q.N == 3 && sizeof(T) == 2 && q.labels && q.loss_kind == 0 && narrow_lean_enabled()) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3, true>), g, dim3(GN_NT), 0, st, q);
+    else if (q.N == 3) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3>), g, dim3(GN_NT), 0, st, q);
     else if (q.N == 1) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 1>), g, dim3(GN_NT), 0, st, q);
     else hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 0>), g, dim3(GN_NT), 0, st, q);
     return mi_check_launch("gather_narrow_kernel");
@@ -472,6 +457,30 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     q.bits_out = (dtype == MI_BF16 && relu) ? (uint32_t*)bits_out : nullptr; q.mask_bits = dtype == MI_BF16 ? (const uint32_t*)mask_bits : nullptr;
     if (bits_out && !q.bits_out) return 0;                // the caller asked for ReLU bits this kernel cannot write
     dim3 g((unsigned)((M + 127) / 128));
+    // the model's geometry (K = 48 as 4 rows of 12) in bf16: the instruction-lean form; mode 0 = bias + ReLU (+ bit words), mode 1 = masked by bit words
+    const int lean = (dtype == MI_BF16 && KH == 4 && run == 12 && M * 64 < (1ll << 31) && narrow_lean_enabled())
+                         ? ((bias && relu && !mask && !mask_bits) ? 1 : ((!bias && !relu && mask_bits && !bits_out) ? 2 : 0)) : 0;
+    if (lean) {
+        // persistent: as many four-wave blocks as stay resident (5-8 per compute unit by register count), each wave walks tiles with a one-tile prefetch
+        const long long tiles4 = (M + 127) / 128;
+        static int resident[3][2];                        // [source type][mode]: blocks the device holds at once (queried once)
+        auto grid_of = [&](const void* fn, int si, int mi) {
+            if (!resident[si][mi]) {
+                int per_cu = 0, dev = 0, cus = 256;
+                hipDeviceProp_t pr;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+                resident[si][mi] = per_cu * cus;
+            }
+            return dim3((unsigned)(tiles4 < resident[si][mi] ? tiles4 : resident[si][mi]));
+        };
+#define NC48(TS, SI) do { if (lean == 1) hipLaunchKernelGGL((narrow_conv48_kernel<TS, 0>), grid_of((const void*)narrow_conv48_kernel<TS, 0>, SI, 0), dim3(256), 0, st, q); \
+                          else hipLaunchKernelGGL((narrow_conv48_kernel<TS, 1>), grid_of((const void*)narrow_conv48_kernel<TS, 1>, SI, 1), dim3(256), 0, st, q); } while (0)
+        if (src_f32 == 2) NC48(unsigned char, 0); else if (src_f32) NC48(float, 1); else NC48(bf16_t, 2);
+#undef NC48
+        const int rc = mi_check_launch("narrow_conv48_kernel");
+        return rc == MI_OK ? 1 : rc;
+    }
     if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
     else if (src_f32 == 2) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
     else if (src_f32) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
@@ -667,7 +676,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 2) { prev = g_wgrad_skip; g_wgrad_skip = value; }
     else if (key == 5) { prev = g_tap_variant; g_tap_variant = value; }
     else if (key == 6) { prev = g_tap_direct; g_tap_direct = value ? 1 : 0; }
-    else if (key == 8) { prev = tap_persist(); g_tap_persist = value < 0 ? 0 : value; }
+    else if (key == 8) { prev = 0; }                     // (was: persistent tapconv blocks, removed -- rwconv.hip is the persistent form that won)
     else if (key == 4) { prev = narrow_enabled() ? 1 : 0; g_narrow_on = value ? 1 : 0; }
     else if (key == 3) { prev = tapwgrad_enabled() ? 1 : 0; g_tapwgrad_on = value ? 1 : 0; }
     else if (key == 7) { prev = g_tapwgrad_split; g_tapwgrad_split = value ? 1 : 0; }

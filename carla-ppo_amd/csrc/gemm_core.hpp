@@ -5,7 +5,6 @@
 //                                              (deconv fwd, conv dgrad)
 //   gemm2_tile.hpp  gemm2_kernel               same contractions for the wide layers: LDS-DMA tiles, XOR-swizzled LDS, 128-B K stages
 //   tapconv_tile.hpp tapconv_kernel            stride-2 conv / transposed conv as a stride-1 tap conv on raw-staged slot tiles
-//   tapconv_persist.hpp tapconv_persist_kernel  the same with persistent blocks over tile ranges (experimental, off: mi_set_tuning key 8)
 //   wgrad_tile.hpp  wgrad_kernel               dW[kc,n] += sum_m im2col(big)[m,kc] * small[m,n]   (conv/deconv/dense wgrad)
 //
 //   tapwgrad_tile.hpp tapwgrad_kernel          bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles
@@ -19,7 +18,6 @@
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
 #include "tapconv_tile.hpp"
-#include "tapconv_persist.hpp"
 #include "wgrad_tile.hpp"
 #include "tapwgrad_tile.hpp"
 #include "narrow_tile.hpp"

@@ -22,7 +22,11 @@ template <int CPR> __device__ __forceinline__ int gn_swz(int row) { return CPR =
 
 // C (input channels) * sizeof(T) must be 64 or 128 bytes: CPR = 4 | 8 sixteen-byte chunks per pixel
 // NOUT: output channels when known at compile time (3 rgb, 1 segmentation: packed dword stores), 0 = generic element stores
-template <typename T, int TAPS, int CPR, int NOUT>
+// FASTBCE (bf16 storage, loss_kind 0 only): the fused sigmoid-cross-entropy on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32,
+// 1 ulp each, arguments in (1, 2]) -- 13 VALU instructions per logit against 93 for the correctly rounded library forms.  The layer is VALU-issue
+// bound (a wave64 VALU instruction holds the 16-lane SIMD for 4 cycles; 1,100 of them per 32 positions were 55 us of a 72 us launch), so the
+// instruction count IS its run time; the fp32 engine (parity mode) keeps the library forms.
+template <typename T, int TAPS, int CPR, int NOUT, bool FASTBCE = false>
 __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_narrow_kernel(const TapParams p) {
     constexpr int ESZ = (int)sizeof(T);
     constexpr int VE = 16 / ESZ;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
         const bool rowok = ne < p.NE;
         const uint32_t cls = rowok ? p.div_n.div((uint32_t)ne) : 0u;
         const int n = ne - (int)cls * p.N;
-        const T* __restrict__ W = (const T*)p.b;
+        // through a descriptor that ends with the kernel: rows / taps / channel chunks outside it read 0 from the range check (no per-element selects)
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.b, 0, p.KH * p.KW * p.N * p.C * ESZ, 0x00020000);
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             const int ta = tap / TAPS, tb = tap % TAPS;
@@ -94,11 +99,8 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
             for (int kk = 0; kk < NKK; ++kk) {
                 const int c0 = (2 * kk + lgrp) * VE;
                 const bool ok = rowok && kh < p.KH && kw < p.KW && c0 < p.C;
-                const T* src = ok ? W + ((long long)(kh * p.KW + kw) * p.N + n) * p.C + c0 : W;
-                freg v = *(const freg*)src;
-#pragma unroll
-                for (int e = 0; e < (int)(sizeof(freg) / sizeof(v[0])); ++e) v[e] = ok ? v[e] : (decltype(v[0] + 0))0;
-                wf[tap][kk] = v;
+                const uint32_t off = ok ? (uint32_t)((((kh * p.KW + kw) * p.N + n) * p.C + c0) * ESZ) : G2_OOB;
+                wf[tap][kk] = __builtin_bit_cast(freg, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)off, 0, 0));
             }
         }
     }
@@ -192,6 +194,18 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
                 for (int j = 0; j < CNT; ++j) {
                     float xv;
                     if constexpr (ESZ == 2) xv = bf16_to_f32((bf16_t)(j & 1 ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu)); else xv = v[j];
+                    if constexpr (FASTBCE) {                 // loss_kind 0: max(x, 0) - x y + log(1 + exp(-|x|)), gradient sigmoid(x) - y
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
+                        const float s1 = 1.0f + e;
+                        const float r = __builtin_amdgcn_rcpf(s1);
+                        const float sg = xv >= 0.f ? r : e * r;
+                        lsum += fmaf(__builtin_amdgcn_logf(s1), 0.69314718f, fmaf(-xv, yv[j], fmaxf(xv, 0.f)));
+                        gq[j] = Elem<T>::from_f32((sg - yv[j]) * p.inv_b);
+                        const float gst = Elem<T>::to_f32(gq[j]);
+                        const int c = j % NOUT;
+                        if (c == 0) gs0 += gst; else if (c == 1) gs1 += gst; else gs2 += gst;
+                        continue;
+                    }
                     const float e = __expf(-fabsf(xv));
                     const float r = __frcp_rn(1.0f + e);
                     const float sg = xv >= 0.f ? r : e * r;
@@ -614,6 +628,142 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[k].v[t]) > 0.f ? o.v[t] : (T)0;
         }
         *(PackN<T, VE>*)((T*)p.out + off) = o;
+    }
+}
+
+// =====================================================================================================================
+// narrow_conv48_kernel — the bf16 form of narrow_conv_kernel for the geometry the model has (KH = 4, KW * Cs = 12: K = 48), rebuilt around
+// its real bound.  The layer moves 120-150 MB for 5 GFLOP, but at ~570 VALU instructions per 32-pixel tile (a wave64 VALU instruction holds
+// the 16-lane SIMD for 4 cycles) 49 k tiles were 45-50 us of VALU issue against a 16-18 us HBM floor.  Here a tile costs ~150:
+//   * no per-element selects: rows past M recompute the last pixel and their stores fall outside the output descriptor; weights come
+//     through a descriptor; the 6 patch groups of a lane are two precomputed (per half-wave) offset sets,
+//   * bias is the INITIAL accumulator (its 16 loads land directly in the MFMA's C operand), ReLU is one v_pk_max_i16 per two outputs,
+//   * no LDS: one v_permlane32_swap per dword gives every lane 16 CONSECUTIVE channels of its pixel (32 bytes, two 16-byte stores) --
+//     which is also exactly one ReLU bit word, so the words are produced / consumed without crossing lanes.
+// MODE 0: out = relu(conv + bias) (conv1 forward), bits_out optional; MODE 1: out = conv masked by mask_bits (deconv4 input gradient).
+// =====================================================================================================================
+typedef uint32_t nc_u32x4 __attribute__((ext_vector_type(4)));
+template <typename TS, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void narrow_conv48_kernel(const NarrowConvParams p) {
+    constexpr int SSZ = (int)sizeof(TS), GSZ = 4 * SSZ;   // bytes of one 4-value patch group
+    constexpr int GDW = GSZ / 4;                          // dwords per group: 1 (bytes) | 2 (bf16) | 4 (fp32)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lgrp = lane >> 5;
+    const int ntiles = (p.M + 31) >> 5, nw = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    const uint32_t rowb = (uint32_t)(p.IW * p.Cs * SSZ);
+
+    // ---- per wave, once: weights (MFMA step s, row n = lrow, this half-wave's 8 k), bias as the initial accumulator, descriptors ----
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 32 * 48 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.M * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsBI = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? (const void*)p.mask_bits : (const void*)p.out), 0, MODE == 1 ? p.M * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsBO = __builtin_amdgcn_make_buffer_rsrc(p.bits_out ? (void*)p.bits_out : p.out, 0, (MODE == 0 && p.bits_out) ? p.M * 8 : 0, 0x00020000);
+    u16x8 wf[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wf[s] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (lrow * 48 + s * 16 + lgrp * 8) * 2, 0, 0));
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 bb = *(const f32x4*)(p.bias + 8 * qd + 4 * lgrp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc0[4 * qd + t] = bb[t];
+        }
+    }
+    // group j = 2 s + gi of this lane: q = 4 s + gi (+ 2 for the upper half-wave) -> kernel row q / 3, value offset (q % 3) * 4
+    uint32_t goff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int qa = 4 * (j >> 1) + (j & 1), qb = qa + 2;
+        goff[j] = lgrp ? (uint32_t)(qb / 3) * rowb + (uint32_t)((qb % 3) * GSZ) : (uint32_t)(qa / 3) * rowb + (uint32_t)((qa % 3) * GSZ);
+    }
+
+    // the raw patch of one tile: 6 groups per lane, requested one tile AHEAD of its use (a wave walks tiles tile, tile + nw, ...; the
+    // persistent grid keeps 8 waves per SIMD resident, and within a wave the next tile's loads fly under this tile's arithmetic and stores)
+    struct Raw { uint32_t d[6][GDW]; uint32_t mw; };
+    auto request = [&](int t, Raw& r) {
+        const int m = min(t * 32 + lrow, p.M - 1);       // pixels past M recompute the last one; their stores fall outside the descriptors
+        uint32_t b, rem, y, x;
+        p.div_ohw.divmod((uint32_t)m, b, rem);
+        p.div_ow.divmod(rem, y, x);
+        const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+        const unsigned char* pix = (const unsigned char*)p.src + fr * p.frame_stride * SSZ + (2u * y * (uint32_t)p.IW + 2u * x) * (uint32_t)(p.Cs * SSZ);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
+#pragma unroll
+            for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
+        }
+        if constexpr (MODE == 1) r.mw = __builtin_amdgcn_raw_buffer_load_b32(rsBI, (t * 32 + lrow) * 8 + lgrp * 4, 0, 0);
+    };
+    Raw cur, nxt;
+    request(tile, cur);
+    for (; tile < ntiles; tile += nw) {
+        request(min(tile + nw, ntiles - 1), nxt);        // (the last iteration re-requests its own tile: no branch in the loop body)
+        u16x8 xf[3];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            uint32_t* dst = (uint32_t*)&xf[j >> 1] + 2 * (j & 1);
+            if constexpr (SSZ == 2) { dst[0] = cur.d[j][0]; dst[1] = cur.d[j][1]; }      // bf16 source: the fragment's 8 bytes as they are
+            else {
+                float f[4];
+                if constexpr (SSZ == 1) {                 // camera bytes: k * (1 / 255), which rounds to the same bf16 as the exact quotient (common.hpp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = (float)((cur.d[j][0] >> (8 * e)) & 255u) * U8_RCP255;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, cur.d[j][e]);
+                }
+                const PackN<uint32_t, 2> h = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(f));
+                dst[0] = h.v[0]; dst[1] = h.v[1];
+            }
+        }
+        f32x16 acc = acc0;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, xf[s]), acc, 0, 0, 0);
+
+        // ---- epilogue: lane (pixel, lgrp) holds channels 8 qd + 4 lgrp .. + 3 (qd = 0..3) as two dwords R[qd][0..1] ----
+        uint32_t R[4][2];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+            const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                uint32_t u = w.v[d];
+                if constexpr (MODE == 0) asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d]));      // ReLU on two bf16: negative floats are negative int16
+                R[qd][d] = u;
+            }
+        }
+        // half-wave exchange: (R[0], R[2]) and (R[1], R[3]) -> lane (pixel, g) owns channels 16 g .. 16 g + 15 in the order R0 R2 R1 R3
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            auto r0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = r0[0]; R[2][d] = r0[1];
+            auto r1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = r1[0]; R[3][d] = r1[1];
+        }
+        uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
+        if constexpr (MODE == 1) {                        // ReluGrad: bit d / bit 16 + d of the word select the two halves of dword d
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] &= ((cur.mw >> d) & 0x00010001u) * 0xffffu;
+        }
+        const uint32_t mr = (uint32_t)(tile * 32 + lrow);
+        const uint32_t obyte = mr * 64u + (uint32_t)lgrp * 32u;
+        __builtin_amdgcn_raw_buffer_store_b128(nc_u32x4{o[0], o[1], o[2], o[3]}, rsO, (int)obyte, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(nc_u32x4{o[4], o[5], o[6], o[7]}, rsO, (int)obyte + 16, 0, 0);
+        if constexpr (MODE == 0) {                        // ReLU bits of the stored (non-negative) values: min(x, 1) per 16-bit half = "non-zero"
+            uint32_t word = 0;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                uint32_t nz;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(o[d]), "v"(0x00010001u));
+                word |= nz << d;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(word, rsBO, (int)(mr * 8u + (uint32_t)lgrp * 4u), 0, 0);     // (no bit words wanted: empty descriptor)
+        }
+        cur = nxt;
     }
 }
 

@@ -20,10 +20,8 @@ DECONVS = [  # IH, IW, Cin, Cout, k
 # Every conv / deconv entry point is served by several kernel generations (first-generation register-staged tiles, gemm2 LDS-DMA
 # tiles, raw-staged tapconv / tapwgrad, the narrow-layer kernels); `auto` is what production picks at these (small) sizes, the
 # other two pin the dispatch through mi_set_tuning so that EVERY generation meets the same float64 reference on every geometry.
-# `persist` = `newest` with the experimental persistent tapconv blocks (mi_set_tuning key 8; capped at 3 blocks per output column so that
-# every block walks SEVERAL tiles at these small sizes; bf16 only -- the fp32 path has no persistent form)
 # `rwconv` = `newest` with the register-weight kernel forced for the thin gather-form layers (key 13 = 2; auto takes it only on chip-filling grids)
-GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0}, "persist": {0: 1, 1: 1, 3: 1, 4: 1, 8: 3, 13: 0},
+GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0},
                "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2}}
 
 
@@ -51,8 +49,8 @@ def _nhwc(a):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("geom", CONVS)
 def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
-    if kernels in ("persist", "rwconv") and dt != "bf16":
-        pytest.skip("persistent tapconv / register-weight kernel are bf16 only")
+    if kernels == "rwconv" and dt != "bf16":
+        pytest.skip("the register-weight kernel is bf16 only")
     L = milib.get()
     code, td = DT[dt]
     IH, IW, Ci, Co, k = geom
@@ -113,8 +111,8 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("geom", DECONVS)
 def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
-    if kernels in ("persist", "rwconv") and dt != "bf16":
-        pytest.skip("persistent tapconv / register-weight kernel are bf16 only")
+    if kernels == "rwconv" and dt != "bf16":
+        pytest.skip("the register-weight kernel is bf16 only")
     L = milib.get()
     code, td = DT[dt]
     IH, IW, Ci, Co, k = geom
@@ -163,8 +161,6 @@ def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_dgrad_into_larger_input(dt, kernels):
-    if kernels == "persist":
-        pytest.skip("covered by the newest generation")
     """conv2 reads a 39x79 map but its VALID s2 windows never touch the last row/col: their gradient must be 0."""
     L = milib.get()
     code, td = DT[dt]

@@ -1,6 +1,6 @@
 """Debug: per-phase cycle breakdown of the tapconv kernel on one layer (s_memtime stamps of lane 0 of every wave).
 usage: python tools/trace_tapconv.py <layer>   layer in conv2.fwd conv3.fwd deconv3.fwd conv2.dgrad deconv2.dgrad deconv3.dgrad
-       python tools/trace_tapconv.py variants | persist   per-layer timing of the tile / epilogue variants | of the persistent-block form"""
+       python tools/trace_tapconv.py variants  per-layer timing of the tile / epilogue variants"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
@@ -71,16 +71,6 @@ if name == "variants":                                     # timing only: big ti
             us, _ = run(nm, False)
             for k, v in prev.items():
                 L.mi_set_tuning(k, v)
-            res.append("%s %.1f" % (label, us))
-        print("%-14s %s" % (nm, "   ".join(res)))
-    sys.exit(0)
-if name == "persist":                                      # timing only: one block per tile vs persistent blocks (mi_set_tuning key 8), production tile choice
-    for nm in LAYERS:
-        res = []
-        for label, v in (("per-tile", 0), ("persistent", 1), ("persistent<=128", 128)):
-            prev = L.mi_set_tuning(8, v)
-            us, _ = run(nm, False)
-            L.mi_set_tuning(8, prev)
             res.append("%s %.1f" % (label, us))
         print("%-14s %s" % (nm, "   ".join(res)))
     sys.exit(0)
