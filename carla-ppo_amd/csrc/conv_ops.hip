@@ -297,7 +297,8 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     const long long slab_floats = (long long)gy * q.npairs * kt_tiles * 1024;
     q.slabs = nullptr; q.slab_stride = slab_floats;
     if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * 4 && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
-    dim3 g(splits, gy, 1);
+    q.gx = splits; q.gy = gy;
+    dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
     const bool split = g_tapwgrad_split && taps == 2 && q.npairs == 8;   // wave = (tap, position half): fewer LDS reads per MFMA
     if (mode == TC_CONV) {
         if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);

@@ -33,7 +33,11 @@ struct TapWgradParams {
     int KH, KW;
     int GH, GW, HY, HX;
     int KC, NE, MP;
-    int nkb;                         // channel blocks (blockIdx.y = nb * nkb + kb)
+    int nkb;                         // channel blocks (block column by = nb * nkb + kb)
+    int gx, gy;                      // position splits x block columns.  The launch is 1-D over ceil(gx / 8) * 8 * gy blocks: block id -> XCD id % 8, slot
+                                     // id / 8; the gy column blocks of one position split take consecutive slots of ONE XCD, so the slot / gradient tiles
+                                     // that several column blocks read (each covers a channel x output slice of dW) are fetched from HBM once and
+                                     // served to the others by that XCD's L2 (conv3 / deconv2 filter gradients read 126 / 119 MB for 64 MB of tensors before)
     int pos_per_split;               // multiple of TW_BP
     int npairs;                      // (tap, output tile) pairs of a block, dealt round-robin to the 8 waves
     unsigned char pair_tap[TW_MAXPAIR], pair_nt[TW_MAXPAIR], pair_first[TW_MAXPAIR];   // first: first pair of its output tile
@@ -115,13 +119,16 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tr_n = 0;
-    long long* const tr = p.trace ? p.trace + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (tid >> 6)) * 32 : nullptr;
-    const bool tr_on = tr && ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
+    const int bslot = (int)blockIdx.x >> 3;
+    const int by = bslot % p.gy, bx = (bslot / p.gy) * 8 + ((int)blockIdx.x & 7);
+    if (bx >= p.gx) return;
+    long long* const tr = p.trace ? p.trace + ((long long)(by * p.gx + bx) * 8 + (tid >> 6)) * 32 : nullptr;
+    const bool tr_on = tr && ((long long)(by * p.gx + bx) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
 #define TW_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     TW_STAMP();
-    const int kb = blockIdx.y % p.nkb, nb = blockIdx.y / p.nkb;
+    const int kb = by % p.nkb, nb = by / p.nkb;
     const int kc0 = kb * KCB, ne0 = nb * NEB;
-    const int Pbeg = blockIdx.x * p.pos_per_split;
+    const int Pbeg = bx * p.pos_per_split;
     const int Pend = min(p.MP, Pbeg + p.pos_per_split);
     if (Pbeg >= Pend) return;
     const int nsteps = (Pend - Pbeg + TW_BP - 1) / TW_BP;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     // Without scratch: fp32 atomics straight into dW.
     auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
         if (p.slabs) {
-            float* const dst = p.slabs + (long long)blockIdx.x * p.slab_stride + ((long long)(blockIdx.y * p.npairs + pi) * KT) * 1024 + lane * 4;
+            float* const dst = p.slabs + (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll

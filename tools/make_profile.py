@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Assemble profiles/<name>.md + profiles/r01_pmc_traffic.json from the files one GPU call leaves in gpurun_out/:
+"""Assemble profiles/<name>.md + profiles/rNN_pmc_traffic.json from the files one GPU call leaves in gpurun_out/:
     prof_<tag>.md (rocprofv3 --kernel-trace --stats via tools/rocpd_summary.py), pmc_<tag>_sq.md / _fetch.md / _write.md (tools/pmc_pass.sh),
     bench_<tag>_full.json (bench.py), timeline_<tag>.md (tools/timeline.sh; optional).  tools/profile_round.sh produces all of them.   usage: python tools/make_profile.py <tag> <out-name> "<title>" """
 import json, os, sys
@@ -25,7 +25,8 @@ sqr = {(r[0], r[1]): dict(zip(hdr, r)) for r in rows(sq)}
 fer = {(r[0], r[1]): float(r[4]) for r in rows(fe)}
 wrr = {(r[0], r[1]): float(r[4]) for r in rows(wr)}
 # (kernel, grid) -> op at the bench geometry (B = 512, bf16); grids identify the layer
-NAMES = [("tapconv_kernel<bf16, 1, 128, 3, 256, 96>", "1848x1x1", "deconv3.fwd"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "1722x1x1", "conv2.dgrad"),
+# round 1 dispatch (kept so that profiles/r01_* can be regenerated); round 2: the register-weight kernels, the lean narrow kernels
+NAMES_R01 = [("tapconv_kernel<bf16, 1, 128, 3, 256, 96>", "1848x1x1", "deconv3.fwd"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "1722x1x1", "conv2.dgrad"),
          ("tapconv_kernel<bf16, 1, 128, 2, 128, 48>", "800x2x1", "deconv2.fwd / conv3.dgrad"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "100x4x1", "deconv1.fwd / conv4.dgrad"),
          ("tapconv_kernel<bf16, 0, 128, 2, 128, 48>", "684x1x1", "conv3.fwd / deconv2.dgrad"), ("tapconv_kernel<bf16, 0, 64, 2, 256, 96>", "1482x1x1", "conv2.fwd"),
          ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "2736x1x1", "deconv3.dgrad"), ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "96x4x1", "conv4.fwd / deconv1.dgrad"),
@@ -34,6 +35,18 @@ NAMES = [("tapconv_kernel<bf16, 1, 128, 3, 256, 96>", "1848x1x1", "deconv3.fwd")
          ("narrow_wgrad_kernel<float, 3, 1, 12>", None, "conv1.wgrad (+bias)"), ("narrow_wgrad_kernel<bf16, 3, 0, 12>", None, "deconv4.wgrad"),
          ("narrow_conv_kernel<bf16, float>", None, "conv1.fwd"), ("narrow_conv_kernel<bf16, bf16>", None, "deconv4.dgrad"),
          ("gather_narrow_kernel<bf16, 2, 4, 3>", None, "deconv4.fwd + loss")]
+NAMES_R02 = [("rwconv_gather_kernel<3, 5, true, 0, true, 0>", None, "deconv3.fwd"), ("rwconv_gather_kernel<2, 4, false, 2, false, 0>", None, "conv2.dgrad"),
+         ("tapconv_kernel<bf16, 1, 128, 2, 128, 48>", "800x2x1", "deconv2.fwd / conv3.dgrad"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "100x4x1", "deconv1.fwd / conv4.dgrad"),
+         ("tapconv_kernel<bf16, 0, 128, 2, 128, 48>", "684x1x1", "conv3.fwd / deconv2.dgrad"), ("tapconv_kernel<bf16, 0, 64, 2, 256, 96>", "1482x1x1", "conv2.fwd"),
+         ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "2736x1x1", "deconv3.dgrad"), ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "96x4x1", "conv4.fwd / deconv1.dgrad"),
+         ("tapwgrad_kernel<1, 3, 2, 4, 4, false>", "247x1x1", "deconv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "247x1x1", "conv2.wgrad"),
+         ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "63x4x1", "conv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "16x16x1", "conv4.wgrad"),
+         ("tapwgrad_kernel<1, 2, 4, 2, 2, true>", "62x4x1", "deconv2.wgrad"), ("tapwgrad_kernel<1, 2, 4, 2, 2, true>", "16x16x1", "deconv1.wgrad"),
+         ("narrow_wgrad_kernel<unsigned char, 3, 1, 12>", None, "conv1.wgrad (+bias)"), ("narrow_wgrad_kernel<bf16, 3, 0, 12>", None, "deconv4.wgrad"),
+         ("narrow_conv48_kernel<unsigned char, 0>", None, "conv1.fwd"), ("narrow_conv48_kernel<bf16, 1>", None, "deconv4.dgrad"),
+         ("gather_narrow_kernel<bf16, 2, 4, 3, true>", None, "deconv4.fwd + loss"), ("reduce_fused_kernel", None, "filter-gradient slab reduce (6 layers)"),
+         ("adam_tf_kernel", None, "adam")]
+NAMES = NAMES_R01 if tag.startswith("r01") else NAMES_R02
 lines, traffic = [], {}
 for kern, grid, op in NAMES:
     keys = [k for k in sqr if k[0].strip("`") == kern and (grid is None or k[1] == grid)]
@@ -49,7 +62,7 @@ for kern, grid, op in NAMES:
 doc = """# %s
 
 ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  Sources: `rocprofv3 --kernel-trace --stats` of
-`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
+`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-replay` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
 `rocprofv3 --pmc` passes (`tools/pmc_pass.sh`: SQ/GRBM counters, FETCH_SIZE alone, WRITE_SIZE alone -- one TCC-derived counter per pass, no trace
 domains combined with --pmc).  Assembled by `tools/make_profile.py`.
 
@@ -62,7 +75,7 @@ domains combined with --pmc).  Assembled by `tools/make_profile.py`.
 
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  HBM bytes = 2 x FETCH_SIZE (the gfx950 correction of
 MI355X_MICROARCH.md: wide coalesced reads are tallied at half their size; calibrated for 16-byte-per-lane reads, the 8-byte fp32 frame reads of the
-conv1 kernels may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv3.  Last column: (read + write) / duration; 8 TB/s spec, ~6.3 achievable.
+conv1 kernels of round 1 may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv3.  Last column: (read + write) / duration; 8 TB/s spec, ~6.3 achievable.
 
 | op | kernel, grid | us | MFMA util | HBM read MB | HBM write MB | HBM TB/s |
 |---|---|---:|---:|---:|---:|---:|
@@ -90,5 +103,5 @@ conv1 kernels may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv
 """ % (title, json.dumps(bench), "\n".join(lines), stats, timeline, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
 open(R + "profiles/%s.md" % outname, "w").write(doc)
 json.dump({"provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, batch 512 bf16; FETCH_SIZE doubled per MI355X_MICROARCH.md",
-           "ops": traffic}, open(R + "profiles/r01_pmc_traffic.json", "w"), indent=1)
+           "ops": traffic}, open(R + "profiles/%s_pmc_traffic.json" % ("r01" if tag.startswith("r01") else "r02"), "w"), indent=1)
 print("\n".join(lines))
