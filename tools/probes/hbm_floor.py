@@ -11,9 +11,9 @@ def t(f, n=20):
 for mb in (101, 160, 404):
     n = mb * 1000 * 1000 // 2
     x = torch.empty(n, dtype=torch.bfloat16, device="cuda"); y = torch.empty_like(x)
-    us = t(lambda: x.zero_()); print("write %d MB: %.1f us = %.2f TB/s" % (mb, us, mb / us / 1e3 * 1e0))
-    us = t(lambda: y.copy_(x)); print("copy  %d MB (read + write %d MB): %.1f us = %.2f TB/s" % (mb, 2 * mb, us, 2 * mb / us / 1e3))
-    us = t(lambda: x.sum()); print("read  %d MB (reduction): %.1f us = %.2f TB/s" % (mb, us, mb / us / 1e3))
+    us = t(lambda: x.zero_()); print("write %d MB: %.1f us = %.2f TB/s" % (mb, us, mb / us))
+    us = t(lambda: y.copy_(x)); print("copy  %d MB (read + write %d MB): %.1f us = %.2f TB/s" % (mb, 2 * mb, us, 2 * mb / us))
+    us = t(lambda: x.sum()); print("read  %d MB (reduction): %.1f us = %.2f TB/s" % (mb, us, mb / us))
 # cold: 1.2 GB of unrelated traffic before every timed launch (single launch between two events)
 junk = torch.empty(600 * 500000, dtype=torch.bfloat16, device="cuda"); junk2 = torch.empty_like(junk)
 def cold(f, n=20):

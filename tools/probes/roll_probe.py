@@ -12,7 +12,7 @@ vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=d + "/v", training=Fal
 class Box:
     low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
 agent = PPO(np.array([67]), Box(), model_dir=d + "/p"); agent.init_session(init_logging=False)
-step = RolloutStep(vae, agent)
+step = RolloutStep(vae, agent, io="device")      # (the staged form has the device buffers the copy variants below time)
 rng = np.random.RandomState(0)
 u8 = rng.randint(0, 256, (64, 80, 160, 3), dtype=np.uint8)
 meas = rng.rand(64, 3)
