@@ -224,6 +224,7 @@ int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
 int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
+int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
@@ -309,7 +310,9 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     }
     else {
         if (q.npairs > 32) return 0;
-        hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
+        // k = 5 with caller scratch: a wave per (parity class, tap row), the shifted slot fragments formed in registers (mi_set_tuning key 14 = 0: the pair layout)
+        if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) hipLaunchKernelGGL(tapwgrad_cw_kernel, g, dim3(TWC_NT), 0, st, q);
+        else hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
     int rc = mi_check_launch("tapwgrad_kernel");
     if (rc == MI_OK && q.slabs) {
@@ -686,6 +689,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 12) { prev = g_tap_mask_prefetch; g_tap_mask_prefetch = value ? 1 : 0; }
     else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
     else if (key == 13) { prev = mi_rwconv_mode(value < 0 ? 0 : value); }
+    else if (key == 14) { prev = g_tapwgrad_cw; g_tapwgrad_cw = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

@@ -419,6 +419,209 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #undef TW_STAMP
 }
 
+// =====================================================================================================================
+// tapwgrad_cw_kernel — the k = 5 gather-form filter gradient (3 x 3 slot taps, C = 64 channels, 4 parity classes x 32 outputs) with a wave per
+// (parity class, tap ROW) instead of per (tap, output tile) pair.
+//
+// tapwgrad_kernel's step for this layer is bound by LDS reads: every (tap, class) pair re-reads its gradient fragment and both slot fragments
+// (six ds_read_b64_tr_b16 per two MFMAs; 1,536 per 128-position step = 6.1k LDS-pipe cycles against 4.1k MFMA cycles per SIMD).  Here a wave keeps
+// the live taps of ONE tap row of its class for both 32-channel tiles (3 x 2 or 2 x 2 accumulator tiles), reads the class's gradient fragment
+// once per k-step, and reads only the ALIGNED (tb = 0) slot fragments of its row: the tb = 1, 2 operands are the same 8 positions shifted by one /
+// two, formed in registers from this k-step's fragment and the next one's first dword (one v_perm_b32 per dword / a dword move).  For that the
+// positions are mapped so that a lane's k-step j + 1 continues its k-step j: lane half g walks positions 64 g + 8 j .. + 7 (a sum over
+// positions does not care about its order).  Per k-step a wave issues 2 + 4 transpose reads for 4 or 6 MFMAs: 480 per block step -> MFMA-bound.
+// The live (class, tap row) units of k = 5 are 3 + 3 + 2 + 2 = TEN: ten waves per block, dealt to the SIMDs (wave w runs on SIMD w % 4) so that
+// with the four BiasAddGrad MFMAs (ones x D, one wave per class) every SIMD issues 14 / 14 / 13 / 13 MFMAs per k-step (the pair layout: 16).
+// Staging (LDS-DMA of the slot range and the gradient rows, two stages), the slab layout and the reduce are tapwgrad_kernel's.
+// =====================================================================================================================
+constexpr int TWC_NW = 10, TWC_NT = TWC_NW * 64;
+__global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParams p) {
+    constexpr int TAPS = 3, KT = 2, NTB = 4;
+    constexpr int ESZ = 2, VE = 8;
+    constexpr int KCB = 32 * KT, NEB = 32 * NTB;
+    constexpr int PA = KCB * ESZ, PD = NEB * ESZ;        // 128 | 256 B
+    constexpr int CPA = PA / 16, CPD = PD / 16;
+    constexpr int SPI_A = 1024 / PA, SPI_D = 1024 / PD;
+    constexpr int MAXSLOT = TW_BP + TC_MAXHALO;
+    constexpr int NINSD = TW_BP / SPI_D;                  // gradient-tile DMA instructions per step (32)
+    constexpr int NIA = (MAXSLOT / SPI_A + TWC_NW - 1) / TWC_NW, NID = (NINSD + TWC_NW - 1) / TWC_NW;
+    constexpr int ASTAGE = MAXSLOT * PA, DSTAGE = TW_BP * PD, STAGE = ASTAGE + DSTAGE;
+    static_assert(2 * STAGE + 64 <= 160 * 1024, "tile config");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE + 64];          // (+ 64: the last k-step's look-ahead read may run past the gradient tile)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bslot = (int)blockIdx.x >> 3;
+    const int by = bslot % p.gy, bx = (bslot / p.gy) * 8 + ((int)blockIdx.x & 7);
+    if (bx >= p.gx) return;
+    const int kb = by % p.nkb, nb = by / p.nkb;
+    const int kc0 = kb * KCB, ne0 = nb * NEB;
+    const int Pbeg = bx * p.pos_per_split;
+    const int Pend = min(p.MP, Pbeg + p.pos_per_split);
+    if (Pbeg >= Pend) return;
+    const int nsteps = (Pend - Pbeg + TW_BP - 1) / TW_BP;
+    const int halo = (TAPS - 1) * p.GW + TAPS - 1;
+    const int ninstrA = (TW_BP + halo + SPI_A - 1) / SPI_A;
+    const u32x4 rsA = make_srd(p.a, p.a_bytes), rsD = make_srd(p.d, p.d_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    // ---------------- DMA roles (as tapwgrad_kernel, gather form; instruction t = wave + 10 i) ----------------
+    const int rA = lane / CPA, cA = (lane % CPA) ^ tw_swz<CPA>(rA);
+    const int rD = lane / CPD, cD = (lane % CPD) ^ tw_swz<CPD>(rD);
+    const bool a_kok = kc0 + cA * VE < p.KC;
+    const uint32_t a_koff = (uint32_t)(kc0 + cA * VE) * ESZ;
+    uint32_t d_koff; int d_cls; bool d_kok;
+    {
+        const int ne = ne0 + cD * VE;
+        d_kok = ne < p.NE;
+        uint32_t c4, n;
+        p.div_n.divmod((uint32_t)(d_kok ? ne : 0), c4, n);
+        d_cls = (int)c4;
+        d_koff = ((((c4 >> 1) * p.OW + (c4 & 1)) * p.N) + n) * ESZ;
+    }
+    auto issue_one = [&](int step, int buf, int idx) {
+        const int Ps = Pbeg + step * TW_BP;
+        const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (idx < NIA) {
+            const int t = wave + TWC_NW * idx;
+            if (t >= ninstrA) return;                     // wave-uniform
+            const int P = Ps + SPI_A * t + rA;
+            const bool ok = P < p.MP && a_kok;
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)(ok ? P : 0), g, gx);
+            p.div_g.divmod(g, b, gy);
+            const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
+            const bool v = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            dma16_asm(rsA, As + t * 1024, v ? (((b * p.IH + iy) * p.IW + ix) * p.C) * ESZ + a_koff : G2_OOB);
+        } else {
+            const int t = wave + TWC_NW * (idx - NIA);
+            if (t >= NINSD) return;                       // wave-uniform
+            const int P = Ps + SPI_D * t + rD;
+            const bool ok = P < Pend && d_kok;
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)(ok ? P : 0), g, gx);
+            p.div_g.divmod(g, b, gy);
+            const int oy = 2 * (int)gy + (d_cls >> 1), ox = 2 * (int)gx + (d_cls & 1);
+            const bool v = ok && oy < p.OH && ox < p.OW;
+            dma16_asm(rsD, Ds + t * 1024, v ? (((b * p.OH + 2 * gy) * p.OW + 2 * gx) * p.N) * ESZ + d_koff : G2_OOB);
+        }
+    };
+    constexpr int NDMA = NIA + NID, NKS = TW_BP / 16;    // 8 k16-steps per position step; at most one DMA instruction per wave and k-step
+    static_assert(NDMA <= NKS, "DMA schedule");
+
+    // ---------------- role: (class, tap row) -- k = 5: class (ph, pw) keeps tap rows ta >= ph and taps tb >= pw ----------------
+    //   SIMD 0: w0 (c0, row 2)  w4 (c1, row 0)         w8 (c1, row 1)       6 + 4 + 4       = 14
+    //   SIMD 1: w1 (c1, row 2)+ w5 (c3, row 1)+        w9 (c3, row 2)       4+1 + 4+1 + 4   = 14      (+ = carries its class's bias MFMA)
+    //   SIMD 2: w2 (c0, row 0)+ w6 (c2, row 1)                              6+1 + 6         = 13
+    //   SIMD 3: w3 (c0, row 1)  w7 (c2, row 2)+                             6 + 6+1         = 13
+    const int cls = (int)((0x3122310010ull >> (4 * wave)) & 15ull);    // nibble w: class of wave w   {0,1,0,0,1,3,2,2,1,3}
+    const int ta = (int)((0x2121101022ull >> (4 * wave)) & 15ull);    //                 tap row      {2,2,0,1,0,1,1,2,1,2}
+    const bool bias_wave = (0x0A6 >> wave) & 1;           // waves 1, 2, 5, 7
+    const int pw = cls & 1;
+    const bool cls_live = ne0 + cls * 32 < p.NE;
+    const bool bias_on = p.dbias && kb == 0 && bias_wave && cls_live;
+
+    // transpose-read offsets: lane half g walks positions 64 g + 8 j (+ 0..7): row = 64 (l >> 5) + ((l & 15) >> 2) (+ 4 for the high half), + 8 rows per k-step
+    const int trow = 64 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tcol = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    uint32_t aoff[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int row = trow + ta * p.GW, col = kt * 32 + tcol;
+        aoff[kt] = (uint32_t)(row * PA + ((((col >> 3) ^ tw_swz<CPA>(row))) << 4) + (col & 7) * ESZ);
+    }
+    uint32_t doff;
+    {
+        const int col = cls * 32 + tcol;
+        doff = (uint32_t)(ASTAGE + trow * PD + ((((col >> 3) ^ tw_swz<CPD>(trow))) << 4) + (col & 7) * ESZ);
+    }
+    const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    typedef __attribute__((address_space(3))) s16x4* lds_v4;
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4_f __attribute__((ext_vector_type(4)));
+    auto tr_half = [&](uint32_t off) -> u32x2_t {         // 4 consecutive positions of this lane's column: two dwords
+        return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + off)));
+    };
+    auto tr_full = [&](uint32_t off, int pitch) -> u32x4_f {
+        const u32x2_t lo = tr_half(off), hi = tr_half(off + 4 * pitch);
+        return u32x4_f{lo[0], lo[1], hi[0], hi[1]};
+    };
+
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+
+    // The position loop and the epilogue, specialised on the first live tap of the row (tb >= TB0): every tap loop is a literal loop
+    auto run = [&](auto tb0_c) {
+        constexpr int TB0 = decltype(tb0_c)::value;
+        f32x16 acc[TAPS][KT], accb;
+#pragma unroll
+        for (int tb = TB0; tb < TAPS; ++tb)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tb][kt][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = step + 1 < nsteps;
+            const uint32_t sb = (uint32_t)(cur * STAGE);
+            // Fa[kt][j & 1] = the aligned fragment of k-step j, the other slot the next one's; Dq likewise.  The slot a k-step has consumed is
+            // refilled (k-step j + 2) right behind the MFMAs that read it: two k-steps of look-ahead with no registers beyond the two slots
+            u32x4_f Fa[KT][2], Dq[2];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) { Fa[kt][0] = tr_full(sb + aoff[kt], PA); Fa[kt][1] = tr_full(sb + aoff[kt] + 8 * PA, PA); }
+            Dq[0] = tr_full(sb + doff, PD); Dq[1] = tr_full(sb + doff + 8 * PD, PD);
+#pragma unroll
+            for (int j = 0; j < NKS; ++j) {
+                if (more && j < NDMA) issue_one(step + 1, cur ^ 1, j);
+                const bf16x8 dfrag = __builtin_bit_cast(bf16x8, Dq[j & 1]);
+                if (bias_on) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), dfrag, accb, 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const u32x4_f f0 = Fa[kt][j & 1], f1 = Fa[kt][(j + 1) & 1];
+#pragma unroll
+                    for (int tb = TB0; tb < TAPS; ++tb) {
+                        u32x4_f fr;
+                        if (tb == 0) fr = f0;
+                        else if (tb == 1)                   // positions + 1: every dword takes its upper half and the next dword's lower half
+                            fr = u32x4_f{__builtin_amdgcn_alignbit(f0[1], f0[0], 16), __builtin_amdgcn_alignbit(f0[2], f0[1], 16),
+                                         __builtin_amdgcn_alignbit(f0[3], f0[2], 16), __builtin_amdgcn_alignbit(f1[0], f0[3], 16)};
+                        else fr = u32x4_f{f0[1], f0[2], f0[3], f1[0]};      // positions + 2: one dword on
+                        acc[tb][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dfrag, __builtin_bit_cast(bf16x8, fr), acc[tb][kt], 0, 0, 0);
+                    }
+                    if (j + 2 < NKS) Fa[kt][j & 1] = tr_full(sb + aoff[kt] + (j + 2) * 8 * PA, PA);
+                    else if (j + 2 == NKS) { const u32x2_t lo = tr_half(sb + aoff[kt] + (j + 2) * 8 * PA); Fa[kt][j & 1] = u32x4_f{lo[0], lo[1], 0u, 0u}; }
+                }
+                if (j + 2 < NKS) Dq[j & 1] = tr_full(sb + doff + (j + 2) * 8 * PD, PD);
+            }
+        }
+        if (bias_on && lane < 32) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
+            const int ne = ne0 + cls * 32 + lane;
+            if (ne < p.NE) atomicAdd(&p.dbias[ne - (int)p.div_n.div((uint32_t)ne) * p.N], accb[0]);
+        }
+        if (!cls_live) return;
+        // dW tiles: same accumulator order / slab layout as tapwgrad_kernel (pair index looked up in the host's (tap, output tile) list)
+#pragma unroll
+        for (int tb = TB0; tb < TAPS; ++tb) {
+            const int tap = ta * TAPS + tb;
+            int pi = -1;
+            for (int i = 0; i < p.npairs; ++i) if (p.pair_tap[i] == tap && p.pair_nt[i] == cls) pi = i;
+            if (pi < 0) continue;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const f32x16& t = acc[tb][kt];
+                float* const dst = p.slabs + (long long)bx * p.slab_stride + (((long long)(by * p.npairs + pi) * KT) + kt) * 1024 + lane * 4;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) *(f32x4*)(dst + g4 * 256) = f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]};
+            }
+        }
+    };
+    if (pw == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
+}
+
 // dW += sum over the position-split slabs written in accumulator order by tapwgrad_kernel.  One thread per 16-byte group
 // (block column, pair, kt, row group, lane); blockIdx.y takes every gridDim.y-th slab so that small filters still fill the chip:
 // gridDim.y == 1 is a plain read-modify-write in a fixed order (deterministic), otherwise the partial sums meet in atomics.
