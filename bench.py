@@ -248,6 +248,29 @@ def fp32_extra(tmp, B, pool_u8, idx, steps=40, warm=5):
             "storage": "fp32 activations / weights, exact-fp32 MFMA; fp32 frame table"}
 
 
+def mlp_extra(tmp, B, pool_u8, idx, steps=30, warm=5):
+    """the MlpVAE (vae/models.py:271-299, 38400-512-256 | 64 | 256-512-38400) SGD step on the same frames, bf16 storage."""
+    from vae.models import MlpVAE
+    m = MlpVAE(np.array([80, 160, 3]), z_dim=64, model_dir=os.path.join(tmp, "mlp"), precision="bf16", seed=0)
+    m.init_session(init_logging=False)
+    m.dev.ensure_batch(B)
+    n = min(pool_u8.shape[0], 1024)
+    pool = torch.empty(n, 38400, device=pool_u8.device)
+    m.dev.L.mi_u8_to_unit_f32(m.dev.stream(), pool_u8.data_ptr(), pool.data_ptr(), pool.numel())
+    sel = (idx.to(torch.int64) % n).to(torch.int32).contiguous()
+    for i in range(warm):
+        m._train_minibatch(pool, pool, sel[i], B, 1.0 / B, m._eps(B))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        m._train_minibatch(pool, pool, sel[(warm + i) % sel.shape[0]], B, 1.0 / B, m._eps(B))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops = 6.0 * B * (38400 * 512 + 512 * 256 + 256 * 128 + 64 * 256 + 256 * 512 + 512 * 38400)
+    return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "dense_tflops": flops * steps / dt / 1e12,
+            "note": "dense-layer kernels of the C ABI sequenced from the host (mi355/mlp_vae_device.py); 39.5 M parameters: the Adam pass alone moves 1.2 GB per step"}
+
+
 def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
     """BASELINE configs[4] on ONE GPU: encode 1024 x 129 uint8 frames, values, GAE, PPO minibatch SGD (global minibatch 2048)."""
     import replay
@@ -301,6 +324,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true")
     ap.add_argument("--no-fp32", action="store_true")
+    ap.add_argument("--no-mlp", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
     ap.add_argument("--replay-rows", type=int, default=1024)
     args = ap.parse_args()
@@ -456,6 +480,11 @@ def main():
                 out["parity"] = parity_object(tmp, ref, B)
             except Exception as e:
                 out["parity"] = {"error": repr(e)}
+        if world == 1 and not args.no_mlp and args.precision == "bf16":
+            try:
+                out["mlp_vae"] = mlp_extra(tmp, B, pool_u8, idx)
+            except Exception as e:
+                out["mlp_vae"] = {"error": repr(e)}
         if world == 1 and not args.no_fp32 and args.precision == "bf16":
             try:
                 out["fp32"] = fp32_extra(tmp, B, pool_u8, idx)

@@ -460,6 +460,30 @@ inline int grid_for(long long n, int per_block, int cap = 2048) {
 
 }  // namespace
 
+namespace mi {
+// out[m, n] = mask(act(sum_s slabs[s][m][n] + bias[n])): the finishing pass of a split-K dense layer (MlpVAE's 38400-long reductions)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, long long mn, int N, const float* __restrict__ bias, int relu,
+                                                            const T* __restrict__ mask, T* __restrict__ out_t, float* __restrict__ out_f) {
+    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= mn) return;
+    f32x4 s = *(const f32x4*)(slabs + i4);
+    for (int k = 1; k < nsplit; ++k) s += *(const f32x4*)(slabs + (long long)k * mn + i4);
+    const int n = (int)(i4 % N);                          // N % 4 == 0: the four values share a row
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = s[e] + (bias ? bias[n + e] : 0.f);
+        if (relu) x = fmaxf(x, 0.f);
+        if (mask && !(Elem<T>::to_f32(mask[i4 + e]) > 0.f)) x = 0.f;
+        v[e] = x;
+    }
+    if (out_f) *(f32x4*)(out_f + i4) = f32x4{v[0], v[1], v[2], v[3]};
+    else *(PackN<T, 4>*)(out_t + i4) = pack4<T>(v);
+}
+
+}  // namespace mi
+
 extern "C" {
 
 int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv,
@@ -541,6 +565,15 @@ int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* g
     hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, n, alpha, alpha_dev,
                        1.0f - beta1, 1.0f - beta2, epsilon, (bf16_t*)bf16_shadow, clear_grad);
     return mi_check_launch("adam_tf");
+}
+
+int mi_splitk_finish(void* stream, int dtype, const float* slabs, int nsplit, int M, int N, const float* bias, int relu, const void* mask, void* out, int out_f32) {
+    if (!slabs || !out || nsplit < 1 || M < 1 || N < 4 || N % 4 != 0) return mi_fail(MI_ERR_ARG, "mi_splitk_finish: bad arguments (N must be a multiple of 4)");
+    const long long mn = (long long)M * N;
+    const dim3 g((unsigned)((mn / 4 + 255) / 256));
+    if (dtype == MI_F32) hipLaunchKernelGGL(splitk_finish_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, slabs, nsplit, mn, N, bias, relu, (const float*)mask, out_f32 ? nullptr : (float*)out, out_f32 ? (float*)out : nullptr);
+    else hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, slabs, nsplit, mn, N, bias, relu, (const bf16_t*)mask, out_f32 ? nullptr : (bf16_t*)out, out_f32 ? (float*)out : nullptr);
+    return mi_check_launch("splitk_finish");
 }
 
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n) {

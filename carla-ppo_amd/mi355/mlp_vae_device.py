@@ -66,6 +66,15 @@ class MlpVaeDevice:
         self.adam_m = z() if with_optimizer else None
         self.adam_v = z() if with_optimizer else None
         self.shadow = z(torch.bfloat16) if self.bf16 else None
+        # K-contiguous copies [N][K] of every dense kernel for the forward GEMMs (the MFMA kernels stream the B operand along K): refreshed after
+        # every optimiser step by mi_transpose_weights; the input gradients read the [K, N] originals, which ARE K-contiguous for x * W^T
+        self.weights_t = z(self.T)
+        kern = [(self.layout[name + "/kernel"][0], k, n) for name, k, n in self.enc] + [(self.layout["@heads/kernel"][0], self.enc_sizes[-1], 2 * self.z_dim)] \
+            + [(self.layout[name + "/kernel"][0], k, n) for name, k, n in self.dec]
+        self._tr_off = np.array([o for o, _, _ in kern], np.int64)
+        self._tr_k = np.array([k for _, k, _ in kern], np.int32)
+        self._tr_n = np.array([n for _, _, n in kern], np.int32)
+        self.slab = None                                    # split-K partial sums of the long-K layers (allocated on first use)
         self.metrics = torch.zeros(3, device=self.device)
         self.losses = torch.zeros(2, device=self.device)
         self.nchunks = int(self.L.mi_recon_loss_chunks(self.P))
@@ -112,6 +121,15 @@ class MlpVaeDevice:
     def sync_shadow(self):
         if self.bf16:
             self.L.mi_cast_f32_to_bf16(self.stream(), self.params.data_ptr(), self.shadow.data_ptr(), self.n_flat)
+        self._refresh_transposed()
+
+    def _refresh_transposed(self):
+        self.L.mi_transpose_weights(self.stream(), self.dtype, self.params.data_ptr(), self.weights_t.data_ptr(), self._tr_off.ctypes.data, self._tr_k.ctypes.data,
+                                    self._tr_n.ctypes.data, len(self._tr_off))
+
+    def _wt(self, name):
+        o, _ = self.layout[name]
+        return self.weights_t[o:].data_ptr()
 
     # ---- TF-named variables <-> flat layout ----
     def _to_flat(self, named):
@@ -164,9 +182,25 @@ class MlpVaeDevice:
         return self._from_flat(self.grads.cpu().numpy())
 
     # ---- building blocks ----
+    SPLIT_K = 4096                                          # reductions at least this long are split over the chip (38400 -> 30 slabs) and finished by mi_splitk_finish
+
     def _dense(self, a, M, K, wname, N, bias, relu, out, out_f32=0, w_layout=0, mask=None):
-        self.L.mi_gemm_bias_act(self.stream(), self.dtype, a.data_ptr(), int(M), int(K), self._w(wname), int(w_layout), int(N),
-                                bias, int(relu), mask.data_ptr() if mask is not None else None, out.data_ptr(), int(out_f32), 1)
+        """out = mask(act(a W + bias)).  w_layout 0: forward, through the K-contiguous copy; 1: input gradient (x * W^T on the [K, N] original)."""
+        M, K, N = int(M), int(K), int(N)
+        w = self._wt(wname) if w_layout == 0 else self._w(wname)
+        mk = mask.data_ptr() if mask is not None else None
+        if K >= self.SPLIT_K and K % 128 == 0:
+            ns = max(1, min(32, K // 1280))
+            while K % (ns * 128) != 0 and ns > 1:
+                ns -= 1
+            if ns > 1:
+                need = ns * M * N
+                if self.slab is None or self.slab.numel() < need:
+                    self.slab = torch.empty(need, device=self.device, dtype=torch.float32)
+                self.L.mi_gemm_bias_act(self.stream(), self.dtype, a.data_ptr(), M, K, w, 1, N, None, 0, None, self.slab.data_ptr(), 1, ns)
+                self.L.mi_splitk_finish(self.stream(), self.dtype, self.slab.data_ptr(), ns, M, N, bias, int(relu), mk, out.data_ptr(), int(out_f32))
+                return
+        self.L.mi_gemm_bias_act(self.stream(), self.dtype, a.data_ptr(), M, K, w, 1, N, bias, int(relu), mk, out.data_ptr(), int(out_f32), 1)
 
     def _stage_input(self, src, idx, B):
         rows = src if idx is None else src.index_select(0, idx.to(torch.int64))               # plumbing: row gather of the frame table
@@ -248,6 +282,7 @@ class MlpVaeDevice:
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.L.mi_adam_tf_flat(self.stream(), self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.grads.data_ptr(), self.n_flat,
                                float(alpha), float(beta1), float(beta2), float(epsilon), self.shadow.data_ptr() if self.bf16 else None, 1)
+        self._refresh_transposed()
 
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)

@@ -117,6 +117,9 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
 /* tf.layers.dense (MatMul + BiasAdd + Relu) and its input gradient — vae/models.py:97-98,259; utils.py:25-28; ppo.py:43-55.
  * w_layout 0: W[K,N]; 1: W[N,K] (x * W^T).  nsplit > 1: split-K raw fp32 slabs out[nsplit][M][N]. */
 int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const void* w, int w_layout, int N, const float* bias, int relu, const void* mask, void* out, int out_f32, int nsplit);
+/* the finishing pass of a split-K dense layer: out[m,n] = mask(act(sum_s slabs[s][m][n] + bias[n])) -- the bias / ReLU / ReluGrad epilogue mi_gemm_bias_act
+ * cannot apply to raw slabs (MlpVAE, vae/models.py:271-299: the 38400-long reductions of its first layer and of its last layer's input gradient) */
+int mi_splitk_finish(void* stream, int dtype, const float* slabs, int nsplit, int M, int N, const float* bias, int relu, const void* mask, void* out, int out_f32);
 /* dense kernel gradient dw[K,N] += a^T dy */
 int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw);
 

@@ -2,7 +2,7 @@
 # usage: tools/gpu_ab.sh "ENV_A" "ENV_B" [reps]   -> interleaved bench runs of two environments on the SAME box (boxes differ by up to 20 %)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-X="--no-cpu-baseline --no-ppo --no-fp32 --no-replay --steps 100"
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --steps 100"
 for r in $(seq 1 ${3:-2}); do
 for tag in A B; do
   if [ $tag = A ]; then E="$1"; else E="$2"; fi
