@@ -2,6 +2,7 @@
 // Every conv on this path is NHWC, stride 2, VALID (reference vae/models.py:250-253,261-264).
 #include <stdlib.h>
 #include "gemm_core.hpp"
+#include "tallk_tile.hpp"
 #include "mi_internal.hpp"
 #include "mi355_carla.h"
 
@@ -668,6 +669,12 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 
 void mi_get_trace(long long** buf, int* cap) { *buf = g_trace; *cap = g_trace_cap; }
 
+static bool tallk_enabled() {                              // MI355_TALLK=0: the general split-K kernel for the latent-side layers (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_TALLK"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
 extern "C" {
 
 // debug: device buffer of int64 stamps, 32 per wave of every tapconv block (see tools/trace_tapconv.py); nullptr switches it off
@@ -883,6 +890,19 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
         DenseSmallParams q = {(const float*)a, (const float*)w, bias, (float*)out, M, N, K, relu};
         hipLaunchKernelGGL(dense_smallm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, q);
         return mi_check_launch("dense_smallm_kernel");
+    }
+    // long reduction into a narrow output, K-contiguous weights, raw split-K slabs wanted (the latent-side layers): tallk_tile.hpp
+    if (dtype == MI_BF16 && w_layout == 1 && nsplit > 1 && out_f32 && !bias && !relu && !mask && tallk_enabled() && (N == 32 || N == 64 || N == 128) &&
+        K % (nsplit * 16) == 0 && ((((uintptr_t)a) | ((uintptr_t)w)) & 15) == 0 && (long long)M * K * 2 < (1ll << 30) && (long long)N * K * 2 < (1ll << 30)) {
+        const int nt = N / 32, kp = 4 / nt;
+        if (nsplit % kp == 0) {
+            TallKParams q = {a, w, (float*)out, M, N, K, K / nsplit, (unsigned)((long long)M * K * 2), (unsigned)((long long)N * K * 2)};
+            const dim3 g((M + 31) / 32, nsplit / kp);
+            if (nt == 4) hipLaunchKernelGGL(tallk_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, q);
+            else if (nt == 2) hipLaunchKernelGGL(tallk_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL(tallk_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, q);
+            return mi_check_launch("tallk_kernel");
+        }
     }
     GemmParams p = {};
     p.a = a; p.a_frame_idx = nullptr;

@@ -59,10 +59,16 @@ __global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int nspli
         float klacc = 0.f;
         for (int j = lane; j < Z; j += WAVE) {
             float mu = bias_mean[j], lv = bias_lv[j];
-            for (int s = 0; s < nsplit; ++s) {
-                const float* h = heads + ((long long)s * B + row) * (2 * Z);
-                mu += h[j];
-                lv += h[Z + j];
+            for (int s0 = 0; s0 < nsplit; s0 += 8) {       // eight slabs requested together, added in slab order (a plain loop pays one latency per slab)
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = s0 + u < nsplit;
+                    const float* h = heads + ((long long)(ok ? s0 + u : 0) * B + row) * (2 * Z);
+                    a[u] = ok ? h[j] : 0.f; b[u] = ok ? h[Z + j] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { mu += a[u]; lv += b[u]; }
             }
             mean[(long long)row * Z + j] = mu;
             logvar[(long long)row * Z + j] = lv;
@@ -110,7 +116,13 @@ __global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit,
     const float act = (kl_floor > 0.f && kl_row[row] < kl_floor) ? 0.f : 1.f;
     for (int j = lane; j < Z; j += WAVE) {
         float dz = 0.f;
-        for (int s = 0; s < nsplit; ++s) dz += dzs[((long long)s * B + row) * Z + j];
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {           // eight slabs requested together, added in slab order
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? dzs[((long long)(s0 + u) * B + row) * Z + j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dz += a[u];
+        }
         const float mu = mean[(long long)row * Z + j], lv = logvar[(long long)row * Z + j];
         const float e = eps[(long long)row * Z + j];
         const float dmu = dz + beta * mu * inv_b * act;
