@@ -51,6 +51,14 @@ __device__ __forceinline__ void pf_mma_chunked(int sb, int se, FA load_a, FB loa
     }
 }
 
+// operands through buffer descriptors: rows are clamped, reads past a tensor return 0.0 from the hardware range check, stores past it are dropped --
+// no per-lane guard branches (at one wave per SIMD the instruction count is the kernel time: rollout.hip)
+#define PF_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define PF_OOB 0x40000000u
+__device__ __forceinline__ float pf_ld(const __amdgpu_buffer_rsrc_t r, unsigned byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0)); }
+__device__ __forceinline__ f32x4 pf_ld4(const __amdgpu_buffer_rsrc_t r, unsigned byte_off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0)); }
+__device__ __forceinline__ void pf_st(const __amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0); }
+
 // TF ApplyAdam on one element
 __device__ __forceinline__ void pf_adam(float* p, float* m, float* v, float g, const PpoFusedParams& q) {
     float mm = *m, vv = *v;
@@ -78,32 +86,29 @@ __global__ __launch_bounds__(256) void ppo_l1_kernel(const PpoFusedParams q) {
     const float* th = pf_theta(q, net);
     const float* W = th + pf_off(q, net, 0);
     const float* bias = th + pf_off(q, net, 1);
-    const int m = m0 + lrow, n = n0 + lrow;
-    const bool mok = m < q.M, nok = n < q.H1;
-    const float* srow = q.states + (long long)(mok ? m : 0) * q.din;
+    const int n = n0 + lrow;
+    // states rows are din long, W1 has kin >= din rows of which the last kin - din are zero (and stay zero: their gradient is never formed): a k past
+    // din reads the next row's finite values against a zero weight row; past the tensors the range check returns 0.0
+    const __amdgpu_buffer_rsrc_t rsS = PF_RSRC(q.states, (long long)q.M * q.din * 4), rsW = PF_RSRC(W, (long long)q.kin * q.H1 * 4);
+    const unsigned arow = (unsigned)min(m0 + lrow, q.M - 1) * (unsigned)q.din, H1u = (unsigned)q.H1;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     pf_mma_chunked<9>(0, (q.kin + 7) / 8,
-        [&](int s_) { const int k = s_ * 8 + lgrp * 4; f32x4 a;
+        [&](int s_) { const unsigned k = (unsigned)(s_ * 8 + lgrp * 4); f32x4 a;
 #pragma unroll
-                      for (int e = 0; e < 4; ++e) {
-                          const int ke = k + e;
-                          a[e] = (mok && ke < q.din) ? srow[ke] : 0.f;
-                      }
+                      for (int e = 0; e < 4; ++e) a[e] = pf_ld(rsS, (arow + k + e) * 4u);
                       return a; },
-        [&](int s_) { const int k = s_ * 8 + lgrp * 4; f32x4 b;
+        [&](int s_) { const unsigned k = (unsigned)(s_ * 8 + lgrp * 4); f32x4 b;
 #pragma unroll
-                      for (int e = 0; e < 4; ++e) b[e] = (nok && k + e < q.kin) ? W[(long long)(k + e) * q.H1 + n] : 0.f;
+                      for (int e = 0; e < 4; ++e) b[e] = pf_ld(rsW, ((k + e) * H1u + (unsigned)n) * 4u);
                       return b; }, acc);
-    if (nok) {
-        const float bn = bias[n];
-        float* out = q.h1 + (long long)net * q.M * q.H1;
+    {
+        const float bn = pf_ld(PF_RSRC(bias, (long long)q.H1 * 4), (unsigned)n * 4u);
+        const __amdgpu_buffer_rsrc_t rsO = PF_RSRC(q.h1 + (long long)net * q.M * q.H1, (long long)q.M * q.H1 * 4);
+        const unsigned col = n < q.H1 ? (unsigned)n * 4u : PF_OOB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = m0 + pf_row(r, lgrp);
-            if (mm < q.M) out[(long long)mm * q.H1 + n] = fmaxf(acc[r] + bn, 0.f);
-        }
+        for (int r = 0; r < 16; ++r) pf_st(rsO, (unsigned)(m0 + pf_row(r, lgrp)) * H1u * 4u + col, fmaxf(acc[r] + bn, 0.f));      // rows past M fall outside the descriptor
     }
 }
 
@@ -121,37 +126,31 @@ __global__ __launch_bounds__(256) void ppo_l2_kernel(const PpoFusedParams q) {
     const int K = q.H1;
     const int ksteps = (K + 7) / 8, per = (ksteps + 3) / 4;
     const int sb = wave * per, se = min(ksteps, sb + per);
-    const int m = m0 + lrow, n = n0 + lrow;
-    const bool mok = m < q.M, nok = n < q.H2;
-    const float* xrow = x + (long long)(mok ? m : 0) * K;
+    const int n = n0 + lrow;
+    const __amdgpu_buffer_rsrc_t rsX = PF_RSRC(x, (long long)q.M * K * 4), rsW = PF_RSRC(W, (long long)K * q.H2 * 4);
+    const unsigned arow = (unsigned)min(m0 + lrow, q.M - 1) * (unsigned)K, H2u = (unsigned)q.H2;
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pf_mma_chunked<16>(sb, se,
-        [&](int s_) { const int k = s_ * 8 + lgrp * 4; f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                      if (mok && k + 4 <= K) a = *(const f32x4*)(xrow + k);
-                      else if (mok) {
+    pf_mma_chunked<16>(sb, se,                            // K % 4 == 0; a k past K reads the next row of x against weights past the tensor (0.0)
+        [&](int s_) { return pf_ld4(rsX, (arow + (unsigned)(s_ * 8 + lgrp * 4)) * 4u); },
+        [&](int s_) { const unsigned k = (unsigned)(s_ * 8 + lgrp * 4); f32x4 b;
 #pragma unroll
-                          for (int e = 0; e < 4; ++e) a[e] = k + e < K ? xrow[k + e] : 0.f;
-                      }
-                      return a; },
-        [&](int s_) { const int k = s_ * 8 + lgrp * 4; f32x4 b;
-#pragma unroll
-                      for (int e = 0; e < 4; ++e) b[e] = (nok && k + e < K) ? W[(long long)(k + e) * q.H2 + n] : 0.f;
+                      for (int e = 0; e < 4; ++e) b[e] = pf_ld(rsW, ((k + e) * H2u + (unsigned)n) * 4u);
                       return b; }, acc);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
     }
     __syncthreads();
-    if (wave == 0 && nok) {
-        const float bn = bias[n];
-        float* out = q.h2 + (long long)net * q.M * q.H2;
+    if (wave == 0) {
+        const float bn = pf_ld(PF_RSRC(bias, (long long)q.H2 * 4), (unsigned)n * 4u);
+        const __amdgpu_buffer_rsrc_t rsO = PF_RSRC(q.h2 + (long long)net * q.M * q.H2, (long long)q.M * q.H2 * 4);
+        const unsigned col = n < q.H2 ? (unsigned)n * 4u : PF_OOB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]));
-            const int mm = m0 + pf_row(r, lgrp);
-            if (mm < q.M) out[(long long)mm * q.H2 + n] = fmaxf(v + bn, 0.f);
+            pf_st(rsO, (unsigned)(m0 + pf_row(r, lgrp)) * H2u * 4u + col, fmaxf(v + bn, 0.f));
         }
     }
 }
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256) void ppo_l2_kernel(const PpoFusedParams q) {
 constexpr int PF_H2MAX = 320;                             // head kernels staged in LDS: H2 <= 320 (the reference: 300)
 template <int NA>
 __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams q) {
-    __shared__ float sWm[PF_H2MAX * PF_MAX_ACT], sWo[PF_H2MAX * PF_MAX_ACT], sWv[PF_H2MAX];
+    __shared__ __attribute__((aligned(16))) float sWm[PF_H2MAX * PF_MAX_ACT], sWo[PF_H2MAX * PF_MAX_ACT], sWv[PF_H2MAX];
     __shared__ float su[32][NA], suo[32][NA], sv[32], sdu[32][NA], sdv[32], spart[32][PF_NPART];
     const int tid = threadIdx.x, m0 = blockIdx.x * 32, A = q.A, H2 = q.H2;
     const float* __restrict__ Wm = q.theta + q.off[4]; const float* __restrict__ bm = q.theta + q.off[5];
@@ -214,6 +213,23 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
         float au[NA], ao[NA], av = 0.f;
 #pragma unroll
         for (int a = 0; a < NA; ++a) { au[a] = 0.f; ao[a] = 0.f; }
+        if constexpr (NA == 2) {                          // exactly two actions (the reference; the host picks this instantiation only then): head-kernel rows of 4 consecutive j are two 16-byte LDS reads
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int f = min(part + 8 * i, nf - 1);  // (threads past the row re-read its last piece: their h2 registers are zero)
+                const f32x4 wv = *(const f32x4*)(sWv + 4 * f);
+                const f32x4 wa = *(const f32x4*)(sWm + 8 * f), wb = *(const f32x4*)(sWm + 8 * f + 4);
+                const f32x4 oa = *(const f32x4*)(sWo + 8 * f), ob = *(const f32x4*)(sWo + 8 * f + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    av += hv[i][e] * wv[e];
+                    const float w0 = e < 2 ? wa[2 * e] : wb[2 * e - 4], w1 = e < 2 ? wa[2 * e + 1] : wb[2 * e - 3];
+                    const float o0 = e < 2 ? oa[2 * e] : ob[2 * e - 4], o1 = e < 2 ? oa[2 * e + 1] : ob[2 * e - 3];
+                    au[0] += hp[i][e] * w0; au[NA > 1 ? 1 : 0] += hp[i][e] * w1;
+                    ao[0] += ho[i][e] * o0; ao[NA > 1 ? 1 : 0] += ho[i][e] * o1;
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = part + 8 * i;
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
                 av += hv[i][e] * sWv[j];
                 _Pragma("unroll") for (int a = 0; a < NA; ++a) if (a < A) { au[a] += hp[i][e] * sWm[j * A + a]; ao[a] += ho[i][e] * sWo[j * A + a]; }
             }
+        }
         }
 #pragma unroll
         for (int o = 4; o > 0; o >>= 1) {
@@ -304,6 +321,18 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
             const int f = part + 8 * i;
             if (f >= nf) continue;
             f32x4 gp, gv;
+            if constexpr (NA == 2) {
+                const f32x4 wv = *(const f32x4*)(sWv + 4 * f);
+                const f32x4 wa = *(const f32x4*)(sWm + 8 * f), wb = *(const f32x4*)(sWm + 8 * f + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float w0 = e < 2 ? wa[2 * e] : wb[2 * e - 4], w1 = e < 2 ? wa[2 * e + 1] : wb[2 * e - 3];
+                    float sa = dus[0] * w0;
+                    sa += dus[NA > 1 ? 1 : 0] * w1;
+                    gp[e] = hp[i][e] > 0.f ? sa : 0.f;
+                    gv[e] = hv[i][e] > 0.f ? dvs * wv[e] : 0.f;
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = 4 * f + e;
@@ -311,6 +340,7 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
                 _Pragma("unroll") for (int a = 0; a < NA; ++a) if (a < A) sa += dus[a] * sWm[j * A + a];
                 gp[e] = hp[i][e] > 0.f ? sa : 0.f;
                 gv[e] = hv[i][e] > 0.f ? dvs * sWv[j] : 0.f;
+            }
             }
             *(f32x4*)(dh2p + 4 * f) = gp;
             *(f32x4*)(dh2v + 4 * f) = gv;
@@ -333,30 +363,32 @@ __global__ __launch_bounds__(256) void ppo_dh1_kernel(const PpoFusedParams q) {
     float* dh1 = q.dh1 + (long long)net * M * H1;
     const int nsteps = (H2 + 7) / 8, per = (nsteps + 3) / 4;
     const int sb = wave * per, se = min(nsteps, sb + per);
-    const int kk = k0 + lrow, m = m0 + lrow;
-    const bool kok = kk < H1, mok = m < M;
+    const int kk = k0 + lrow;
+    const __amdgpu_buffer_rsrc_t rsG = PF_RSRC(dh2, (long long)M * H2 * 4), rsW = PF_RSRC(W2, (long long)H1 * H2 * 4), rsH = PF_RSRC(h1, (long long)M * H1 * 4);
+    const unsigned grow = (unsigned)min(m0 + lrow, M - 1) * (unsigned)H2, wrow = (unsigned)min(kk, H1 - 1) * (unsigned)H2, H1u = (unsigned)H1;
+    const unsigned col = kk < H1 ? (unsigned)kk * 4u : PF_OOB;
     float hmask[16];                                      // relu'(h1) of this lane's outputs, requested with the operands
     if (wave == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const int mm = m0 + pf_row(r, lgrp); hmask[r] = (kok && mm < M) ? h1[(long long)mm * H1 + kk] : 0.f; }
+        for (int r = 0; r < 16; ++r) hmask[r] = pf_ld(rsH, (unsigned)(m0 + pf_row(r, lgrp)) * H1u * 4u + col);
     }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    pf_mma_chunked<10>(sb, se,
-        [&](int s_) { const int n = s_ * 8 + lgrp * 4; return (mok && n + 4 <= H2) ? *(const f32x4*)(dh2 + (long long)m * H2 + n) : f32x4{0.f, 0.f, 0.f, 0.f}; },
-        [&](int s_) { const int n = s_ * 8 + lgrp * 4; return (kok && n + 4 <= H2) ? *(const f32x4*)(W2 + (long long)kk * H2 + n) : f32x4{0.f, 0.f, 0.f, 0.f}; }, acc);
+    pf_mma_chunked<10>(sb, se,                            // H2 % 4 == 0; the reduction index past H2 must read zeros on one side: the W2 row is cut off there
+        [&](int s_) { return pf_ld4(rsG, (grow + (unsigned)(s_ * 8 + lgrp * 4)) * 4u); },
+        [&](int s_) { const int n = s_ * 8 + lgrp * 4; return pf_ld4(rsW, n < H2 ? (wrow + (unsigned)n) * 4u : PF_OOB); }, acc);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
     }
     __syncthreads();
-    if (wave == 0 && kok) {
+    if (wave == 0) {
+        const __amdgpu_buffer_rsrc_t rsO = PF_RSRC(q.dh1 + (long long)net * M * H1, (long long)M * H1 * 4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]));
-            const int mm = m0 + pf_row(r, lgrp);
-            if (mm < M) dh1[(long long)mm * H1 + kk] = hmask[r] > 0.f ? v : 0.f;
+            pf_st(rsO, (unsigned)(m0 + pf_row(r, lgrp)) * H1u * 4u + col, hmask[r] > 0.f ? v : 0.f);
         }
     }
 }
@@ -376,20 +408,27 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
     const int per_net = KT2 * NT2 + KT1 * NT1 + KTH;
     int t = blockIdx.x * 4 + wave;
     if (t == 2 * per_net) {                               // spare wave: loss scalars + logstd (fixed block order: deterministic)
-        if (lane != 0) return;
+        // lane k sums column k of the per-block partials (one load chain per lane instead of PF_NPART chains on lane 0: this wave's latency was
+        // the kernel's duration), lane 0 collects them with shuffles; exp / log through the hardware units (arguments O(1), ~1e-7 relative)
+        float col = 0.f;
+        if (lane < PF_NPART) for (int b = 0; b < q.n_loss_blocks; ++b) col += q.partial[(long long)b * PF_NPART + lane];
         float sum[PF_NPART];
-        for (int k = 0; k < PF_NPART; ++k) sum[k] = 0.f;
-        for (int b = 0; b < q.n_loss_blocks; ++b)
-            for (int k = 0; k < PF_NPART; ++k) sum[k] += q.partial[(long long)b * PF_NPART + k];
-        const float* logstd = q.theta + q.off[6];
+#pragma unroll
+        for (int k = 0; k < PF_NPART; ++k) sum[k] = __shfl(col, k, 64);
+        const float ls_l = lane < q.A ? q.theta[q.off[6] + lane] : 0.f;      // logstd[a] on lane a
+        const float sd_l = __expf(ls_l);
         float ent = 0.f, sd[PF_MAX_ACT];
-        for (int a = 0; a < q.A; ++a) { sd[a] = expf(logstd[a]); ent += 0.5f + PF_HALF_LOG_2PI + logf(sd[a]); }
+#pragma unroll
+        for (int a = 0; a < PF_MAX_ACT; ++a) { sd[a] = __shfl(sd_l, a, 64); if (a < q.A) ent += 0.5f + PF_HALF_LOG_2PI + __logf(sd[a]); }
+        if (lane != 0) return;
         const float pl = sum[0] * q.inv_m, vl = sum[1] * q.inv_m * q.value_scale, el = ent * q.entropy_scale;
         float* L = q.losses;                               // [0..4] policy, value, entropy, total, mean ratio ; [5..5+A) mean action_mean ; [5+A..5+2A) std
         L[0] = pl; L[1] = vl; L[2] = el; L[3] = -pl + vl - el; L[4] = sum[2] * q.inv_m;
-        for (int a = 0; a < q.A; ++a) { L[5 + a] = sum[3 + PF_MAX_ACT + a] * q.inv_m; L[5 + q.A + a] = sd[a]; }
+#pragma unroll
+        for (int a = 0; a < PF_MAX_ACT; ++a) if (a < q.A) { L[5 + a] = sum[3 + PF_MAX_ACT + a] * q.inv_m; L[5 + q.A + a] = sd[a]; }
         // the entropy term is state independent: under data parallelism grad_scale = local_M / global_M shares it across the ranks
-        for (int a = 0; a < q.A; ++a) pf_emit<FUSE>(q, q.off[6] + a, sum[3 + a] - q.entropy_scale * q.grad_scale);
+#pragma unroll
+        for (int a = 0; a < PF_MAX_ACT; ++a) if (a < q.A) pf_emit<FUSE>(q, q.off[6] + a, sum[3 + a] - q.entropy_scale * q.grad_scale);
         return;
     }
     if (t > 2 * per_net) return;
@@ -412,16 +451,21 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         oW = pf_off(q, net, 4); ob = pf_off(q, net, 5); ldw = A; kvalid = H2;
     }
     const int k = kt * 32 + lrow, n = nt * 32 + lrow;
-    const bool kok = k < Kx, nok = n < Ng;
+    const bool nok = n < Ng;
+    // descriptors: X / G end with the minibatch (rows past M read 0.0), a column past the tensor is sent past the descriptor; the weight tile's
+    // descriptor ends at row Kx, so the optimiser state of rows past it reads 0.0 and their stores are dropped
+    const __amdgpu_buffer_rsrc_t rsX = PF_RSRC(X, (long long)M * ldx * 4), rsG = PF_RSRC(G, (long long)M * ldg * 4);
+    const unsigned xcol = k < Kx ? (unsigned)k * 4u : PF_OOB, gcol = nok ? (unsigned)n * 4u : PF_OOB;
+    const unsigned ldxb = (unsigned)ldx * 4u, ldgb = (unsigned)ldg * 4u, ldwb = (unsigned)ldw * 4u;
+    const long long wbytes = (long long)Kx * ldw * 4;
+    const __amdgpu_buffer_rsrc_t rsP = PF_RSRC(q.theta + oW, wbytes), rsM = PF_RSRC(q.adam_m + oW, wbytes), rsV = PF_RSRC(q.adam_v + oW, wbytes);
     // the tile's optimiser state is requested together with the operands (FUSE): one memory round trip for the whole wave
     float pw[16], pm[16], pv[16];
     if constexpr (FUSE) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kr = kt * 32 + pf_row(r, lgrp);
-            const bool ok = nok && kr < Kx;
-            const long long idx = oW + (long long)kr * ldw + n;
-            pw[r] = ok ? q.theta[idx] : 0.f; pm[r] = ok ? q.adam_m[idx] : 0.f; pv[r] = ok ? q.adam_v[idx] : 0.f;
+            const unsigned off = (unsigned)(kt * 32 + pf_row(r, lgrp)) * ldwb + gcol;
+            pw[r] = pf_ld(rsP, off); pm[r] = pf_ld(rsM, off); pv[r] = pf_ld(rsV, off);
         }
     }
     f32x16_t acc, accb;
@@ -434,9 +478,9 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int mm = (s0 + u) * 8 + lgrp * 4 + e;
-                a[u][e] = (kok && mm < M) ? X[(long long)mm * ldx + k] : 0.f;
-                b[u][e] = (nok && mm < M) ? G[(long long)mm * ldg + n] : 0.f;
+                const unsigned mm = (unsigned)((s0 + u) * 8 + lgrp * 4 + e);
+                a[u][e] = pf_ld(rsX, mm * ldxb + xcol);
+                b[u][e] = pf_ld(rsG, mm * ldgb + gcol);
             }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -445,18 +489,23 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         }
     }
     if (!nok) return;
+    if constexpr (FUSE) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int kr = kt * 32 + pf_row(r, lgrp);
-        const long long idx = oW + (long long)kr * ldw + n;
-        if (kr < Kx) {
-            if constexpr (FUSE) {
-                float mm_ = pm[r], vv_ = pv[r];
-                mm_ += (acc[r] - mm_) * q.omb1; vv_ += (acc[r] * acc[r] - vv_) * q.omb2;
-                q.adam_m[idx] = mm_; q.adam_v[idx] = vv_;
-                q.theta[idx] = pw[r] - (mm_ * q.alpha) / (sqrtf(vv_) + q.epsilon);
-            } else q.grads[idx] = acc[r];
-        } else if (!FUSE && kr < kvalid) q.grads[idx] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const unsigned off = (unsigned)(kt * 32 + pf_row(r, lgrp)) * ldwb + gcol;
+            float mm_ = pm[r], vv_ = pv[r];
+            mm_ += (acc[r] - mm_) * q.omb1; vv_ += (acc[r] * acc[r] - vv_) * q.omb2;
+            pf_st(rsM, off, mm_); pf_st(rsV, off, vv_);
+            pf_st(rsP, off, pw[r] - (mm_ * q.alpha) / (sqrtf(vv_) + q.epsilon));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = kt * 32 + pf_row(r, lgrp);
+            const long long idx = oW + (long long)kr * ldw + n;
+            if (kr < Kx) q.grads[idx] = acc[r];
+            else if (kr < kvalid) q.grads[idx] = 0.f;
+        }
     }
     if (kt == 0 && lgrp == 0) pf_emit<FUSE>(q, ob + n, accb[0]);
 }
@@ -552,7 +601,7 @@ int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
     if (q.H2 > PF_H2MAX || q.H2 % 4 != 0 || q.kin > 96) return mi_fail(MI_ERR_SHAPE, "ppo fused step: hidden sizes outside the staged range (H2 <= 320, multiple of 4; inputs <= 96)");
-    if (q.A <= 2) hipLaunchKernelGGL(ppo_head_loss_kernel<2>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);     // (action loops are compile-time unrolled)
+    if (q.A == 2) hipLaunchKernelGGL(ppo_head_loss_kernel<2>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);     // (action loops are compile-time unrolled)
     else hipLaunchKernelGGL(ppo_head_loss_kernel<PF_MAX_ACT>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);
     hipLaunchKernelGGL(ppo_dh1_kernel, dim3((q.H1 + 31) / 32, 2, (q.M + 31) / 32), dim3(256), 0, st, q);
     const int nt1 = (q.H1 + 31) / 32, nt2 = (q.H2 + 31) / 32, kt1 = (q.kin + 31) / 32;
