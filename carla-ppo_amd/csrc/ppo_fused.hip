@@ -515,11 +515,14 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
 // value = h2_v Wv + bv.  with logp_out: log pi(a | s) of GIVEN actions under net `lp_net` (0 policy, 2 old policy) instead (the cache of
 // log pi_old for a whole horizon batch).  grid ceil(M / 32) blocks; 8 threads per sample.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NA>
+// LG: log2 of the threads per sample: 3 (32 samples per block) for batches, 6 (a wave per sample: 5 instead of 38 dependent steps over the 300 columns)
+// for the handful of samples of an interactive predict
+template <int NA, int LG>
 __global__ __launch_bounds__(256) void ppo_predict_head_kernel(const PpoFusedParams q, const float* __restrict__ noise, int greedy,
                                                                float* __restrict__ action, float* __restrict__ value, float* __restrict__ logp_out, int lp_net) {
-    const int tid = threadIdx.x, m0 = blockIdx.x * 32, A = q.A, H2 = q.H2;
-    const int sm = tid >> 3, part = tid & 7, m = m0 + sm;
+    constexpr int TPS = 1 << LG, SPB = 256 / TPS;
+    const int tid = threadIdx.x, m0 = blockIdx.x * SPB, A = q.A, H2 = q.H2;
+    const int sm = tid >> LG, part = tid & (TPS - 1), m = m0 + sm;
     const float* th = lp_net == 2 ? q.theta_old : q.theta;
     const float* Wm = th + q.off[4]; const float* bm = th + q.off[5]; const float* logstd = th + q.off[6];
     const float* Wv = q.theta + q.off[11]; const float* bv = q.theta + q.off[12];
@@ -528,14 +531,14 @@ __global__ __launch_bounds__(256) void ppo_predict_head_kernel(const PpoFusedPar
 #pragma unroll
     for (int a = 0; a < NA; ++a) au[a] = 0.f;
     if (m < q.M) {
-        for (int j = part; j < H2; j += 8) {
+        for (int j = part; j < H2; j += TPS) {
             const float hp = h2p[(long long)m * H2 + j];
             if (!logp_out) av += h2v[(long long)m * H2 + j] * Wv[j];
             _Pragma("unroll") for (int a = 0; a < NA; ++a) if (a < A) au[a] += hp * Wm[(long long)j * A + a];
         }
     }
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
+    for (int o = TPS / 2; o > 0; o >>= 1) {
         av += __shfl_xor(av, o, 64);
 #pragma unroll
         for (int a = 0; a < NA; ++a) au[a] += __shfl_xor(au[a], o, 64);
@@ -567,8 +570,11 @@ int mi_ppo_fused_predict(hipStream_t st, PpoFusedParams& q, const float* noise, 
     q.n_nets = 2;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
-    if (q.A <= 2) hipLaunchKernelGGL(ppo_predict_head_kernel<2>, dim3((q.M + 31) / 32), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
-    else hipLaunchKernelGGL(ppo_predict_head_kernel<PF_MAX_ACT>, dim3((q.M + 31) / 32), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
+    if (q.M <= 8) {                                       // a wave per sample
+        if (q.A <= 2) hipLaunchKernelGGL((ppo_predict_head_kernel<2, 6>), dim3((q.M + 3) / 4), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
+        else hipLaunchKernelGGL((ppo_predict_head_kernel<PF_MAX_ACT, 6>), dim3((q.M + 3) / 4), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
+    } else if (q.A <= 2) hipLaunchKernelGGL((ppo_predict_head_kernel<2, 3>), dim3((q.M + 31) / 32), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
+    else hipLaunchKernelGGL((ppo_predict_head_kernel<PF_MAX_ACT, 3>), dim3((q.M + 31) / 32), dim3(256), 0, st, q, noise, greedy, action, value, (float*)nullptr, 0);
     return mi_check_launch("ppo_predict_head");
 }
 
@@ -579,8 +585,8 @@ int mi_ppo_fused_logp_old(hipStream_t st, PpoFusedParams& q, float* out) {
     q.n_nets = 3;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
-    if (q.A <= 2) hipLaunchKernelGGL(ppo_predict_head_kernel<2>, dim3((q.M + 31) / 32), dim3(256), 0, st, q, (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, out, 2);
-    else hipLaunchKernelGGL(ppo_predict_head_kernel<PF_MAX_ACT>, dim3((q.M + 31) / 32), dim3(256), 0, st, q, (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, out, 2);
+    if (q.A <= 2) hipLaunchKernelGGL((ppo_predict_head_kernel<2, 3>), dim3((q.M + 31) / 32), dim3(256), 0, st, q, (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, out, 2);
+    else hipLaunchKernelGGL((ppo_predict_head_kernel<PF_MAX_ACT, 3>), dim3((q.M + 31) / 32), dim3(256), 0, st, q, (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, out, 2);
     return mi_check_launch("ppo_logp_old");
 }
 
