@@ -42,6 +42,10 @@ NAMES_R02 = [("rwconv_gather_kernel<3, 5, true, 0, true, 0>", None, "deconv3.fwd
          ("tapwgrad_kernel<1, 3, 2, 4, 4, false>", "247x1x1", "deconv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "247x1x1", "conv2.wgrad"),
          ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "63x4x1", "conv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "16x16x1", "conv4.wgrad"),
          ("tapwgrad_kernel<1, 2, 4, 2, 2, true>", "62x4x1", "deconv2.wgrad"), ("tapwgrad_kernel<1, 2, 4, 2, 2, true>", "16x16x1", "deconv1.wgrad"),
+         # after the 1-D XCD-grouped launch (and the class / tap-row kernel for k = 5): conv3 / conv4 and deconv2 / deconv1 share kernel AND grid
+         ("tapwgrad_cw_kernel", None, "deconv3.wgrad"), ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "248x1x1", "conv2.wgrad"),
+         ("tapwgrad_kernel<0, 2, 4, 2, 2, true>", "256x1x1", "conv3.wgrad + conv4.wgrad (same kernel and grid: averaged)"),
+         ("tapwgrad_kernel<1, 2, 4, 2, 2, true>", "256x1x1", "deconv2.wgrad + deconv1.wgrad (same kernel and grid: averaged)"),
          ("narrow_wgrad_kernel<unsigned char, 3, 1, 12>", None, "conv1.wgrad (+bias)"), ("narrow_wgrad_kernel<bf16, 3, 0, 12>", None, "deconv4.wgrad"),
          ("narrow_conv48_kernel<unsigned char, 0>", None, "conv1.fwd"), ("narrow_conv48_kernel<bf16, 1>", None, "deconv4.dgrad"),
          ("gather_narrow_kernel<bf16, 2, 4, 3, true>", None, "deconv4.fwd + loss"), ("reduce_fused_kernel", None, "filter-gradient slab reduce (6 layers)"),
