@@ -330,9 +330,12 @@ def main():
     args = ap.parse_args()
 
     from mi355 import dist as midist
-    world, rank, local = midist.init_from_env("nccl")
+    # (test hook: MI355_BENCH_BACKEND=gloo MI355_BENCH_ONE_DEVICE=1 runs the N > 1 code path with all ranks on cuda:0 -- RCCL wants one device per rank)
+    world, rank, local = midist.init_from_env(os.environ.get("MI355_BENCH_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if os.environ.get("MI355_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     from vae.models import ConvVAE
 

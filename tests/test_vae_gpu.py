@@ -658,3 +658,25 @@ def test_captured_graph_step_equals_eager_step(tmp_path, precision, monkeypatch)
     for k in p0:
         frac = np.mean(np.abs(p0[k] - p1[k]) > 0.5 * 1e-4)                          # an Adam step moves a weight by ~lr = 1e-4
         assert frac < (1e-3 if precision == "fp32" else 2e-2), (k, frac)
+
+
+def test_bench_data_parallel_path_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, two ranks), with the two ranks sharing this GPU over gloo
+    (RCCL refuses two ranks on one device): the weak-scaling bookkeeping, the per-rank gather, the exposed all-reduce measurement and the
+    parameter re-broadcast run end to end and the one JSON line has the contract's fields."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", MI355_BENCH_BACKEND="gloo", MI355_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "64", "--pool", "256"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(128 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+    dp = d["data_parallel"]
+    assert len(dp["ms_per_step_by_rank"]) == 2 and dp["gradient_bytes_per_step"] > 0 and "transport" in dp
+    assert d["roofline"] is not None and d["cpu_baseline"] is None
