@@ -39,8 +39,9 @@ __device__ __forceinline__ uint32_t pk_positive_mask(uint32_t m, uint32_t ones, 
 // waits a full LDS latency), whatever distance the source puts between them.  asm volatile keeps the issue order; the wait names the fragment
 // it releases as an in/out operand, so the MFMAs that consume it cannot be scheduled above the wait.  LDS returns in order: lgkmcnt(N) = all
 // but the N most recent reads have landed (an outstanding scalar load can only make the wait stricter).
-__device__ __forceinline__ void lds_read_b128_pair(u16x8& a, u16x8& b, uint32_t addr) {      // rows q and q + 32 (the next 32-position tile)
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(a), "=&v"(b) : "v"(addr));
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_pair(u16x8& a, u16x8& b, uint32_t addr) {      // rows q and q + 32 (the next 32-position tile: OFF = 32 rows)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(a), "=&v"(b) : "v"(addr), "n"(OFF));
 }
 template <int N> __device__ __forceinline__ void lds_wait_pair(u16x8& a, u16x8& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
@@ -54,64 +55,90 @@ template <int N> __device__ __forceinline__ void lds_wait_pair(u16x8& a, u16x8& 
 // half walks its own 128 positions of a 256-position chunk and the second half takes the classes in REVERSE order: waves w and w + 4 share
 // a SIMD (the dispatcher places a workgroup's waves on the SIMDs cyclically), which pairs the classes {0,3} and {1,2}: 13 and 12 tap-units
 // per SIMD instead of 9 | 6 | 6 | 4.  (The pairing is a performance assumption only: every wave computes its own class whatever its SIMD.)
-template <int TAPS> struct RwCfg {
-    static constexpr int NW = TAPS == 2 ? 4 : 8;                      // waves per block
+// CK = C / 64 = N / 32 (1: the 64 -> 32 channel layers; 2, k = 4 only: 128 -> 64 channels -- deconv2 forward, conv3's input gradient): slot rows of
+// 128 CK bytes, 4 CK k-steps per tap, the weights of ONE 32-output tile of a class in registers (64 CK VGPRs for k = 4), 4 CK waves = (class, tile)
+template <int TAPS, int CK = 1> struct RwCfg {
+    static constexpr int NW = TAPS == 2 ? 4 * CK : 8;                 // waves per block
     static constexpr int NTILE = 4;                                   // 32-position tiles per wave and chunk
-    static constexpr int BMT = 32 * NTILE * (NW / 4);                 // positions per chunk
+    static constexpr int BMT = 32 * NTILE * (TAPS == 2 ? 1 : 2);      // positions per chunk (k = 5: two position halves of four waves)
     static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;               // largest (TAPS-1) * GW + TAPS - 1 the buffers are sized for
-    static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 352 rows of 128 B
-    static constexpr int BUF = MAXSLOT * 128;                         // 22 | 44 KB per buffer, two buffers: 3 blocks | 1 block per CU
-    static constexpr int NIA = (MAXSLOT / 8 + NW - 1) / NW;           // DMA instructions per wave and chunk (upper bound)
+    static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 352 rows
+    static constexpr int RB = 128 * CK;                               // bytes per slot row
+    static constexpr int BUF = MAXSLOT * RB;                          // 22 | 44 | 44 KB per buffer, two buffers: 3 blocks | 1 block | 1 block per CU
+    static constexpr int RPI = 1024 / RB;                             // rows per DMA instruction (8 | 4)
+    static constexpr int NIA = ((MAXSLOT + RPI - 1) / RPI + NW - 1) / NW;   // DMA instructions per wave and chunk (upper bound)
 };
 
 // stage the slot range [P0, P0 + BMT + halo) into `buf`: instruction t = wave + 4 i fills rows 8 t .. 8 t + 7 (lane: row 8 t + lane / 8,
 // physical 16-byte chunk lane % 8, fetching the logical chunk (lane % 8) ^ ((row >> 1) & 7): the swizzle of tapconv_tile.hpp)
-template <int TAPS>
+template <int TAPS, int CK = 1>
 __device__ __forceinline__ void rw_stage(const TapParams& p, const __amdgpu_buffer_rsrc_t rsA, unsigned char* buf, int P0, int wave, int lane, int ninstr) {
-    constexpr int NW = RwCfg<TAPS>::NW;
-    const int r8 = lane >> 3;
-    // slot -> (frame, gy, gx) once per chunk; the following instructions of this wave are 8 NW slots further each (GW > 32 on this path: at
-    // most NW / 4 row wraps per step)
-    uint32_t g, gx, b, gy;
-    const int Pf = P0 + 8 * wave + r8;
-    p.div_gw.divmod((uint32_t)Pf, g, gx);
-    p.div_g.divmod(g, b, gy);
+    typedef RwCfg<TAPS, CK> Cfg;
+    constexpr int NW = Cfg::NW;
+    if constexpr (CK == 1) {
+        const int r8 = lane >> 3;
+        // slot -> (frame, gy, gx) once per chunk; the following instructions of this wave are 8 NW slots further each (GW > 32 on this path: at
+        // most NW / 4 row wraps per step)
+        uint32_t g, gx, b, gy;
+        const int Pf = P0 + 8 * wave + r8;
+        p.div_gw.divmod((uint32_t)Pf, g, gx);
+        p.div_g.divmod(g, b, gy);
 #pragma unroll
-    for (int i = 0; i < RwCfg<TAPS>::NIA; ++i) {
-        const int t = wave + NW * i;
-        if (t >= ninstr) break;                           // wave-uniform
-        const int q = 8 * t + r8;
-        const int c = (lane & 7) ^ ((q >> 1) & 7);
-        const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
-        const bool in = P0 + q < p.MP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const uint32_t vo = in ? (((b * p.IH + iy) * p.IW + ix) * 64u + c * 8u) * 2u : G2_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(buf + t * 1024), 16, (int)vo, 0, 0, 0);
-        gx += 8 * NW;
+        for (int i = 0; i < Cfg::NIA; ++i) {
+            const int t = wave + NW * i;
+            if (t >= ninstr) break;                           // wave-uniform
+            const int q = 8 * t + r8;
+            const int c = (lane & 7) ^ ((q >> 1) & 7);
+            const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
+            const bool in = P0 + q < p.MP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const uint32_t vo = in ? (((b * p.IH + iy) * p.IW + ix) * 64u + c * 8u) * 2u : G2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(buf + t * 1024), 16, (int)vo, 0, 0, 0);
+            gx += 8 * NW;
 #pragma unroll
-        for (int r = 0; r < NW / 4; ++r)
-            if ((int)gx >= p.GW) { gx -= p.GW; ++gy; if ((int)gy >= p.GH) { gy = 0; ++b; } }
+            for (int r = 0; r < NW / 4; ++r)
+                if ((int)gx >= p.GW) { gx -= p.GW; ++gy; if ((int)gy >= p.GH) { gy = 0; ++b; } }
+        }
+    } else {
+        // 256-byte rows: instruction t fills rows 4 t .. 4 t + 3 (lane: row 4 t + lane / 16, physical chunk lane % 16; the swizzle permutes the 8
+        // chunks of each 128-byte half).  The slot grid of these layers is narrow (GW = 20): a plain slot decode per instruction, 6 per wave and chunk
+        const int r4 = lane >> 4, cp = lane & 15;
+#pragma unroll
+        for (int i = 0; i < Cfg::NIA; ++i) {
+            const int t = wave + NW * i;
+            if (t >= ninstr) break;                           // wave-uniform
+            const int q = 4 * t + r4;
+            const int c = (cp & 8) | ((cp & 7) ^ ((q >> 1) & 7));
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)min(P0 + q, p.MP - 1), g, gx);
+            p.div_g.divmod(g, b, gy);
+            const int iy = (int)gy - p.HY, ix = (int)gx - p.HX;
+            const bool in = P0 + q < p.MP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const uint32_t vo = in ? (((b * p.IH + iy) * p.IW + ix) * (uint32_t)(64 * CK) + c * 8u) * 2u : G2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(buf + t * 1024), 16, (int)vo, 0, 0, 0);
+        }
     }
 }
 
 // One wave = one output parity class CLS (ph = CLS >> 1, pw = CLS & 1).  TAPS taps per axis, KH kernel size (compile time: which
 // (tap, class) pairs exist), C = 64 input channels (one 128-byte row per slot), N = 32 output channels per class.
-template <int TAPS, int KH, int CLS, bool RELU, int MASK, bool BITS, int DBG = 0>
+template <int TAPS, int KH, int CLS, bool RELU, int MASK, bool BITS, int DBG = 0, int CK = 1>
 __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds, const float* bias_lds, const __amdgpu_buffer_rsrc_t rsA,
-                                         int chunk, const int cstride, const int cend, int wave, int half, int lane, long long* tr, int tr_n) {
-    typedef RwCfg<TAPS> Cfg;
-    constexpr int RB = 128, NT = TAPS * TAPS, NTILE = Cfg::NTILE;
+                                         int chunk, const int cstride, const int cend, int wave, int half, int lane, long long* tr, int tr_n, int nt = 0) {
+    typedef RwCfg<TAPS, CK> Cfg;
+    constexpr int RB = Cfg::RB, NT = TAPS * TAPS, NTILE = Cfg::NTILE, KS = 4 * CK;      // KS: k-steps of 16 channels per tap
+    constexpr uint32_t NCH = 32u * CK;                    // output channels per pixel (nt: this wave's 32-channel tile of them)
     constexpr int PH = CLS >> 1, PW = CLS & 1, H = TAPS - 1;
     typedef u16x8 freg;
     const int lrow = lane & 31, lgrp = lane >> 5;
     const int halo = (TAPS - 1) * p.GW + TAPS - 1;
-    const int ninstr = (Cfg::BMT + halo + 7) >> 3;
+    const int ninstr = (Cfg::BMT + halo + Cfg::RPI - 1) / Cfg::RPI;
 
-    rw_stage<TAPS>(p, rsA, lds, chunk * Cfg::BMT, wave, lane, ninstr);           // first chunk -> buffer 0
+    rw_stage<TAPS, CK>(p, rsA, lds, chunk * Cfg::BMT, wave, lane, ninstr);       // first chunk -> buffer 0
 #define RW_STAMP() do { if (tr && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     RW_STAMP();                                           // 1: first slot range requested
 
     // ---- weights: fragment (tap, kk) = 8 consecutive input channels (kk*16 + lgrp*8) of output channel lrow, straight from L2, ONCE ----
-    freg wf[NT][4];
+    freg wf[NT][KS];
     {
         const bf16_t* __restrict__ W = (const bf16_t*)p.b;
 #pragma unroll
@@ -119,9 +146,9 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
             const int ta = tap / TAPS, tb = tap % TAPS;
             const int kh = PH + 2 * (H - ta), kw = PW + 2 * (H - tb);
             if (kh >= KH || kw >= KH) continue;           // literal after unrolling: this class does not reach that kernel row / column
-            const bf16_t* wrow = W + ((long long)(kh * KH + kw) * 32 + lrow) * 64 + lgrp * 8;
+            const bf16_t* wrow = W + ((long long)(kh * KH + kw) * (int)NCH + nt * 32 + lrow) * (64 * CK) + lgrp * 8;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wf[tap][kk] = *(const freg*)(wrow + kk * 16);
+            for (int kk = 0; kk < KS; ++kk) wf[tap][kk] = *(const freg*)(wrow + kk * 16);
         }
     }
     RW_STAMP();                                           // 2: weights requested
@@ -150,7 +177,7 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
 #pragma unroll 1
     for (; chunk < cend; chunk += cstride, cur ^= 1) {
         RW_STAMP();                                       // 3 + 2 i: chunk i landed, buffers handed over
-        if (chunk + cstride < cend) rw_stage<TAPS>(p, rsA, lds + (cur ^ 1) * Cfg::BUF, (chunk + cstride) * Cfg::BMT, wave, lane, ninstr);
+        if (chunk + cstride < cend) rw_stage<TAPS, CK>(p, rsA, lds + (cur ^ 1) * Cfg::BUF, (chunk + cstride) * Cfg::BMT, wave, lane, ninstr);
         const int P0 = chunk * Cfg::BMT + half * 32 * NTILE;                                  // this wave's half of the chunk
         const uint32_t bufoff = (uint32_t)(cur * Cfg::BUF + half * 32 * NTILE * RB);
         // two 32-position tiles at a time: two independent accumulator chains, and the fragment reads run RW_AHEAD (tap, k-step) pairs ahead
@@ -169,7 +196,7 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
                 p.div_g.divmod(g, b, gy);
                 const int oy = 2 * (int)gy + PH, ox = 2 * (int)gx + PW;
                 ok[h] = pin && oy < p.OH && ox < p.OW;
-                e0[h] = ok[h] ? ((b * p.OH + oy) * p.OW + ox) * 32u + 8u * lgrp : 0u;       // element offset of unit 0 (unit 1: + 16)
+                e0[h] = ok[h] ? ((b * p.OH + oy) * p.OW + ox) * NCH + (uint32_t)(nt * 32) + 8u * lgrp : 0u;   // element offset of unit 0 (unit 1: + 16)
                 if constexpr (MASK == 1) {
                     umk[h][0] = *(const PackN<uint32_t, 4>*)(maskp + e0[h]);                 // offset 0 is always readable
                     umk[h][1] = *(const PackN<uint32_t, 4>*)(maskp + e0[h] + 16);
@@ -182,19 +209,19 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
             f32x16 acc[2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *(const f32x4*)(bias_lds + 8 * q + 4 * lgrp);
+                const f32x4 b4 = *(const f32x4*)(bias_lds + nt * 32 + 8 * q + 4 * lgrp);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = b4[t]; acc[1][4 * q + t] = b4[t]; }
             }
             const uint32_t toff = bufoff + (uint32_t)(tile * 32 * RB);                       // wave-uniform
             // live (tap, k-step) steps of this class in issue order (compile time)
-            struct Steps { int n; int id[NT * 4]; };
+            struct Steps { int n; int id[NT * KS]; };
             constexpr Steps ST = [] {
                 Steps r = {0, {}};
                 for (int tap = 0; tap < NT; ++tap) {
                     const int ta = tap / TAPS, tb = tap % TAPS;
                     if (PH + 2 * (H - ta) >= KH || PW + 2 * (H - tb) >= KH) continue;
-                    for (int kk = 0; kk < 4; ++kk) r.id[r.n++] = tap * 4 + kk;
+                    for (int kk = 0; kk < KS; ++kk) r.id[r.n++] = tap * KS + kk;
                 }
                 return r;
             }();
@@ -202,9 +229,10 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
             freg ring[AH + 1][2];
             auto fetch = [&](int k) {                     // k-th live step -> ring slot k % (AH + 1)
                 const int sid = ST.id[k];
-                const uint32_t vt = (vtap0[sid >> 2] + toff) ^ (uint32_t)((sid & 3) << 5);
-                if constexpr (DBG == 2) { if (k < AH + 1) lds_read_b128_pair(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt); }   // debug: no LDS traffic beyond the first reads
-                else lds_read_b128_pair(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
+                const int tap_ = sid / KS, kk_ = sid % KS;                                    // k-step kk: 128-byte half kk >> 2, swizzled chunk pair kk & 3
+                const uint32_t vt = ((vtap0[tap_] + toff) ^ (uint32_t)((kk_ & 3) << 5)) + (uint32_t)((kk_ >> 2) * 128);
+                if constexpr (DBG == 2) { if (k < AH + 1) lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt); }   // debug: no LDS traffic beyond the first reads
+                else lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
             };
 #pragma unroll
             for (int k = 0; k < AH && k < ST.n; ++k) fetch(k);
@@ -220,11 +248,11 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
                 else lds_wait_pair<0>(cur_[0], cur_[1]);
                 const int sid = ST.id[k];
                 if constexpr (DBG == 3) {                 // debug: no MFMAs (the fragments are still consumed)
-                    acc[0][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[0][0] | ((uint32_t)wf[sid >> 2][sid & 3][0] << 16));
-                    acc[1][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[1][0] | ((uint32_t)wf[sid >> 2][sid & 3][1] << 16));
+                    acc[0][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[0][0] | ((uint32_t)wf[sid / KS][sid % KS][0] << 16));
+                    acc[1][k & 15] += __builtin_bit_cast(float, (uint32_t)cur_[1][0] | ((uint32_t)wf[sid / KS][sid % KS][1] << 16));
                 } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid >> 2][sid & 3]), __builtin_bit_cast(bf16x8, cur_[0]), acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid >> 2][sid & 3]), __builtin_bit_cast(bf16x8, cur_[1]), acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid / KS][sid % KS]), __builtin_bit_cast(bf16x8, cur_[0]), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[sid / KS][sid % KS]), __builtin_bit_cast(bf16x8, cur_[1]), acc[1], 0, 0, 0);
                 }
             }
 
@@ -293,15 +321,17 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
 #undef RW_STAMP
 }
 
-template <int TAPS, int KH, bool RELU, int MASK, bool BITS, int DBG = 0>
-__global__ __launch_bounds__(RwCfg<TAPS>::NW * 64, TAPS == 2 ? 3 : 2) void rwconv_gather_kernel(const TapParams p, const int nchunks) {
-    typedef RwCfg<TAPS> Cfg;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 128];
+template <int TAPS, int KH, bool RELU, int MASK, bool BITS, int DBG = 0, int CK = 1>
+__global__ __launch_bounds__((RwCfg<TAPS, CK>::NW * 64), ((TAPS == 2 && CK == 1) ? 3 : 2)) void rwconv_gather_kernel(const TapParams p, const int nchunks) {
+    static_assert(CK == 1 || TAPS == 2, "128-channel rows: k = 4 only");
+    typedef RwCfg<TAPS, CK> Cfg;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 128 * CK];
     float* const bias_lds = (float*)(lds + 2 * Cfg::BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, cls = half ? 3 - (wave & 3) : (wave & 3);
+    // k = 5: two position halves of four class waves (second half in reverse class order); k = 4, CK = 2: wave = (class, 32-output tile), one position range
+    const int half = CK == 1 ? wave >> 2 : 0, nt = CK == 1 ? 0 : wave >> 2, cls = CK == 1 ? (half ? 3 - (wave & 3) : (wave & 3)) : (wave & 3);
     // chunk schedule: XCD x (= blockIdx % 8: the dispatcher's round-robin) owns a contiguous range of chunks; at any time its blocks work on
     // neighbouring chunks (shared halo rows stay in that XCD's L2)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;                 // the host launches a multiple of 8 blocks
@@ -311,14 +341,14 @@ __global__ __launch_bounds__(RwCfg<TAPS>::NW * 64, TAPS == 2 ? 3 : 2) void rwcon
     long long* tr = nullptr; int tr_n = 0;
     if (p.trace && ((long long)blockIdx.x * 8 + 8) * 32 <= p.trace_cap && lane == 0) tr = p.trace + ((long long)blockIdx.x * 8 + wave) * 32;
     if (tr) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime();       // 0: start
-    if (tid < 32) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
+    if (tid < 32 * CK) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
     if (cbeg + j >= cend) return;                         // block-uniform: more blocks than chunks on this XCD
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     // each wave: stage its share of the first chunk, request its class's weight fragments, then the chunk loop (one block barrier per chunk)
-    if (cls == 0) rw_class<TAPS, KH, 0, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else if (cls == 1) rw_class<TAPS, KH, 1, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else if (cls == 2) rw_class<TAPS, KH, 2, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
-    else rw_class<TAPS, KH, 3, RELU, MASK, BITS, DBG>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n);
+    if (cls == 0) rw_class<TAPS, KH, 0, RELU, MASK, BITS, DBG, CK>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n, nt);
+    else if (cls == 1) rw_class<TAPS, KH, 1, RELU, MASK, BITS, DBG, CK>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n, nt);
+    else if (cls == 2) rw_class<TAPS, KH, 2, RELU, MASK, BITS, DBG, CK>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n, nt);
+    else rw_class<TAPS, KH, 3, RELU, MASK, BITS, DBG, CK>(p, lds, bias_lds, rsA, cbeg + j, per, cend, wave, half, lane, tr, tr_n, nt);
     if (tr) tr[31] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID of this wave (wave / SIMD / CU placement)
 }
 
@@ -342,14 +372,17 @@ int mi_rwconv_mode(int set) {                            // set < 0: query
 int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                          int KH, int KW, void* out, const float* bias, const void* mask, int relu, const void* mask_bits, void* bits_out) {
     mi_rwconv_mode(-1);
-    if (dtype != MI_BF16 || C != 64 || N != 32 || KH != KW || (KH != 4 && KH != 5)) return 0;
+    static int wide = -1;                                 // MI355_RWCONV_WIDE=0: the 128 -> 64 channel layers stay on tapconv (A/B runs)
+    if (wide < 0) { const char* ev = getenv("MI355_RWCONV_WIDE"); wide = (ev && ev[0] == '0') ? 0 : 1; }
+    const int ck = (C == 128 && N == 64 && KH == 4 && wide) ? 2 : 1;                      // 128 -> 64 channels: k = 4 only
+    if (dtype != MI_BF16 || C != 64 * ck || N != 32 * ck || KH != KW || (KH != 4 && KH != 5)) return 0;
     if ((((uintptr_t)a) | ((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)mask)) & 15) return 0;
     if ((long long)B * OH * OW * N >= (1ll << 31)) return 0;
     TapParams q = {};
     q.TH = q.TW = (KH + 1) / 2; q.HY = q.HX = q.TH - 1;
     q.GH = (OH + 1) / 2 + q.HY; q.GW = (OW + 1) / 2 + q.HX;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
-    if (halo > (q.TH == 2 ? RwCfg<2>::MAXHALO : RwCfg<3>::MAXHALO) || q.GW <= 32) return 0;     // (GW > 32: the staging loop's incremental slot decode)
+    if (halo > (q.TH == 2 ? RwCfg<2>::MAXHALO : RwCfg<3>::MAXHALO) || (ck == 1 && q.GW <= 32)) return 0;     // (GW > 32: the incremental slot decode of the 128-byte-row staging loop)
     const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * 2;
     if (MP >= (1ll << 30) || a_bytes <= 0 || a_bytes >= (long long)G2_OOB) return 0;
     const long long o_bytes = (long long)B * OH * OW * N * 2;
@@ -368,7 +401,7 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     // persistent grid: as many blocks as stay resident (3 per CU for k = 4, 2 for k = 5), a multiple of 8 (one share per XCD)
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-    int per_xcd = (n_cu / 8) * (KH == 4 ? 3 : 1);
+    int per_xcd = (n_cu / 8) * ((KH == 4 && ck == 1) ? 3 : 1);
     if (g_rwconv_blocks > 0) per_xcd = g_rwconv_blocks;
     if (per_xcd > (nchunks + 7) / 8) per_xcd = (nchunks + 7) / 8;
     const dim3 g((unsigned)(8 * per_xcd));
@@ -385,6 +418,15 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
         if (g_rwconv_dbg == 1) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 1>), g, dim3(512), 0, st, q, nchunks);
         else if (g_rwconv_dbg == 2) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 2>), g, dim3(512), 0, st, q, nchunks);
         else hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 3>), g, dim3(512), 0, st, q, nchunks);
+    } else if (KH == 4 && ck == 2) {
+        const dim3 t_(512);
+        if (relu && q.bits_out && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, true, 0, true, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (bits_out) return 0;
+        else if (relu && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, true, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu && q.mask_bits) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 2, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 1, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else return 0;
     } else if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
 #undef RW_LAUNCH
     const int rc = mi_check_launch("rwconv_gather_kernel");
