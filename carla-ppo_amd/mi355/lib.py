@@ -68,6 +68,9 @@ class _Lib:
         if not os.path.exists(LIB_PATH):
             raise MiError("libmi355_carla.so not found at %s — run `python __graft_entry__.py` (build()) first; "
                           "there is no CPU fallback" % LIB_PATH)
+        # PyTorch first: it bundles its own libamdhip64.so.7 / libhsa-runtime64 and every device buffer this library is handed comes from it.  Loaded
+        # the other way round, the loader binds BOTH to the system ROCm's runtime (same SONAME) and PyTorch's build then finds no device.
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self.cdll.mi_last_error.restype = ctypes.c_char_p
