@@ -461,12 +461,18 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             if (i == NCONV - 1 ? !upper : !lower) continue;
             const void* gy = e->at(W.gact[i + 1]);
             const void* x = i == 0 ? (const void*)src : e->at(W.act[i]);
-            // conv1 has no input gradient, so the caller's stream would idle while the (longer) filter-gradient stream drains: its
-            // filter gradient runs there instead -- without the shared split scratch, which the side stream may still be using
-            void* sg = i == 0 ? st : sw;
-            if (i > 0) release();
+            // The filter-gradient stream is the longer one of the two: conv1 has no input gradient, and since the register-weight kernels shortened
+            // conv2's / conv3's input gradients the caller's stream has room for one more -- the filter gradients of conv1 AND conv3 run there (mask 5,
+            // measured against 1 / 3 / 9 / 13 interleaved on one box: 1.068 vs 1.090 / 1.111 / 1.078 / 1.079 ms per step; moving a decoder layer's
+            // filter gradient instead: no gain), without the shared split scratch, which the other stream may still be using (fp32 atomics into dW).
+            // MI355_WGRAD_MAIN_MASK: bit i = conv(i+1).
+            static int main_mask = -1;
+            if (main_mask < 0) { const char* ev = getenv("MI355_WGRAD_MAIN_MASK"); main_mask = ev ? atoi(ev) : 5; }
+            const bool on_main = ((main_mask >> i) & 1) != 0;
+            void* sg = on_main ? st : sw;
+            if (!on_main) release();
             TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
-                                                                   (i == 0 && fork) ? nullptr : scratch_of(), (i == 0 && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
+                                                                   (on_main && fork) ? nullptr : scratch_of(), (on_main && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
