@@ -99,7 +99,7 @@ void fill_fused(const PpoEngine* e, PpoFusedParams& q, const float* states, int 
     q = PpoFusedParams{};
     q.theta = e->params; q.theta_old = e->params_old; q.adam_m = e->m; q.adam_v = e->v; q.grads = e->grads;
     for (int i = 0; i < 13; ++i) q.off[i] = e->off[i];
-    q.kin = e->kin; q.din = d.input_dim; q.H1 = d.h1; q.H2 = d.h2; q.A = d.num_actions; q.M = M;
+    q.kin = e->kin; q.din = d.input_dim; q.H1 = d.h1; q.H2 = d.h2; q.A = d.num_actions; q.M = M; q.n_params = e->total;
     q.states = states; q.low = (const float*)e->at(e->low); q.high = (const float*)e->at(e->high);
     q.h1 = (float*)e->at(e->f_h1); q.h2 = (float*)e->at(e->f_h2); q.dh1 = (float*)e->at(e->f_dh1); q.dh2 = (float*)e->at(e->f_dh2);
     q.du = (float*)e->at(e->du); q.dv = (float*)e->at(e->dv); q.partial = (float*)e->at(e->f_part); q.losses = (float*)e->at(e->losses);
@@ -228,7 +228,7 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_forward_backward: batch outside [1, max_batch]");
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_ppo_forward_backward: engine created without a gradient buffer");
-    if (fused_enabled() && M <= 256) {                    // 5 launches; gradients written (not accumulated) into the flat buffer
+    if (fused_enabled()) {                                // 5 launches; gradients written (not accumulated) into the flat buffer (M > 256: zeroed, then row chunks meet in atomics)
         PpoFusedParams q; fill_fused(e, q, states, M);
         q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
         e->last_M = M;
@@ -300,10 +300,17 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step: batch outside [1, max_batch]");
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step: engine created without optimiser buffers");
-    if (M > 256) {
-        // large minibatches (the synthetic replay: 2048 rows per GPU): the fused kernels sum over the minibatch rows inside a few blocks, which
-        // is right for the reference's 32 rows and wrong here -- the tiled fp32 MFMA kernels (one launch per layer op) fill the chip instead
-        CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale));
+    if (M > 256 || !fused_enabled()) {
+        // large minibatches (the synthetic replay: 2048 rows per GPU): the weight-gradient launch splits the rows into chunks of 256 whose partial
+        // sums meet in atomics, so the Adam update is its own (flat) launch; everything before it is the same five-kernel chain
+        if (!fused_enabled()) { CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale)); }
+        else {
+            PpoFusedParams q; fill_fused(e, q, states, M);
+            q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
+            q.logp_old = logp_old; q.n_nets = logp_old ? 2 : 3;
+            e->last_M = M;
+            CK(mi_ppo_fused_step((hipStream_t)stream, q, 0));
+        }
         return mi_ppo_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
     }
     PpoFusedParams q; fill_fused(e, q, states, M);

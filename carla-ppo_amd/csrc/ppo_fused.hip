@@ -407,6 +407,8 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
     const int KT1 = (q.kin + 31) / 32, NT1 = (H1 + 31) / 32, KT2 = NT1, NT2 = (H2 + 31) / 32, KTH = NT2;
     const int per_net = KT2 * NT2 + KT1 * NT1 + KTH;
     int t = blockIdx.x * 4 + wave;
+    const bool split = !FUSE && q.m_chunk > 0;            // large minibatches: blockIdx.y = row chunk
+    if (t == 2 * per_net && blockIdx.y != 0) return;
     if (t == 2 * per_net) {                               // spare wave: loss scalars + logstd (fixed block order: deterministic)
         // lane k sums column k of the per-block partials (one load chain per lane instead of PF_NPART chains on lane 0: this wave's latency was
         // the kernel's duration), lane 0 collects them with shuffles; exp / log through the hardware units (arguments O(1), ~1e-7 relative)
@@ -471,8 +473,9 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
     f32x16_t acc, accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
-    const int msteps = (M + 7) / 8;
-    for (int s0 = 0; s0 < msteps; s0 += 4) {
+    const int m_beg = split ? (int)blockIdx.y * q.m_chunk : 0, m_end = split ? min(M, m_beg + q.m_chunk) : M;
+    const int msteps = (m_end + 7) / 8;
+    for (int s0 = m_beg / 8; s0 < msteps; s0 += 4) {
         f32x4 a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -503,11 +506,12 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         for (int r = 0; r < 16; ++r) {
             const int kr = kt * 32 + pf_row(r, lgrp);
             const long long idx = oW + (long long)kr * ldw + n;
-            if (kr < Kx) q.grads[idx] = acc[r];
+            if (split) { if (kr < Kx) atomicAdd(q.grads + idx, acc[r]); }      // (the buffer was zeroed by the host side of the launch)
+            else if (kr < Kx) q.grads[idx] = acc[r];
             else if (kr < kvalid) q.grads[idx] = 0.f;
         }
     }
-    if (kt == 0 && lgrp == 0) pf_emit<FUSE>(q, ob + n, accb[0]);
+    if (kt == 0 && lgrp == 0) { if (split) atomicAdd(q.grads + ob + n, accb[0]); else pf_emit<FUSE>(q, ob + n, accb[0]); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -612,7 +616,14 @@ int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
     hipLaunchKernelGGL(ppo_dh1_kernel, dim3((q.H1 + 31) / 32, 2, (q.M + 31) / 32), dim3(256), 0, st, q);
     const int nt1 = (q.H1 + 31) / 32, nt2 = (q.H2 + 31) / 32, kt1 = (q.kin + 31) / 32;
     const int tiles = 2 * (nt1 * nt2 + kt1 * nt1 + nt2) + 1;         // + the wave that finalises the loss scalars
-    if (fuse_adam) hipLaunchKernelGGL(ppo_wgrad_kernel<true>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
+    q.m_chunk = 0;
+    if (fuse_adam) {
+        if (q.M > 256) return mi_fail(MI_ERR_ARG, "ppo fused step: the in-kernel Adam update needs the whole minibatch in one wave (M <= 256)");
+        hipLaunchKernelGGL(ppo_wgrad_kernel<true>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
+    } else if (q.M > 256) {                               // row chunks of 256, gradients meet in atomics on the zeroed buffer
+        q.m_chunk = 256;
+        if (hipMemsetAsync(q.grads, 0, (size_t)q.n_params * 4, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "ppo fused step: memset failed");
+        hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4, (q.M + 255) / 256), dim3(256), 0, st, q);
+    } else hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
     return mi_check_launch("ppo_fused_step");
 }

@@ -9,6 +9,7 @@ struct PpoFusedParams {
     float *theta, *adam_m, *adam_v, *grads; const float* theta_old;
     long long off[13];
     int kin, din, H1, H2, A, M;
+    long long n_params;                                   // floats in each flat buffer
     // activations (workspace): [net][M][H] with net 0 = policy, 1 = value, 2 = old policy
     const float *states, *actions, *returns, *adv, *low, *high;
     float *h1, *h2, *dh1, *dh2;                           // h1/h2: 3 nets; dh1/dh2: 2 nets
@@ -19,6 +20,8 @@ struct PpoFusedParams {
     float clip_eps, value_scale, entropy_scale, inv_m, grad_scale;
     float alpha, omb1, omb2, epsilon;                     // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); omb = 1 - beta
     int n_loss_blocks;
+    int m_chunk;                                          // weight-gradient launch: 0 = one wave sums the whole minibatch of its tile (M <= 256); > 0: rows per
+                                                          // blockIdx.y (multiple of 32), partial sums meet in fp32 atomics on the zeroed gradient buffer (no fused Adam)
 };
 
 }  // namespace mi
