@@ -498,6 +498,8 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
 int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
     if (p.a_frame_idx || p.ksplit_len > 0) return 0;
     if (p.stride == 2 && !p.out_f32) {
+        const int r5 = mi_try_rwconv_conv(st, dtype, p.a, p.b, p.nbatch, p.IH, p.IW, p.C, p.OH, p.OW, p.N, p.KH, p.KW, p.ldb, p.out, p.bias, p.mask, p.relu);
+        if (r5 != 0) return r5;
         const int r3 = try_tapconv(st, dtype, TC_CONV, p.a, p.b, p.nbatch, p.IH, p.IW, p.C, p.OH, p.OW, p.N, p.KH, p.KW, p.ldb, p.out, p.bias, p.mask, p.relu);
         if (r3 != 0) return r3;
     }
@@ -697,6 +699,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 11) { prev = g_dense_wgrad_blocks; g_dense_wgrad_blocks = value < 1 ? 1 : value; }
     else if (key == 13) { prev = mi_rwconv_mode(value < 0 ? 0 : value); }
     else if (key == 14) { prev = g_tapwgrad_cw; g_tapwgrad_cw = value ? 1 : 0; }
+    else if (key == 15) { prev = mi_rwconv_conv_mode(value < 0 ? 0 : value); }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

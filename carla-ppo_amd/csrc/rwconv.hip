@@ -99,15 +99,15 @@ __device__ __forceinline__ void rw_stage(const TapParams& p, const __amdgpu_buff
                 if ((int)gx >= p.GW) { gx -= p.GW; ++gy; if ((int)gy >= p.GH) { gy = 0; ++b; } }
         }
     } else {
-        // 256-byte rows: instruction t fills rows 4 t .. 4 t + 3 (lane: row 4 t + lane / 16, physical chunk lane % 16; the swizzle permutes the 8
-        // chunks of each 128-byte half).  The slot grid of these layers is narrow (GW = 20): a plain slot decode per instruction, 6 per wave and chunk
+        // 256-byte rows: instruction t fills rows 4 t .. 4 t + 3 (lane: row 4 t + lane / 16, physical chunk lane % 16, logical chunk ^ (row & 15)).
+        // The slot grid of these layers is narrow (GW = 20): a plain slot decode per instruction, 6 per wave and chunk
         const int r4 = lane >> 4, cp = lane & 15;
 #pragma unroll
         for (int i = 0; i < Cfg::NIA; ++i) {
             const int t = wave + NW * i;
             if (t >= ninstr) break;                           // wave-uniform
             const int q = 4 * t + r4;
-            const int c = (cp & 8) | ((cp & 7) ^ ((q >> 1) & 7));
+            const int c = cp ^ (q & 15);                      // 4-bit swizzle (see vtap0 in rw_class)
             uint32_t g, gx, b, gy;
             p.div_gw.divmod((uint32_t)min(P0 + q, p.MP - 1), g, gx);
             p.div_g.divmod(g, b, gy);
@@ -159,7 +159,9 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
         const int q = lrow + (tap / TAPS) * p.GW + (tap % TAPS);
-        vtap0[tap] = (uint32_t)(q * RB + ((lgrp ^ ((q >> 1) & 7)) << 4));
+        // 256-byte rows span all 64 banks, so rows q and q + 1 must not keep a chunk in the same place: the lane groups of ds_read_b128 hold 16 rows with
+        // 16 different values of q & 15 (MI355X_MICROARCH.md, LDS) -- the 3-bit term of the 128-byte rows left every read 2-way conflicted here
+        vtap0[tap] = CK == 1 ? (uint32_t)(q * RB + ((lgrp ^ ((q >> 1) & 7)) << 4)) : (uint32_t)(q * RB + ((lgrp ^ (q & 15)) << 4));
     }
     const bf16_t* __restrict__ maskp = (const bf16_t*)p.mask;
 
@@ -230,7 +232,7 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
             auto fetch = [&](int k) {                     // k-th live step -> ring slot k % (AH + 1)
                 const int sid = ST.id[k];
                 const int tap_ = sid / KS, kk_ = sid % KS;                                    // k-step kk: 128-byte half kk >> 2, swizzled chunk pair kk & 3
-                const uint32_t vt = ((vtap0[tap_] + toff) ^ (uint32_t)((kk_ & 3) << 5)) + (uint32_t)((kk_ >> 2) * 128);
+                const uint32_t vt = (vtap0[tap_] + toff) ^ (uint32_t)(kk_ << 5);          // k-step kk: chunk pair kk (CK = 1: kk < 4); toff: whole rows
                 if constexpr (DBG == 2) { if (k < AH + 1) lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt); }   // debug: no LDS traffic beyond the first reads
                 else lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
             };
@@ -352,6 +354,235 @@ __global__ __launch_bounds__((RwCfg<TAPS, CK>::NW * 64), ((TAPS == 2 && CK == 1)
     if (tr) tr[31] = (long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID of this wave (wave / SIMD / CU placement)
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// CONV form (tapconv_tile.hpp): out[b,oy,ox,n] = sum_{ta,tb} sum_{ph,pw,c} x[b,2(oy+ta)+ph,2(ox+tb)+pw,c] W[n][(2ta+ph) KH + 2tb+pw][c], 32 -> 64 channels
+// (deconv3's input gradient, k = 5; conv2 forward, k = 4; vae/models.py:236-239, 250-253).  A slot is the 2 x 2 pixel block: 4 x 32 channels =
+// one 256-byte row, i.e. the addressing of the CK = 2 rows above with 8 k-steps per tap (k-step s = 4 ph + 2 pw + kk), of which k = 5 leaves
+// 50 of 72 alive.  There are no parity classes to hand to the waves, so a wave owns one 32-OUTPUT tile (nt = wave & 1) for ALL of K -- 50 | 32
+// weight fragments = 200 | 128 registers, the reason for one wave per SIMD and one block per CU -- and one 64-position half of the 128-position
+// chunk (wave >> 1).  Every fragment read serves two MFMAs (the two 32-position tiles of the half).  im2col-gather tiles (gemm2) move every
+// input pixel through the per-CU load path 6.25 times for this layer (562 MB of L2 -> LDS traffic for a 101 MB tensor) and re-stage the 102 KB of
+// weights per 128 x 64 tile; here a pixel is staged 1.6 times (halo) and the weights are read once per CU.
+template <int KH> struct RcCfg {
+    static constexpr int TAPS = (KH + 1) / 2;
+    static constexpr int NW = 4, NTILE = 2, BMT = 128;                // two position halves x two 32-position tiles
+    static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;
+    static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 224 rows
+    static constexpr int RB = 256;
+    static constexpr int BUF = MAXSLOT * RB;                          // 44 | 56 KB per buffer, two buffers
+    static constexpr int NIA = ((MAXSLOT + 3) / 4 + NW - 1) / NW;     // DMA instructions per wave and chunk (upper bound): 11 | 14
+};
+
+// stage slots [P0, P0 + BMT + halo): instruction t = wave + 4 i fills rows 4 t .. 4 t + 3 (lane: row 4 t + lane / 16, physical chunk lane % 16).
+// Logical chunk c = 8 ph + 4 pw + (16-byte quarter of the pixel's 32 channels): pixel (2 gy + ph, 2 gx + pw).  A wave's instructions are 16
+// slots apart, so row & 15 -- the swizzle term: physical chunk = c ^ (row & 15) -- and with it c are the same for all of them, and the slot walk is
+// incremental (GW > 16):
+// one decode per chunk, then ~10 VALU instructions per DMA instruction.
+struct RcWalk {
+    int P, sy, sx;                   // slot number, input row 2 gy + ph, input column 2 gx of this lane's next row
+    uint32_t srow;                   // (b IH + sy) IW
+    __device__ __forceinline__ void start(const TapParams& p, int Pq, int ph) {
+        uint32_t g, gx, b, gy;
+        p.div_gw.divmod((uint32_t)Pq, g, gx);
+        p.div_g.divmod(g, b, gy);
+        P = Pq; sy = 2 * (int)gy + ph; sx = 2 * (int)gx; srow = (b * p.IH + (uint32_t)sy) * p.IW;
+    }
+    __device__ __forceinline__ uint32_t offset(const TapParams& p, int pw, uint32_t cofs) const {
+        const bool in = P < p.MP && sy < p.IH && sx + pw < p.IW;
+        return in ? (srow + (uint32_t)sx) * 64u + cofs : G2_OOB;
+    }
+    __device__ __forceinline__ void advance(const TapParams& p) {                 // 16 slots on
+        P += 16; sx += 32;
+        if (sx >= 2 * p.GW) {
+            sx -= 2 * p.GW; sy += 2; srow += 2 * p.IW;
+            if (sy >= 2 * p.GH) { sy -= 2 * p.GH; srow += (uint32_t)((p.IH - 2 * p.GH) * p.IW); }
+        }
+    }
+};
+
+template <int KH, bool RELU, bool MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rwconv_conv_kernel(const TapParams p, const int nchunks) {
+    typedef RcCfg<KH> Cfg;
+    constexpr int TAPS = Cfg::TAPS, NT = TAPS * TAPS, RB = Cfg::RB;
+    typedef u16x8 freg;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 256];
+    float* const bias_lds = (float*)(lds + 2 * Cfg::BUF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = wave & 1, half = wave >> 1;
+    const int lrow = lane & 31, lgrp = lane >> 5;
+    // chunk schedule of rwconv_gather_kernel: XCD x owns a contiguous range of chunks
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q8 = nchunks >> 3, r8 = nchunks & 7;
+    const int cbeg = xcd * q8 + (xcd < r8 ? xcd : r8), cend = cbeg + q8 + (xcd < r8 ? 1 : 0);
+    // debug (mi_debug_set_trace): s_memtime stamps of lane 0 of every wave: 0 start, 1 first slot range requested, 2 weights requested, then per
+    // chunk: handed over / pixel decode + mask requests done / MFMA loop done / epilogue done (tools/trace_rwconv.py deconv3.dgrad)
+    long long* tr = nullptr; int tr_n = 0;
+    if (p.trace && ((long long)blockIdx.x * 8 + 8) * 32 <= p.trace_cap && lane == 0) tr = p.trace + ((long long)blockIdx.x * 8 + wave) * 32;
+#define RC_STAMP() do { if (tr && tr_n < 31) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    RC_STAMP();
+    if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
+    int chunk = cbeg + jb;
+    if (chunk >= cend) return;                               // block-uniform
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+    const int halo = (TAPS - 1) * p.GW + TAPS - 1;
+    const int ninstr = (Cfg::BMT + halo + 3) / 4;
+    // DMA lane role (see RcWalk)
+    const int sq0 = 4 * wave + (lane >> 4);
+    const int sc = (lane & 15) ^ (sq0 & 15);                 // 4-bit swizzle: 16 consecutive 256-byte rows put a given logical chunk on 16 different bank groups
+    const int sph = sc >> 3, spw = (sc >> 2) & 1;
+    const uint32_t scofs = (uint32_t)(sc & 7) * 16u;
+    RcWalk walk;
+    walk.start(p, chunk * Cfg::BMT + sq0, sph);
+#pragma unroll
+    for (int i = 0; i < Cfg::NIA; ++i) {
+        if (wave + Cfg::NW * i >= ninstr) break;             // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
+        walk.advance(p);
+    }
+    RC_STAMP();
+
+    // live (tap, k-step) pairs in issue order (compile time): k-step s = 4 ph + 2 pw + kk reaches kernel row 2 ta + ph, column 2 tb + pw
+    struct Steps { int n; int id[NT * 8]; };
+    constexpr Steps ST = [] {
+        Steps r = {0, {}};
+        for (int tap = 0; tap < NT; ++tap)
+            for (int s = 0; s < 8; ++s)
+                if (2 * (tap / TAPS) + (s >> 2) < KH && 2 * (tap % TAPS) + ((s >> 1) & 1) < KH) r.id[r.n++] = tap * 8 + s;
+        return r;
+    }();
+    static_assert(ST.n == KH * KH * 2, "live steps");
+
+    // ---- weights: step k -> 8 consecutive input channels (16 kk + 8 lgrp) of kernel position (kh, kw), output channel 32 nt + lrow; ONCE per block ----
+    freg wf[ST.n];
+    {
+        const bf16_t* __restrict__ wrow = (const bf16_t*)p.b + (long long)(nt * 32 + lrow) * p.ldb + lgrp * 8;
+#pragma unroll
+        for (int k = 0; k < ST.n; ++k) {
+            const int tap = ST.id[k] >> 3, s = ST.id[k] & 7;
+            const int kh = 2 * (tap / TAPS) + (s >> 2), kw = 2 * (tap % TAPS) + ((s >> 1) & 1);
+            wf[k] = *(const freg*)(wrow + (kh * KH + kw) * 32 + (s & 1) * 16);
+        }
+    }
+    RC_STAMP();
+    uint32_t vtap0[NT];
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+        const int q = lrow + (tap / TAPS) * p.GW + (tap % TAPS);
+        vtap0[tap] = (uint32_t)(q * RB + ((lgrp ^ (q & 15)) << 4));          // k-step s of the tap: ^ (s << 5)
+    }
+    const bf16_t* __restrict__ maskp = (const bf16_t*)p.mask;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.b_bytes, 0x00020000);    // (b_bytes carries the OUTPUT size in bytes)
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+#pragma unroll 1
+    for (; chunk < cend; chunk += per, cur ^= 1) {
+        RC_STAMP();
+        const bool more = chunk + per < cend;                // block-uniform: the next chunk's slot range goes to the other buffer during the MFMA loop
+        unsigned char* const nbuf = lds + (cur ^ 1) * Cfg::BUF;
+        if (more) {
+            // A wave's 14 pieces take ~2.5k cycles to ISSUE (22 B/clk per CU with four waves at it: tools/trace_rwconv.py deconv3.dgrad), here as well
+            // as spread between the MFMA steps (where the MFMA loop grew from 3.7k to 6.1k cycles), as LDS-DMA as well as through registers + ds_write:
+            // the CU's load path, not the instruction form.  With one wave per SIMD nothing covers it; it is 30 % of the chunk's time.
+            walk.start(p, (chunk + per) * Cfg::BMT + sq0, sph);
+#pragma unroll
+            for (int i = 0; i < Cfg::NIA; ++i) {
+                if (wave + Cfg::NW * i >= ninstr) break;         // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(nbuf + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
+                walk.advance(p);
+            }
+        }
+        const int P0 = chunk * Cfg::BMT + half * 64;
+        const uint32_t toff = (uint32_t)(cur * Cfg::BUF + half * 64 * RB);
+        // ---- this lane's two output pixels (conv form: slot (gy, gx) IS output pixel (gy, gx) when inside the output) ----
+        uint32_t e0[2]; bool ok[2];
+        PackN<uint32_t, 4> umk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int P = P0 + h * 32 + lrow;
+            const bool pin = P < p.MP;
+            uint32_t g, gx, b, gy;
+            p.div_gw.divmod((uint32_t)(pin ? P : 0), g, gx);
+            p.div_g.divmod(g, b, gy);
+            ok[h] = pin && (int)gy < p.OH && (int)gx < p.OW;
+            e0[h] = ok[h] ? ((b * p.OH + gy) * p.OW + gx) * 64u + (uint32_t)(nt * 32) + 8u * lgrp : 0u;
+            if constexpr (MASK) {
+                umk[h][0] = *(const PackN<uint32_t, 4>*)(maskp + e0[h]);
+                umk[h][1] = *(const PackN<uint32_t, 4>*)(maskp + e0[h] + 16);
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(bias_lds + nt * 32 + 8 * q + 4 * lgrp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { acc[0][4 * q + t] = b4[t]; acc[1][4 * q + t] = b4[t]; }
+        }
+        RC_STAMP();
+        constexpr int AH = 3;                             // steps of fragment reads in flight (6 measured the same: the loop runs at 37 cycles per MFMA)
+        freg ring[AH + 1][2];
+        auto fetch = [&](int k) {
+            const int tap_ = ST.id[k] >> 3, s_ = ST.id[k] & 7;
+            const uint32_t vt = (vtap0[tap_] + toff) ^ (uint32_t)(s_ << 5);          // (toff: whole rows, a multiple of 256)
+            lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
+        };
+#pragma unroll
+        for (int k = 0; k < AH; ++k) fetch(k);
+#pragma unroll
+        for (int k = 0; k < ST.n; ++k) {
+            if (k + AH < ST.n) fetch(k + AH);
+            freg (&cur_)[2] = ring[k % (AH + 1)];
+            const int after = (ST.n - 1 - k) < AH ? (ST.n - 1 - k) : AH;
+            if (after == 3) lds_wait_pair<6>(cur_[0], cur_[1]);
+            else if (after == 2) lds_wait_pair<4>(cur_[0], cur_[1]);
+            else if (after == 1) lds_wait_pair<2>(cur_[0], cur_[1]);
+            else lds_wait_pair<0>(cur_[0], cur_[1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[k]), __builtin_bit_cast(bf16x8, cur_[0]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[k]), __builtin_bit_cast(bf16x8, cur_[1]), acc[1], 0, 0, 0);
+        }
+        RC_STAMP();
+        // ---- epilogue (rw_class's): bf16, ReLU, pair the 4-channel groups of the two half-waves, mask, two 16-byte stores per tile ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t w[4][2];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float v[4] = {acc[h][4 * gq], acc[h][4 * gq + 1], acc[h][4 * gq + 2], acc[h][4 * gq + 3]};
+                const PackN<bf16_t, 4> pk = pack4<bf16_t>(v);
+                w[gq][0] = (uint32_t)pk.v[0] | ((uint32_t)pk.v[1] << 16); w[gq][1] = (uint32_t)pk.v[2] | ((uint32_t)pk.v[3] << 16);
+                if constexpr (RELU) { w[gq][0] = pk_relu_bf16(w[gq][0]); w[gq][1] = pk_relu_bf16(w[gq][1]); }
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto r = __builtin_amdgcn_permlane32_swap(w[2 * x][d], w[2 * x + 1][d], false, false);
+                    w[2 * x][d] = r[0]; w[2 * x + 1][d] = r[1];
+                }
+            if constexpr (MASK) {
+                const uint32_t ones = 0x00010001u, ffff = 0xffffffffu;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) w[gq][d] &= pk_positive_mask(umk[h][gq >> 1].v[2 * (gq & 1) + d], ones, ffff);
+            }
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const uint32_t bo = ok[h] ? e0[h] * 2u : G2_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, 0);
+        }
+        RC_STAMP();
+        // the next chunk's slot range was requested before this chunk's 4 stores (and mask loads, long complete): all but the stores have landed
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (the mask loads, newer than the DMA pieces, were consumed by the epilogue: only the 4 stores are younger)
+        __builtin_amdgcn_s_barrier();
+    }
+#undef RC_STAMP
+}
+
 }  // namespace mi
 
 using namespace mi;
@@ -430,5 +661,54 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     } else if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
 #undef RW_LAUNCH
     const int rc = mi_check_launch("rwconv_gather_kernel");
+    return rc == MI_OK ? 1 : rc;
+}
+
+int g_rwconv_conv = -1;                                  // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4 (default)
+int mi_rwconv_conv_mode(int set) {                       // set < 0: query
+    if (g_rwconv_conv < 0) { const char* e = getenv("MI355_RWCONV_CONV"); g_rwconv_conv = e ? atoi(e) : 2; if (g_rwconv_conv < 0 || g_rwconv_conv > 2) g_rwconv_conv = 2; }
+    const int prev = g_rwconv_conv;
+    if (set >= 0) g_rwconv_conv = set > 2 ? 2 : set;
+    return prev;
+}
+
+// conv-form layer on the register-weight kernel: x [B,IH,IW,32] bf16, w [64][ldb] bf16 (K-contiguous, k = (kh KW + kw) 32 + c), out / mask [B,OH,OW,64]
+// bf16.  Same contract as try_tapconv: 1 launched, 0 not eligible, < 0 error.  mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4 (default).
+int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
+                       int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu) {
+    const int on = mi_rwconv_conv_mode(-1);
+    mi_rwconv_mode(-1);
+    if (!on || g_rwconv_mode == 0 || dtype != MI_BF16 || C != 32 || N != 64 || KH != KW || (KH != 5 && !(KH == 4 && on >= 2))) return 0;
+    if (OH != (IH - KH) / 2 + 1 || OW != (IW - KW) / 2 + 1 || (ldb % 8) != 0 || ldb < KH * KW * C) return 0;
+    if ((((uintptr_t)a) | ((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)mask)) & 15) return 0;
+    TapParams q = {};
+    q.TH = q.TW = (KH + 1) / 2;
+    q.GH = OH + q.TH - 1; q.GW = OW + q.TW - 1;
+    const int halo = (q.TH - 1) * q.GW + q.TW - 1;
+    if (halo > (KH == 4 ? RcCfg<4>::MAXHALO : RcCfg<5>::MAXHALO) || q.GW <= 16) return 0;            // (GW > 16: the incremental slot decode of rc_stage)
+    const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * 2, o_bytes = (long long)B * OH * OW * N * 2;
+    if (MP >= (1ll << 30) || a_bytes <= 0 || a_bytes >= (long long)G2_OOB || o_bytes >= (long long)G2_OOB) return 0;
+    if (g_rwconv_mode == 1 && MP < 75000) return 0;
+    q.a = a; q.a_bytes = (uint32_t)a_bytes; q.b = w; q.b_bytes = (uint32_t)o_bytes; q.ldb = ldb;
+    q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
+    q.KC = 4 * C; q.NE = N;
+    q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW);
+    q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
+    mi_get_trace(&q.trace, &q.trace_cap);
+    const int nchunks = (int)((MP + 127) / 128);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    int per_xcd = n_cu / 8;
+    if (g_rwconv_blocks > 0) per_xcd = g_rwconv_blocks;
+    if (per_xcd > (nchunks + 7) / 8) per_xcd = (nchunks + 7) / 8;
+    const dim3 g((unsigned)(8 * per_xcd)), t(256);
+#define RC_LAUNCH(KH_) do { \
+        if (relu && mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, true>), g, t, 0, st, q, nchunks); \
+        else if (relu) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, false>), g, t, 0, st, q, nchunks); \
+        else if (mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, false, true>), g, t, 0, st, q, nchunks); \
+        else hipLaunchKernelGGL((rwconv_conv_kernel<KH_, false, false>), g, t, 0, st, q, nchunks); } while (0)
+    if (KH == 5) RC_LAUNCH(5); else RC_LAUNCH(4);
+#undef RC_LAUNCH
+    const int rc = mi_check_launch("rwconv_conv_kernel");
     return rc == MI_OK ? 1 : rc;
 }

@@ -20,9 +20,10 @@ DECONVS = [  # IH, IW, Cin, Cout, k
 # Every conv / deconv entry point is served by several kernel generations (first-generation register-staged tiles, gemm2 LDS-DMA
 # tiles, raw-staged tapconv / tapwgrad, the narrow-layer kernels); `auto` is what production picks at these (small) sizes, the
 # other two pin the dispatch through mi_set_tuning so that EVERY generation meets the same float64 reference on every geometry.
-# `rwconv` = `newest` with the register-weight kernel forced for the thin gather-form layers (key 13 = 2; auto takes it only on chip-filling grids)
+# `rwconv` = `newest` with the register-weight kernels forced for the thin gather-form layers (key 13 = 2; auto takes them only on chip-filling grids)
+# and for both 32 -> 64 channel conv-form layers (key 15 = 2: k = 4 as well as k = 5)
 GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0},
-               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2}}
+               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2, 15: 2}}
 
 
 @pytest.fixture(params=list(GENERATIONS))

@@ -19,6 +19,12 @@ if name == "deconv3.fwd":
     x = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).to(bf); w = (torch.randn(k, k, Co, Ci, device="cuda", generator=g) * 0.05).to(bf)
     b = torch.zeros(Co, device="cuda"); out = torch.empty(B, OH, OW, Co, device="cuda", dtype=bf)
     f = lambda: L.mi_deconv2d_nhwc_fwd(st, 1, x.data_ptr(), B, IH, IW, Ci, w.data_ptr(), b.data_ptr(), k, k, Co, 1, out.data_ptr())
+elif name == "deconv3.dgrad":                      # conv-form register-weight kernel: 4 stamps per chunk
+    IH, IW, Ci, Co, k = 18, 38, 64, 32, 5
+    OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
+    dy = torch.randn(B, OH, OW, Co, device="cuda", generator=g).to(bf); wt = (torch.randn(Ci, k * k * Co, device="cuda", generator=g) * 0.05).to(bf)
+    mask = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).relu().to(bf); dx = torch.empty(B, IH, IW, Ci, device="cuda", dtype=bf)
+    f = lambda: L.mi_deconv2d_nhwc_dgrad(st, 1, dy.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, mask.data_ptr(), dx.data_ptr())
 else:
     IH, IW, Ci, Co, k = 39, 79, 32, 64, 4
     OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
@@ -46,6 +52,16 @@ t = raw.astype(np.float64); t[:, :, 31] = 0
 nb = t.shape[0]
 nw = int((t[0, :, 0] != 0).sum())
 print("%s: %.1f us / launch alone; %d blocks traced, %d waves per block" % (name, us, nb, nw))
+if name == "deconv3.dgrad":
+    for c in range(nw):
+        w_ = t[:, c, :31]
+        n = int((w_ > 0).sum(axis=1).min())
+        nch = (n - 3) // 4
+        d = lambda a, b_: (w_[:, a] - w_[:, b_]).mean()
+        print("wave %d: stage-req %.0f weights-req %.0f | per chunk (decode+mask-req, MFMA loop, epilogue, wait+barrier): %s | lifetime %.0f" % (
+            c, d(1, 0), d(2, 1), "  ".join("%.0f/%.0f/%.0f/%.0f" % (d(4 + 4 * i, 3 + 4 * i), d(5 + 4 * i, 4 + 4 * i), d(6 + 4 * i, 5 + 4 * i),
+                                                                    d(7 + 4 * i, 6 + 4 * i) if 7 + 4 * i < n else 0) for i in range(nch)), (w_.max(axis=1) - w_[:, 0]).mean()))
+    sys.exit(0)
 for c in range(nw):
     w_ = t[:, c, :31]
     n = (w_ > 0).sum(axis=1)                       # stamps per wave: 3 + 2 chunks
