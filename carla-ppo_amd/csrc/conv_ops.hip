@@ -700,6 +700,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 13) { prev = mi_rwconv_mode(value < 0 ? 0 : value); }
     else if (key == 14) { prev = g_tapwgrad_cw; g_tapwgrad_cw = value ? 1 : 0; }
     else if (key == 15) { prev = mi_rwconv_conv_mode(value < 0 ? 0 : value); }
+    else if (key == 16) { prev = mi_rwconv_blocks(value < 0 ? 0 : value); }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

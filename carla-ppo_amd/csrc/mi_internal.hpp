@@ -18,5 +18,6 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
 int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                        int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu);   // rwconv.hip, conv form (32 -> 64 channels)
 int mi_rwconv_conv_mode(int set);                // mi_set_tuning key 15: 0 off, 1 k = 5 layers, 2 also k = 4; set < 0 queries
+int mi_rwconv_blocks(int set);                   // mi_set_tuning key 16: persistent blocks per XCD (0 = resident maximum); set < 0 queries
 int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace

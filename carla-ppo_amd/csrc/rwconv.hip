@@ -367,14 +367,20 @@ __global__ __launch_bounds__((RwCfg<TAPS, CK>::NW * 64), ((TAPS == 2 && CK == 1)
 template <int KH> struct RcCfg {
     static constexpr int TAPS = (KH + 1) / 2;
     static constexpr int NW = 4, NTILE = 2, BMT = 128;                // two position halves x two 32-position tiles
-    static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;
-    static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 224 rows
+    static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;               // staged halo: (TAPS-1) * GW + TAPS - 1 rounded up to 16 rows
+    // A block walks CONSECUTIVE chunks in runs of RUN: the slot rows of a run lie in one linear buffer (row r = slot P_run + r; chunk j of the run reads
+    // rows 128 j .. 128 j + 128 + halo), filled in RUN instalments: rows [0, 128 + H) before the run's first chunk, rows 128 j + H .. 128 (j + 1) + H
+    // during chunk j - 1.  The halo of a chunk is the body of the next one, so a run stages 128 RUN + H rows instead of RUN (128 + H): 10 instead of
+    // 14 DMA pieces per wave and chunk for k = 5 (a piece costs a lone wave ~180 cycles of issue, see the kernel).  While the last chunk of a run reads
+    // rows >= 256, the first instalment of the next run goes to rows [0, 224): no second buffer.
+    static constexpr int RUN = 3;
+    static constexpr int ROWS = RUN * BMT + MAXHALO;                  // 432 | 480 rows
     static constexpr int RB = 256;
-    static constexpr int BUF = MAXSLOT * RB;                          // 44 | 56 KB per buffer, two buffers
-    static constexpr int NIA = ((MAXSLOT + 3) / 4 + NW - 1) / NW;     // DMA instructions per wave and chunk (upper bound): 11 | 14
+    static constexpr int LDSB = ROWS * RB;                            // 108 | 120 KB: one block per CU (its waves fill the register file anyway)
+    static constexpr int NIA = ((BMT + MAXHALO) / 4 + NW - 1) / NW;   // DMA pieces per wave of a run's first instalment (11 | 14); the others: 8
 };
 
-// stage slots [P0, P0 + BMT + halo): instruction t = wave + 4 i fills rows 4 t .. 4 t + 3 (lane: row 4 t + lane / 16, physical chunk lane % 16).
+// An instalment of slots: piece t = wave + 4 i fills rows 4 t .. 4 t + 3 of it (lane: row 4 t + lane / 16, physical chunk lane % 16).
 // Logical chunk c = 8 ph + 4 pw + (16-byte quarter of the pixel's 32 channels): pixel (2 gy + ph, 2 gx + pw).  A wave's instructions are 16
 // slots apart, so row & 15 -- the swizzle term: physical chunk = c ^ (row & 15) -- and with it c are the same for all of them, and the slot walk is
 // incremental (GW > 16):
@@ -406,17 +412,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     typedef RcCfg<KH> Cfg;
     constexpr int TAPS = Cfg::TAPS, NT = TAPS * TAPS, RB = Cfg::RB;
     typedef u16x8 freg;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Cfg::BUF + 256];
-    float* const bias_lds = (float*)(lds + 2 * Cfg::BUF);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDSB + 256];
+    float* const bias_lds = (float*)(lds + Cfg::LDSB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = wave & 1, half = wave >> 1;
     const int lrow = lane & 31, lgrp = lane >> 5;
-    // chunk schedule of rwconv_gather_kernel: XCD x owns a contiguous range of chunks
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const int q8 = nchunks >> 3, r8 = nchunks & 7;
-    const int cbeg = xcd * q8 + (xcd < r8 ? xcd : r8), cend = cbeg + q8 + (xcd < r8 ? 1 : 0);
+    // block b owns the chunks [c0, c1): consecutive, so that a chunk's halo rows are the next chunk's body (RcCfg)
+    const int nbk = (int)gridDim.x, bk = (int)blockIdx.x;
+    const int qn = nchunks / nbk, rn = nchunks % nbk;
+    const int c0 = bk * qn + (bk < rn ? bk : rn), c1 = c0 + qn + (bk < rn ? 1 : 0);
     // debug (mi_debug_set_trace): s_memtime stamps of lane 0 of every wave: 0 start, 1 first slot range requested, 2 weights requested, then per
     // chunk: handed over / pixel decode + mask requests done / MFMA loop done / epilogue done (tools/trace_rwconv.py deconv3.dgrad)
     long long* tr = nullptr; int tr_n = 0;
@@ -424,11 +430,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define RC_STAMP() do { if (tr && tr_n < 31) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     RC_STAMP();
     if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
-    int chunk = cbeg + jb;
-    if (chunk >= cend) return;                               // block-uniform
+    int chunk = c0;
+    if (chunk >= c1) return;                                 // block-uniform
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     const int halo = (TAPS - 1) * p.GW + TAPS - 1;
-    const int ninstr = (Cfg::BMT + halo + 3) / 4;
+    const int hs = (halo + 15) & ~15;                        // staged halo rows: instalments start on multiples of 16 rows (the swizzle term of a DMA lane is fixed)
+    const int np0 = (Cfg::BMT + hs) / 4;                     // pieces of a run's first instalment
     // DMA lane role (see RcWalk)
     const int sq0 = 4 * wave + (lane >> 4);
     const int sc = (lane & 15) ^ (sq0 & 15);                 // 4-bit swizzle: 16 consecutive 256-byte rows put a given logical chunk on 16 different bank groups
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     walk.start(p, chunk * Cfg::BMT + sq0, sph);
 #pragma unroll
     for (int i = 0; i < Cfg::NIA; ++i) {
-        if (wave + Cfg::NW * i >= ninstr) break;             // wave-uniform
+        if (wave + Cfg::NW * i >= np0) break;                // wave-uniform
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
         walk.advance(p);
     }
@@ -478,26 +485,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int cur = 0;
+    int jrun = 0;                                            // position of `chunk` in its run
 #pragma unroll 1
-    for (; chunk < cend; chunk += per, cur ^= 1) {
+    for (; chunk < c1; ++chunk) {
         RC_STAMP();
-        const bool more = chunk + per < cend;                // block-uniform: the next chunk's slot range goes to the other buffer during the MFMA loop
-        unsigned char* const nbuf = lds + (cur ^ 1) * Cfg::BUF;
+        const bool more = chunk + 1 < c1;                    // block-uniform
+        const int jn = jrun == Cfg::RUN - 1 ? 0 : jrun + 1;
         if (more) {
-            // A wave's 14 pieces take ~2.5k cycles to ISSUE (22 B/clk per CU with four waves at it: tools/trace_rwconv.py deconv3.dgrad), here as well
-            // as spread between the MFMA steps (where the MFMA loop grew from 3.7k to 6.1k cycles), as LDS-DMA as well as through registers + ds_write:
-            // the CU's load path, not the instruction form.  With one wave per SIMD nothing covers it; it is 30 % of the chunk's time.
-            walk.start(p, (chunk + per) * Cfg::BMT + sq0, sph);
+            // the next chunk's instalment.  A wave's pieces take ~180 cycles EACH to issue (22 B/clk per CU with four waves at it: tools/trace_rwconv.py
+            // deconv3.dgrad), here as well as spread between the MFMA steps (where the MFMA loop grew from 3.7k to 6.1k cycles), as LDS-DMA as well as
+            // through registers + ds_write: the CU's load path, not the instruction form.  With one wave per SIMD nothing covers it.
+            const int fs = (chunk + 1) * Cfg::BMT + (jn ? hs : 0), drow = jn ? jn * Cfg::BMT + hs : 0, np = jn ? Cfg::BMT / 4 : np0;
+            walk.start(p, fs + sq0, sph);
 #pragma unroll
             for (int i = 0; i < Cfg::NIA; ++i) {
-                if (wave + Cfg::NW * i >= ninstr) break;         // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(nbuf + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
+                if (wave + Cfg::NW * i >= np) break;             // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + drow * RB + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
                 walk.advance(p);
             }
         }
         const int P0 = chunk * Cfg::BMT + half * 64;
-        const uint32_t toff = (uint32_t)(cur * Cfg::BUF + half * 64 * RB);
+        const uint32_t toff = (uint32_t)((jrun * Cfg::BMT + half * 64) * RB);
         // ---- this lane's two output pixels (conv form: slot (gy, gx) IS output pixel (gy, gx) when inside the output) ----
         uint32_t e0[2]; bool ok[2];
         PackN<uint32_t, 4> umk[2][2];
@@ -545,7 +553,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[k]), __builtin_bit_cast(bf16x8, cur_[1]), acc[1], 0, 0, 0);
         }
         RC_STAMP();
-        // ---- epilogue (rw_class's): bf16, ReLU, pair the 4-channel groups of the two half-waves, mask, two 16-byte stores per tile ----
+        // ---- epilogue (rw_class's): bf16, ReLU, pair the 4-channel groups of the two half-waves, mask, two 16-byte stores per tile.  (Running its tail --
+        //      pairing, mask, stores -- one chunk late between the next chunk's MFMA steps was measured: the stamps showed the epilogue gone and the loop
+        //      +630 cycles; un-instrumented the kernel was 4 % SLOWER.  Stores do not stall a wave; instructions between MFMAs do.) ----
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint32_t w[4][2];
@@ -576,9 +586,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, 0);
         }
         RC_STAMP();
-        // the next chunk's slot range was requested before this chunk's 4 stores (and mask loads, long complete): all but the stores have landed
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (the mask loads, newer than the DMA pieces, were consumed by the epilogue: only the 4 stores are younger)
+        // the next chunk's instalment was requested before this chunk's mask loads (consumed above) and 4 stores: everything but the stores has landed
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        jrun = jn;
     }
 #undef RC_STAMP
 }
@@ -664,6 +675,12 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     return rc == MI_OK ? 1 : rc;
 }
 
+int mi_rwconv_blocks(int set) {                          // mi_set_tuning key 16: persistent blocks per XCD of the register-weight kernels, 0 = one (k = 4 gather: three) per CU
+    mi_rwconv_mode(-1);
+    const int prev = g_rwconv_blocks;
+    if (set >= 0) g_rwconv_blocks = set;
+    return prev;
+}
 int g_rwconv_conv = -1;                                  // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4 (default)
 int mi_rwconv_conv_mode(int set) {                       // set < 0: query
     if (g_rwconv_conv < 0) { const char* e = getenv("MI355_RWCONV_CONV"); g_rwconv_conv = e ? atoi(e) : 2; if (g_rwconv_conv < 0 || g_rwconv_conv > 2) g_rwconv_conv = 2; }
@@ -698,10 +715,9 @@ int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, 
     const int nchunks = (int)((MP + 127) / 128);
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-    int per_xcd = n_cu / 8;
-    if (g_rwconv_blocks > 0) per_xcd = g_rwconv_blocks;
-    if (per_xcd > (nchunks + 7) / 8) per_xcd = (nchunks + 7) / 8;
-    const dim3 g((unsigned)(8 * per_xcd)), t(256);
+    int nblk = g_rwconv_blocks > 0 ? 8 * g_rwconv_blocks : n_cu;       // one persistent block per CU; each walks a contiguous range of chunks
+    if (nblk > nchunks) nblk = nchunks;
+    const dim3 g((unsigned)nblk), t(256);
 #define RC_LAUNCH(KH_) do { \
         if (relu && mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, true>), g, t, 0, st, q, nchunks); \
         else if (relu) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, false>), g, t, 0, st, q, nchunks); \

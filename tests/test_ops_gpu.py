@@ -21,9 +21,9 @@ DECONVS = [  # IH, IW, Cin, Cout, k
 # tiles, raw-staged tapconv / tapwgrad, the narrow-layer kernels); `auto` is what production picks at these (small) sizes, the
 # other two pin the dispatch through mi_set_tuning so that EVERY generation meets the same float64 reference on every geometry.
 # `rwconv` = `newest` with the register-weight kernels forced for the thin gather-form layers (key 13 = 2; auto takes them only on chip-filling grids)
-# and for both 32 -> 64 channel conv-form layers (key 15 = 2: k = 4 as well as k = 5)
+# and for both 32 -> 64 channel conv-form layers (key 15 = 2: k = 4 as well as k = 5), on 8 persistent blocks (key 16 = 1: several chunks per block)
 GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0},
-               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2, 15: 2}}
+               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2, 15: 2, 16: 1}}
 
 
 @pytest.fixture(params=list(GENERATIONS))
@@ -107,6 +107,45 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
                                P(dev(mask, td)), dx.data_ptr())
         rt, at = tols(dt, float(dxref.abs().max()))
         assert_close(host(dx), dxref.numpy(), rt, at, "conv dgrad")
+
+
+@pytest.mark.parametrize("blocks_per_xcd", [1, 2, 0])
+@pytest.mark.parametrize("k,B", [(5, 7), (4, 7), (5, 20)])
+def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, blocks_per_xcd):
+    """rwconv_conv_kernel (32 -> 64 channels, stride 2): a block walks CONSECUTIVE 128-position chunks whose slot rows are staged in runs of three
+    instalments; 8 or 16 blocks over 44 / 125 chunks make every block cross run boundaries, start runs at every phase and end on every instalment.
+    Checked against the float64 convolution of the same bf16 values, with and without bias + ReLU / ReluGrad mask."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    prev = {key: L.mi_set_tuning(key, v) for key, v in ((13, 2), (15, 2), (16, blocks_per_xcd))}
+    try:
+        rng = np.random.RandomState(10 * k + B)
+        IH, IW, Ci, Co = 39, 79, 32, 64
+        OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
+        x = rng.randn(B, IH, IW, Ci).astype(np.float32)
+        w = (rng.randn(k, k, Ci, Co) / np.sqrt(k * k * Ci)).astype(np.float32)
+        b = (0.1 * rng.randn(Co)).astype(np.float32)
+        mask = rng.randn(B, OH, OW, Co).astype(np.float32)
+        y = F.conv2d(_nchw(rounded(x, td)), rounded(w, td).permute(3, 2, 0, 1), torch.from_numpy(b).double(), stride=2)
+        wt = torch.zeros(k * k * Ci * Co, device="cuda", dtype=td)
+        offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Ci], np.int32), np.array([Co], np.int32)
+        L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+        xd, bd = dev(x, td), dev(b)
+        out = torch.full((B, OH, OW, Co), 3.0, device="cuda", dtype=td)
+        L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), None, 0, B, IH, IW, Ci, wt.data_ptr(), 1, bd.data_ptr(), k, k, Co, 1, out.data_ptr())
+        yref = _nhwc(F.relu(y)).numpy()
+        rt, at = tols("bf16", float(np.abs(yref).max()))
+        assert_close(host(out), yref, rt, at, "conv-form fwd, bias + relu")
+        # the same contraction as the input gradient of a transposed conv (deconv3.dgrad: no bias, ReluGrad mask): dY = x, weights [Cin_of_deconv = 64][k k 32]
+        dx = torch.full((B, OH, OW, Co), 3.0, device="cuda", dtype=td)
+        L.mi_deconv2d_nhwc_dgrad(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wt.data_ptr(), 1, k, k, Co, P(dev(mask, td)), dx.data_ptr())
+        y0 = F.conv2d(_nchw(rounded(x, td)), rounded(w, td).permute(3, 2, 0, 1), None, stride=2)
+        dref = (_nhwc(y0) * (rounded(mask, td) > 0)).numpy()
+        rt, at = tols("bf16", float(np.abs(dref).max()))
+        assert_close(host(dx), dref, rt, at, "conv-form as a deconv input gradient, mask")
+    finally:
+        for key, v in prev.items():
+            L.mi_set_tuning(key, v)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
