@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--set", action="append", default=[])
+    ap.add_argument("--nomask", action="store_true", help="input gradients without their ReluGrad mask (upper bound of what bit words can save)")
     args = ap.parse_args()
     L = milib.get()
     for kv in args.set:
@@ -50,7 +51,7 @@ def main():
             if kind == "fwd":
                 call = lambda: L.mi_conv2d_nhwc_fwd(st, 1, x.data_ptr(), None, 0, B, ih, iw, ci, wt.data_ptr(), 1, bias.data_ptr(), k, k, co, 1, out.data_ptr())   # noqa: E731
             else:
-                call = lambda: L.mi_conv2d_nhwc_dgrad(st, 1, y.data_ptr(), B, oh, ow, co, wb.data_ptr(), k, k, ci, ih, iw, x.data_ptr(), out.data_ptr())   # noqa: E731
+                call = lambda: L.mi_conv2d_nhwc_dgrad(st, 1, y.data_ptr(), B, oh, ow, co, wb.data_ptr(), k, k, ci, ih, iw, None if args.nomask else x.data_ptr(), out.data_ptr())   # noqa: E731
             flops = 2.0 * oh * ow * co * k * k * ci * B
         else:
             ih, iw, ci, co, k = DEC[layer]
@@ -64,7 +65,7 @@ def main():
             if kind == "fwd":
                 call = lambda: L.mi_deconv2d_nhwc_fwd(st, 1, x.data_ptr(), B, ih, iw, ci, wb.data_ptr(), bias.data_ptr(), k, k, co, 1, out.data_ptr())   # noqa: E731
             else:
-                call = lambda: L.mi_deconv2d_nhwc_dgrad(st, 1, y.data_ptr(), B, oh, ow, co, wt.data_ptr(), 1, k, k, ci, x.data_ptr() if layer != "deconv1" else None, out.data_ptr())   # noqa: E731
+                call = lambda: L.mi_deconv2d_nhwc_dgrad(st, 1, y.data_ptr(), B, oh, ow, co, wt.data_ptr(), 1, k, k, ci, x.data_ptr() if layer != "deconv1" and not args.nomask else None, out.data_ptr())   # noqa: E731
             flops = 2.0 * ih * iw * ci * k * k * co * B
         for _ in range(5):
             call()
