@@ -364,20 +364,24 @@ __global__ __launch_bounds__((RwCfg<TAPS, CK>::NW * 64), ((TAPS == 2 && CK == 1)
 // chunk (wave >> 1).  Every fragment read serves two MFMAs (the two 32-position tiles of the half).  im2col-gather tiles (gemm2) move every
 // input pixel through the per-CU load path 6.25 times for this layer (562 MB of L2 -> LDS traffic for a 101 MB tensor) and re-stage the 102 KB of
 // weights per 128 x 64 tile; here a pixel is staged 1.6 times (halo) and the weights are read once per CU.
-template <int KH> struct RcCfg {
+template <int KH, int CK = 1> struct RcCfg {
     static constexpr int TAPS = (KH + 1) / 2;
-    static constexpr int NW = 4, NTILE = 2, BMT = 128;                // two position halves x two 32-position tiles
-    static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;               // staged halo: (TAPS-1) * GW + TAPS - 1 rounded up to 16 rows
+    // CK = 1: 32 -> 64 channels, waves = 2 output tiles x 2 position halves of a 128-position chunk.  CK = 2 (k = 4 only): 64 -> 128 channels (conv3
+    // forward, deconv2's input gradient): 512-byte slot rows, 16 k-steps per tap, 64 weight fragments = 256 registers per wave, waves = the 4 output
+    // tiles of ONE 64-position range (every fragment read then serves one of four waves' MFMA pairs: 128 B/clk of the LDS's 256)
+    static constexpr int NW = 4, NTILE = 2, BMT = CK == 1 ? 128 : 64;
+    static constexpr int MAXHALO = TAPS == 2 ? (CK == 1 ? 48 : 32) : 96;     // staged halo: (TAPS-1) * GW + TAPS - 1 rounded up to 16 rows
     // A block walks CONSECUTIVE chunks in runs of RUN: the slot rows of a run lie in one linear buffer (row r = slot P_run + r; chunk j of the run reads
-    // rows 128 j .. 128 j + 128 + halo), filled in RUN instalments: rows [0, 128 + H) before the run's first chunk, rows 128 j + H .. 128 (j + 1) + H
-    // during chunk j - 1.  The halo of a chunk is the body of the next one, so a run stages 128 RUN + H rows instead of RUN (128 + H): 10 instead of
+    // rows BMT j .. BMT j + BMT + halo), filled in RUN instalments: rows [0, BMT + H) before the run's first chunk, rows BMT j + H .. BMT (j + 1) + H
+    // during chunk j - 1.  The halo of a chunk is the body of the next one, so a run stages BMT RUN + H rows instead of RUN (BMT + H): 10 instead of
     // 14 DMA pieces per wave and chunk for k = 5 (a piece costs a lone wave ~180 cycles of issue, see the kernel).  While the last chunk of a run reads
-    // rows >= 256, the first instalment of the next run goes to rows [0, 224): no second buffer.
+    // the rows of its own range, the first instalment of the next run goes to rows [0, BMT + H): no second buffer.
     static constexpr int RUN = 3;
-    static constexpr int ROWS = RUN * BMT + MAXHALO;                  // 432 | 480 rows
-    static constexpr int RB = 256;
-    static constexpr int LDSB = ROWS * RB;                            // 108 | 120 KB: one block per CU (its waves fill the register file anyway)
-    static constexpr int NIA = ((BMT + MAXHALO) / 4 + NW - 1) / NW;   // DMA pieces per wave of a run's first instalment (11 | 14); the others: 8
+    static constexpr int ROWS = RUN * BMT + MAXHALO;                  // 432 | 480 rows (CK = 2: 224)
+    static constexpr int RB = 256 * CK;
+    static constexpr int RPP = 1024 / RB;                             // rows per DMA piece: 4 | 2
+    static constexpr int LDSB = ROWS * RB;                            // 108 | 120 KB (CK = 2: 112 KB): one block per CU (its waves fill the register file anyway)
+    static constexpr int NIA = ((BMT + MAXHALO) / RPP + NW - 1) / NW; // DMA pieces per wave of a run's first instalment (11 | 14 | 12); the others: 8
 };
 
 // An instalment of slots: piece t = wave + 4 i fills rows 4 t .. 4 t + 3 of it (lane: row 4 t + lane / 16, physical chunk lane % 16).
@@ -385,7 +389,7 @@ template <int KH> struct RcCfg {
 // slots apart, so row & 15 -- the swizzle term: physical chunk = c ^ (row & 15) -- and with it c are the same for all of them, and the slot walk is
 // incremental (GW > 16):
 // one decode per chunk, then ~10 VALU instructions per DMA instruction.
-struct RcWalk {
+template <int CK> struct RcWalk {
     int P, sy, sx;                   // slot number, input row 2 gy + ph, input column 2 gx of this lane's next row
     uint32_t srow;                   // (b IH + sy) IW
     __device__ __forceinline__ void start(const TapParams& p, int Pq, int ph) {
@@ -396,10 +400,11 @@ struct RcWalk {
     }
     __device__ __forceinline__ uint32_t offset(const TapParams& p, int pw, uint32_t cofs) const {
         const bool in = P < p.MP && sy < p.IH && sx + pw < p.IW;
-        return in ? (srow + (uint32_t)sx) * 64u + cofs : G2_OOB;
+        return in ? (srow + (uint32_t)sx) * (64u * CK) + cofs : G2_OOB;
     }
-    __device__ __forceinline__ void advance(const TapParams& p) {                 // 16 slots on
-        P += 16; sx += 32;
+    __device__ __forceinline__ void advance(const TapParams& p) {                 // to this wave's next piece: 16 | 8 slots on (GW is larger)
+        constexpr int STEP = 4 * (4 / CK);
+        P += STEP; sx += 2 * STEP;
         if (sx >= 2 * p.GW) {
             sx -= 2 * p.GW; sy += 2; srow += 2 * p.IW;
             if (sy >= 2 * p.GH) { sy -= 2 * p.GH; srow += (uint32_t)((p.IH - 2 * p.GH) * p.IW); }
@@ -407,17 +412,18 @@ struct RcWalk {
     }
 };
 
-template <int KH, bool RELU, bool MASK>
+template <int KH, int CK, bool RELU, bool MASK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rwconv_conv_kernel(const TapParams p, const int nchunks) {
-    typedef RcCfg<KH> Cfg;
-    constexpr int TAPS = Cfg::TAPS, NT = TAPS * TAPS, RB = Cfg::RB;
+    static_assert(CK == 1 || (CK == 2 && KH == 4), "64 -> 128 channels: k = 4 only");
+    typedef RcCfg<KH, CK> Cfg;
+    constexpr int TAPS = Cfg::TAPS, NT = TAPS * TAPS, RB = Cfg::RB, RPP = Cfg::RPP, SPT = 8 * CK;      // SPT: k-steps per tap
     typedef u16x8 freg;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDSB + 256];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[Cfg::LDSB + 256 * CK];
     float* const bias_lds = (float*)(lds + Cfg::LDSB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = wave & 1, half = wave >> 1;
+    const int nt = CK == 1 ? (wave & 1) : wave, half = CK == 1 ? (wave >> 1) : 0;
     const int lrow = lane & 31, lgrp = lane >> 5;
     // block b owns the chunks [c0, c1): consecutive, so that a chunk's halo rows are the next chunk's body (RcCfg)
     const int nbk = (int)gridDim.x, bk = (int)blockIdx.x;
@@ -429,38 +435,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (p.trace && ((long long)blockIdx.x * 8 + 8) * 32 <= p.trace_cap && lane == 0) tr = p.trace + ((long long)blockIdx.x * 8 + wave) * 32;
 #define RC_STAMP() do { if (tr && tr_n < 31) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     RC_STAMP();
-    if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
+    if (tid < 64 * CK) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
     int chunk = c0;
     if (chunk >= c1) return;                                 // block-uniform
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
     const int halo = (TAPS - 1) * p.GW + TAPS - 1;
     const int hs = (halo + 15) & ~15;                        // staged halo rows: instalments start on multiples of 16 rows (the swizzle term of a DMA lane is fixed)
-    const int np0 = (Cfg::BMT + hs) / 4;                     // pieces of a run's first instalment
-    // DMA lane role (see RcWalk)
-    const int sq0 = 4 * wave + (lane >> 4);
-    const int sc = (lane & 15) ^ (sq0 & 15);                 // 4-bit swizzle: 16 consecutive 256-byte rows put a given logical chunk on 16 different bank groups
-    const int sph = sc >> 3, spw = (sc >> 2) & 1;
-    const uint32_t scofs = (uint32_t)(sc & 7) * 16u;
-    RcWalk walk;
+    const int np0 = (Cfg::BMT + hs) / RPP;                   // pieces of a run's first instalment
+    // DMA lane role (see RcWalk): row r of the piece, physical chunk cp; logical chunk = cp ^ (row & 15) on its low 4 bits.  A wave's pieces are 16 rows
+    // apart (CK = 1: one role) or 8 (CK = 2: the role of odd pieces has the other row & 15, i.e. the other pixel of the pair)
+    constexpr int LPR = RB / 16;                             // lanes per row
+    const int sq0 = RPP * wave + lane / LPR;
+    const int scp = lane % LPR;
+    int spw[2]; uint32_t scofs[2];
+    int sph = 0;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int sc = (scp & ~15) | ((scp & 15) ^ ((sq0 + par * 4 * RPP) & 15));
+        sph = sc >> (2 + CK); spw[par] = (sc >> (1 + CK)) & 1; scofs[par] = (uint32_t)(sc & (8 * CK - 1)) * 16u;
+    }
+    RcWalk<CK> walk;
     walk.start(p, chunk * Cfg::BMT + sq0, sph);
 #pragma unroll
     for (int i = 0; i < Cfg::NIA; ++i) {
         if (wave + Cfg::NW * i >= np0) break;                // wave-uniform
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw[i & 1], scofs[i & 1]), 0, 0, 0);
         walk.advance(p);
     }
     RC_STAMP();
 
     // live (tap, k-step) pairs in issue order (compile time): k-step s = 4 ph + 2 pw + kk reaches kernel row 2 ta + ph, column 2 tb + pw
-    struct Steps { int n; int id[NT * 8]; };
+    struct Steps { int n; int id[NT * SPT]; };
     constexpr Steps ST = [] {
         Steps r = {0, {}};
         for (int tap = 0; tap < NT; ++tap)
-            for (int s = 0; s < 8; ++s)
-                if (2 * (tap / TAPS) + (s >> 2) < KH && 2 * (tap % TAPS) + ((s >> 1) & 1) < KH) r.id[r.n++] = tap * 8 + s;
+            for (int s = 0; s < SPT; ++s)
+                if (2 * (tap / TAPS) + s / (4 * CK) < KH && 2 * (tap % TAPS) + (s / (2 * CK)) % 2 < KH) r.id[r.n++] = tap * SPT + s;
         return r;
     }();
-    static_assert(ST.n == KH * KH * 2, "live steps");
+    static_assert(ST.n == KH * KH * 2 * CK, "live steps");
 
     // ---- weights: step k -> 8 consecutive input channels (16 kk + 8 lgrp) of kernel position (kh, kw), output channel 32 nt + lrow; ONCE per block ----
     freg wf[ST.n];
@@ -468,9 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bf16_t* __restrict__ wrow = (const bf16_t*)p.b + (long long)(nt * 32 + lrow) * p.ldb + lgrp * 8;
 #pragma unroll
         for (int k = 0; k < ST.n; ++k) {
-            const int tap = ST.id[k] >> 3, s = ST.id[k] & 7;
-            const int kh = 2 * (tap / TAPS) + (s >> 2), kw = 2 * (tap % TAPS) + ((s >> 1) & 1);
-            wf[k] = *(const freg*)(wrow + (kh * KH + kw) * 32 + (s & 1) * 16);
+            const int tap = ST.id[k] / SPT, s = ST.id[k] % SPT;
+            const int kh = 2 * (tap / TAPS) + s / (4 * CK), kw = 2 * (tap % TAPS) + (s / (2 * CK)) % 2;
+            wf[k] = *(const freg*)(wrow + (kh * KH + kw) * (32 * CK) + (s % (2 * CK)) * 16);
         }
     }
     RC_STAMP();
@@ -495,12 +508,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // the next chunk's instalment.  A wave's pieces take ~180 cycles EACH to issue (22 B/clk per CU with four waves at it: tools/trace_rwconv.py
             // deconv3.dgrad), here as well as spread between the MFMA steps (where the MFMA loop grew from 3.7k to 6.1k cycles), as LDS-DMA as well as
             // through registers + ds_write: the CU's load path, not the instruction form.  With one wave per SIMD nothing covers it.
-            const int fs = (chunk + 1) * Cfg::BMT + (jn ? hs : 0), drow = jn ? jn * Cfg::BMT + hs : 0, np = jn ? Cfg::BMT / 4 : np0;
+            const int fs = (chunk + 1) * Cfg::BMT + (jn ? hs : 0), drow = jn ? jn * Cfg::BMT + hs : 0, np = jn ? Cfg::BMT / RPP : np0;
             walk.start(p, fs + sq0, sph);
 #pragma unroll
             for (int i = 0; i < Cfg::NIA; ++i) {
                 if (wave + Cfg::NW * i >= np) break;             // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + drow * RB + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw, scofs), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr)(lds + drow * RB + (wave + Cfg::NW * i) * 1024), 16, (int)walk.offset(p, spw[i & 1], scofs[i & 1]), 0, 0, 0);
                 walk.advance(p);
             }
         }
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             p.div_gw.divmod((uint32_t)(pin ? P : 0), g, gx);
             p.div_g.divmod(g, b, gy);
             ok[h] = pin && (int)gy < p.OH && (int)gx < p.OW;
-            e0[h] = ok[h] ? ((b * p.OH + gy) * p.OW + gx) * 64u + (uint32_t)(nt * 32) + 8u * lgrp : 0u;
+            e0[h] = ok[h] ? ((b * p.OH + gy) * p.OW + gx) * (64u * CK) + (uint32_t)(nt * 32) + 8u * lgrp : 0u;
             if constexpr (MASK) {
                 umk[h][0] = *(const PackN<uint32_t, 4>*)(maskp + e0[h]);
                 umk[h][1] = *(const PackN<uint32_t, 4>*)(maskp + e0[h] + 16);
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int AH = 3;                             // steps of fragment reads in flight (6 measured the same: the loop runs at 37 cycles per MFMA)
         freg ring[AH + 1][2];
         auto fetch = [&](int k) {
-            const int tap_ = ST.id[k] >> 3, s_ = ST.id[k] & 7;
+            const int tap_ = ST.id[k] / SPT, s_ = ST.id[k] % SPT;
             const uint32_t vt = (vtap0[tap_] + toff) ^ (uint32_t)(s_ << 5);          // (toff: whole rows, a multiple of 256)
             lds_read_b128_pair<32 * RB>(ring[k % (AH + 1)][0], ring[k % (AH + 1)][1], vt);
         };
@@ -681,28 +694,31 @@ int mi_rwconv_blocks(int set) {                          // mi_set_tuning key 16
     if (set >= 0) g_rwconv_blocks = set;
     return prev;
 }
-int g_rwconv_conv = -1;                                  // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4 (default)
+int g_rwconv_conv = -1;                                  // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4, 3 also the 64 -> 128 channel shape (default)
 int mi_rwconv_conv_mode(int set) {                       // set < 0: query
-    if (g_rwconv_conv < 0) { const char* e = getenv("MI355_RWCONV_CONV"); g_rwconv_conv = e ? atoi(e) : 2; if (g_rwconv_conv < 0 || g_rwconv_conv > 2) g_rwconv_conv = 2; }
+    if (g_rwconv_conv < 0) { const char* e = getenv("MI355_RWCONV_CONV"); g_rwconv_conv = e ? atoi(e) : 3; if (g_rwconv_conv < 0 || g_rwconv_conv > 3) g_rwconv_conv = 3; }
     const int prev = g_rwconv_conv;
-    if (set >= 0) g_rwconv_conv = set > 2 ? 2 : set;
+    if (set >= 0) g_rwconv_conv = set > 3 ? 3 : set;
     return prev;
 }
 
-// conv-form layer on the register-weight kernel: x [B,IH,IW,32] bf16, w [64][ldb] bf16 (K-contiguous, k = (kh KW + kw) 32 + c), out / mask [B,OH,OW,64]
-// bf16.  Same contract as try_tapconv: 1 launched, 0 not eligible, < 0 error.  mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4 (default).
+// conv-form layer on the register-weight kernel: x [B,IH,IW,C] bf16, w [N][ldb] bf16 (K-contiguous, k = (kh KW + kw) C + c), out / mask [B,OH,OW,N]
+// bf16, (C, N) = (32, 64) with k = 4 | 5 or (64, 128) with k = 4.  Same contract as try_tapconv: 1 launched, 0 not eligible, < 0 error.
+// mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 the k = 5 layer, 2 also 32 -> 64 channels k = 4, 3 also 64 -> 128 channels (default).
 int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                        int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu) {
     const int on = mi_rwconv_conv_mode(-1);
     mi_rwconv_mode(-1);
-    if (!on || g_rwconv_mode == 0 || dtype != MI_BF16 || C != 32 || N != 64 || KH != KW || (KH != 5 && !(KH == 4 && on >= 2))) return 0;
+    const int ck = (C == 64 && N == 128) ? 2 : 1;
+    if (!on || g_rwconv_mode == 0 || dtype != MI_BF16 || C != 32 * ck || N != 64 * ck || KH != KW) return 0;
+    if (!((KH == 5 && ck == 1) || (KH == 4 && ck == 1 && on >= 2) || (KH == 4 && ck == 2 && on >= 3))) return 0;
     if (OH != (IH - KH) / 2 + 1 || OW != (IW - KW) / 2 + 1 || (ldb % 8) != 0 || ldb < KH * KW * C) return 0;
     if ((((uintptr_t)a) | ((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)mask)) & 15) return 0;
     TapParams q = {};
     q.TH = q.TW = (KH + 1) / 2;
     q.GH = OH + q.TH - 1; q.GW = OW + q.TW - 1;
     const int halo = (q.TH - 1) * q.GW + q.TW - 1;
-    if (halo > (KH == 4 ? RcCfg<4>::MAXHALO : RcCfg<5>::MAXHALO) || q.GW <= 16) return 0;            // (GW > 16: the incremental slot decode of rc_stage)
+    if (halo > (ck == 2 ? RcCfg<4, 2>::MAXHALO : KH == 4 ? RcCfg<4>::MAXHALO : RcCfg<5>::MAXHALO) || q.GW <= 16) return 0;     // (GW > 16: the incremental slot walk of the staging)
     const long long MP = (long long)B * q.GH * q.GW, a_bytes = (long long)B * IH * IW * C * 2, o_bytes = (long long)B * OH * OW * N * 2;
     if (MP >= (1ll << 30) || a_bytes <= 0 || a_bytes >= (long long)G2_OOB || o_bytes >= (long long)G2_OOB) return 0;
     if (g_rwconv_mode == 1 && MP < 75000) return 0;
@@ -712,18 +728,19 @@ int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, 
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW);
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     mi_get_trace(&q.trace, &q.trace_cap);
-    const int nchunks = (int)((MP + 127) / 128);
+    const int bmt = ck == 2 ? RcCfg<4, 2>::BMT : RcCfg<5>::BMT;
+    const int nchunks = (int)((MP + bmt - 1) / bmt);
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; hipDeviceProp_t pr; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
     int nblk = g_rwconv_blocks > 0 ? 8 * g_rwconv_blocks : n_cu;       // one persistent block per CU; each walks a contiguous range of chunks
     if (nblk > nchunks) nblk = nchunks;
     const dim3 g((unsigned)nblk), t(256);
-#define RC_LAUNCH(KH_) do { \
-        if (relu && mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, true>), g, t, 0, st, q, nchunks); \
-        else if (relu) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, true, false>), g, t, 0, st, q, nchunks); \
-        else if (mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, false, true>), g, t, 0, st, q, nchunks); \
-        else hipLaunchKernelGGL((rwconv_conv_kernel<KH_, false, false>), g, t, 0, st, q, nchunks); } while (0)
-    if (KH == 5) RC_LAUNCH(5); else RC_LAUNCH(4);
+#define RC_LAUNCH(KH_, CK_) do { \
+        if (relu && mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, true, true>), g, t, 0, st, q, nchunks); \
+        else if (relu) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, true, false>), g, t, 0, st, q, nchunks); \
+        else if (mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, false, true>), g, t, 0, st, q, nchunks); \
+        else hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, false, false>), g, t, 0, st, q, nchunks); } while (0)
+    if (KH == 5) RC_LAUNCH(5, 1); else if (ck == 1) RC_LAUNCH(4, 1); else RC_LAUNCH(4, 2);
 #undef RC_LAUNCH
     const int rc = mi_check_launch("rwconv_conv_kernel");
     return rc == MI_OK ? 1 : rc;

@@ -78,8 +78,8 @@ unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
  * key 12: tapconv ReluGrad-mask prefetch in the last main-loop step on/off;
  * key 13: register-weight kernel of the thin gather-form layers (rwconv.hip: deconv3 fwd, conv2 dgrad): 0 off, 1 auto (grids that fill the
  * chip), 2 whenever the layer is eligible (MI355_RWCONV); key 14: the column-walk filter-gradient kernel of deconv3 on/off;
- * key 15: register-weight kernel of the 32 -> 64 channel conv-form layers (rwconv.hip: deconv3 dgrad k = 5, conv2 fwd k = 4): 0 off, 1 the k = 5
- * layer, 2 both (default; MI355_RWCONV_CONV); subject to key 13's off / auto / always; key 16: persistent blocks per XCD of the
+ * key 15: register-weight kernel of the conv-form layers (rwconv.hip): 0 off, 1 deconv3 dgrad (32 -> 64 channels, k = 5), 2 also conv2 fwd (k = 4),
+ * 3 also the 64 -> 128 channel k = 4 shape, conv3 fwd / deconv2 dgrad (default; MI355_RWCONV_CONV); subject to key 13's off / auto / always; key 16: persistent blocks per XCD of the
  * register-weight kernels, 0 = as many as stay resident (tests use 1: every block then walks several chunks).  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */

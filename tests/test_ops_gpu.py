@@ -21,9 +21,9 @@ DECONVS = [  # IH, IW, Cin, Cout, k
 # tiles, raw-staged tapconv / tapwgrad, the narrow-layer kernels); `auto` is what production picks at these (small) sizes, the
 # other two pin the dispatch through mi_set_tuning so that EVERY generation meets the same float64 reference on every geometry.
 # `rwconv` = `newest` with the register-weight kernels forced for the thin gather-form layers (key 13 = 2; auto takes them only on chip-filling grids)
-# and for both 32 -> 64 channel conv-form layers (key 15 = 2: k = 4 as well as k = 5), on 8 persistent blocks (key 16 = 1: several chunks per block)
+# and for all conv-form shapes (key 15 = 3: 32 -> 64 channels k = 5 and k = 4, 64 -> 128 channels k = 4), on 8 persistent blocks (key 16 = 1: several chunks per block)
 GENERATIONS = {"auto": None, "gen1": {0: 0, 1: -1, 3: 0, 4: 0, 13: 0}, "newest": {0: 1, 1: 1, 3: 1, 4: 1, 13: 0},
-               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2, 15: 2, 16: 1}}
+               "rwconv": {0: 1, 1: 1, 3: 1, 4: 1, 13: 2, 15: 3, 16: 1}}
 
 
 @pytest.fixture(params=list(GENERATIONS))
@@ -110,17 +110,17 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
 
 
 @pytest.mark.parametrize("blocks_per_xcd", [1, 2, 0])
-@pytest.mark.parametrize("k,B", [(5, 7), (4, 7), (5, 20)])
-def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, blocks_per_xcd):
-    """rwconv_conv_kernel (32 -> 64 channels, stride 2): a block walks CONSECUTIVE 128-position chunks whose slot rows are staged in runs of three
-    instalments; 8 or 16 blocks over 44 / 125 chunks make every block cross run boundaries, start runs at every phase and end on every instalment.
-    Checked against the float64 convolution of the same bf16 values, with and without bias + ReLU / ReluGrad mask."""
+@pytest.mark.parametrize("k,B,wide", [(5, 7, 0), (4, 7, 0), (5, 20, 0), (4, 20, 1), (4, 50, 1)])
+def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, wide, blocks_per_xcd):
+    """rwconv_conv_kernel (32 -> 64 channels, or 64 -> 128 with wide = 1; stride 2): a block walks CONSECUTIVE 128- (64-) position chunks whose slot rows are
+    staged in runs of three instalments; 8 or 16 blocks over 44 / 125 (54 / 134) chunks make every block cross run boundaries, start runs at every phase
+    and end on every instalment.  Checked against the float64 convolution of the same bf16 values, with and without bias + ReLU / ReluGrad mask."""
     L = milib.get()
     code, td = DT["bf16"]
-    prev = {key: L.mi_set_tuning(key, v) for key, v in ((13, 2), (15, 2), (16, blocks_per_xcd))}
+    prev = {key: L.mi_set_tuning(key, v) for key, v in ((13, 2), (15, 3), (16, blocks_per_xcd))}
     try:
         rng = np.random.RandomState(10 * k + B)
-        IH, IW, Ci, Co = 39, 79, 32, 64
+        IH, IW, Ci, Co = (18, 38, 64, 128) if wide else (39, 79, 32, 64)
         OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
         x = rng.randn(B, IH, IW, Ci).astype(np.float32)
         w = (rng.randn(k, k, Ci, Co) / np.sqrt(k * k * Ci)).astype(np.float32)

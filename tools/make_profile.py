@@ -39,6 +39,8 @@ NAMES_R02 = [("rwconv_gather_kernel<3, 5, true, 0, true, 0>", None, "deconv3.fwd
          ("rwconv_gather_kernel<3, 5, true, 0, true, 0, 1>", None, "deconv3.fwd"), ("rwconv_gather_kernel<2, 4, false, 2, false, 0, 1>", None, "conv2.dgrad"),
          ("rwconv_gather_kernel<2, 4, true, 0, false, 0, 2>", None, "deconv2.fwd"), ("rwconv_gather_kernel<2, 4, false, 1, false, 0, 2>", None, "conv3.dgrad"),
          ("rwconv_conv_kernel<5, false, true>", None, "deconv3.dgrad"), ("rwconv_conv_kernel<4, true, false>", None, "conv2.fwd"),
+         ("rwconv_conv_kernel<5, 1, false, true>", None, "deconv3.dgrad"), ("rwconv_conv_kernel<4, 1, true, false>", None, "conv2.fwd"),
+         ("rwconv_conv_kernel<4, 2, true, false>", None, "conv3.fwd"), ("rwconv_conv_kernel<4, 2, false, true>", None, "deconv2.dgrad"),
          ("tapconv_kernel<bf16, 1, 128, 2, 128, 48>", "800x2x1", "deconv2.fwd / conv3.dgrad"), ("tapconv_kernel<bf16, 1, 128, 2, 256, 96>", "100x4x1", "deconv1.fwd / conv4.dgrad"),
          ("tapconv_kernel<bf16, 0, 128, 2, 128, 48>", "684x1x1", "conv3.fwd / deconv2.dgrad"), ("tapconv_kernel<bf16, 0, 64, 2, 256, 96>", "1482x1x1", "conv2.fwd"),
          ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "2736x1x1", "deconv3.dgrad"), ("gemm2_kernel<bf16, 0, 1, 128, 64, false>", "96x4x1", "conv4.fwd / deconv1.dgrad"),
