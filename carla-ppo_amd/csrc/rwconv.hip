@@ -59,7 +59,11 @@ template <int N> __device__ __forceinline__ void lds_wait_pair(u16x8& a, u16x8& 
 // 128 CK bytes, 4 CK k-steps per tap, the weights of ONE 32-output tile of a class in registers (64 CK VGPRs for k = 4), 4 CK waves = (class, tile)
 template <int TAPS, int CK = 1> struct RwCfg {
     static constexpr int NW = TAPS == 2 ? 4 * CK : 8;                 // waves per block
-    static constexpr int NTILE = 4;                                   // 32-position tiles per wave and chunk
+    // 32-position tiles per wave and chunk.  CK = 2: 64-position chunks -- these layers have 102 k slots, i.e. 800 chunks of 128 on 256 blocks
+    // (3.1 each: a quarter of the chip idles through the fourth round); 1,600 chunks of 64 lose a tenth instead, for 14 % more staged halo rows:
+    // conv3.dgrad 40.3 -> 35.7 us, deconv2.fwd 38.3 -> 36.4 (same-box A/B of the two builds).  The same change on the 64 -> 32 channel shapes: k = 4
+    // (3 blocks per CU, 4.5 chunks each) -2 us in the step's conv2.dgrad but nothing on the step; k = 5 +2 % (its halo is two slot rows).
+    static constexpr int NTILE = CK == 2 ? 2 : 4;
     static constexpr int BMT = 32 * NTILE * (TAPS == 2 ? 1 : 2);      // positions per chunk (k = 5: two position halves of four waves)
     static constexpr int MAXHALO = TAPS == 2 ? 48 : 96;               // largest (TAPS-1) * GW + TAPS - 1 the buffers are sized for
     static constexpr int MAXSLOT = BMT + MAXHALO;                     // 176 | 352 rows
@@ -650,7 +654,7 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     q.mask_bits = mask ? (const uint32_t*)mask_bits : nullptr; q.bits_out = relu ? (uint32_t*)bits_out : nullptr;
     if ((bits_out && !q.bits_out) || ((((uintptr_t)mask_bits) | ((uintptr_t)bits_out)) & 7)) return 0;
     mi_get_trace(&q.trace, &q.trace_cap);
-    const int bmt = KH == 4 ? RwCfg<2>::BMT : RwCfg<3>::BMT;
+    const int bmt = KH == 4 ? (ck == 2 ? RwCfg<2, 2>::BMT : RwCfg<2>::BMT) : RwCfg<3>::BMT;
     const int nchunks = (int)((MP + bmt - 1) / bmt);
     if (g_rwconv_mode == 0 || (g_rwconv_mode == 1 && MP < 75000)) return 0;      // auto: only where the grid fills the chip (as tapconv)
     // persistent grid: as many blocks as stay resident (3 per CU for k = 4, 2 for k = 5), a multiple of 8 (one share per XCD)
