@@ -110,17 +110,21 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
 
 
 @pytest.mark.parametrize("blocks_per_xcd", [1, 2, 0])
-@pytest.mark.parametrize("k,B,wide", [(5, 7, 0), (4, 7, 0), (5, 20, 0), (4, 20, 1), (4, 50, 1)])
-def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, wide, blocks_per_xcd):
+@pytest.mark.parametrize("k,B,wide,hw", [(5, 7, 0, None), (4, 7, 0, None), (5, 20, 0, None), (4, 20, 1, None), (4, 50, 1, None),
+                                         (5, 40, 0, (23, 47)), (4, 40, 0, (20, 44)), (4, 60, 1, (14, 40))])
+def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, wide, hw, blocks_per_xcd):
     """rwconv_conv_kernel (32 -> 64 channels, or 64 -> 128 with wide = 1; stride 2): a block walks CONSECUTIVE 128- (64-) position chunks whose slot rows are
     staged in runs of three instalments; 8 or 16 blocks over 44 / 125 (54 / 134) chunks make every block cross run boundaries, start runs at every phase
-    and end on every instalment.  Checked against the float64 convolution of the same bf16 values, with and without bias + ReLU / ReluGrad mask."""
+    and end on every instalment; three more image sizes change the slot grid and the staged halo.  Checked against the float64 convolution of the same bf16
+    values, with and without bias + ReLU / ReluGrad mask."""
     L = milib.get()
     code, td = DT["bf16"]
     prev = {key: L.mi_set_tuning(key, v) for key, v in ((13, 2), (15, 3), (16, blocks_per_xcd))}
     try:
         rng = np.random.RandomState(10 * k + B)
         IH, IW, Ci, Co = (18, 38, 64, 128) if wide else (39, 79, 32, 64)
+        if hw:                                          # other slot grids: GW = 24 / 22 / 20, staged halos of 64 / 32 / 32 rows
+            IH, IW = hw
         OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
         x = rng.randn(B, IH, IW, Ci).astype(np.float32)
         w = (rng.randn(k, k, Ci, Co) / np.sqrt(k * k * Ci)).astype(np.float32)
