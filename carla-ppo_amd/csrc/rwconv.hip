@@ -176,8 +176,11 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.b_bytes, 0x00020000);    // (b_bytes carries the OUTPUT size in bytes here)
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(BITS ? (void*)p.bits_out : p.out, 0, (int)(p.b_bytes >> 3), 0x00020000);   // bit words: 8 of every 64 bytes
 
-    // the first slot range, the bias row and this wave's weight fragments have landed; after the barrier so has everybody's share
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the first slot range (requested BEFORE this class's NLIVE weight fragments: "all but the newest NLIVE - 8 vector-memory operations" covers it,
+    // returns are in order) and the bias row have landed; after the barrier so has everybody's share.  The first chunk's MFMAs start while the tail
+    // of the weights is still on its way (the compiler waits per fragment).
+    constexpr int NLIVE = [] { int n = 0; for (int tap = 0; tap < NT; ++tap) if (PH + 2 * (H - tap / TAPS) < KH && PW + 2 * (H - tap % TAPS) < KH) n += KS; return n; }();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((NLIVE < 63 ? NLIVE : 63) - 8) : "memory");
     __builtin_amdgcn_s_barrier();
     int cur = 0;
 #pragma unroll 1
@@ -500,7 +503,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16_t* __restrict__ maskp = (const bf16_t*)p.mask;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.b_bytes, 0x00020000);    // (b_bytes carries the OUTPUT size in bytes)
 
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the first instalment was requested BEFORE the ST.n weight fragments: "all but the newest ST.n - 8 vector-memory operations" covers it (in-order
+    // returns), and the MFMA loop of the first chunk starts while the tail of the weights is still on its way (the compiler waits per fragment)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((ST.n < 63 ? ST.n : 63) - 8) : "memory");
     __builtin_amdgcn_s_barrier();
     int jrun = 0;                                            // position of `chunk` in its run
 #pragma unroll 1
