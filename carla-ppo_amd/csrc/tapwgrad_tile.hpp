@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 v = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
-                    *(f32x4*)(dst + (kt * 4 + g4) * 256) = v;
+                    __builtin_nontemporal_store(v, (f32x4*)(dst + (kt * 4 + g4) * 256));      // written once, read once by the reduce: streaming
                 }
             return;
         }
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
                 const f32x16& t = acc[tb][kt];
                 float* const dst = p.slabs + (long long)bx * p.slab_stride + (((long long)(by * p.npairs + pi) * KT) + kt) * 1024 + lane * 4;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) *(f32x4*)(dst + g4 * 256) = f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]};
+                for (int g4 = 0; g4 < 4; ++g4) __builtin_nontemporal_store(f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]}, (f32x4*)(dst + g4 * 256));
             }
         }
     };
@@ -645,7 +645,7 @@ __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int n
     const float* src = p.slabs + (long long)gid * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 16
-    for (int k = by; k < nslab; k += nby) s += *(const f32x4*)(src + k * p.slab_stride);
+    for (int k = by; k < nslab; k += nby) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (nby == 1) p.out[base + t * stride] = ov[t] + s[t];
