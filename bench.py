@@ -140,7 +140,9 @@ def cpu_baseline(batch, seed=0, warm=3, timed=10):
     for _ in range(timed):
         o.train_step(frames, frames, eps)
     dt = time.perf_counter() - t0
-    out = {"value": batch * timed / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    out = {"value": batch * timed / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cores_total": os.cpu_count(), "kind": "port",
+           "cores_note": "`cores` = threads actually used (the fastest setting measured for this graph on the 2-socket host; MI355_CPU_BASELINE_THREADS overrides), "
+                         "`cores_total` = os.cpu_count() of this box",
            "sample": "%d warm-up + %d timed ConvVAE fp32 SGD steps at batch %d (torch-CPU oracle of the reference TF graph; TF 1.13 itself is not runnable)" % (warm, timed, batch)}
     # PPO update on the same cores: horizon 128, 4 epochs x 4 minibatches of 32 (configs[2])
     hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
@@ -506,6 +508,7 @@ def main():
         print(json.dumps(out), flush=True)
     midist.barrier()
     if world > 1:
+        midist.shutdown()               # the library's own RCCL communicator first, then the process group it was bootstrapped from
         torch.distributed.destroy_process_group()
 
 

@@ -25,6 +25,10 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
     const char* (*GetErrorString)(ncclResult_t);
 };
 
@@ -43,6 +47,10 @@ int load_rccl() {
     r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
     r.Broadcast = (decltype(r.Broadcast))dlsym(lib, "ncclBroadcast");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(lib, "ncclReduceScatter");      // optional: the two-phase schedule below is skipped without them
+    r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GetErrorString)
         return mi_fail(MI_ERR_STATE, "mi_comm: librccl.so.1 lacks an entry point");
     r.lib = lib;
@@ -58,10 +66,42 @@ struct MiComm {
     int pending;                                          // buckets queued on `side` since the last mi_comm_wait
 };
 
+// Gradient-bucket schedule: 0 = ncclAllReduce (RCCL picks ring / tree / one-shot itself), 1 = reduce-scatter + all-gather: on the
+// fully connected xGMI mesh of one node every rank owns 1/W of the bucket, receives the other ranks' pieces of ITS slice over the seven direct
+// links in one hop, sums, and sends its finished slice back over the same links -- 2 (W-1)/W of the bucket per link direction, no multi-hop ring.
+// MI355_COMM_ALGO=rsag selects it; both forms sit behind mi_allreduce_sum_f32 so callers never see the difference.  (Validated at world size 1
+// only -- no multi-GPU box in this build environment -- hence off by default.)
+int comm_algo() {
+    static int algo = -1;
+    if (algo < 0) { const char* e = getenv("MI355_COMM_ALGO"); algo = (e && strcmp(e, "rsag") == 0) ? 1 : 0; }
+    return algo;
+}
+
 int rccl_fail(const char* what, ncclResult_t r) {
     static thread_local char msg[256];
     snprintf(msg, sizeof(msg), "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
     return mi_fail(MI_ERR_LAUNCH, msg);
+}
+
+// in-place sum of buf[0..n) over the ranks on stream `st`
+int allreduce_on(MiComm* c, float* buf, long long n, hipStream_t st) {
+    const long long chunk = n / c->world;
+    if (comm_algo() == 1 && c->world > 1 && chunk >= 1024 && g_rccl.ReduceScatter && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd) {
+        // slice r of the first chunk * W elements belongs to rank r (both calls in RCCL's in-place form); the n % W tail rides along as a tiny all-reduce
+        float* mine = buf + (long long)c->rank * chunk;
+        ncclResult_t r = g_rccl.ReduceScatter(buf, mine, (size_t)chunk, ncclFloat, ncclSum, c->comm, st);
+        if (r != ncclSuccess) return rccl_fail("ncclReduceScatter", r);
+        r = g_rccl.AllGather(mine, buf, (size_t)chunk, ncclFloat, c->comm, st);
+        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+        const long long tail = n - chunk * c->world;
+        if (tail > 0) {
+            r = g_rccl.AllReduce(buf + chunk * c->world, buf + chunk * c->world, (size_t)tail, ncclFloat, ncclSum, c->comm, st);
+            if (r != ncclSuccess) return rccl_fail("ncclAllReduce (tail)", r);
+        }
+        return MI_OK;
+    }
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, st);
+    return r == ncclSuccess ? MI_OK : rccl_fail("ncclAllReduce", r);
 }
 
 }  // namespace
@@ -69,6 +109,10 @@ int rccl_fail(const char* what, ncclResult_t r) {
 extern "C" {
 
 int mi_comm_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+// binds RCCL (dlopen + every entry point) WITHOUT creating anything: every rank calls this before the collective mi_comm_init, so that a
+// rank whose library is missing can tell the others instead of leaving them inside ncclCommInitRank (mi355/dist.py, step 1)
+int mi_comm_probe(void) { return load_rccl(); }
 
 // rank 0: a fresh rendezvous id (mi_comm_id_bytes() = 128 bytes) to hand to every other rank
 int mi_comm_unique_id(unsigned char* id_out) {
@@ -118,8 +162,7 @@ int mi_allreduce_sum_f32(void* comm, void* stream, float* buf, long long n) {
     MiComm* c = (MiComm*)comm;
     if (!c || !buf || n < 0) return mi_fail(MI_ERR_ARG, "mi_allreduce_sum_f32: bad arguments");
     if (n == 0) return MI_OK;
-    ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, (hipStream_t)stream);
-    return r == ncclSuccess ? MI_OK : rccl_fail("ncclAllReduce", r);
+    return allreduce_on(c, buf, n, (hipStream_t)stream);
 }
 
 // the same sum on the communicator's own stream, after everything queued on `stream` so far; `stream` itself goes on (the next part of the
@@ -130,8 +173,8 @@ int mi_allreduce_sum_f32_async(void* comm, void* stream, float* buf, long long n
     if (n == 0) return MI_OK;
     if (hipEventRecord(c->ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
         return mi_fail(MI_ERR_LAUNCH, "mi_allreduce_sum_f32_async: event chaining failed");
-    ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, c->side);
-    if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    const int rc = allreduce_on(c, buf, n, c->side);
+    if (rc != MI_OK) return rc;
     c->pending += 1;
     return MI_OK;
 }

@@ -94,6 +94,7 @@ def mi_comm():
     try:
         L = milib.get()
         nbytes = L.mi_comm_id_bytes()
+        L.mi_comm_probe()                               # EVERY rank binds librccl here (mi_comm_id_bytes is a sizeof and loads nothing)
     except Exception:
         ok = False
     idt = torch.zeros(nbytes, dtype=torch.uint8)
@@ -127,8 +128,31 @@ def mi_comm():
     if not _all_agree(ok, dev):
         return None
     _mi_comm = c
-    comm_note = "mi_comm (RCCL through the C ABI, on the engine's stream)"
+    comm_note = "mi_comm (RCCL through the C ABI, on the engine's stream%s)" % (
+        "; reduce-scatter + all-gather schedule" if os.environ.get("MI355_COMM_ALGO") == "rsag" else "")
+    if not _atexit_registered[0]:
+        import atexit
+        atexit.register(shutdown)
+        _atexit_registered[0] = True
     return _mi_comm
+
+
+_atexit_registered = [False]
+
+
+def shutdown():
+    """Tears the library communicator down (ncclCommDestroy, its side stream and events) and forgets it, so that a later process group gets a
+    fresh one.  Call it before dist.destroy_process_group(); registered with atexit once a communicator exists."""
+    global _mi_comm, _mi_comm_tried, comm_note
+    c, _mi_comm, _mi_comm_tried = _mi_comm, None, False
+    comm_note = "single process"
+    if c is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            c.L.mi_comm_destroy(c.handle)
+        except Exception:
+            pass                                        # at interpreter exit the device context may already be gone
 
 
 def world_size():

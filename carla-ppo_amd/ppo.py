@@ -15,6 +15,7 @@ import numpy as np
 
 from mi355 import checkpoint as ckpt
 from mi355 import dist as midist
+from mi355 import lib as milib
 from mi355.init import init_ppo, ppo_variables
 
 ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON = 0.9, 0.999, 1e-8
@@ -51,7 +52,7 @@ class PPO():
         self.dev = None
         self.sess = None
         self.train_writer = None
-        self._noise_gen = None
+        self._noise_offset = 0                                 # N(0,1) values drawn so far from this agent's Philox stream (predict)
 
         # Setup model saver and dirs (ppo.py:183-190)
         self.model_dir = model_dir
@@ -174,7 +175,9 @@ class PPO():
         # so that the all-reduced buffer is the gradient of the global mean (mi355/dist.py).  Single process: m_global = m.
         self._step_resident(s, a, r, adv, m, m * midist.world_size())
         if self.train_writer is not None:                      # episodic means (ppo.py:150-163); never on a timed path
-            L = self._global_losses()
+            # NO collective here: whether a rank logs is that rank's own business (rank 0 only, usually), and an all-reduce issued by the
+            # logging ranks alone would pair with the other ranks' next gradient all-reduce.  A data-parallel rank logs ITS rows' means.
+            L = self._local_losses()
             for k, v in zip(("train_loss/policy", "train_loss/value", "train_loss/entropy", "train_loss/loss", "train/prob_ratio"), L):
                 self._metric_sums[k] = self._metric_sums.get(k, 0.0) + float(v)
             ta = np.asarray(taken_actions, np.float64).reshape(m, self.num_actions)
@@ -188,15 +191,29 @@ class PPO():
             self._metric_n += 1
         self.train_step_counter += 1
 
+    def _local_losses(self):
+        """Loss scalars + per-action mean / std of the last step from THIS rank's rows, no communication.  The device holds sums over the local
+        rows / M_global (so that the gradient all-reduce yields the global mean): times the world size that is the mean over the local rows.
+        The entropy term and std = exp(logstd) are state independent -- identical on every rank, left as they are."""
+        L = self.dev.losses.clone().cpu().numpy()
+        w = midist.world_size()
+        if w > 1:
+            A = self.num_actions
+            L[[0, 1, 4]] *= w
+            L[5:5 + A] *= w
+            L[3] = -L[0] + L[1] - L[2]
+        return L
+
     def _global_losses(self):
         """The five loss scalars of the last step as numpy.  Data parallel: the device holds this rank's share of the batch means (sums over
         its rows / M_global) for the policy / value terms and the probability ratio; they are summed over the ranks here, the
         state-independent entropy term is already the global value."""
         L = self.dev.losses.clone()
-        if midist.world_size() > 1:
-            ent = L[2].clone()
+        if midist.world_size() > 1:                            # COLLECTIVE: every rank must call this (train_step() does; train()'s logging does not)
+            A = self.num_actions
+            keep = L[[2] + list(range(5 + A, 5 + 2 * A))].clone()   # entropy term and std = exp(logstd): identical on every rank, not sums
             midist.all_reduce_sum(L)
-            L[2] = ent
+            L[[2] + list(range(5 + A, 5 + 2 * A))] = keep
             L[3] = -L[0] + L[1] - L[2]
         return L.cpu().numpy()
 
@@ -226,10 +243,13 @@ class PPO():
             if noise is not None:
                 nz = self._to_dev(noise, (m, self.num_actions))
             else:
-                if self._noise_gen is None:
-                    self._noise_gen = torch.Generator(device=dev.device)
-                    self._noise_gen.manual_seed(0xAC7 + 1000003 * int(self.seed or 0) + midist.rank())
-                nz = torch.randn(m, self.num_actions, device=dev.device, generator=self._noise_gen)
+                # exploration noise from the library's own Philox4x32-10 + Box-Muller kernel (mi_normal_philox; the same generator the VAE engine
+                # samples with): no torch kernel on the rollout path.  Stream = (seed, rank), offset = values drawn so far.
+                nz = torch.empty(m, self.num_actions, device=dev.device)
+                n = m * self.num_actions
+                milib.get().mi_normal_philox(torch.cuda.current_stream(dev.device).cuda_stream,
+                                             0xAC7 + 1000003 * int(self.seed or 0) + midist.rank(), self._noise_offset, milib.ptr(nz), n)
+                self._noise_offset += n
         action = torch.empty(m, self.num_actions, device=dev.device)
         value = torch.empty(m, device=dev.device)
         dev.predict(s, m, nz, greedy, action, value)

@@ -37,7 +37,7 @@ def encode_resident(vae, frames, chunk=512):
 
 
 def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma=0.99, lam=0.95, num_epochs=3, batch_size=32, encode_chunk=512,
-                  local_rows=False, stage_times=None):
+                  local_rows=False, stage_times=None, return_z=False):
     """One PPO update over R recorded trajectories (see the module docstring).
 
     frames [R, T+1, H, W, C] (uint8 or float in [0,1]; the last frame of a row is the state after its last step), measurements [R, T+1, k],
@@ -47,7 +47,8 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     stage_times: optional dict that receives the wall time (seconds, device synchronised at the stage boundaries) of "encode" (upload + VAE
     encode), "values", "gae" and "sgd".
     Returns a dict: per-minibatch loss records (this rank's device scalars, read back once at the end), and this rank's returns /
-    advantages / values (fp64 / fp64 / fp32 numpy) for inspection."""
+    advantages / values (fp64 / fp64 / fp32 numpy, read back once after the SGD loop) for inspection; return_z=True adds the latents
+    (R*(T+1) x z_dim floats: 34 MB at 1024 x 128 -- only on request)."""
     import torch
     import utils
 
@@ -94,14 +95,15 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
 
     t_stage = mark("values", t_stage)
     # 3. GAE + returns + per-row normalisation (fp64 on the device, bit-exact with numpy / scipy)
-    _, returns, adv = utils.compute_gae_batched(rewards[lo:hi], values.cpu().numpy(), dones[lo:hi], gamma, lam, normalize=True)
+    # (the value estimates never leave the device: widened to fp64 there, exactly)
+    _, returns_d, adv_d = utils.gae_resident(rewards[lo:hi], values, dones[lo:hi], gamma, lam)
 
     t_stage = mark("gae", t_stage)
     # 4. minibatch SGD on the flattened samples of this rank
     s = states_all.view(r_loc, T + 1, -1)[:, :T].reshape(r_loc * T, -1).contiguous()
     a = torch.from_numpy(np.ascontiguousarray(actions[lo:hi].reshape(r_loc * T, -1))).to(device)
-    ret = torch.from_numpy(np.ascontiguousarray(returns.reshape(-1).astype(np.float32))).to(device)      # f64 -> f32 at the feed (ppo.py:108-109)
-    adv_t = torch.from_numpy(np.ascontiguousarray(adv.reshape(-1).astype(np.float32))).to(device)
+    ret = returns_d.reshape(-1).to(torch.float32)                                # f64 -> f32 at the feed (ppo.py:108-109), round-to-nearest-even as numpy's astype
+    adv_t = adv_d.reshape(-1).to(torch.float32)
     n_loc = r_loc * T
     mb_lo, mb_hi = midist.shard_bounds(batch_size, rank, world)
     mb_loc = mb_hi - mb_lo                                                       # this rank's share of a full global minibatch
@@ -133,5 +135,8 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     losses = torch.stack(records).cpu().numpy() if records else np.zeros((0, 5), np.float32)
     mark("sgd", t_stage)
     keys = ("policy_loss", "value_loss", "entropy_loss", "loss", "prob_ratio")
-    return {"losses": [dict(zip(keys, (float(x) for x in row))) for row in losses], "returns": returns, "advantages": adv,
-            "values": values.cpu().numpy(), "z": z.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}
+    out = {"losses": [dict(zip(keys, (float(x) for x in row))) for row in losses], "returns": returns_d.cpu().numpy(), "advantages": adv_d.cpu().numpy(),
+           "values": values.cpu().numpy(), "rows": (lo, hi), "samples_per_rank": n_loc}
+    if return_z:
+        out["z"] = z.cpu().numpy()
+    return out

@@ -38,6 +38,28 @@ def compute_gae_batched(rewards, values, terminals, gamma, lam, normalize=False)
     return raw.cpu().numpy(), ret.cpu().numpy(), adv.cpu().numpy()
 
 
+def gae_resident(rewards, values, terminals, gamma, lam):
+    """Device-resident form for the replay path: `values` is a device tensor [R,T+1] (fp32 or fp64: the value network's own output, widened
+    exactly on the device -- no round trip through the host); rewards / terminals host arrays [R,T].  Returns three fp64 DEVICE tensors
+    [R,T]: raw advantages, returns, per-row normalised advantages (train.py:175-177), bit-identical to compute_gae_batched(normalize=True)."""
+    from mi355 import lib as milib
+    torch, device = _dev()
+    L = milib.get()
+    v = values.to(device=device, dtype=torch.float64).contiguous()
+    R, T = v.shape[0], v.shape[1] - 1
+    r = torch.as_tensor(np.ascontiguousarray(np.asarray(rewards, np.float64)), device=device)
+    d = torch.as_tensor(np.ascontiguousarray(np.asarray(terminals, np.float64)), device=device)
+    if r.shape != (R, T) or d.shape != (R, T):
+        raise ValueError("gae_resident: rewards / terminals [R,T], values [R,T+1]")
+    adv = torch.empty(R, T, device=device, dtype=torch.float64)
+    st = torch.cuda.current_stream(device).cuda_stream
+    L.mi_gae_scan(st, r.data_ptr(), v.data_ptr(), d.data_ptr(), R, T, float(gamma), float(lam), adv.data_ptr())
+    raw = adv.clone()
+    ret = torch.empty(R, T, device=device, dtype=torch.float64)
+    L.mi_adv_normalize(st, adv.data_ptr(), v.data_ptr(), R, T, ret.data_ptr())
+    return raw, ret, adv
+
+
 def compute_gae(rewards, values, bootstrap_values, terminals, gamma, lam):
     """Reference signature and semantics (utils.py:45-50): lists of T rewards / values / terminals + one bootstrap
     value -> np.ndarray [T] float64.  (No done-mask inside the recursion, like the reference.)"""

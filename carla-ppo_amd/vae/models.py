@@ -50,9 +50,9 @@ def _content_hash(a):
     try:
         import xxhash
         return xxhash.xxh3_64_intdigest(buf)
-    except ImportError:
-        import zlib
-        return zlib.crc32(buf)
+    except ImportError:                                # still 64 bits (a 32-bit checksum would let a mutated table through once in 4e9)
+        import hashlib
+        return int.from_bytes(hashlib.blake2b(buf, digest_size=8).digest(), "little")
 
 
 def adam_alpha(lr, beta1_power, beta2_power):

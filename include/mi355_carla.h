@@ -211,7 +211,11 @@ int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char*
  *   mi_allreduce_sum_f32        buf <- sum over ranks, in stream order on `stream` (gradient buffer / metric accumulators)
  *   mi_allreduce_sum_f32_async  the same on the communicator's own stream, after what `stream` holds so far: a gradient bucket's all-reduce
  *                               runs under the next part of the backward pass; mi_comm_wait(comm, stream) joins before the optimiser step
- *   mi_broadcast                rank `root`'s bytes to every rank (the initial parameter replica, vae/models.py / ppo.py init_session) */
+ *   mi_broadcast                rank `root`'s bytes to every rank (the initial parameter replica, vae/models.py / ppo.py init_session)
+ *   mi_comm_probe               binds librccl (dlopen + entry points) and nothing else: called on EVERY rank before the collective mi_comm_init so that
+ *                               a rank that cannot load RCCL is agreed on while everybody can still fall back together
+ * MI355_COMM_ALGO=rsag: the all-reduce of a bucket as reduce-scatter + all-gather (one hop per phase on the fully connected xGMI mesh). */
+int mi_comm_probe(void);
 int mi_comm_id_bytes(void);
 int mi_comm_unique_id(unsigned char* id_out);
 int mi_comm_init(void** comm_out, int rank, int world, const unsigned char* id);

@@ -364,3 +364,86 @@ def test_vae_common_call_chain_is_pinned_to_the_reference(golden_dir):
     for cls in (ConvVAE, MlpVAE):
         sig = inspect.signature(cls.__init__)
         assert any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values())
+
+
+class _ScheduleDev:
+    """Stand-in for VaeDevice in the collective-schedule test: the three gradient buckets of the real layout, no arithmetic."""
+    def __init__(self):
+        import torch
+        self.device = torch.device("cpu")
+        self.n_flat, self.P, self.source_shape = 2584392, 38400, (80, 160, 3)
+        c4, dec = 165600, 1476704                       # conv4 kernel / dense1 kernel offsets of the flat layout (pad-8 TF creation order)
+        self.grad_buckets = [(1, dec, self.n_flat), (3, c4, dec), (4, 0, c4)]
+        self.grads, self.metrics, self.losses = torch.zeros(self.n_flat), torch.zeros(3), torch.zeros(2)
+        self.log = []
+
+    def set_seed(self, s): pass
+    def forward(self, *a, **k): self.log.append(("fwd", a[3]))
+    def backward(self, src, idx, eps, inv, part=0): self.log.append(("bwd", part))
+    def apply_adam(self, *a): self.log.append(("adam",))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dp_collective_schedule_is_identical_on_every_rank(tmp_path, monkeypatch, world):
+    """SURVEY 8e / VERDICT r02 #9: for every global batch B = 8 k every rank must issue the SAME sequence of collectives (op, element count) --
+    three gradient-bucket all-reduces per SGD step in backward's completion order, one metric all-reduce per epoch -- whatever its rank, or the
+    job hangs.  Also: PPO.train's logging path issues none (a rank that logs must not add a collective the others do not)."""
+    import torch
+    from mi355 import dist as midist
+    from vae.models import ConvVAE
+    per_rank = []
+    for B in (8, 64, 512, 4096):
+        seqs = []
+        for r in range(world):
+            calls = []
+            monkeypatch.setattr(midist, "world_size", lambda: world)
+            monkeypatch.setattr(midist, "rank", lambda r=r: r)
+
+            class _W:
+                def wait(self): calls.append(("wait",))
+
+            def fake_allreduce(t, async_op=False):
+                calls.append(("all_reduce_sum", int(t.numel()), bool(async_op)))
+                return _W()
+            monkeypatch.setattr(midist, "all_reduce_sum", fake_allreduce)
+            m = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / ("m%d_%d" % (B, r))), precision="bf16", seed=0)
+            m.dev = _ScheduleDev()
+            monkeypatch.setattr(m, "_frames", lambda arr, *a, **k: torch.zeros(len(arr), 4))
+            np.random.seed(3)                                # every rank draws the same legacy-numpy permutation
+            n = 2 * B + 3                                    # two full steps, remainder dropped
+            table = np.zeros((n, 4), np.float32)
+            m._epoch(table, table, B, True)
+            fw = [x for x in m.dev.log if x[0] == "fwd"]
+            assert [x[1] for x in fw] == [B // world] * 2    # equal shares of every global minibatch
+            seqs.append(calls)
+        assert all(s == seqs[0] for s in seqs[1:]), (B, world)
+        per_step = [c for c in seqs[0] if c[0] == "all_reduce_sum" and c[2]]
+        assert len(per_step) == 6 and sum(c[1] for c in per_step[:3]) == 2584392      # 3 buckets x 2 steps; the buckets tile the flat gradient buffer
+        assert seqs[0][-1] == ("all_reduce_sum", 3, False)                            # the epoch's metric sums
+        per_rank.append(seqs[0])
+    assert all(len(s) == len(per_rank[0]) for s in per_rank)
+
+
+def test_ppo_logging_path_issues_no_collective(tmp_path, monkeypatch):
+    """PPO.train() on a rank with a summary writer must not issue a collective the non-logging ranks do not issue."""
+    import torch
+    import ppo as ppo_mod
+    from mi355 import dist as midist
+    src = inspect.getsource(ppo_mod.PPO.train)
+    assert "_local_losses" in src and "_global_losses" not in src
+    calls = []
+    monkeypatch.setattr(midist, "world_size", lambda: 4)
+    monkeypatch.setattr(midist, "all_reduce_sum", lambda *a, **k: calls.append(a))
+
+    class Box:
+        low, high, shape = np.array([-1.0, 0.0], np.float32), np.array([1.0, 1.0], np.float32), (2,)
+    m = ppo_mod.PPO(np.array([67]), Box(), model_dir=str(tmp_path / "p"), seed=0)
+
+    class Dev:
+        losses = torch.tensor([0.25, 0.5, 0.01, 0.24, 0.25, 0.1, 0.2, 1.0, 1.0])
+    m.dev = Dev()
+    L = m._local_losses()
+    assert not calls
+    # sums over local rows / M_global -> x world = local means; entropy and std (state independent) untouched
+    assert np.allclose(L[[0, 1, 4]], [1.0, 2.0, 1.0]) and np.allclose(L[5:7], [0.4, 0.8]) and np.allclose(L[7:9], [1.0, 1.0]) and np.isclose(L[2], 0.01)
+    assert np.isclose(L[3], -1.0 + 2.0 - 0.01)

@@ -84,6 +84,11 @@ def fake_utils():
             raw.append(g), ret.append(rr), adv.append(aa)
         return np.array(raw), np.array(ret), np.array(adv)
     mod.compute_gae_batched = compute_gae_batched
+
+    def gae_resident(rewards, values, terminals, gamma, lam):          # the device-resident form replay_update calls: tensors in, fp64 tensors out
+        raw, ret, adv = compute_gae_batched(rewards, values.numpy(), terminals, gamma, lam, normalize=True)
+        return torch.from_numpy(raw), torch.from_numpy(ret), torch.from_numpy(adv)
+    mod.gae_resident = gae_resident
     return mod
 
 

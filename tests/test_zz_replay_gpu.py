@@ -24,8 +24,12 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def test_synthetic_replay_matches_oracle_pipeline(tmp_path):
-    R, T, gamma, lam = 4, 16, 0.99, 0.95
+# (4, 16, 24, 2): small, partial last minibatch.  (64, 128, 2048, 1): BASELINE configs[4]'s own shape -- horizon 128, global minibatch 2048 (the
+# large-minibatch form of the fused step: row chunks of 256 + atomics + flat Adam) -- at 1/16 of its 1024 trajectories, which is what the CPU
+# oracle encodes in seconds (8,256 frames); train.py:171-207 end to end.
+@pytest.mark.parametrize("R,T,batch,epochs", [(4, 16, 24, 2), (64, 128, 2048, 1)])
+def test_synthetic_replay_matches_oracle_pipeline(tmp_path, R, T, batch, epochs):
+    gamma, lam = 0.99, 0.95
     rng = np.random.RandomState(11)
     frames = rng.randint(0, 256, (R, T + 1, 80, 160, 3), dtype=np.uint8)
     meas = np.stack([rng.uniform(-1, 1, (R, T + 1)), rng.uniform(0, 1, (R, T + 1)), rng.uniform(0, 30, (R, T + 1))], axis=-1).astype(np.float32)
@@ -45,13 +49,14 @@ def test_synthetic_replay_matches_oracle_pipeline(tmp_path):
     m.init_session(init_logging=False)
 
     np.random.seed(5)
-    out = replay.replay_update(vae, m, frames, meas, actions, rewards, dones, gamma, lam, num_epochs=2, batch_size=24)
-    assert out["rows"] == (0, R) and out["samples_per_rank"] == R * T and len(out["losses"]) == 2 * 3          # 64 samples: 24 + 24 + 16 per epoch
+    out = replay.replay_update(vae, m, frames, meas, actions, rewards, dones, gamma, lam, num_epochs=epochs, batch_size=batch, return_z=True)
+    n_steps = epochs * -(-R * T // batch)                                           # (4, 16, 24, 2): 64 samples = 24 + 24 + 16 per epoch
+    assert out["rows"] == (0, R) and out["samples_per_rank"] == R * T and len(out["losses"]) == n_steps
 
     # the same pipeline from the oracle's pieces
     f32 = frames.reshape(-1, 80, 160, 3).astype(np.float32) / 255.0
     ovae = vo.OracleVAE(params=vparams, training=False)
-    z = ovae.encode(f32)
+    z = np.concatenate([ovae.encode(f32[i:i + 512]) for i in range(0, len(f32), 512)])
     assert rel_err(out["z"], z) < 1e-4                                              # stage 1: encode (fp32 engine vs fp32 oracle)
     states = np.concatenate([out["z"], meas.reshape(-1, 3)], axis=1).astype(np.float32).reshape(R, T + 1, 67)   # the device's own states
     _, v_o = o.predict(states.reshape(-1, 67), greedy=True)
@@ -70,7 +75,7 @@ def test_synthetic_replay_matches_oracle_pipeline(tmp_path):
     ret_flat, adv_flat = out["returns"].reshape(-1), out["advantages"].reshape(-1)
     np.random.seed(5)
     o.update_old_policy()
-    logs = [o.train(s_flat[mb], a_flat[mb], ret_flat[mb], adv_flat[mb]) for mb in po.minibatch_schedule(R * T, 24, 2)]
+    logs = [o.train(s_flat[mb], a_flat[mb], ret_flat[mb], adv_flat[mb]) for mb in po.minibatch_schedule(R * T, batch, epochs)]
     assert len(logs) == len(out["losses"])
     for i, (want, got) in enumerate(zip(logs, out["losses"])):
         assert got["loss"] == pytest.approx(want["loss"], rel=1e-4, abs=1e-4), (i, got, want)      # contains the policy term (abs 1e-4)
@@ -78,4 +83,4 @@ def test_synthetic_replay_matches_oracle_pipeline(tmp_path):
         assert got["policy_loss"] == pytest.approx(want["policy_loss"], abs=1e-4), (i, got, want)
         assert got["prob_ratio"] == pytest.approx(want["ratio_mean"], rel=1e-4), (i, got, want)
     assert out["losses"][0]["prob_ratio"] == pytest.approx(1.0, abs=1e-5)              # theta_old == theta at the first step
-    assert m.get_train_step_idx() == 6
+    assert m.get_train_step_idx() == n_steps

@@ -73,6 +73,7 @@ def main():
                           "last_loss": out["losses"][-1] if out["losses"] else None, "includes": "host->device upload of the uint8 frames, encode, values, GAE, PPO SGD"}))
     midist.barrier()
     if world > 1:
+        midist.shutdown()               # the library's own RCCL communicator first, then the process group it was bootstrapped from
         torch.distributed.destroy_process_group()
 
 
