@@ -10,6 +10,9 @@ using namespace mi;
 
 namespace {
 
+inline int esz_of(int dtype) { return dtype == MI_BF16 ? 2 : 4; }      // MI_F32 and MI_BF16X3 (split storage) are 4-byte elements
+inline bool dtype_ok(int dtype) { return dtype == MI_F32 || dtype == MI_BF16 || dtype == MI_BF16X3; }
+
 template <typename T, typename TIn, int AMODE, int BMODE, int VA, int AALIGN>
 int launch_gemm_bn(hipStream_t st, const GemmParams& p, int M_for_grid, int gz) {
     const int gx = (M_for_grid + GEMM_BM - 1) / GEMM_BM;
@@ -127,7 +130,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
                 int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu) {
     const int minblocks = tapconv_minblocks();
     if (minblocks < 0) return 0;
-    const int esz = dtype == MI_F32 ? 4 : 2;
+    const int esz = esz_of(dtype);
     if (KH != KW || KH < 3 || KH > 6) return 0;
     if ((C * esz) % 16 != 0 || (((uintptr_t)a) & 15) || (((uintptr_t)w) & 15)) return 0;
     // coalesced epilogue: whole 16-byte chunks of one pixel's channels, 32-bit element offsets
@@ -165,9 +168,10 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
     // of blocks (tile quantisation), loses a little on the 4-column grids and ties on the big grids
     const int gy_t = (q.NE + (q.NE >= 128 ? 127 : 63)) / (q.NE >= 128 ? 128 : 64);
     const bool auto_small = blocks >= 300 && blocks <= 1000 && gy_t <= 2;
-    const bool small_tile = halo <= 48 && dtype != MI_F32 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
+    const bool small_tile = halo <= 48 && dtype == MI_BF16 && (g_tap_variant == 2 || (g_tap_variant == 0 && auto_small));
     int rc;
     if (dtype == MI_F32) rc = mode == TC_CONV ? launch_tapconv<float, TC_CONV>(st, q, false) : launch_tapconv<float, TC_GATHER>(st, q, false);
+    else if (dtype == MI_BF16X3) rc = mode == TC_CONV ? launch_tapconv<split_t, TC_CONV>(st, q, false) : launch_tapconv<split_t, TC_GATHER>(st, q, false);
     else rc = mode == TC_CONV ? launch_tapconv<bf16_t, TC_CONV>(st, q, small_tile) : launch_tapconv<bf16_t, TC_GATHER>(st, q, small_tile);
     return rc == MI_OK ? 1 : rc;
 }
@@ -356,7 +360,7 @@ struct NarrowLoss {                                       // optional fused reco
 int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                       int KH, int KW, void* out, const float* bias, const void* mask, int relu, NarrowLoss* loss = nullptr) {
     if (!narrow_enabled() || mask || 4 * N > 32 || KH != KW || KH < 3 || KH > 6) return 0;
-    const int esz = dtype == MI_F32 ? 4 : 2;
+    const int esz = esz_of(dtype);
     const int pa = C * esz;
     if ((pa != 64 && pa != 128) || (((uintptr_t)a) & 15) || (((uintptr_t)w) & 15) || (((uintptr_t)out) & 3) || (2 * N * esz) % 4 != 0) return 0;
     if (!out && !loss) return 0;                          // out == nullptr is the fused-loss form (loss partials / dlogits only)
@@ -384,6 +388,9 @@ int try_gather_narrow(hipStream_t st, int dtype, const void* a, const void* w, i
     if (dtype == MI_F32) {
         if (pa != 128) return 0;
         rc = q.TH == 2 ? launch_gather_narrow<float, 2, 8>(st, q) : launch_gather_narrow<float, 3, 8>(st, q);
+    } else if (dtype == MI_BF16X3) {
+        if (pa != 128) return 0;
+        rc = q.TH == 2 ? launch_gather_narrow<split_t, 2, 8>(st, q) : launch_gather_narrow<split_t, 3, 8>(st, q);
     } else if (pa == 64) rc = q.TH == 2 ? launch_gather_narrow<bf16_t, 2, 4>(st, q) : launch_gather_narrow<bf16_t, 3, 4>(st, q);
     else rc = q.TH == 2 ? launch_gather_narrow<bf16_t, 2, 8>(st, q) : launch_gather_narrow<bf16_t, 3, 8>(st, q);
     return rc == MI_OK ? 1 : rc;
@@ -446,8 +453,10 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
     if (!narrow_enabled() || Cout != 32 || KH != KW || KH > 4) return 0;
     const int run = KW * Cs, K = KH * run;
     if (run % 4 != 0 || K > 48) return 0;
-    const int ssz = src_f32 == 2 ? 1 : (src_f32 ? 4 : 2), esz = dtype == MI_F32 ? 4 : 2;   // src_f32: 0 = bf16, 1 = fp32, 2 = uint8 camera bytes
+    const int ssz = src_f32 == 2 ? 1 : (src_f32 ? 4 : 2), esz = esz_of(dtype);   // src_f32: 0 = bf16, 1 = fp32, 2 = uint8 camera bytes, 3 = split storage
     if (dtype == MI_F32 && src_f32 != 1) return 0;
+    if (dtype == MI_BF16X3 && src_f32 != 1 && src_f32 != 3) return 0;
+    if (dtype == MI_BF16 && src_f32 == 3) return 0;
     if ((((uintptr_t)src) & (2 * ssz - 1)) || ((long long)IW * Cs * ssz) % (2 * ssz) != 0 || (2 * Cs * ssz) % (2 * ssz) != 0 || ((long long)IH * IW * Cs * ssz) % (2 * ssz) != 0) return 0;
     if ((((uintptr_t)wt) & 15) || (K * esz) % 16 != 0 || (((uintptr_t)out) & 15) || (mask && (((uintptr_t)mask) & 15)) || (bias && (((uintptr_t)bias) & 15))) return 0;
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
@@ -487,6 +496,8 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
         return rc == MI_OK ? 1 : rc;
     }
     if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
+    else if (dtype == MI_BF16X3 && src_f32 == 1) hipLaunchKernelGGL((narrow_conv_kernel<split_t, float>), g, dim3(256), 0, st, q);
+    else if (dtype == MI_BF16X3) hipLaunchKernelGGL((narrow_conv_kernel<split_t, split_t>), g, dim3(256), 0, st, q);
     else if (src_f32 == 2) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
     else if (src_f32) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
     else hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, q);
@@ -504,7 +515,7 @@ int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
         if (r3 != 0) return r3;
     }
     if (!gemm2_enabled()) return 0;
-    const int esz = dtype == MI_F32 ? 4 : 2;
+    const int esz = esz_of(dtype);
     const long long a_bytes = (long long)p.nbatch * p.a_frame_stride * esz, b_bytes = (long long)p.N * p.ldb * esz;
     if ((p.C * esz) % 16 != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15) || (p.ldb * esz) % 16 != 0 || p.ldb < p.K) return 0;
     if (!fits_desc(a_bytes) || !fits_desc(b_bytes)) return 0;
@@ -516,6 +527,7 @@ int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
     q.ldb = p.ldb;
     copy_epilogue(q, p);
     int rc = dtype == MI_F32 ? launch_gemm2_tiles<float, A_CONV, B_NK, false>(st, q, q.M, 1)
+           : dtype == MI_BF16X3 ? launch_gemm2_tiles<split_t, A_CONV, B_NK, false>(st, q, q.M, 1)
                              : launch_gemm2_tiles<bf16_t, A_CONV, B_NK, false>(st, q, q.M, 1);
     return rc == MI_OK ? 1 : rc;
 }
@@ -524,7 +536,7 @@ int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
 int try_deconv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p, int maxM) {
     if (!gemm2_enabled()) return 0;
     if (p.N <= 32) return 0;      // measured: narrow gather-form layers (deconv3/4 fwd, conv2 dgrad) are not faster on the DMA tiles
-    const int esz = dtype == MI_F32 ? 4 : 2;
+    const int esz = esz_of(dtype);
     const long long a_bytes = (long long)p.nbatch * p.a_frame_stride * esz, b_bytes = (long long)p.KH * p.KW * p.N * p.C * esz;
     if ((p.C * esz) % 16 != 0 || p.KH > 6 || p.KW > 6 || !fits_desc(a_bytes) || !fits_desc(b_bytes)) return 0;
     Gemm2Params q = {};
@@ -538,6 +550,7 @@ int try_deconv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p, int ma
     const bool utap = (p.C * esz) % 128 == 0;
     int rc;
     if (dtype == MI_F32) rc = utap ? launch_gemm2_tiles<float, A_DECONV, B_DECONV, true>(st, q, maxM, 4) : launch_gemm2_tiles<float, A_DECONV, B_DECONV, false>(st, q, maxM, 4);
+    else if (dtype == MI_BF16X3) rc = utap ? launch_gemm2_tiles<split_t, A_DECONV, B_DECONV, true>(st, q, maxM, 4) : launch_gemm2_tiles<split_t, A_DECONV, B_DECONV, false>(st, q, maxM, 4);
     else rc = utap ? launch_gemm2_tiles<bf16_t, A_DECONV, B_DECONV, true>(st, q, maxM, 4) : launch_gemm2_tiles<bf16_t, A_DECONV, B_DECONV, false>(st, q, maxM, 4);
     return rc == MI_OK ? 1 : rc;
 }
@@ -557,6 +570,18 @@ int conv_form_gemm(hipStream_t st, int dtype, int in_f32, GemmParams& p, int gz)
             return launch_gemm_bn<float, float, A_CONV, BMODE, 4, 8>(st, p, p.M, gz);
         return mi_fail(MI_ERR_SHAPE, "conv-form gemm (f32): channel count / alignment not supported");
     }
+    if (dtype == MI_BF16X3) {                            // split storage: 4-byte elements, same vector rules as fp32; in_f32 = fp32 frames as the A tensor
+        if (in_f32) {
+            if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<split_t, float, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
+            if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
+                return launch_gemm_bn<split_t, float, A_CONV, BMODE, 4, 8>(st, p, p.M, gz);
+        } else {
+            if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<split_t, split_t, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
+            if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
+                return launch_gemm_bn<split_t, split_t, A_CONV, BMODE, 4, 8>(st, p, p.M, gz);
+        }
+        return mi_fail(MI_ERR_SHAPE, "conv-form gemm (split): channel count / alignment not supported");
+    }
     if (in_f32) {
         if (!p.merged && C % 4 == 0 && a16) return launch_gemm_bn<bf16_t, float, A_CONV, BMODE, 4, 16>(st, p, p.M, gz);
         if (p.merged && (p.KW * C) % 4 == 0 && (p.IW * C) % 2 == 0 && (p.stride * C) % 2 == 0 && (p.a_frame_stride % 2) == 0)
@@ -570,7 +595,7 @@ int conv_form_gemm(hipStream_t st, int dtype, int in_f32, GemmParams& p, int gz)
 }
 
 bool vec_ok(const void* ptr, long long ld, int dtype) {
-    const int vb = dtype == MI_F32 ? 4 : 8;
+    const int vb = dtype == MI_BF16 ? 8 : 4;
     return ((((uintptr_t)ptr) & 15) == 0) && (ld % vb == 0);
 }
 
@@ -594,7 +619,7 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
         if (B * oh * ow > maxM) maxM = B * oh * ow;
     }
     p.dc_c = make_fastdiv(C);
-    const int vb = dtype == MI_F32 ? 4 : 8;
+    const int vb = dtype == MI_BF16 ? 8 : 4;
     if (C % vb != 0 || (((uintptr_t)p.a) & 15) || (((uintptr_t)p.b) & 15))
         return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: input channels must be a multiple of the 16-byte vector and pointers 16-B aligned");
     if (KH < 2 || KW < 2) return mi_fail(MI_ERR_SHAPE, "deconv-form gemm: kernel must be >= 2");
@@ -615,11 +640,12 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
         if (r2 != 0) return r2 > 0 ? MI_OK : r2;
     }
     if (dtype == MI_F32) return launch_gemm_bn<float, float, A_DECONV, B_DECONV, 4, 16>(st, p, maxM, 4);
+    if (dtype == MI_BF16X3) return launch_gemm_bn<split_t, split_t, A_DECONV, B_DECONV, 4, 16>(st, p, maxM, 4);
     return launch_gemm_bn<bf16_t, bf16_t, A_DECONV, B_DECONV, 8, 16>(st, p, maxM, 4);
 }
 
 int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks) {
-    const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : WgradCfg<bf16_t>::BP;
+    const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : (dtype == MI_BF16X3 ? WgradCfg<split_t>::BP : WgradCfg<bf16_t>::BP);
     const bool wide = p.Kc > 64;                          // 128 kc rows per block: halves the re-reads of the small tensor
     const int gx = wide ? (p.Kc + 127) / 128 : 1, gy = (p.N + 63) / 64;
     int splits = target_blocks / (gx * gy);
@@ -640,6 +666,16 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
         if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(float, float, 4, 16);
         else if (mergedok) WG_LAUNCH(float, float, 4, 8);
         else return mi_fail(MI_ERR_SHAPE, "wgrad (f32): channel count / alignment not supported");
+    } else if (dtype == MI_BF16X3) {
+        if (in_f32) {
+            if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(split_t, float, 4, 16);
+            else if (mergedok) WG_LAUNCH(split_t, float, 4, 8);
+            else return mi_fail(MI_ERR_SHAPE, "wgrad (split, fp32 input): channel count / alignment not supported");
+        } else {
+            if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(split_t, split_t, 4, 16);
+            else if (mergedok) WG_LAUNCH(split_t, split_t, 4, 8);
+            else return mi_fail(MI_ERR_SHAPE, "wgrad (split): channel count / alignment not supported");
+        }
     } else if (in_f32) {
         if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(bf16_t, float, 4, 16);
         else if (mergedok) WG_LAUNCH(bf16_t, float, 4, 8);
@@ -663,7 +699,7 @@ void fill_wgrad_geom(WgradParams& p, int B, int IH, int IW, int C, int OH, int O
 }
 
 inline bool needs_merge(int C, int dtype, int in_f32) {
-    const int v = (dtype == MI_F32 || in_f32) ? 4 : 8;
+    const int v = (dtype != MI_BF16 || in_f32) ? 4 : 8;
     return C % v != 0;
 }
 
@@ -722,7 +758,7 @@ int mi_conv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, const int* f
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     if (wrote_bits) *wrote_bits = 0;
     if (w_transposed) {
-        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out,
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : (dtype == MI_BF16X3 ? 3 : 0)), frame_idx, w, B, IH, IW, Cin, KH, KW, Cout, bias, relu, nullptr, out,
                                        (dtype == MI_BF16 && relu && Cout == 32) ? relu_bits : nullptr);
         if (r4 > 0 && wrote_bits && relu_bits && dtype == MI_BF16 && relu && Cout == 32) *wrote_bits = 1;
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
@@ -845,7 +881,7 @@ int mi_deconv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, 
                                 const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, const void* mask_bits, void* dx) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     if (w_transposed) {
-        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, dy, dtype == MI_F32, nullptr, w, B, OH, OW, Cout, KH, KW, Cin, nullptr, 0, mask, dx, nullptr, mask_bits);
+        const int r4 = try_narrow_conv((hipStream_t)stream, dtype, dy, dtype == MI_F32 ? 1 : (dtype == MI_BF16X3 ? 3 : 0), nullptr, w, B, OH, OW, Cout, KH, KW, Cin, nullptr, 0, mask, dx, nullptr, mask_bits);
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     GemmParams p = {};
@@ -911,14 +947,14 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
     GemmParams p = {};
     p.a = a; p.a_frame_idx = nullptr;
     fill_conv_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
-    const int vb = dtype == MI_F32 ? 4 : 8;
+    const int vb = dtype == MI_BF16 ? 8 : 4;
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_bias_act: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.b = w; p.ldb = w_layout == 0 ? N : K; p.b_vec = vec_ok(w, p.ldb, dtype);
     p.out = out; p.bias = bias; p.mask = mask; p.relu = relu; p.out_f32 = out_f32;
     int gz = 1;
     if (nsplit > 1) {
         if (bias || relu || mask || !out_f32) return mi_fail(MI_ERR_ARG, "mi_gemm_bias_act: split-K writes raw fp32 slabs only");
-        const int bk = dtype == MI_F32 ? 16 : 32;
+        const int bk = dtype == MI_BF16 ? 32 : 16;
         int len = (K + nsplit - 1) / nsplit;
         len = ((len + bk - 1) / bk) * bk;
         if ((long long)len * (nsplit - 1) >= K) return mi_fail(MI_ERR_ARG, "mi_gemm_bias_act: nsplit too large for K (empty slab)");
@@ -933,7 +969,7 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
     WgradParams p = {};
     p.big = a; p.frame_idx = nullptr;
     fill_wgrad_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
-    const int vb = dtype == MI_F32 ? 4 : 8;
+    const int vb = dtype == MI_BF16 ? 8 : 4;
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
     return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks);

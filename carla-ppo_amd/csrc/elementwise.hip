@@ -8,6 +8,12 @@
 
 using namespace mi;
 
+// one launch statement instantiated for the storage type the dtype code names (TT): fp32, bf16 or split (MI_BF16X3)
+#define BY_DTYPE(dtype, ...) do { \
+        if ((dtype) == MI_F32) { typedef float TT; __VA_ARGS__; } \
+        else if ((dtype) == MI_BF16X3) { typedef split_t TT; __VA_ARGS__; } \
+        else { typedef bf16_t TT; __VA_ARGS__; } } while (0)
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------------
@@ -294,7 +300,9 @@ __global__ __launch_bounds__(FIN_NT) void finalize_losses_kernel(const float* __
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                       float* __restrict__ g, long long n, float alpha_arg, const float* __restrict__ alpha_dev, float omb1,
-                                                      float omb2, float epsilon, bf16_t* __restrict__ shadow, int clear_grad) {
+                                                      float omb2, float epsilon, void* __restrict__ shadow_any, int shadow_split, int clear_grad) {
+    bf16_t* __restrict__ shadow = shadow_split ? nullptr : (bf16_t*)shadow_any;           // the weight copy the MFMA kernels read: bf16, or
+    split_t* __restrict__ shadow_s = shadow_split ? (split_t*)shadow_any : nullptr;       // split storage (hi | lo halves, 4 bytes per weight)
     const float alpha = alpha_dev ? alpha_dev[0] : alpha_arg;      // device-resident step size: a captured step is replayed with a new value
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -314,6 +322,10 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
             for (int e = 0; e < 4; ++e) s[e] = f32_to_bf16(pv[e]);
             ((u16x4*)shadow)[i] = s;
         }
+        if (shadow_s) {
+            const float pf[4] = {pv[0], pv[1], pv[2], pv[3]};
+            *(PackN<split_t, 4>*)(shadow_s + 4 * i) = pack4<split_t>(pf);
+        }
     }
     // tail (n not a multiple of 4)
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -322,7 +334,17 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (clear_grad) g[i] = 0.f;
         if (shadow) shadow[i] = f32_to_bf16(pp);
+        if (shadow_s) shadow_s[i] = split_from_f32(pp);
     }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_split_kernel(const float* __restrict__ src, split_t* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = split_from_f32(src[i]);
+}
+__global__ __launch_bounds__(256) void cast_split_f32_kernel(const split_t* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = split_to_f32(src[i]);
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
@@ -510,8 +532,7 @@ int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int n
                               unsigned long long* rng_state, float* eps_out) {
     if (sample && !eps && !(rng_state && eps_out)) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd: sampling needs eps or a generator state + eps_out");
     dim3 g((B + 3) / 4), b(256);
-    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (float*)z, kl_row, rng_state, eps_out);
-    else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (bf16_t*)z, kl_row, rng_state, eps_out);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(reparam_kl_fwd_kernel<TT>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (TT*)z, kl_row, rng_state, eps_out));
     return mi_check_launch("reparam_kl_fwd");
 }
 
@@ -525,8 +546,7 @@ int mi_normal_philox(void* stream, unsigned long long seed, unsigned long long o
 int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar,
                           const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads) {
     dim3 g((B + 3) / 4), b(256);
-    if (dtype == MI_F32) hipLaunchKernelGGL(reparam_kl_bwd_kernel<float>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (float*)dheads);
-    else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (bf16_t*)dheads);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(reparam_kl_bwd_kernel<TT>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (TT*)dheads));
     return mi_check_launch("reparam_kl_bwd");
 }
 
@@ -545,8 +565,7 @@ int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, cons
     dim3 g(nch, B), b(256);
     if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
     if (dbias && (channels < 1 || channels > 3 || !dlogits)) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd_bias: fused bias gradient needs 1..3 channels and dlogits");
-    if (dtype == MI_F32) hipLaunchKernelGGL(recon_loss_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (float*)dlogits, partial, nch, channels, dbias);
-    else hipLaunchKernelGGL(recon_loss_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (bf16_t*)dlogits, partial, nch, channels, dbias);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(recon_loss_kernel<TT>, g, b, 0, (hipStream_t)stream, (const TT*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (TT*)dlogits, partial, nch, channels, dbias));
     return mi_check_launch("recon_loss");
 }
 
@@ -572,10 +591,17 @@ int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad,
 // same; alpha_dev != NULL: the step size is read from device memory at run time (one float) instead of the argument
 int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2,
                         float epsilon, void* bf16_shadow, int clear_grad) {
+    return mi_adam_tf_flat_shadow(stream, param, m, v, grad, n, alpha, alpha_dev, beta1, beta2, epsilon, bf16_shadow, MI_BF16, clear_grad);
+}
+
+// same; shadow_dtype names the storage type of the shadow weight copy the MFMA kernels read: MI_BF16 (2 bytes per weight) or MI_BF16X3 (split, 4 bytes)
+int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2,
+                           float epsilon, void* shadow, int shadow_dtype, int clear_grad) {
     if ((((uintptr_t)param) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad)) & 15) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: buffers must be 16-byte aligned");
-    if (bf16_shadow && (((uintptr_t)bf16_shadow) & 7)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: bf16 shadow must be 8-byte aligned");
+    if (shadow && shadow_dtype != MI_BF16 && shadow_dtype != MI_BF16X3) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: the shadow copy is bf16 or split storage");
+    if (shadow && (((uintptr_t)shadow) & (shadow_dtype == MI_BF16X3 ? 15 : 7))) return mi_fail(MI_ERR_ARG, "mi_adam_tf_flat: shadow copy must be 8-byte (bf16) / 16-byte (split) aligned");
     hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, n, alpha, alpha_dev,
-                       1.0f - beta1, 1.0f - beta2, epsilon, (bf16_t*)bf16_shadow, clear_grad);
+                       1.0f - beta1, 1.0f - beta2, epsilon, shadow, shadow_dtype == MI_BF16X3 ? 1 : 0, clear_grad);
     return mi_check_launch("adam_tf");
 }
 
@@ -583,14 +609,23 @@ int mi_splitk_finish(void* stream, int dtype, const float* slabs, int nsplit, in
     if (!slabs || !out || nsplit < 1 || M < 1 || N < 4 || N % 4 != 0) return mi_fail(MI_ERR_ARG, "mi_splitk_finish: bad arguments (N must be a multiple of 4)");
     const long long mn = (long long)M * N;
     const dim3 g((unsigned)((mn / 4 + 255) / 256));
-    if (dtype == MI_F32) hipLaunchKernelGGL(splitk_finish_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, slabs, nsplit, mn, N, bias, relu, (const float*)mask, out_f32 ? nullptr : (float*)out, out_f32 ? (float*)out : nullptr);
-    else hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, slabs, nsplit, mn, N, bias, relu, (const bf16_t*)mask, out_f32 ? nullptr : (bf16_t*)out, out_f32 ? (float*)out : nullptr);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(splitk_finish_kernel<TT>, g, dim3(256), 0, (hipStream_t)stream, slabs, nsplit, mn, N, bias, relu, (const TT*)mask, out_f32 ? nullptr : (TT*)out, out_f32 ? (float*)out : nullptr));
     return mi_check_launch("splitk_finish");
 }
 
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     return mi_check_launch("cast_f32_bf16");
+}
+
+// fp32 <-> split storage (MI_BF16X3): x -> (bf16(x) << 16 | bf16(x - bf16(x))) and back (hi + lo)
+int mi_cast_f32_to_split(void* stream, const float* src, void* dst, long long n) {
+    hipLaunchKernelGGL(cast_f32_split_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst, n);
+    return mi_check_launch("cast_f32_split");
+}
+int mi_cast_split_to_f32(void* stream, const void* src, float* dst, long long n) {
+    hipLaunchKernelGGL(cast_split_f32_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const split_t*)src, dst, n);
+    return mi_check_launch("cast_split_f32");
 }
 
 int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n) {
@@ -610,44 +645,39 @@ int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, c
         tiles += ((K[i] + 31) / 32) * ((N[i] + 31) / 32);
     }
     tb.tile0[count] = tiles; tb.count = count;
-    if (dtype == MI_F32) hipLaunchKernelGGL(transpose_weights_kernel<float>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, tb);
-    else hipLaunchKernelGGL(transpose_weights_kernel<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, tb);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(transpose_weights_kernel<TT>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, src, (TT*)dst, tb));
     return mi_check_launch("transpose_weights");
 }
 
 // out[N] += column sums of x[M,N]   (BiasAddGrad)
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out) {
     if (M <= 0 || N <= 0) return MI_OK;
-    const int vec = dtype == MI_F32 ? 4 : 8;
+    const int vec = dtype == MI_BF16 ? 8 : 4;
     if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
         // <= 512 blocks: every block ends with N atomics on the same N addresses, so block count (not bytes) sets the floor
         long long rows = (M + 511) / 512;
         if (rows * N < 32768) rows = (32768 + N - 1) / N;
         const int gx = (int)((M + rows - 1) / rows);
-        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
-        else hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_vec_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
         return mi_check_launch("colsum_vec");
     }
     if (N <= 256) {
         long long rows = (M + 1023) / 1024;
         if (rows * N < 4096) rows = (4096 + N - 1) / N;
         const int gx = (int)((M + rows - 1) / rows);
-        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
-        else hipLaunchKernelGGL(colsum_small_kernel<bf16_t>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_small_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
     } else {
         long long rows = (M + 63) / 64;
         if (rows < 8) rows = 8;
         const int gx = (int)((M + rows - 1) / rows);
         const int gy = (N + 255) / 256;
-        if (dtype == MI_F32) hipLaunchKernelGGL(colsum_wide_kernel<float>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, M, N, (int)rows, out);
-        else hipLaunchKernelGGL(colsum_wide_kernel<bf16_t>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, N, (int)rows, out);
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_wide_kernel<TT>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
     }
     return mi_check_launch("colsum");
 }
 
 int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n) {
-    if (dtype == MI_F32) hipLaunchKernelGGL(sigmoid_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, n);
-    else hipLaunchKernelGGL(sigmoid_kernel<bf16_t>, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, n);
+    BY_DTYPE(dtype, hipLaunchKernelGGL(sigmoid_kernel<TT>, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, (const TT*)x, out, n));
     return mi_check_launch("sigmoid");
 }
 

@@ -14,6 +14,7 @@
 //   bf16: one 32x32x16 MFMA;  f32: four 32x32x2 MFMAs (element s of the float4 -> MFMA s).
 //   C/D: acc reg r of lane l -> row (r&3) + 8*(r>>2) + 4*g, col l&31   (dtype independent on gfx950).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace mi {
@@ -66,6 +67,25 @@ template <> struct Frag<bf16_t> {
     typedef u16x8 reg;
     static __device__ __forceinline__ void mma(const reg& a, const reg& b, f32x16& c) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// split storage: a fragment is four (lo, hi) elements = the bf16x8 vector [l0 h0 l1 h1 l2 h2 l3 h3] per lane.  a . b + a . swap16(b) = the
+// full (ha + la)(hb + lb) products of the lane group's four k-values (common.hpp); the swap is one v_alignbit_b32 per dword of the FIRST operand
+// (callers pass the operand they reuse across the inner tile loop first, so the compiler hoists the four rotates out of it).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <> struct Frag<split_t> {
+    typedef u32x4 reg;
+    static __device__ __forceinline__ reg swap16(const reg& a) {
+        reg r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_alignbit(a[e], a[e], 16);
+        return r;
+    }
+    static __device__ __forceinline__ void mma(const reg& a, const reg& b, f32x16& c) {
+        const reg as = swap16(a);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
                 const TIn* src = ok ? Ag + a_base[i] + off : Ag;
                 const PackU<TIn, VA, AALIGN> t = *(const PackU<TIn, VA, AALIGN>*)src;
 #pragma unroll
-                for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : (TIn)0;
+                for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : zero_of<TIn>();
             }
         } else {
             uint32_t tap, c, th, tw;
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
                 const TIn* src = ok ? Ag + a_base[i] + ((long long)ih * p.IW + iw) * p.C + c : Ag;
                 const PackU<TIn, VA, AALIGN> t = *(const PackU<TIn, VA, AALIGN>*)src;
 #pragma unroll
-                for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : (TIn)0;
+                for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : zero_of<TIn>();
             }
         }
     };
@@ -325,8 +345,8 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
             PackN<T, VA> t;
 #pragma unroll
             for (int e = 0; e < VA; ++e) {
-                if constexpr (sizeof(TIn) == sizeof(T)) t.v[e] = (T)a_reg[i].v[e];
-                else t.v[e] = Elem<T>::from_f32((float)a_reg[i].v[e]);
+                if constexpr (std::is_same<TIn, T>::value) t.v[e] = a_reg[i].v[e];
+                else t.v[e] = Elem<T>::from_f32((float)a_reg[i].v[e]);      // fp32 frames into a bf16 / split engine
             }
             *(PackN<T, VA>*)(&lds[buf][r * PITCH + a_kv * VA * (int)sizeof(T)]) = t;
         }
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + i * NT;
 #pragma unroll
-            for (int e = 0; e < VB; ++e) b_reg[i].v[e] = (T)0;
+            for (int e = 0; e < VB; ++e) b_reg[i].v[e] = zero_of<T>();
             if (v >= NVB_TOT) continue;
             if constexpr (BMODE == B_KN) {                // W[k*ldb + n], n contiguous
                 constexpr int VPR = BN / VB;
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
                     const T* src = ok ? Bg + (long long)n * p.ldb + k0 : Bg;
                     const PackN<T, VB> t = *(const PackN<T, VB>*)src;
 #pragma unroll
-                    for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : (T)0;
+                    for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : zero_of<T>();
                 } else if (ok) {
                     const T* src = Bg + (long long)n * p.ldb + k0;
 #pragma unroll
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm_kernel(const GemmParams p) {
                 const T* src = ok ? Bg + (((long long)kh * p.KW + kw) * p.N + n) * p.C + c : Bg;
                 const PackN<T, VB> t = *(const PackN<T, VB>*)src;
 #pragma unroll
-                for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : (T)0;
+                for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : zero_of<T>();
             }
         }
     };

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { MI_F32 = 0, MI_BF16 = 1 };
+enum { MI_F32 = 0, MI_BF16 = 1, MI_BF16X3 = 2 };   // MI_BF16X3: split storage (hi | lo bf16 halves per 4-byte element), common.hpp
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_SHAPE = -2, MI_ERR_LAUNCH = -3, MI_ERR_STATE = -4 };
 
 int mi_fail(int code, const char* msg);          // records msg (thread-local) and returns code

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
             if constexpr (ESZ == 2) {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) w[d] = (uint32_t)f32_to_bf16(v[2 * d]) | ((uint32_t)f32_to_bf16(v[2 * d + 1]) << 16);
+            } else if constexpr (is_split<T>::value) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) w[d] = split_from_f32(v[d]).u;
             } else {
 #pragma unroll
                 for (int d = 0; d < ND; ++d) w[d] = __builtin_bit_cast(uint32_t, v[d]);
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(GN_NT) __attribute__((amdgpu_waves_per_eu(7, 8))) v
 #pragma unroll
                 for (int j = 0; j < CNT; ++j) {
                     float xv;
-                    if constexpr (ESZ == 2) xv = bf16_to_f32((bf16_t)(j & 1 ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu)); else xv = v[j];
+                    if constexpr (ESZ == 2) xv = bf16_to_f32((bf16_t)(j & 1 ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu));
+                    else if constexpr (is_split<T>::value) { split_t sv; sv.u = w[j]; xv = split_to_f32(sv); }
+                    else xv = v[j];
                     if constexpr (FASTBCE) {                 // loss_kind 0: max(x, 0) - x y + log(1 + exp(-|x|)), gradient sigmoid(x) - y
                         const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
                         const float s1 = 1.0f + e;
@@ -543,7 +548,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         freg xv;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-            if constexpr (sizeof(T) == 2) xv[e] = f32_to_bf16(pv[e]); else xv[e] = pv[e];
+            if constexpr (sizeof(T) == 2) xv[e] = f32_to_bf16(pv[e]);
+            else if constexpr (is_split<T>::value) xv[e] = split_from_f32(pv[e]).u;
+            else xv[e] = pv[e];
         }
         xf[s] = xv;
     }
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (!pok) continue;
         if (!use_bits && maskp) {
 #pragma unroll
-            for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[k].v[t]) > 0.f ? o.v[t] : (T)0;
+            for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[k].v[t]) > 0.f ? o.v[t] : zero_of<T>();
         }
         *(PackN<T, VE>*)((T*)p.out + off) = o;
     }

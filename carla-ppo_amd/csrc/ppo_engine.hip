@@ -88,11 +88,15 @@ __global__ void head_dgrad_kernel(const float* __restrict__ du, const float* __r
 
 #define CK(call) do { int rc__ = (call); if (rc__ != MI_OK) return rc__; } while (0)
 
-bool fused_enabled() {                                   // MI355_PPO_FUSED=0: the first-generation step (one launch per layer op), for A/B runs
+bool fused_switch() {                                    // MI355_PPO_FUSED=0: the first-generation step (one launch per layer op), for A/B runs
     static int on = -1;
     if (on < 0) { const char* ev = getenv("MI355_PPO_FUSED"); on = (ev && ev[0] == '0') ? 0 : 1; }
     return on != 0;
 }
+// the fused kernels serve the shapes they were built for (the reference's 500 / 300 trunk, <= 8 actions); anything else takes the per-layer path
+bool fused_enabled(const PpoEngine* e);
+
+bool fused_enabled(const PpoEngine* e) { return fused_switch() && mi_ppo_fused_shape_ok(e->d.num_actions, e->d.h2, e->kin); }
 
 void fill_fused(const PpoEngine* e, PpoFusedParams& q, const float* states, int M) {
     const MiPpoDesc& d = e->d;
@@ -210,7 +214,7 @@ int mi_ppo_predict(void* h, void* stream, const float* states, int M, const floa
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_predict: batch outside [1, max_batch]");
     if (!greedy && !noise) return mi_fail(MI_ERR_ARG, "mi_ppo_predict: sampling needs noise");
-    if (fused_enabled()) {                                // 3 launches: layer 1, layer 2 (policy + value), heads
+    if (fused_enabled(e)) {                                // 3 launches: layer 1, layer 2 (policy + value), heads
         PpoFusedParams q; fill_fused(e, q, states, M);
         return mi_ppo_fused_predict((hipStream_t)stream, q, noise, greedy, action, value);
     }
@@ -228,7 +232,7 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_forward_backward: batch outside [1, max_batch]");
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_ppo_forward_backward: engine created without a gradient buffer");
-    if (fused_enabled()) {                                // 5 launches; gradients written (not accumulated) into the flat buffer (M > 256: zeroed, then row chunks meet in atomics)
+    if (fused_enabled(e)) {                                // 5 launches; gradients written (not accumulated) into the flat buffer (M > 256: zeroed, then row chunks meet in atomics)
         PpoFusedParams q; fill_fused(e, q, states, M);
         q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
         e->last_M = M;
@@ -300,10 +304,10 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step: batch outside [1, max_batch]");
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step: engine created without optimiser buffers");
-    if (M > 256 || !fused_enabled()) {
+    if (M > 256 || !fused_enabled(e)) {
         // large minibatches (the synthetic replay: 2048 rows per GPU): the weight-gradient launch splits the rows into chunks of 256 whose partial
         // sums meet in atomics, so the Adam update is its own (flat) launch; everything before it is the same five-kernel chain
-        if (!fused_enabled()) { CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale)); }
+        if (!fused_enabled(e)) { CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale)); }
         else {
             PpoFusedParams q; fill_fused(e, q, states, M);
             q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;

@@ -14,6 +14,7 @@
 // gradient never goes through HBM as a separate buffer: the block that finishes a weight tile's gradient (it sums over ALL minibatch rows)
 // applies tf.train.AdamOptimizer to that tile at once.  Data parallel (more than one rank) uses the same kernels with FUSE_ADAM = false: they
 // write the flat gradient buffer, the host all-reduces it and mi_adam_tf_flat applies the update.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.hpp"
 #include "mi_internal.hpp"
@@ -570,7 +571,17 @@ __global__ __launch_bounds__(256) void ppo_predict_head_kernel(const PpoFusedPar
 
 using namespace mi;
 
+// shapes the fused kernels are built for (checked BEFORE anything is launched; the engine falls back to the per-layer path otherwise)
+bool mi_ppo_fused_shape_ok(int A, int H2, int kin) { return A >= 1 && A <= PF_MAX_ACT && H2 <= PF_H2MAX && H2 % 4 == 0 && kin <= 96; }
+static int pf_check_shape(const PpoFusedParams& q, const char* who) {
+    if (mi_ppo_fused_shape_ok(q.A, q.H2, q.kin)) return MI_OK;
+    static thread_local char msg[160];
+    snprintf(msg, sizeof(msg), "%s: shape outside the fused kernels' range (1 <= num_actions <= 8, H2 <= 320 and a multiple of 4, inputs <= 96)", who);
+    return mi_fail(MI_ERR_SHAPE, msg);
+}
+
 int mi_ppo_fused_predict(hipStream_t st, PpoFusedParams& q, const float* noise, int greedy, float* action, float* value) {
+    { const int rc0 = pf_check_shape(q, "ppo fused predict"); if (rc0 != MI_OK) return rc0; }
     q.n_nets = 2;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
@@ -586,6 +597,7 @@ int mi_ppo_fused_predict(hipStream_t st, PpoFusedParams& q, const float* noise, 
 int mi_ppo_fused_logp_old(hipStream_t st, PpoFusedParams& q, float* out) {
     // only net 2 is needed: run the trunk kernels over the grid's net range [2, 3) by offsetting nothing -- the kernels index nets by blockIdx.y,
     // so all three are computed (M x 1.2 MFLOP, once per horizon batch)
+    { const int rc0 = pf_check_shape(q, "ppo fused logp_old"); if (rc0 != MI_OK) return rc0; }
     q.n_nets = 3;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
@@ -606,11 +618,11 @@ int mi_ppo_fused_trunks(hipStream_t st, const PpoFusedParams& q) {
 
 // the whole minibatch step; fuse_adam = 0: gradients to q.grads instead of the in-place optimiser update
 int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
-    if (q.A < 1 || q.A > PF_MAX_ACT) return mi_fail(MI_ERR_ARG, "ppo fused step: 1 <= num_actions <= 8");
+    { const int rc0 = pf_check_shape(q, "ppo fused step"); if (rc0 != MI_OK) return rc0; }         // before the first launch
+    if (fuse_adam && q.M > 256) return mi_fail(MI_ERR_ARG, "ppo fused step: the in-kernel Adam update needs the whole minibatch in one wave (M <= 256)");
     q.n_loss_blocks = (q.M + 31) / 32;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
-    if (q.H2 > PF_H2MAX || q.H2 % 4 != 0 || q.kin > 96) return mi_fail(MI_ERR_SHAPE, "ppo fused step: hidden sizes outside the staged range (H2 <= 320, multiple of 4; inputs <= 96)");
     if (q.A == 2) hipLaunchKernelGGL(ppo_head_loss_kernel<2>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);     // (action loops are compile-time unrolled)
     else hipLaunchKernelGGL(ppo_head_loss_kernel<PF_MAX_ACT>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);
     hipLaunchKernelGGL(ppo_dh1_kernel, dim3((q.H1 + 31) / 32, 2, (q.M + 31) / 32), dim3(256), 0, st, q);
@@ -618,7 +630,6 @@ int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
     const int tiles = 2 * (nt1 * nt2 + kt1 * nt1 + nt2) + 1;         // + the wave that finalises the loss scalars
     q.m_chunk = 0;
     if (fuse_adam) {
-        if (q.M > 256) return mi_fail(MI_ERR_ARG, "ppo fused step: the in-kernel Adam update needs the whole minibatch in one wave (M <= 256)");
         hipLaunchKernelGGL(ppo_wgrad_kernel<true>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
     } else if (q.M > 256) {                               // row chunks of 256, gradients meet in atomics on the zeroed buffer
         q.m_chunk = 256;

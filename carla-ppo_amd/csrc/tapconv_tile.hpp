@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
                         if (maskp) {
                             const PackN<T, 4> mk = __builtin_bit_cast(PackN<T, 4>, umk[i][j][u]);
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : (T)0;
+                            for (int t = 0; t < 4; ++t) o.v[t] = Elem<T>::to_f32(mk.v[t]) > 0.f ? o.v[t] : zero_of<T>();
                         }
                         if (uok[i][j]) *(PackN<T, 4>*)((T*)p.out + uoff[i][j][u]) = o;
                     }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(BMT * 2) void tapconv_kernel(const TapParams p) {
             PackN<T, VE> o = *(const PackN<T, VE>*)(stg + pos * PITCH + c16 * 16);
             if (maskp) {
 #pragma unroll
-                for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[u].v[t]) > 0.f ? o.v[t] : (T)0;
+                for (int t = 0; t < VE; ++t) o.v[t] = Elem<T>::to_f32(mk[u].v[t]) > 0.f ? o.v[t] : zero_of<T>();
             }
             if (ok[u]) *(PackN<T, VE>*)((T*)p.out + off[u]) = o;
         }

@@ -124,8 +124,9 @@ struct VaeEngine {
     hipGraphExec_t gexec;
     hipStream_t cap; int cap_ok;        // engine-owned stream the step is recorded on
     struct GraphKey { const void *src, *tgt, *eps, *metrics, *stream; int u8, has_idx, B; float inv_batch, b1, b2, epsilon, mw; } gkey;
-    const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const unsigned short*)shadow + L.off[t]); }
-    const void* wtptr(int t) const { return d.dtype == MI_F32 ? (const void*)((const float*)wt + L.off[t]) : (const void*)((const unsigned short*)wt + L.off[t]); }
+    // weights as the MFMA kernels read them: the fp32 masters (MI_F32) or the shadow copy Adam keeps in the engine's storage type (bf16 / split)
+    const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const char*)shadow + L.off[t] * esz); }
+    const void* wtptr(int t) const { return (const void*)((const char*)wt + L.off[t] * esz); }
     const float* bptr(int t) const { return params + L.off[t]; }
     float* gptr(int t) const { return grads + L.off[t]; }
     void* at(long long off) const { return ws + off; }
@@ -183,8 +184,8 @@ bool init_engine(VaeEngine& e, const MiVaeDesc* desc) {
     e.d = *desc;
     if (!make_geom(e.d, e.g)) return false;
     make_layout(e.d, e.g, e.L);
-    e.esz = e.d.dtype == MI_F32 ? 4 : 2;
-    const int bk = e.d.dtype == MI_F32 ? 16 : 32;
+    e.esz = e.d.dtype == MI_BF16 ? 2 : 4;                  // MI_F32 and MI_BF16X3 (split storage) are 4-byte elements
+    const int bk = e.d.dtype == MI_BF16 ? 32 : 16;
     e.ns_heads = pick_split(e.d.max_batch, 2 * e.d.z_dim, e.g.flat, bk);
     e.ns_dz = pick_split(e.d.max_batch, e.d.z_dim, e.g.flat, bk);
     e.nchunks = mi_recon_loss_chunks(e.g.dh[4] * e.g.dw[4] * e.g.dc[4]);
@@ -300,8 +301,8 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
     VaeEngine* e = (VaeEngine*)calloc(1, sizeof(VaeEngine));
     if (!e) { mi_fail(MI_ERR_STATE, "mi_vae_create: out of host memory"); return nullptr; }
     if (!d || !init_engine(*e, d)) { free(e); mi_fail(MI_ERR_SHAPE, "mi_vae_create: unsupported geometry"); return nullptr; }
-    if (d->dtype != MI_F32 && d->dtype != MI_BF16) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: dtype must be 0 (f32) or 1 (bf16)"); return nullptr; }
-    if (d->dtype == MI_BF16 && !bf16_shadow) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: bf16 mode needs the shadow weight buffer"); return nullptr; }
+    if (d->dtype != MI_F32 && d->dtype != MI_BF16 && d->dtype != MI_BF16X3) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: dtype must be 0 (f32), 1 (bf16) or 2 (split storage, bf16x3)"); return nullptr; }
+    if (d->dtype != MI_F32 && !bf16_shadow) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: bf16 / split mode needs the shadow weight buffer (2 / 4 bytes per parameter)"); return nullptr; }
     if (!params || !weights_t || !workspace || workspace_bytes < e->W.total) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: missing buffers or workspace too small"); return nullptr; }
     if ((((uintptr_t)params) | ((uintptr_t)workspace) | ((uintptr_t)bf16_shadow) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: buffers must be 256-byte aligned"); return nullptr; }
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->wt = weights_t; e->ws = (char*)workspace;
@@ -322,6 +323,7 @@ int mi_vae_sync_shadow(void* h, void* stream) {
     VaeEngine* e = (VaeEngine*)h;
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
     if (e->d.dtype == MI_BF16) CK(mi_cast_f32_to_bf16(stream, e->params, e->shadow, e->L.total));
+    if (e->d.dtype == MI_BF16X3) CK(mi_cast_f32_to_split(stream, e->params, e->shadow, e->L.total));
     return refresh_transposed(e, stream);
 }
 
@@ -485,8 +487,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
 // tf.train.AdamOptimizer step over all 22 reference variables at once; alpha = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
 static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon) {
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_vae_apply_adam: engine created without optimiser buffers");
-    TOP(e, stream, OP_ADAM, mi_adam_tf_flat_dev(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, alpha_dev, beta1, beta2, epsilon,
-                                                e->d.dtype == MI_BF16 ? e->shadow : nullptr, 1));
+    TOP(e, stream, OP_ADAM, mi_adam_tf_flat_shadow(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, alpha_dev, beta1, beta2, epsilon,
+                                                   e->d.dtype != MI_F32 ? e->shadow : nullptr, e->d.dtype == MI_BF16X3 ? MI_BF16X3 : MI_BF16, 1));
     return refresh_transposed(e, stream);
 }
 
@@ -629,6 +631,8 @@ int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out
     if (d.dtype == MI_F32) {
         if (hipMemcpyAsync(e->at(e->W.z), z, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return mi_fail(MI_ERR_LAUNCH, "mi_vae_decode: copy failed");
+    } else if (d.dtype == MI_BF16X3) {
+        CK(mi_cast_f32_to_split(stream, z, e->at(e->W.z), n));
     } else {
         CK(mi_cast_f32_to_bf16(stream, z, e->at(e->W.z), n));
     }

@@ -28,6 +28,7 @@ struct WgradParams {
 template <typename T> struct WgradCfg;
 template <> struct WgradCfg<float>  { static constexpr int BP = 16; };
 template <> struct WgradCfg<bf16_t> { static constexpr int BP = 64; };
+template <> struct WgradCfg<split_t> { static constexpr int BP = 32; };   // split storage: 8 pixels per MFMA pair, 4 pairs per step and accumulator
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
     constexpr int VPR_B = BN / VB;
     constexpr int NVB = VPR_B / TPP;
     static_assert(NVA >= 1 && NVB >= 1 && VPR_A % TPP == 0 && VPR_B % TPP == 0, "wgrad thread mapping");
-    constexpr int KSTEP = (sizeof(T) == 2) ? 16 : 2;     // pixels per MFMA
+    constexpr int KSTEP = (sizeof(T) == 2) ? 16 : (is_split<T>::value ? 8 : 2);     // pixels per MFMA (split: per MFMA pair)
 
     __shared__ __attribute__((aligned(16))) T lds[2][BP * LDA + BP * LDB];
 
@@ -111,19 +112,19 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             const TIn* src = ok ? arow + a_koff[i] : Ag;
             const PackU<TIn, VA, AALIGN> t = *(const PackU<TIn, VA, AALIGN>*)src;
 #pragma unroll
-            for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : (TIn)0;
+            for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : zero_of<TIn>();
         }
         const T* srow = Sg + (long long)(mok ? m : 0) * p.N;
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int n = n0 + (tsub + i * TPP) * VB;
 #pragma unroll
-            for (int e = 0; e < VB; ++e) b_reg[i].v[e] = (T)0;
+            for (int e = 0; e < VB; ++e) b_reg[i].v[e] = zero_of<T>();
             if (p.s_vec) {                                // wave-uniform: N % VB == 0, whole vectors in range
                 const bool ok = mok && n < p.N;
                 const PackN<T, VB> t = *(const PackN<T, VB>*)(ok ? srow + n : Sg);
 #pragma unroll
-                for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : (T)0;
+                for (int e = 0; e < VB; ++e) b_reg[i].v[e] = ok ? t.v[e] : zero_of<T>();
             } else if (mok) {
 #pragma unroll
                 for (int e = 0; e < VB; ++e) if (n + e < p.N) b_reg[i].v[e] = srow[n + e];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             PackN<T, VA> t;
 #pragma unroll
             for (int e = 0; e < VA; ++e) {
-                if constexpr (sizeof(TIn) == sizeof(T)) t.v[e] = (T)a_reg[i].v[e];
+                if constexpr (std::is_same<TIn, T>::value) t.v[e] = a_reg[i].v[e];
                 else t.v[e] = Elem<T>::from_f32((float)a_reg[i].v[e]);
             }
             *(PackN<T, VA>*)(&As[(tsub + i * TPP) * VA]) = t;
@@ -169,6 +170,21 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
                 for (int i = 0; i < TMW; ++i) {
                     const u16x8 a = tr_fragment((const bf16_t*)As, LDA, kk * 16, (wm * TMW + i) * 32, lane);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+                }
+            } else if constexpr (is_split<T>::value) {
+                // lane (row, g) gathers the (lo, hi) words of pixels 8 kk + 4 g .. + 3 of its channel: the bf16x8 fragment [l0 h0 .. l3 h3];
+                // a . b + a . swap16(b) = all four partial products (gemm_tile.hpp, Frag<split_t>); the swap is shared by the TMW tiles
+                u32x4 b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = Bs[(kk * 8 + lgrp * 4 + j) * LDB + wn * 32 + lrow].u;
+                const u32x4 bs = Frag<split_t>::swap16(b);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    u32x4 a;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = As[(kk * 8 + lgrp * 4 + j) * LDA + (wm * TMW + i) * 32 + lrow].u;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bs), acc[i], 0, 0, 0);
                 }
             } else {
                 const float b = Bs[(kk * 2 + lgrp) * LDB + wn * 32 + lrow];

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 HEADER = os.path.join(ROOT, "include", "mi355_carla.h")
 LIB_PATH = os.path.join(HERE, "libmi355_carla.so")
 
-MI_F32, MI_BF16 = 0, 1
+MI_F32, MI_BF16, MI_BF16X3 = 0, 1, 2              # MI_BF16X3: split storage (two bf16 halves hi | lo per 4-byte element), include/mi355_carla.h
 
 _CTYPES = {
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,

@@ -27,6 +27,8 @@ class MlpVaeDevice:
         self.z_dim = int(z_dim)
         self.precision = precision
         self.dtype = PRECISIONS[precision]
+        if self.dtype == milib.MI_BF16X3:
+            raise ValueError("MlpVAE: precision 'bf16x3' (split storage) is built for the ConvVAE engine; use 'fp32' (1e-4 parity) or 'bf16'")
         self.bf16 = self.dtype == milib.MI_BF16
         self.T = torch.bfloat16 if self.bf16 else torch.float32
         self.loss_kind = LOSS_KINDS[loss_fn]

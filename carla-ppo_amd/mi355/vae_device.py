@@ -14,7 +14,7 @@ from . import lib as milib
 from .init import vae_variables
 
 LOSS_KINDS = {"bce": 0, "bce_v2": 1, "mse": 2}
-PRECISIONS = {"fp32": milib.MI_F32, "f32": milib.MI_F32, "bf16": milib.MI_BF16}
+PRECISIONS = {"fp32": milib.MI_F32, "f32": milib.MI_F32, "bf16": milib.MI_BF16, "bf16x3": milib.MI_BF16X3}
 
 # device tensor order inside the flat buffer (see mi_vae_param_layout)
 _DEVICE_ORDER = (["vae/encoder/conv%d/%s" % (i, k) for i in (1, 2, 3, 4) for k in ("kernel", "bias")] +
@@ -71,8 +71,10 @@ class VaeDevice:
         self.grads = z() if self.with_optimizer else None
         self.adam_m = z() if self.with_optimizer else None
         self.adam_v = z() if self.with_optimizer else None
-        self.shadow = z(torch.bfloat16) if self.dtype == milib.MI_BF16 else None
-        self.weights_t = z(torch.bfloat16 if self.dtype == milib.MI_BF16 else torch.float32)     # K-contiguous kernel copies
+        # the weight copies the MFMA kernels read, in the engine's storage type: bf16, or split storage (bf16x3: hi | lo halves in one 32-bit word)
+        store = {milib.MI_F32: torch.float32, milib.MI_BF16: torch.bfloat16, milib.MI_BF16X3: torch.int32}[self.dtype]
+        self.shadow = z(store) if self.dtype != milib.MI_F32 else None
+        self.weights_t = z(store)                                                                # K-contiguous kernel copies
         self.metrics = torch.zeros(3, device=self.device)
         self.decoder_offset = self.layout["vae/decoder/dense1/kernel"][0]   # grads[decoder_offset:] are ready first in backward
         # data-parallel gradient buckets in the order backward completes them: (engine part, first float, one past the last float).

@@ -83,8 +83,10 @@ class VAE():
         # the bf16 throughput mode (BASELINE configs[1]) is opted into with precision="bf16" or MI355_PRECISION=bf16 and carries its own,
         # looser, stated tolerances (README parity table)
         self.precision = precision or os.environ.get("MI355_PRECISION", "fp32")
-        if self.precision not in ("bf16", "fp32", "f32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        # "bf16x3": split storage -- every element is two bf16 halves (hi + lo) and every product runs on the bf16 MFMA pipe as hi/lo partial products
+        # with fp32 accumulation: ~2^-17 relative per operand, within the 1e-4 tolerance, at a quarter of the exact-fp32 MFMA time
+        if self.precision not in ("bf16", "fp32", "f32", "bf16x3"):
+            raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
         self.seed = seed                               # None: derived from numpy's global RNG state at init_session (mi355.init.seed_from_numpy_state)
         self._variables = self._variable_table()
         self._init_values = None

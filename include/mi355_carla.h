@@ -12,7 +12,10 @@
  *   - return value: 0 = ok, negative = error (MI_ERR_*); message via mi_last_error() (thread local).
  *   - no allocation inside the library: all buffers/workspaces are passed in (sizes via *_floats / *_bytes queries).
  *   - dtype: 0 = fp32 storage + v_mfma_f32_32x32x2_f32 (parity mode), 1 = bf16 storage + v_mfma_f32_32x32x16_bf16
- *     (throughput mode; fp32 accumulate, fp32 master weights / grads / optimiser state).
+ *     (throughput mode; fp32 accumulate, fp32 master weights / grads / optimiser state), 2 = SPLIT storage ("bf16x3" precision): every
+ *     activation / weight element is 4 bytes = two bf16 halves hi + lo of one value (hi = bf16(x), lo = bf16(x - hi); word = hi << 16 | lo),
+ *     products formed on the bf16 MFMA pipe as a.b + a.swap16(b) (all four partial products, fp32 accumulate): 16-17 significand bits per
+ *     operand at a quarter of the exact-fp32 MFMA time -- the fast mode that meets the 1e-4 tolerance.  Same sizes / alignments as dtype 0.
  *   - layouts are TensorFlow's: activations NHWC, conv kernels HWIO [kh,kw,in,out], transposed-conv kernels
  *     [kh,kw,out,in], dense kernels [in,out].  All convolutions are stride 2, VALID.
  *
@@ -27,6 +30,7 @@ extern "C" {
 
 #define MI_F32 0
 #define MI_BF16 1
+#define MI_BF16X3 2
 
 #define MI_OK 0
 #define MI_ERR_ARG (-1)
@@ -37,7 +41,7 @@ extern "C" {
 
 /* ---- engine descriptors (all 4-byte fields; mirrored as ctypes.Structure in carla-ppo_amd/mi355/lib.py) ---- */
 typedef struct MiVaeDesc {
-    int dtype;          /* MI_F32 | MI_BF16 */
+    int dtype;          /* MI_F32 | MI_BF16 | MI_BF16X3 */
     int max_batch;      /* largest per-GPU minibatch the workspace is sized for */
     int ih, iw, cin;    /* source frame shape (80,160,3) — NHWC */
     int ct;             /* target depth: 3 (rgb) or 1 (segmentation) */
@@ -148,7 +152,12 @@ int mi_vae_finalize_losses_flat(void* stream, const float* partial, int n_partia
 int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 /* same; alpha_dev != NULL: the step size is read from device memory (a captured step is replayed with a new value) */
 int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
+/* same; the shadow weight copy the MFMA kernels read is of storage type shadow_dtype: MI_BF16 (2 bytes per weight) or MI_BF16X3 (split, 4 bytes) */
+int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, int shadow_dtype, int clear_grad);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
+/* fp32 <-> split storage (dtype MI_BF16X3): word = bf16(x) << 16 | bf16(x - bf16(x)); back: hi + lo */
+int mi_cast_f32_to_split(void* stream, const float* src, void* dst, long long n);
+int mi_cast_split_to_f32(void* stream, const void* src, float* dst, long long n);
 /* raw uint8 frames -> float32(k) / float32(255), correctly rounded: the reference's host preprocessing (vae/train_vae.py:15-18) done on the device */
 int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n);
 /* K-contiguous copies of the [K,N] kernels for the MFMA B operand: dst[off + n*K + k] = (T) src[off + k*N + n], count <= 16 tensors */

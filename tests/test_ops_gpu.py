@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from hip_helpers import DT, P, assert_close, dev, host, rounded, stream, tols  # noqa: E402
+from hip_helpers import DT, DTS, P, X3, alloc, assert_close, dev, host, rounded, stream, tols  # noqa: E402
 from mi355 import lib as milib  # noqa: E402
 
 CONVS = [  # IH, IW, Cin, Cout, k
@@ -47,7 +47,7 @@ def _nhwc(a):
     return a.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("geom", CONVS)
 def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
     if kernels == "rwconv" and dt != "bf16":
@@ -78,16 +78,19 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
 
     xd = dev(x, torch.float32 if first else td)
     wd, bd = dev(w, td), dev(b)
-    out = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
+    out = alloc(td, B, OH, OW, Co)
     L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), P(dev(idx, torch.int32)) if first else None, int(first),
                          B, IH, IW, Ci, wd.data_ptr(), 0, bd.data_ptr(), k, k, Co, 1, out.data_ptr())
     rt, at = tols(dt, float(yref.abs().max()))
     assert_close(host(out), yref.detach().numpy(), rt, at, "conv fwd")
     # K-contiguous kernel copy made by mi_transpose_weights: same result through the conflict-free B staging
-    wt = torch.zeros(k * k * Ci * Co, device="cuda", dtype=td)
+    wt = alloc(td, k * k * Ci * Co, fill=0.0)
     offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Ci], np.int32), np.array([Co], np.int32)
     L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
-    assert torch.equal(wt.view(Co, k * k * Ci).cpu(), torch.from_numpy(w.reshape(-1, Co).T.copy()).to(td))
+    if td is X3:
+        assert np.array_equal(host(wt).reshape(Co, k * k * Ci), rounded(w.reshape(-1, Co).T.copy(), td).numpy())
+    else:
+        assert torch.equal(wt.view(Co, k * k * Ci).cpu(), torch.from_numpy(w.reshape(-1, Co).T.copy()).to(td))
     out2 = torch.empty_like(out)
     L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), P(dev(idx, torch.int32)) if first else None, int(first),
                          B, IH, IW, Ci, wt.data_ptr(), 1, bd.data_ptr(), k, k, Co, 1, out2.data_ptr())
@@ -98,11 +101,11 @@ def test_conv_fwd_dgrad_wgrad(dt, geom, kernels):
     idxd = dev(idx, torch.int32) if first else None
     L.mi_conv2d_nhwc_wgrad(stream(), code, xd.data_ptr(), idxd.data_ptr() if first else None, int(first), B, IH, IW, Ci,
                            dyd.data_ptr(), k, k, Co, dw.data_ptr())
-    rt, at = tols("f32" if dt == "f32" else "bf16", float(dwref.abs().max()))
-    assert_close(host(dw), dwref.numpy(), rt if dt == "f32" else 1e-4, at if dt == "f32" else 1e-4 * float(dwref.abs().max()), "conv wgrad")
+    rt, at = tols("f32" if dt != "bf16" else "bf16", float(dwref.abs().max()))
+    assert_close(host(dw), dwref.numpy(), rt if dt != "bf16" else 1e-4, at if dt != "bf16" else 1e-4 * float(dwref.abs().max()), "conv wgrad")
 
     if not first:                                        # conv1's input gradient is never needed
-        dx = torch.full((B, IH, IW, Ci), 7.0, device="cuda", dtype=td)
+        dx = alloc(td, B, IH, IW, Ci, fill=7.0)
         L.mi_conv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), k, k, Ci, IH, IW,
                                P(dev(mask, td)), dx.data_ptr())
         rt, at = tols(dt, float(dxref.abs().max()))
@@ -131,17 +134,17 @@ def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, wide, hw, b
         b = (0.1 * rng.randn(Co)).astype(np.float32)
         mask = rng.randn(B, OH, OW, Co).astype(np.float32)
         y = F.conv2d(_nchw(rounded(x, td)), rounded(w, td).permute(3, 2, 0, 1), torch.from_numpy(b).double(), stride=2)
-        wt = torch.zeros(k * k * Ci * Co, device="cuda", dtype=td)
+        wt = alloc(td, k * k * Ci * Co, fill=0.0)
         offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Ci], np.int32), np.array([Co], np.int32)
         L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
         xd, bd = dev(x, td), dev(b)
-        out = torch.full((B, OH, OW, Co), 3.0, device="cuda", dtype=td)
+        out = alloc(td, B, OH, OW, Co, fill=3.0)
         L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), None, 0, B, IH, IW, Ci, wt.data_ptr(), 1, bd.data_ptr(), k, k, Co, 1, out.data_ptr())
         yref = _nhwc(F.relu(y)).numpy()
         rt, at = tols("bf16", float(np.abs(yref).max()))
         assert_close(host(out), yref, rt, at, "conv-form fwd, bias + relu")
         # the same contraction as the input gradient of a transposed conv (deconv3.dgrad: no bias, ReluGrad mask): dY = x, weights [Cin_of_deconv = 64][k k 32]
-        dx = torch.full((B, OH, OW, Co), 3.0, device="cuda", dtype=td)
+        dx = alloc(td, B, OH, OW, Co, fill=3.0)
         L.mi_deconv2d_nhwc_dgrad(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wt.data_ptr(), 1, k, k, Co, P(dev(mask, td)), dx.data_ptr())
         y0 = F.conv2d(_nchw(rounded(x, td)), rounded(w, td).permute(3, 2, 0, 1), None, stride=2)
         dref = (_nhwc(y0) * (rounded(mask, td) > 0)).numpy()
@@ -152,7 +155,7 @@ def test_conv_form_register_weight_kernel_walks_runs_of_chunks(k, B, wide, hw, b
             L.mi_set_tuning(key, v)
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("geom", DECONVS)
 def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
     if kernels == "rwconv" and dt != "bf16":
@@ -180,30 +183,30 @@ def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
     dwref = wr.grad
 
     xd, wd, bd = dev(x, td), dev(w, td), dev(b)
-    out = torch.full((B, OH, OW, Co), 9.0, device="cuda", dtype=td)
+    out = alloc(td, B, OH, OW, Co, fill=9.0)
     L.mi_deconv2d_nhwc_fwd(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, int(relu), out.data_ptr())
     rt, at = tols(dt, float(yref.abs().max()))
     assert_close(host(out), yref.detach().numpy(), rt, at, "deconv fwd")
 
     dyd = dev(dy, td)
-    dx = torch.full((B, IH, IW, Ci), 5.0, device="cuda", dtype=td)
+    dx = alloc(td, B, IH, IW, Ci, fill=5.0)
     L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wd.data_ptr(), 0, k, k, Ci, P(dev(mask, td)), dx.data_ptr())
     rt, at = tols(dt, float(dxref.abs().max()))
     assert_close(host(dx), dxref.numpy(), rt, at, "deconv dgrad")
-    wt = torch.zeros(k * k * Co * Ci, device="cuda", dtype=td)
+    wt = alloc(td, k * k * Co * Ci, fill=0.0)
     offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
     L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
-    dx2 = torch.full((B, IH, IW, Ci), 5.0, device="cuda", dtype=td)
+    dx2 = alloc(td, B, IH, IW, Ci, fill=5.0)
     L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, P(dev(mask, td)), dx2.data_ptr())
     assert_close(host(dx2), dxref.numpy(), rt, at, "deconv dgrad (transposed kernel)")
 
     dw = torch.zeros(k, k, Co, Ci, device="cuda")
     L.mi_deconv2d_nhwc_wgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw.data_ptr())
     s = float(dwref.abs().max())
-    assert_close(host(dw), dwref.numpy(), 1e-5 if dt == "f32" else 1e-4, (2e-5 if dt == "f32" else 1e-4) * s, "deconv wgrad")
+    assert_close(host(dw), dwref.numpy(), 1e-5 if dt != "bf16" else 1e-4, (2e-5 if dt != "bf16" else 1e-4) * s, "deconv wgrad")
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 def test_conv_dgrad_into_larger_input(dt, kernels):
     """conv2 reads a 39x79 map but its VALID s2 windows never touch the last row/col: their gradient must be 0."""
     L = milib.get()
@@ -212,13 +215,13 @@ def test_conv_dgrad_into_larger_input(dt, kernels):
     B, IH, IW, Ci, Co, k = 2, 39, 79, 32, 64, 4
     dy = rng.randn(B, 18, 38, Co).astype(np.float32)
     w = rng.randn(k, k, Ci, Co).astype(np.float32) * 0.05
-    dx = torch.full((B, IH, IW, Ci), 3.0, device="cuda", dtype=td)
+    dx = alloc(td, B, IH, IW, Ci, fill=3.0)
     L.mi_conv2d_nhwc_dgrad(stream(), code, P(dev(dy, td)), B, 18, 38, Co, P(dev(w, td)), k, k, Ci, IH, IW, None, dx.data_ptr())
     g = host(dx)
     assert (g[:, 38] == 0).all() and (g[:, :, 78] == 0).all() and np.abs(g[:, :38, :78]).max() > 0
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape", [(5, 6144, 128, 0, 12), (5, 64, 6144, 0, 1), (5, 128, 6144, 1, 1), (7, 6144, 64, 1, 8),
                                    (32, 72, 500, 0, 1), (130, 500, 300, 0, 1), (32, 300, 2, 0, 1), (32, 300, 1, 0, 1),
                                    (33, 304, 504, 1, 1)])
@@ -243,7 +246,7 @@ def test_dense_gemm_variants(dt, shape):
         return
     ref = ref + torch.from_numpy(b).double()
     ref = F.relu(ref) * (rounded(mask, td) > 0)
-    out = torch.empty(M, N, device="cuda", dtype=td)
+    out = alloc(td, M, N)
     L.mi_gemm_bias_act(stream(), code, P(dev(a, td)), M, K, wd.data_ptr(), layout, N, P(dev(b)), 1, P(dev(mask, td)), out.data_ptr(), 0, 1)
     rt, at = tols(dt, float(ref.abs().max()))
     assert_close(host(out), ref.numpy(), rt, at, "gemm+bias+relu+mask")
@@ -254,7 +257,7 @@ def test_dense_gemm_variants(dt, shape):
     assert_close(host(out32), ref2.numpy(), 1e-5, 3e-5 * float(ref2.abs().max()), "gemm f32 out")
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape", [(6, 6144, 128), (6, 64, 6144), (40, 72, 500), (40, 500, 300), (40, 304, 2), (40, 304, 1), (2100, 64, 64)])
 def test_dense_wgrad(dt, shape):
     L = milib.get()
@@ -272,7 +275,7 @@ def test_dense_wgrad(dt, shape):
     assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 def test_reparam_kl_fwd_bwd(dt):
     L = milib.get()
     code, td = DT[dt]
@@ -291,7 +294,7 @@ def test_reparam_kl_fwd_bwd(dt):
     loss = (z * torch.from_numpy(dzs).double().sum(0)).sum() + beta * kl.mean()
     loss.backward()
     mean = torch.empty(B, Z, device="cuda"); logvar = torch.empty(B, Z, device="cuda")
-    zd = torch.empty(B, Z, device="cuda", dtype=td); klr = torch.empty(B, device="cuda")
+    zd = alloc(td, B, Z); klr = torch.empty(B, device="cuda")
     epsd = dev(eps)
     L.mi_vae_reparam_kl_fwd(stream(), code, P(dev(heads)), ns, P(dev(bm)), P(dev(bl)), epsd.data_ptr(), 1, B, Z,
                             mean.data_ptr(), logvar.data_ptr(), zd.data_ptr(), klr.data_ptr())
@@ -299,7 +302,7 @@ def test_reparam_kl_fwd_bwd(dt):
     assert_close(host(klr), kl.detach().numpy(), 1e-5, 1e-5, "kl rows")
     rt, at = tols(dt, float(z.abs().max()))
     assert_close(host(zd), z.detach().numpy(), rt, at, "z")
-    dh = torch.empty(B, 2 * Z, device="cuda", dtype=td)
+    dh = alloc(td, B, 2 * Z)
     L.mi_vae_reparam_kl_bwd(stream(), code, P(dev(dzs)), 2, mean.data_ptr(), logvar.data_ptr(), epsd.data_ptr(), klr.data_ptr(),
                             beta, tol, 1.0 / B, B, Z, dh.data_ptr())
     ref = torch.cat([mu.grad, lv.grad], 1).numpy()
@@ -318,7 +321,7 @@ def test_reparam_kl_fwd_bwd(dt):
     assert (g[below] == 0).all() and (np.abs(g[~below]).sum(1) > 0).all()
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Co,kind", [(3, 0), (3, 2), (1, 0), (1, 1)])
 def test_deconv_fwd_with_fused_reconstruction_loss(dt, Co, kind):
     """mi_deconv2d_nhwc_fwd_bce (deconv4 + loss in one kernel) against the float64 statement of the two reference ops
@@ -349,8 +352,8 @@ def test_deconv_fwd_with_fused_reconstruction_loss(dt, Co, kind):
     (per.sum() * inv_b).backward()
     cap = 4096
     lp, bp = torch.zeros(cap, device="cuda"), torch.zeros(cap, 4, device="cuda")
-    logits = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
-    dl = torch.empty(B, OH, OW, Co, device="cuda", dtype=td)
+    logits = alloc(td, B, OH, OW, Co)
+    dl = alloc(td, B, OH, OW, Co)
     n = ctypes.c_int(0)
     L.mi_deconv2d_nhwc_fwd_bce(stream(), code, P(dev(x, td)), B, IH, IW, Ci, P(dev(w, td)), P(dev(b)), k, k, Co, logits.data_ptr(),
                                P(dev(frames)), P(dev(idx, torch.int32)), OH * OW * Co, kind, inv_b, dl.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap,
@@ -359,7 +362,7 @@ def test_deconv_fwd_with_fused_reconstruction_loss(dt, Co, kind):
     assert 0 < n.value <= cap, "the 32 -> %d channel layer is eligible for the fused kernel" % Co
     rt, at = tols(dt, float(logits_ref.abs().max()))
     assert_close(host(logits), _nhwc(y).detach().numpy(), rt, at, "logits")
-    assert abs(float(lp[:n.value].double().sum()) / float(per.sum()) - 1) < (1e-5 if dt == "f32" else 3e-3)
+    assert abs(float(lp[:n.value].double().sum()) / float(per.sum()) - 1) < (1e-5 if dt != "bf16" else 3e-3)
     rt, at = tols(dt, float(logits_ref.grad.abs().max()))
     assert_close(host(dl), logits_ref.grad.numpy(), rt, at, "dlogits")
     bias_ref = logits_ref.grad.sum((0, 1, 2)).numpy()
@@ -367,7 +370,7 @@ def test_deconv_fwd_with_fused_reconstruction_loss(dt, Co, kind):
     assert_close(got, bias_ref, 2e-3 if dt == "bf16" else 1e-5, 2e-3 * float(np.abs(bias_ref).max()) + 1e-7, "fused bias gradient")
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_recon_loss_fwd_bwd(dt, kind):
     L = milib.get()
@@ -389,7 +392,7 @@ def test_recon_loss_fwd_bwd(dt, kind):
     (rows.sum() / 16.0).backward()                       # inv_batch = 1/16 (global batch under data parallelism)
     nch = L.mi_recon_loss_chunks(NP)
     partial = torch.zeros(B, nch, device="cuda")
-    dl = torch.empty(B, NP, device="cuda", dtype=td)
+    dl = alloc(td, B, NP)
     L.mi_bce_logits_fwd_bwd(stream(), code, P(dev(logits, td)), P(dev(frames)), P(dev(idx, torch.int32)), NP, B, NP, kind,
                             1.0 / 16.0, dl.data_ptr(), partial.data_ptr())
     assert_close(host(partial).sum(1), rows.detach().numpy(), 2e-6, 1e-3, "row losses")
@@ -430,7 +433,7 @@ def test_adam_tf_flat_bit_exact_vs_c_restatement():
     assert torch.equal(shadow[:n].cpu(), torch.from_numpy(pc).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("MN", [(3 * 12800, 3), (3 * 3081, 32), (1000, 64), (77, 256), (9, 6144), (40, 500), (40, 300), (40, 2), (40, 1), (5, 128)])
 def test_colsum(dt, MN):
     L = milib.get()
@@ -557,7 +560,7 @@ def test_relu_bit_words_producers_and_consumers():
         w = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)
         b = (0.1 * rng.randn(32)).astype(np.float32)
         wt = torch.from_numpy(w).permute(3, 0, 1, 2).reshape(32, -1).contiguous()
-        out = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        out = alloc(td, B, 39, 79, 32)
         bits = torch.zeros(B * 39 * 79 * 2, device="cuda", dtype=torch.int32)
         wrote = np.zeros(1, np.int32)
         L.mi_conv2d_nhwc_fwd_bits(stream(), code, P(dev(x)), None, 1, B, 80, 160, 3, P(dev(wt, td)), 1, P(dev(b)), 4, 4, 32, 1, out.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
@@ -568,7 +571,7 @@ def test_relu_bit_words_producers_and_consumers():
         # --- consumer 1: conv2 input gradient with those words == with the full mask
         dy = rng.randn(B, 18, 38, 64).astype(np.float32)
         w2 = (rng.randn(4, 4, 32, 64) / np.sqrt(512)).astype(np.float32)
-        dx_full = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        dx_full = alloc(td, B, 39, 79, 32)
         dx_bits = torch.empty_like(dx_full)
         dyd, w2d = dev(dy, td), dev(w2, td)
         L.mi_conv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, 18, 38, 64, w2d.data_ptr(), 4, 4, 32, 39, 79, out.data_ptr(), dx_full.data_ptr())
@@ -578,7 +581,7 @@ def test_relu_bit_words_producers_and_consumers():
         # --- producer 2: deconv3 forward 18x38x64 -> 39x79x32 (k5)
         x3 = np.maximum(rng.randn(B, 18, 38, 64), 0).astype(np.float32)
         w3 = (rng.randn(5, 5, 32, 64) / np.sqrt(25 * 64 / 4)).astype(np.float32)
-        o3 = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        o3 = alloc(td, B, 39, 79, 32)
         o3_ref = torch.empty_like(o3)
         bits3 = torch.zeros(B * 39 * 79 * 2, device="cuda", dtype=torch.int32)
         x3d, w3d, b3d = dev(x3, td), dev(w3, td), dev(b)
@@ -592,7 +595,7 @@ def test_relu_bit_words_producers_and_consumers():
         dl = rng.randn(B, 80, 160, 3).astype(np.float32)
         w4 = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)                      # [kh,kw,co=3,ci=32]
         w4t = torch.from_numpy(w4).permute(3, 0, 1, 2).reshape(32, -1).contiguous()          # [Cin][kh*kw*co]
-        g_full = torch.empty(B, 39, 79, 32, device="cuda", dtype=td)
+        g_full = alloc(td, B, 39, 79, 32)
         g_bits = torch.empty_like(g_full)
         dld, w4d = dev(dl, td), dev(w4t, td)
         L.mi_deconv2d_nhwc_dgrad(stream(), code, dld.data_ptr(), B, 80, 160, 3, w4d.data_ptr(), 1, 4, 4, 32, o3.data_ptr(), g_full.data_ptr())
@@ -601,3 +604,55 @@ def test_relu_bit_words_producers_and_consumers():
         assert torch.equal(g_full, g_bits) and float(g_full.float().abs().max()) > 0
     finally:
         L.mi_set_tuning(13, prev)
+
+
+def test_split_storage_casts_and_adam_shadow():
+    """Split storage (precision "bf16x3"): the device's split_from_f32 / split_to_f32 against their host restatement (hip_helpers.split_encode /
+    split_decode) bit for bit -- normal values over 60 binades, zeros, tiny values -- the representation error bound hi + lo = x (1 + 2^-17), and
+    the split shadow weights written by the fused Adam kernel."""
+    from hip_helpers import split_decode, split_encode
+    L = milib.get()
+    rng = np.random.RandomState(0)
+    n = 200003
+    x = (rng.randn(n) * 10.0 ** rng.uniform(-30, 30, n)).astype(np.float32)
+    x[:7] = [0.0, -0.0, 1.0, -1.0, 1e-30, 3.0e38, 255.0 / 256.0]
+    xs = torch.empty(n, device="cuda", dtype=torch.int32)
+    L.mi_cast_f32_to_split(stream(), P(dev(x)), xs.data_ptr(), n)
+    torch.cuda.synchronize()
+    assert np.array_equal(xs.cpu().numpy().view(np.uint32), split_encode(x))
+    back = torch.empty(n, device="cuda")
+    L.mi_cast_split_to_f32(stream(), xs.data_ptr(), back.data_ptr(), n)
+    got = host(back)
+    assert np.array_equal(got, split_decode(split_encode(x)).astype(np.float32).astype(np.float64))
+    big = np.abs(x) > 1e-30                                   # (the lo half of a value near the bottom of the fp32 range is subnormal in bf16)
+    assert np.abs(got[big] / x[big].astype(np.float64) - 1).max() <= 2.0 ** -16
+    # Adam: fp32 masters updated exactly as before, shadow = split(masters)
+    m4 = (n + 7) // 8 * 8
+    p, g = rng.randn(m4).astype(np.float32), rng.randn(m4).astype(np.float32)
+    buf = [dev(p), torch.zeros(m4, device="cuda"), torch.zeros(m4, device="cuda"), dev(g)]
+    ref = [dev(p), torch.zeros(m4, device="cuda"), torch.zeros(m4, device="cuda"), dev(g)]
+    shadow = torch.zeros(m4, device="cuda", dtype=torch.int32)
+    L.mi_adam_tf_flat_shadow(stream(), buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr(), buf[3].data_ptr(), n, 1e-3, None, 0.9, 0.999, 1e-8,
+                             shadow.data_ptr(), milib.MI_BF16X3, 1)
+    L.mi_adam_tf_flat(stream(), ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), ref[3].data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, None, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(buf[0], ref[0]) and torch.equal(buf[1], ref[1]) and torch.equal(buf[2], ref[2])
+    assert np.array_equal(shadow[:n].cpu().numpy().view(np.uint32), split_encode(buf[0][:n].cpu().numpy()))
+
+
+def test_split_storage_products_carry_sixteen_bits():
+    """What the split mode buys: a long dot product of UNROUNDED fp32 operands.  bf16 storage is ~2^-9 per operand, split storage ~2^-17: the
+    dense layer of the model's longest reduction (K = 6144) on fp32 inputs through each storage type against float64."""
+    L = milib.get()
+    rng = np.random.RandomState(5)
+    M, K, N = 64, 6144, 128
+    a, w = rng.randn(M, K).astype(np.float32), (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    err = {}
+    for dt in DTS:
+        code, td = DT[dt]
+        out = torch.empty(M, N, device="cuda")
+        L.mi_gemm_bias_act(stream(), code, P(dev(a, td)), M, K, P(dev(w, td)), 1, N, None, 0, None, out.data_ptr(), 1, 1)
+        err[dt] = float(np.abs(host(out) - ref).max() / np.abs(ref).max())
+    print("dense K = 6144, fp32 operands: max error / max |ref| by storage type:", err)
+    assert err["f32"] < 2e-6 and err["x3"] < 2e-5 and err["bf16"] > 20 * err["x3"], err

@@ -45,7 +45,7 @@ def trained_like_params(seed=0, target_c=3):
     return p
 
 
-@pytest.mark.parametrize("precision,storage,tol_loss,tol_grad", [("fp32", "fp32", 1e-4, 1e-4), ("bf16", "bf16", 2e-3, 3e-2)])
+@pytest.mark.parametrize("precision,storage,tol_loss,tol_grad", [("fp32", "fp32", 1e-4, 1e-4), ("bf16x3", "fp32", 1e-4, 1e-4), ("bf16", "bf16", 2e-3, 3e-2)])
 def test_train_step_losses_grads_and_adam(tmp_path, precision, storage, tol_loss, tol_grad):
     params = trained_like_params()
     B = 6
@@ -59,10 +59,10 @@ def test_train_step_losses_grads_and_adam(tmp_path, precision, storage, tol_loss
     got = m.dev.losses.cpu().numpy()
     assert abs(got[0] / recon - 1) < tol_loss and abs(got[1] / kl - 1) < max(tol_loss, 2e-3 if precision == "bf16" else 0), (got, recon, kl)
     mean = m.dev._view(1, B * 64).cpu().numpy().reshape(B, 64)
-    assert rel_err(mean, fw["mean"].numpy()) < (1e-4 if precision == "fp32" else 2e-2)
+    assert rel_err(mean, fw["mean"].numpy()) < (1e-4 if precision != "bf16" else 2e-2)
     m.dev.backward(src, None, e, 1.0 / B, 0)
     g = m.dev.export_grads()
-    if precision == "fp32":
+    if precision != "bf16":
         worst = {k: rel_err(g[k], grads[k]) for k in grads}
         bad = {k: v for k, v in worst.items() if v > tol_grad}
     else:
@@ -83,37 +83,38 @@ def test_train_step_losses_grads_and_adam(tmp_path, precision, storage, tol_loss
         ee = np.random.RandomState(100 + s).standard_normal((B, 64)).astype(np.float32)
         ro, ko = o.train_step(frames, frames, ee)
         rg, kg = m2.train_step(frames, frames, eps=ee)
-        assert abs(rg / ro - 1) < tol_loss * (1 if precision == "fp32" else 3), (s, rg, ro)
+        assert abs(rg / ro - 1) < tol_loss * (1 if precision != "bf16" else 3), (s, rg, ro)
     got_p = m2.dev.export_params()
     for k, v in o.params.items():
         # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE, not the value
         upd_ref, upd_got = v - params[k], got_p[k] - params[k]
-        frac_bad = np.mean(np.abs(upd_got - upd_ref) > (0.02 if precision == "fp32" else 0.5) * 3e-4)
-        assert frac_bad < (1e-3 if precision == "fp32" else 0.05), (k, frac_bad)
+        frac_bad = np.mean(np.abs(upd_got - upd_ref) > (0.02 if precision != "bf16" else 0.5) * 3e-4)
+        assert frac_bad < (1e-3 if precision == "fp32" else (5e-3 if precision == "bf16x3" else 0.05)), (k, frac_bad)
     assert m2.beta1_power == pytest.approx(0.9 ** 4, rel=1e-6)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 3e-2)])
 def test_encode_reconstruct_generate(tmp_path, precision, tol):
     params = trained_like_params(3)
     frames = synth_frames(5, seed=7)
-    o = vo.OracleVAE(params=params, training=False, storage="fp32" if precision == "fp32" else "bf16")
+    o = vo.OracleVAE(params=params, training=False, storage="fp32" if precision != "bf16" else "bf16")
     m = make(tmp_path, precision, params=params, training=False)
     assert rel_err(m.encode(frames), o.encode(frames)) < tol
     assert m.encode([frames[0]])[0].shape == (64,)                       # vae_common.py:48 call pattern
     rec, rec_o = m.reconstruct(frames), o.reconstruct(frames)
     assert len(rec) == 5 and rec[0].shape == (80, 160, 3)
-    assert np.abs(np.stack(rec) - np.stack(rec_o)).max() < (2e-5 if precision == "fp32" else 2e-2)
+    assert np.abs(np.stack(rec) - np.stack(rec_o)).max() < (2e-5 if precision != "bf16" else 2e-2)
     z = np.random.RandomState(0).standard_normal((3, 64)).astype(np.float32)
     g, g_o = m.generate_from_latent(z), o.generate_from_latent(z)
-    assert g.shape == (3, 38400) and np.abs(g - g_o).max() < (2e-5 if precision == "fp32" else 2e-2)
+    assert g.shape == (3, 38400) and np.abs(g - g_o).max() < (2e-5 if precision != "bf16" else 2e-2)
     assert np.array_equal(m.decode(z), g)
     with pytest.raises(ValueError):
         m.encode(frames * 1.5)                                           # verify_range
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("variant", ["seg", "kl_tol", "bce_v2", "mse"])
-def test_variants_fp32(tmp_path, variant):
+def test_variants_fp32(tmp_path, variant, precision):
     tc = 1 if variant == "seg" else 3
     params = trained_like_params(5, tc)
     B = 4
@@ -122,7 +123,7 @@ def test_variants_fp32(tmp_path, variant):
     eps = np.random.RandomState(9).standard_normal((B, 64)).astype(np.float32)
     kw = dict(beta=1.0, kl_tolerance=0.5 if variant == "kl_tol" else 0.0, loss_fn={"bce_v2": "bce_v2", "mse": "mse"}.get(variant, "bce"))
     (recon, kl, _), grads, _ = vo.vae_loss_and_grads(params, frames, tgt, eps, **kw)
-    m = make(tmp_path, "fp32", target_c=tc, params=params, kl_tolerance=kw["kl_tolerance"],
+    m = make(tmp_path, precision, target_c=tc, params=params, kl_tolerance=kw["kl_tolerance"],
              loss_fn={"bce": bce_loss, "bce_v2": bce_loss_v2, "mse": mse_loss}[kw["loss_fn"]])
     src = m._frames(frames, 38400, "src")
     tg = src if tc == 3 else m._frames(tgt, 12800, "tgt")
@@ -136,7 +137,8 @@ def test_variants_fp32(tmp_path, variant):
     assert not bad, bad
 
 
-def test_config1_epoch_evaluate_then_train_fp32(tmp_path):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_config1_epoch_evaluate_then_train_fp32(tmp_path, precision):
     """BASELINE config 1: 1k synthetic frames, val = first 10 %, batch 32: evaluate() then train_one_epoch() (28 steps),
     same legacy-numpy permutations and injected noise in oracle and HIP path -> identical epoch metrics (1e-4)."""
     N, bs = 1000, 32
@@ -153,7 +155,7 @@ def test_config1_epoch_evaluate_then_train_fp32(tmp_path):
     ov = o.evaluate(val, val, bs, lambda n: next(it))
     it = iter(eps_t)
     ot = o.train_one_epoch(train, train, bs, lambda n: next(it))
-    m = make(tmp_path, "fp32", params=params)
+    m = make(tmp_path, precision, params=params)
     np.random.seed(0)
     gv = m.evaluate(val, val, bs, eps=eps_v)
     m.train_one_epoch(train, train, bs, eps=eps_t)
@@ -199,7 +201,7 @@ def test_checkpoint_roundtrip_and_tf_names(tmp_path, golden_dir, fmt, monkeypatc
     assert m3.load_latest_checkpoint() is None
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_full_batch_properties_b512(tmp_path, precision):
     """Size-independent properties at BASELINE's full per-GPU batch (512): zero weights => logits 0 => recon = P*ln2,
     KL = 0, dlogits = (0.5 - y)/B exactly representable sums; one Adam step moves every deconv4 bias by exactly lr."""
@@ -224,7 +226,7 @@ def _dev_table(title, rows):
         print("  %-38s %s" % (k, v))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_b512_train_step_against_the_oracle(tmp_path, precision):
     """BASELINE configs[1] AT ITS BENCHMARKED SIZE (batch 512): one full SGD step -- forward losses, posterior mean, all 22 gradient tensors,
     TF-Adam update -- of the HIP path against the CPU oracle on the same seeded inputs (not against another HIP engine).
@@ -245,7 +247,7 @@ def test_b512_train_step_against_the_oracle(tmp_path, precision):
     params = trained_like_params()
     frames = synth_frames(B)
     eps = np.random.RandomState(4321).standard_normal((B, 64)).astype(np.float32)
-    storage = "fp32" if precision == "fp32" else "bf16"
+    storage = "fp32" if precision != "bf16" else "bf16"
     (recon, kl, _), grads, fw = vo.vae_loss_and_grads(params, frames, frames, eps, beta=1.0, storage=storage)
     m = make(tmp_path, precision, params=params)
     src = m._frames(frames, 38400, "src")
@@ -258,15 +260,18 @@ def test_b512_train_step_against_the_oracle(tmp_path, precision):
     d_recon, d_kl, d_mean = abs(got[0] / recon - 1), abs(got[1] / kl - 1), rel_err(mean, fw["mean"].numpy())
     worst = {k: rel_err(g[k], grads[k]) for k in grads}
     rows = [("reconstruction loss rel", "%.3e" % d_recon), ("kl loss rel", "%.3e" % d_kl), ("posterior mean / max", "%.3e" % d_mean)]
-    if precision == "fp32":
+    if precision != "bf16":
+        # bf16x3 (split storage, ~2^-17 per operand): the same statement as fp32 for losses and outputs (1e-4); its gradient floor is 5e-4 of the
+        # tensor max instead of 2e-4 (operand noise 2^-17 instead of 2^-24 moves more near-zero pre-activations across the ReLU threshold)
+        floor = 2e-4 if precision == "fp32" else 5e-4
         _, exact, _ = vo.vae_loss_and_grads(params, frames, frames, eps, beta=1.0, dtype=torch.float64)
         bad = {}
         for k in grads:
             e_dev, e_o32 = rel_err(g[k], exact[k]), rel_err(grads[k], exact[k])
             rows.append(("grad " + k, "dev-vs-exact %.3e  fp32-oracle-vs-exact %.3e  dev-vs-fp32-oracle %.3e" % (e_dev, e_o32, worst[k])))
-            if e_dev > max(2e-4, 2.0 * e_o32):
+            if e_dev > max(floor, 2.0 * e_o32):
                 bad[k] = (e_dev, e_o32)
-        _dev_table("B=512 fp32 HIP path vs the oracle (limits 1e-4 / 1e-4 / 1e-4 / max(2e-4, 2 x the fp32 oracle's own distance from float64)):", rows)
+        _dev_table("B=512 %s HIP path vs the oracle (limits 1e-4 / 1e-4 / 1e-4 / max(%.0e, 2 x the fp32 oracle's own distance from float64)):" % (precision, floor), rows)
         assert d_recon < 1e-4 and d_kl < 1e-4 and d_mean < 1e-4, rows[:3]
         assert not bad, bad
     else:
@@ -286,10 +291,10 @@ def test_b512_train_step_against_the_oracle(tmp_path, precision):
     adam.step(want, grads, 1e-4)
     m._adam_step()
     got_p = m.dev.export_params()
-    lim = (0.02 if precision == "fp32" else 0.5) * 1e-4
+    lim = (0.02 if precision == "fp32" else (0.05 if precision == "bf16x3" else 0.5)) * 1e-4
     frac = {k: float(np.mean(np.abs((got_p[k] - params[k]) - (want[k] - params[k])) > lim)) for k in want}
     _dev_table("fraction of weights whose Adam update differs by more than %.0e:" % lim, [(k, "%.2e" % v) for k, v in frac.items()])
-    assert max(frac.values()) < (5e-3 if precision == "fp32" else 0.05), frac
+    assert max(frac.values()) < (5e-3 if precision == "fp32" else (2e-2 if precision == "bf16x3" else 0.05)), frac
 
 
 def test_kernel_generations_agree_at_batch_512(tmp_path):
