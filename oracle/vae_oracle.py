@@ -268,26 +268,31 @@ class AdamTF:
     beta1=0.9, beta2=0.999, epsilon=1e-8 — "epsilon hat" form, NOT torch.optim.Adam's.
     """
 
-    def __init__(self, names_shapes, beta1=0.9, beta2=0.999, epsilon=1e-8):
-        self.b1, self.b2, self.eps = np.float32(beta1), np.float32(beta2), np.float32(epsilon)
-        self.m = OrderedDict((k, np.zeros(s, np.float32)) for k, s in names_shapes.items())
-        self.v = OrderedDict((k, np.zeros(s, np.float32)) for k, s in names_shapes.items())
-        self.beta1_power, self.beta2_power = np.float32(beta1), np.float32(beta2)
+    def __init__(self, names_shapes, beta1=0.9, beta2=0.999, epsilon=1e-8, dtype=np.float32):
+        # dtype=np.float64: the same recurrence without float32 rounding -- the "exact trajectory" the parity tests measure BOTH float32
+        # implementations (this oracle's and the device's) against
+        self.ft = ft = dtype
+        self.b1, self.b2, self.eps = ft(beta1), ft(beta2), ft(epsilon)
+        self.m = OrderedDict((k, np.zeros(s, ft)) for k, s in names_shapes.items())
+        self.v = OrderedDict((k, np.zeros(s, ft)) for k, s in names_shapes.items())
+        self.beta1_power, self.beta2_power = ft(beta1), ft(beta2)
 
     def alpha(self, lr):
-        one = np.float32(1.0)
-        return np.float32(np.float32(lr) * np.sqrt(one - self.beta2_power, dtype=np.float32) / (one - self.beta1_power))
+        ft = self.ft
+        one = ft(1.0)
+        return ft(ft(lr) * np.sqrt(one - self.beta2_power, dtype=ft) / (one - self.beta1_power))
 
     def step(self, params, grads, lr):
+        ft = self.ft
         a = self.alpha(lr)
-        one = np.float32(1.0)
+        one = ft(1.0)
         for k in self.m:
-            g = np.asarray(grads[k], np.float32)
+            g = np.asarray(grads[k], ft)
             self.m[k] += (g - self.m[k]) * (one - self.b1)
             self.v[k] += (g * g - self.v[k]) * (one - self.b2)
             params[k] -= (self.m[k] * a) / (np.sqrt(self.v[k]) + self.eps)
-        self.beta1_power = np.float32(self.beta1_power * self.b1)
-        self.beta2_power = np.float32(self.beta2_power * self.b2)
+        self.beta1_power = ft(self.beta1_power * self.b1)
+        self.beta2_power = ft(self.beta2_power * self.b2)
 
 
 class OracleVAE:

@@ -90,12 +90,37 @@ def test_config3_full_update_matches_oracle(tmp_path, epochs):
     assert m.get_train_step_idx() == 4 * epochs
     got = m.dev.export_params()
     p0 = make_pair(tmp_path)[0].params
+    # Where the two fp32 implementations differ after 16 Adam steps comes from fp32 rounding in BOTH of them (early Adam is sign-like: a last-bit
+    # gradient difference near zero moves a weight by up to 2 lr).  So both are measured against the SAME update run in float64 (losses, gradients and
+    # the Adam recurrence, identical minibatches): the device path must be no further from that exact trajectory than the fp32 oracle is -- factor 2
+    # on the per-tensor RMS of the update error, floor 0.02 % of the update scale (the fp32 oracle itself: ~4e-6) -- and likewise for the last minibatch loss.
+    import torch
+    from collections import OrderedDict
+    ex = OrderedDict((k, v.astype(np.float64)) for k, v in p0.items())
+    adam64 = po.AdamTF(OrderedDict((k, v.shape) for k, v in ex.items()), dtype=np.float64)
+    ex_old = {k.replace("policy/", "policy_old/", 1): torch.from_numpy(v.copy()) for k, v in ex.items()}      # update_old_policy() before the first step
+    t64 = lambda a: torch.from_numpy(np.asarray(a, np.float32).astype(np.float64))                            # noqa: E731  (inputs are rounded to f32 at the feed)
+    np.random.seed(0)
+    loss64 = None
+    for mb in po.minibatch_schedule(128, 32, epochs):
+        pt = OrderedDict((k, torch.from_numpy(v.copy()).requires_grad_(True)) for k, v in ex.items())
+        L64 = po.ppo_losses(pt, ex_old, t64(s_arr[mb]), t64(a_arr[mb]), t64(returns[mb]), t64(advantages[mb]), o.low, o.high, 0.2, 1.0, 0.01)
+        L64["loss"].backward()
+        adam64.step(ex, {k: v.grad.numpy() for k, v in pt.items()}, 1e-4)
+        loss64 = float(L64["loss"].detach())
+    rows = []
     for k, v in o.params.items():
-        upd_ref, upd_got = v - p0[k], got[k] - p0[k]
-        scale = max(np.abs(upd_ref).max(), 1e-12)
-        assert np.abs(upd_got - upd_ref).max() / scale < 2e-2, (k, np.abs(upd_got - upd_ref).max(), scale)
+        upd_x = ex[k] - p0[k].astype(np.float64)
+        e_o = np.sqrt(np.mean(((v.astype(np.float64) - p0[k]) - upd_x) ** 2))
+        e_d = np.sqrt(np.mean(((got[k].astype(np.float64) - p0[k]) - upd_x) ** 2))
+        scale = max(np.abs(upd_x).max(), 1e-12)
+        rows.append((k, e_d / scale, e_o / scale))
+        assert e_d <= 2.0 * e_o + 2e-4 * scale, (k, e_d / scale, e_o / scale)
+    print("\nPPO 16-step update, RMS update error / max |update| vs the float64 trajectory (device, fp32 oracle):")
+    for r in rows:
+        print("  %-34s %.3e  %.3e" % r)
     last_losses = m.dev.losses.cpu().numpy()
-    assert last_losses[3] == pytest.approx(logs[-1]["loss"], rel=2e-3, abs=1e-5)
+    assert abs(float(last_losses[3]) - loss64) <= 2.0 * abs(logs[-1]["loss"] - loss64) + 1e-5 * max(1.0, abs(loss64)), (float(last_losses[3]), logs[-1]["loss"], loss64)
 
 
 def test_partial_minibatch_and_predict_shapes(tmp_path):
