@@ -53,6 +53,7 @@ long long* g_trace = nullptr; int g_trace_cap = 0;
 int g_wgrad_skip = 0;
 int g_tap_mask_prefetch = 1;                                // tapconv: touch the ReluGrad-mask lines in the last main-loop step; mi_set_tuning key 12
 int g_gemm2_on = -1;
+int g_gemm2_tile = 2;                                       // wide-output gemm2 layers: 0 auto (64 x 64 tiles on small grids), 1 always 64 x 64, 2 never; mi_set_tuning key 17
 int g_tap_min = -2;
 bool gemm2_enabled() {
     if (g_gemm2_on < 0) { const char* e = getenv("MI355_GEMM2"); g_gemm2_on = (e && e[0] == '0') ? 0 : 1; }
@@ -69,6 +70,13 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
         dim3 g((M_for_grid + 127) / 128, 1, gz);
         hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
     } else {
+        if (g_gemm2_tile == 1 || (g_gemm2_tile == 0 && (long long)((M_for_grid + 127) / 128) * ((p.N + 63) / 64) * gz < 512)) {
+            // small grids (conv4 forward / deconv1 input gradient at batch 512: 96 x 4 tiles of 128 x 64 = 1.5 blocks per CU, each a serial chain of
+            // 32 latency-bound k-steps): 64 x 64 tiles double the blocks in flight (32 KB of LDS each: four resident per CU cover each other's waits)
+            dim3 g((M_for_grid + 63) / 64, (p.N + 63) / 64, gz);
+            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 64, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+            return mi_check_launch("gemm2_kernel");
+        }
         const int gx = (M_for_grid + 127) / 128;
         if ((long long)gx * ((p.N + 127) / 128) * gz >= 384) {
             dim3 g(gx, (p.N + 127) / 128, gz);
@@ -737,6 +745,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 14) { prev = g_tapwgrad_cw; g_tapwgrad_cw = value ? 1 : 0; }
     else if (key == 15) { prev = mi_rwconv_conv_mode(value < 0 ? 0 : value); }
     else if (key == 16) { prev = mi_rwconv_blocks(value < 0 ? 0 : value); }
+    else if (key == 17) { prev = g_gemm2_tile; g_gemm2_tile = value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }
