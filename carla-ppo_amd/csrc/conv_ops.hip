@@ -879,6 +879,61 @@ int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, i
     return MI_OK;
 }
 
+// The decoder tail of a training step in ONE launch (dectail_tile.hpp): deconv4 forward, the reconstruction loss on its logits, and the two gradients of
+// that layer -- dx = gradient wrt deconv3's pre-activation (ReluGrad mask = x itself), dw += filter gradient -- with logits and dlogits kept on chip.
+// w: kernel [kh,kw,out,in]; w_t: its K-contiguous copy [in][kh*kw*out] (mi_transpose_weights); loss / bias partial sums per block as
+// mi_deconv2d_nhwc_fwd_bce.  scratch: >= mi_deconv2d_tail_blocks() * 6144 bytes.  *n_partial = blocks written, or 0 when the layer is not eligible
+// (bf16, 32 -> 3 channels, k = 4; nothing was launched: use the separate ops).
+static int dectail_grid(int fast) {
+    static int resident[2];
+    if (!resident[fast]) {
+        int per_cu = 0, dev = 0, cus = 256;
+        hipDeviceProp_t pr;
+        const void* fn = fast ? (const void*)dectail_kernel<true> : (const void*)dectail_kernel<false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        resident[fast] = per_cu * cus;
+    }
+    return resident[fast];
+}
+int mi_deconv2d_tail_blocks(void) { const int a = dectail_grid(0), b = dectail_grid(1); return a > b ? a : b; }
+
+int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const void* w_t, const float* bias, int KH, int KW, int Cout,
+                           const void* labels, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch,
+                           void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes) {
+    if (!n_partial || !labels || !loss_partial || !bias_partial || !x || !w || !w_t || !dx || !dw) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_fused: missing buffers");
+    *n_partial = 0;
+    if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_fused: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_DECTAIL"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || !narrow_enabled() || dtype != MI_BF16 || Cin != 32 || Cout != 3 || KH != 4 || KW != 4 || B < 1 || IH < 1 || IW < 1) return MI_OK;
+    if (((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)w_t) | ((uintptr_t)dx) | ((uintptr_t)scratch) | ((uintptr_t)dw)) & 15) || !scratch) return MI_OK;
+    if (labels_u8 ? false : ((((uintptr_t)labels) & 3) != 0)) return MI_OK;
+    DecTailParams q = {};
+    q.x = (const bf16_t*)x; q.B = B; q.IH = IH; q.IW = IW; q.w = (const bf16_t*)w; q.wt = (const bf16_t*)w_t; q.bias = bias;
+    q.labels = labels; q.lab_u8 = labels_u8 ? 1 : 0; q.lab_idx = frame_idx; q.lab_stride = label_stride; q.loss_kind = loss_kind; q.inv_b = inv_batch;
+    q.dx = (bf16_t*)dx; q.lpart = loss_partial; q.bpart = bias_partial;
+    q.OH = 2 * IH + 2; q.OW = 2 * IW + 2; q.GH = IH + 1; q.GW = IW + 1;
+    const int tiles_y = (q.GH + DT_TY - 1) / DT_TY;
+    q.tiles_x = (q.GW + DT_TX - 1) / DT_TX; q.tiles_per_frame = tiles_y * q.tiles_x;
+    const long long ntiles = (long long)B * q.tiles_per_frame;
+    if (ntiles >= (1ll << 30) || (long long)B * q.OH * q.OW * 3 >= (1ll << 40)) return MI_OK;
+    q.ntiles = (int)ntiles; q.div_tpf = make_fastdiv(q.tiles_per_frame); q.div_tx = make_fastdiv(q.tiles_x);
+    const int fast = loss_kind == 0 ? 1 : 0;
+    int nblocks = dectail_grid(fast);
+    if (nblocks > q.ntiles) nblocks = q.ntiles;
+    if (nblocks > partial_capacity || scratch_bytes < (long long)nblocks * DT_SLAB * 4) return MI_OK;
+    q.slabs = (float*)scratch;
+    if (fast) hipLaunchKernelGGL(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    int rc = mi_check_launch("dectail_kernel");
+    if (rc != MI_OK) return rc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(DT_SLAB, nblocks), dim3(256), 0, (hipStream_t)stream, q.slabs, (long long)DT_SLAB, nblocks, (long long)DT_SLAB, dw);
+    rc = mi_check_launch("reduce_slabs_kernel");
+    if (rc == MI_OK) *n_partial = nblocks;
+    return rc;
+}
+
 // conv2d_transpose input gradient = plain stride-2 conv of dy with the same kernel read as HWIO [kh,kw,I=co,O=ci]
 // w_transposed = 1: w holds the kernel as [Cin][KH*KW*Cout]
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout,

@@ -13,6 +13,8 @@
 //                    narrow_wgrad_kernel       filter gradient of the layers with a 1..3-channel side (conv1, deconv4)
 //                    narrow_conv_kernel        conv from a 1..3-channel tensor into 32 channels (conv1 fwd, deconv4 dgrad)
 //
+//   dectail_tile.hpp dectail_kernel            deconv4 forward + reconstruction loss + its input and filter gradients in one launch (round 3)
+//
 // Launchers (C ABI) live in conv_ops.hip.
 #pragma once
 #include "gemm_tile.hpp"
@@ -21,3 +23,4 @@
 #include "wgrad_tile.hpp"
 #include "tapwgrad_tile.hpp"
 #include "narrow_tile.hpp"
+#include "dectail_tile.hpp"

@@ -113,6 +113,7 @@ struct VaeEngine {
     int ns_heads, ns_dz, nchunks, partial_cap;
     int last_B;
     int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
+    int tail_fused;                     // ... and (decoder tail in one launch, dectail_tile.hpp) deconv4's filter gradient and deconv3's output gradient
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
@@ -361,11 +362,23 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
         return mi_fail(MI_ERR_STATE, "mi_vae_forward(want_grad=1): the previous forward's gradient was never consumed by mi_vae_backward "
                                      "(its deconv4 bias gradient is already in the gradient buffer)");
     e->b4_fused = fuse_b4 ? 1 : 0;
-    // decoder tail: deconv4 with the reconstruction loss fused into its epilogue where the narrow kernel is eligible (logits are still written)
-    CK(run_decoder(e, stream, B, 3, want_grad));
+    // decoder tail.  Training pass, bf16, rgb target: ONE launch computes deconv4, the loss, deconv4's filter gradient (straight into the gradient
+    // buffer) and the gradient of deconv3's output (dectail_tile.hpp): dlogits never exist in HBM, deconv3's output is read once instead of three
+    // times, and the backward pass starts at deconv3.  Otherwise: deconv4 with the loss fused into its epilogue (dlogits written), or the plain ops.
+    static int tail_on = -1;
+    if (tail_on < 0) { const char* ev = getenv("MI355_DECTAIL"); tail_on = (ev && ev[0] == '0') ? 0 : 1; }
+    const bool tail_try = tail_on && want_grad && e->grads && d.dtype == MI_BF16 && d.ct == 3 && g.dc[3] == 32 && DEC_K[3] == 4 && e->W.scratch_bytes > 0;
+    e->tail_fused = 0;
+    CK(run_decoder(e, stream, B, 3, want_grad && !tail_try));
     int nblk = 0;
-    // (the fused form never stores the logits: only the loss partial sums and dlogits leave the kernel)
-    TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce_u8(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
+    if (tail_try) {
+        TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
+                                           tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, e->at(e->W.gdec[3]), e->gptr(18),
+                                           (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk, e->at(e->W.scratch), e->W.scratch_bytes / SCRATCH_REGIONS));
+        if (nblk > 0) e->tail_fused = 1;
+    }
+    // (the fused forms never store the logits: only the loss partial sums and dlogits / the gradients leave the kernel)
+    if (nblk == 0) TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce_u8(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                             nullptr, tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, want_grad ? e->at(e->W.gdec[4]) : nullptr,
                                             (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk));
     if (nblk > 0) {
@@ -432,6 +445,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     struct DeferGuard { bool on; ~DeferGuard() { if (on) mi_tapwgrad_defer(0); } } guard{defer};
     if (part == 0 || part == 1) {
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
+            if (i == 3 && e->tail_fused) continue;           // deconv4's two gradients were computed by the forward pass's decoder-tail kernel
             const void* gy = e->at(W.gdec[i + 1]);
             release();                                       // gy is complete on st (loss pass / previous input gradient)
             // BiasAddGrad is fused into the filter-gradient call
@@ -439,7 +453,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
         }
-        e->b4_fused = 0;
+        e->b4_fused = 0; e->tail_fused = 0;
         // dense1: h = z W1 + b1
         release();
         TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));

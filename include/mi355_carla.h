@@ -116,6 +116,14 @@ int mi_deconv2d_nhwc_fwd(void* stream, int dtype, const void* x, int B, int IH, 
 int mi_deconv2d_nhwc_fwd_bce(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, void* logits, const float* labels, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial);
 /* same; labels_u8 != 0: labels are raw uint8 frames (label_stride in bytes), normalised to exactly float32(k) / float32(255) in registers; logits == NULL: the logits are not stored */
 int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const float* bias, int KH, int KW, int Cout, void* logits, const void* labels_any, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dlogits, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial);
+/* The decoder tail of a TRAINING step in one launch (round 3): conv2d_transpose into the 3-channel logits (vae/models.py:264), the reconstruction loss of
+ * vae/models.py:11-22,123-128, and both gradients of that layer behind tf.gradients (vae/models.py:142: Conv2D of dlogits + ReluGrad -> dx, the gradient
+ * wrt the previous layer's pre-activation; Conv2DBackpropFilter -> dw +=) -- logits and dlogits never leave the chip.  x: [B,IH,IW,32] (post-ReLU: it is
+ * its own ReluGrad mask); w: [kh,kw,out,in]; w_t: the K-contiguous copy [in][kh*kw*out]; labels as mi_deconv2d_nhwc_fwd_bce_u8; loss_partial[] /
+ * bias_partial[][4] per block as there; scratch >= mi_deconv2d_tail_blocks() * 6144 bytes.  *n_partial = blocks written, or 0 when the layer is not
+ * eligible (bf16 storage, 32 -> 3 channels, k = 4 only; nothing was launched: use the separate ops). */
+int mi_deconv2d_tail_blocks(void);
+int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const void* w_t, const float* bias, int KH, int KW, int Cout, const void* labels, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */

@@ -657,3 +657,62 @@ def test_split_storage_products_carry_sixteen_bits():
     print("dense K = 6144, fp32 operands: max error / max |ref| by storage type:", err)
     # measured on MI355X: fp32 2.5e-6 (K = 6144 fmaf chain), split 3.2e-6, bf16 1.9e-3
     assert err["f32"] < 6e-6 and err["x3"] < 2e-5 and err["bf16"] > 50 * err["x3"], err
+
+
+@pytest.mark.parametrize("kind,u8", [(0, True), (0, False), (1, True), (2, False)])
+@pytest.mark.parametrize("B,IH,IW", [(3, 39, 79), (2, 7, 15), (1, 10, 33)])
+def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
+    """mi_deconv2d_tail_fused (deconv4 forward + loss + its input gradient + its filter gradient in one launch, dectail_tile.hpp) against the three
+    separately validated ops it replaces (mi_deconv2d_nhwc_fwd_bce_u8, mi_deconv2d_nhwc_dgrad with the activation as ReluGrad mask,
+    mi_deconv2d_nhwc_wgrad) on the model's geometry and on two ragged ones (tiles of 8 x 16 pixels that overhang the image, a single tile row):
+    the input gradient bit for bit (same summation order), loss and bias-gradient sums to fp32 summation order, the filter gradient to 1e-5 of its
+    max; the gradient buffer is ACCUMULATED into."""
+    import ctypes
+    L = milib.get()
+    code, td = DT["bf16"]
+    Ci, Co, k = 32, 3, 4
+    OH, OW = 2 * IH + 2, 2 * IW + 2
+    rng = np.random.RandomState(B * 100 + IH + kind)
+    x = np.maximum(rng.randn(B, IH, IW, Ci), 0).astype(np.float32)                       # post-ReLU activations (about half of them zero)
+    w = (rng.randn(k, k, Co, Ci) / np.sqrt(4 * Ci)).astype(np.float32)
+    b = (0.1 * rng.randn(Co)).astype(np.float32)
+    n_frames = B + 2
+    frames_u8 = rng.randint(0, 256, (n_frames, OH * OW * Co)).astype(np.uint8)
+    idx = rng.permutation(n_frames)[:B].astype(np.int32)
+    labels = dev(frames_u8, torch.uint8) if u8 else dev(frames_u8.astype(np.float32) / 255.0)
+    inv_b = 1.0 / 16.0
+    xd, wd, bd, idxd = dev(x, td), dev(w, td), dev(b), dev(idx, torch.int32)
+    wt = torch.zeros(k * k * Co * Ci, device="cuda", dtype=td)
+    offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
+    L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+    cap = 16384
+    # --- the three ops ---
+    lp, bp = torch.zeros(cap, device="cuda"), torch.zeros(cap, 4, device="cuda")
+    dl = alloc(td, B, OH, OW, Co, fill=0.0)
+    n = ctypes.c_int(0)
+    L.mi_deconv2d_nhwc_fwd_bce_u8(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, None, labels.data_ptr(), int(u8), idxd.data_ptr(),
+                                  OH * OW * Co, kind, inv_b, dl.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap, ctypes.addressof(n))
+    torch.cuda.synchronize()
+    assert n.value > 0
+    loss_ref = float(lp[:n.value].double().sum()); bias_ref = bp[:n.value, :Co].double().sum(0).cpu().numpy()
+    dx_ref = alloc(td, B, IH, IW, Ci, fill=3.0)
+    L.mi_deconv2d_nhwc_dgrad(stream(), code, dl.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, xd.data_ptr(), dx_ref.data_ptr())
+    dw_ref = torch.zeros(k, k, Co, Ci, device="cuda")
+    L.mi_deconv2d_nhwc_wgrad(stream(), code, dl.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw_ref.data_ptr())
+    # --- one launch ---
+    nb = L.mi_deconv2d_tail_blocks()
+    scratch = torch.empty(nb * 6144, device="cuda", dtype=torch.uint8)
+    lp2, bp2 = torch.zeros(cap, device="cuda"), torch.zeros(cap, 4, device="cuda")
+    dx = alloc(td, B, IH, IW, Ci, fill=5.0)
+    dw = torch.full((k, k, Co, Ci), 0.25, device="cuda")
+    n2 = ctypes.c_int(0)
+    L.mi_deconv2d_tail_fused(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), wt.data_ptr(), bd.data_ptr(), k, k, Co, labels.data_ptr(), int(u8), idxd.data_ptr(),
+                             OH * OW * Co, kind, inv_b, dx.data_ptr(), dw.data_ptr(), lp2.data_ptr(), bp2.data_ptr(), cap, ctypes.addressof(n2), scratch.data_ptr(), scratch.numel())
+    torch.cuda.synchronize()
+    assert 0 < n2.value <= nb
+    assert abs(float(lp2[:n2.value].double().sum()) / loss_ref - 1) < 2e-6
+    got_b = bp2[:n2.value, :Co].double().sum(0).cpu().numpy()
+    assert_close(got_b, bias_ref, 1e-5, 1e-5 * float(np.abs(bias_ref).max()) + 1e-7, "bias gradient sums")
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), float((dx.float() - dx_ref.float()).abs().max())
+    s = float(dw_ref.abs().max())
+    assert_close(host(dw) - 0.25, host(dw_ref), 1e-5, 2e-5 * s, "filter gradient")
