@@ -908,7 +908,8 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     if (on < 0) { const char* e = getenv("MI355_DECTAIL"); on = (e && e[0] == '0') ? 0 : 1; }
     if (!on || !narrow_enabled() || dtype != MI_BF16 || Cin != 32 || Cout != 3 || KH != 4 || KW != 4 || B < 1 || IH < 1 || IW < 1) return MI_OK;
     if (((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)w_t) | ((uintptr_t)dx) | ((uintptr_t)scratch) | ((uintptr_t)dw)) & 15) || !scratch) return MI_OK;
-    if (labels_u8 ? false : ((((uintptr_t)labels) & 3) != 0)) return MI_OK;
+    // the label tile is staged in 4-value items: rows of 3 OW values must be a whole number of items, frames 4-byte (uint8) / 16-byte (fp32) aligned
+    if ((3 * (2 * IW + 2)) % 4 != 0 || label_stride % 4 != 0 || (((uintptr_t)labels) & (labels_u8 ? 3 : 15))) return MI_OK;
     DecTailParams q = {};
     q.x = (const bf16_t*)x; q.B = B; q.IH = IH; q.IW = IW; q.w = (const bf16_t*)w; q.wt = (const bf16_t*)w_t; q.bias = bias;
     q.labels = labels; q.lab_u8 = labels_u8 ? 1 : 0; q.lab_idx = frame_idx; q.lab_stride = label_stride; q.loss_kind = loss_kind; q.inv_b = inv_batch;

@@ -33,6 +33,8 @@ constexpr int DT_DLBYTES = (2 * DT_TY + 2) * DT_DLPITCH;  // 3672
 constexpr int DT_XS = DT_NPIX * 64;                       // 11520: staged input pixels, 64 bytes each (32 bf16 channels), chunk-swizzled
 constexpr int DT_PT = 32 * 128;                           // per wave: transposed-read tile of its 32 patches, 64 columns (48 used)
 constexpr int DT_SLAB = 48 * 32;                          // floats of dW per block
+constexpr int DT_LBC = 104;                               // label tile: 18 rows x 102 values (34 pixels x 3) as fp32, 104-float pitch
+constexpr int DT_LBBYTES = (2 * DT_TY + 2) * DT_LBC * 4;  // 7488
 
 struct DecTailParams {
     const bf16_t* x; int B, IH, IW;                      // deconv3's output [B, IH, IW, 32] (post-ReLU)
@@ -48,11 +50,14 @@ struct DecTailParams {
     FastDiv div_tpf, div_tx;
 };
 
+// block barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)), which would make the
+// software prefetch of the next tile wait at the first barrier it meets
+__device__ __forceinline__ void dt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int dt_swz(int q) { return (q >> 2) & 3; }      // 64-byte rows read by 32 consecutive rows (gn_swz<4>)
 
 template <bool FASTBCE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dectail_kernel(const DecTailParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[DT_XS + 4 * DT_PT + 3840 + 4 * 12 * 64];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[DT_XS + 4 * DT_PT + 3840 + 4 * 13 * 64 + DT_LBBYTES];
     unsigned char* const xs = lds;                        // staged input pixels
     unsigned char* const pt = lds + DT_XS;                // 4 wave-private patch tiles (the cross-wave reduction at the very end reuses them)
     unsigned char* const dl = lds + DT_XS + 4 * DT_PT;    // dlogits tile (+ 16 floats of block reduction behind it)
@@ -66,14 +71,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // ---- per block, once: the forward weights into LDS as [tap][row ne = class * 3 + channel (12 live rows)][32 channels] (3 KB: in registers they
     // cost 32 VGPRs, which at three waves per SIMD spilled); the input-gradient weights (12 VGPRs) stay in registers ----
     unsigned char* const wl = dl + 3840;
-    if (tid < 4 * 12 * 4) {
-        const int tap = tid / 48, rem = tid - tap * 48, ne = rem >> 2, ch = rem & 3;
+    if (tid < 4 * 13 * 4) {                               // row 12 of every tap is all zero: lanes 12 .. 31 of the MFMA's A operand read it
+        const int tap = tid / 52, rem = tid - tap * 52, ne = rem >> 2, ch = rem & 3;
         const int cls = ne / 3, n = ne - cls * 3;
         const int kh = (cls >> 1) + 2 * (1 - (tap >> 1)), kw = (cls & 1) + 2 * (1 - (tap & 1));
-        *(f32x4*)(wl + (tap * 12 + ne) * 64 + ch * 16) = *(const f32x4*)(p.w + ((kh * 4 + kw) * 3 + n) * 32 + ch * 8);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ne < 12) v = *(const f32x4*)(p.w + ((kh * 4 + kw) * 3 + n) * 32 + ch * 8);
+        *(f32x4*)(wl + (tap * 13 + ne) * 64 + ch * 16) = v;
     }
-    const bool wrow_ok = lrow < 12;
-    const int wrow = wrow_ok ? lrow : 0;
+    float* const lab = (float*)(wl + 4 * 13 * 64);        // the tile's labels as fp32 (a global byte load per logit made the loss loop a chain of memory latencies)
+    const int wrow = lrow < 12 ? lrow : 12;
     // input gradient: MFMA step s, row ci = lrow, this half-wave's 8 k (narrow_conv48_kernel's layout)
     u16x8 wtf[3];
 #pragma unroll
@@ -95,32 +102,101 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int tg = lane >> 4, tc = lane & 15;
     const int trow = (tg >> 1) * 8 + (tc >> 2), tcol = (tg & 1) * 16 + (tc & 3) * 4;
 
+    // The staged data of a tile -- 720 sixteen-byte chunks of input pixels (3 per thread), 468 four-value label items (2 per thread) -- is REQUESTED one
+    // tile ahead: the loads of tile t + 1 are issued right after the barrier that publishes tile t and land under its three phases (a block that stages,
+    // waits, computes was a chain of one HBM latency per tile: with three blocks per CU that was half the kernel).  Per-thread roles are fixed:
+    int sq[3], spc[3]; bool sin3[3];                       // input chunk i: tile pixel, physical chunk
+    int lr[2], ld4[2]; bool lin2[2];                       // label item i: tile row, item
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int id = tid + 256 * i; sin3[i] = id < DT_NPIX * 4; sq[i] = sin3[i] ? id >> 2 : 0; spc[i] = id & 3; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int id = tid + 256 * i; lin2[i] = id < (2 * DT_TY + 2) * (DT_LBC / 4); lr[i] = lin2[i] ? id / (DT_LBC / 4) : 0; ld4[i] = lin2[i] ? id - lr[i] * (DT_LBC / 4) : 0; }
+    // the label frame of a tile (minibatch gather): looked up TWO tiles ahead, so that the requests of the next tile never wait for it
+    // (kept in a VECTOR register on purpose -- `vzero` is 0 in every lane but divergent to the compiler: a uniform value is moved to a scalar
+    //  register with v_readfirstlane right behind its load, i.e. behind an s_waitcnt vmcnt(0) that would also drain the prefetch just issued)
+    const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
+    auto frame_of = [&](int tile) -> int { const int b = (int)p.div_tpf.div((uint32_t)tile) + vzero; return p.lab_idx ? p.lab_idx[b] : b; };
+    struct Staged { f32x4 x[3]; f32x4 l[2]; uint32_t ok; };   // (uint8 labels: the raw dword travels in l[i][0]); ok: bit i = item i lies inside the tensors
+    // Branch-free: an item outside the image / the frame reads a valid address anyway (the tensor base) and is zeroed when it is committed.  With
+    // exec-masked loads the compiler loses count of what is in flight and falls back to s_waitcnt vmcnt(0) -- which drains the prefetch.
+    auto request = [&](int tile, int frame, Staged& R) {
+        uint32_t b, rem, ty, tx;
+        p.div_tpf.divmod((uint32_t)tile, b, rem);
+        p.div_tx.divmod(rem, ty, tx);
+        const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
+        const long long fr = frame;                        // (its load was issued one tile ago: the only wait in front of the five requests below)
+        const bf16_t* xb = p.x + (long long)b * p.IH * p.IW * 32;
+        uint32_t ok = 0;
+        // labels of the 18 x 34 output pixels the tile's slots cover: row r = output row 2 y0 + r, 102 consecutive values from column 2 x0 (4 values per
+        // item; whole items only: the host guarantees 3 OW % 4 == 0, so a row's valid part ends on an item boundary; the rest reads 0)
+        const unsigned char* lsrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = 2 * y0 + lr[i], j0 = 6 * x0 + 4 * ld4[i];      // value offset inside the output row
+            const bool in = lin2[i] && oy < p.OH && j0 + 4 <= 3 * p.OW;
+            ok |= in ? 8u << i : 0u;
+            const long long off = in ? fr * p.lab_stride + (long long)oy * (3 * p.OW) + j0 : 0ll;
+            lsrc[i] = (const unsigned char*)p.labels + off * (p.lab_u8 ? 1 : 4);
+        }
+        const bf16_t* xsrc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = sq[i] / DT_PC, c = sq[i] - r * DT_PC;
+            const int y = y0 - 1 + r, x = x0 - 1 + c;
+            const bool in = sin3[i] && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+            ok |= in ? 1u << i : 0u;
+            const int lc = spc[i] ^ dt_swz(sq[i]);        // the logical chunk that lives in this physical one
+            xsrc[i] = in ? xb + ((long long)y * p.IW + x) * 32 + lc * 8 : p.x;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) R.x[i] = *(const f32x4*)xsrc[i];
+        if (p.lab_u8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) R.l[i][0] = __builtin_bit_cast(float, *(const uint32_t*)lsrc[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) R.l[i] = *(const f32x4*)lsrc[i];
+        }
+        R.ok = ok;
+    };
+    auto commit = [&](const Staged& R) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            f32x4 v = R.x[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (R.ok >> i) & 1u ? v[e] : 0.f;
+            if (sin3[i]) *(f32x4*)(xs + sq[i] * 64 + spc[i] * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v = R.l[i];
+            if (p.lab_u8) {
+                const uint32_t u = __builtin_bit_cast(uint32_t, (float)R.l[i][0]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = u8_to_unit_exact((float)((u >> (8 * e)) & 255u));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (R.ok >> (3 + i)) & 1u ? v[e] : 0.f;
+            if (lin2[i]) *(f32x4*)(lab + lr[i] * DT_LBC + 4 * ld4[i]) = v;
+        }
+    };
+    Staged cur;
+    int t_nxt = min((int)blockIdx.x + (int)gridDim.x, p.ntiles - 1);     // (past the end: a valid tile is requested again -- no branch around the loads)
+    int fr_req = frame_of((int)blockIdx.x);
+    request((int)blockIdx.x, fr_req, cur);
+    fr_req = frame_of(t_nxt);
     for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
         uint32_t b, rem, ty, tx;
         p.div_tpf.divmod((uint32_t)tile, b, rem);
         p.div_tx.divmod(rem, ty, tx);
         const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
-        const bf16_t* xb = p.x + (long long)b * p.IH * p.IW * 32;
-
-        // ---- stage the (TY + 2) x (TX + 2) input pixels around the tile: 720 sixteen-byte chunks, zero outside the image ----
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int id = tid + 256 * i;
-            if (id < DT_NPIX * 4) {
-                const int q = id >> 2, pc = id & 3;       // tile pixel, PHYSICAL chunk
-                const int r = q / DT_PC, c = q - r * DT_PC;
-                const int y = y0 - 1 + r, x = x0 - 1 + c;
-                const bool in = y >= 0 && y < p.IH && x >= 0 && x < p.IW;
-                const int lc = pc ^ dt_swz(q);            // the logical chunk that lives there
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (in) v = *(const f32x4*)(xb + ((long long)y * p.IW + x) * 32 + lc * 8);
-                *(f32x4*)(xs + q * 64 + pc * 16) = v;
-            }
-        }
+        commit(cur);
         __syncthreads();
+        request(t_nxt, fr_req, cur);
+        t_nxt = min(t_nxt + (int)gridDim.x, p.ntiles - 1);
+        fr_req = frame_of(t_nxt);
 
         // ---- phase 1: logits of the 9 x 17 slots, loss, dlogits into the LDS tile ----
-        const long long fr = p.lab_idx ? (long long)p.lab_idx[b] : (long long)b;
         for (int g = wave; g * 32 < DT_NSLOT; g += 4) {
             const int sidx = min(g * 32 + lrow, DT_NSLOT - 1);
             const bool sv = g * 32 + lrow < DT_NSLOT;
@@ -135,60 +211,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const u16x8 af = *(const u16x8*)(xs + q * 64 + (((2 * kk + lgrp) ^ sw) << 4));
-                    u32x4 wv = *(const u32x4*)(wl + (tap * 12 + wrow) * 64 + (2 * kk + lgrp) * 16);      // rows >= 12 of the MFMA's A operand are zero
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) wv[e] = wrow_ok ? wv[e] : 0u;
+                    const u32x4 wv = *(const u32x4*)(wl + (tap * 13 + wrow) * 64 + (2 * kk + lgrp) * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
                 }
             }
-            // D rows: register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h; rows 0 .. 11 = class * 3 + channel are live:
-            // h = 0: registers 0..3 (rows 0..3) and 4..7 (rows 8..11); h = 1: registers 0..3 (rows 4..7)
+            // D rows: register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h; rows 0 .. 11 = class * 3 + channel are live: h = 0 holds rows 0..3
+            // (registers 0..3) and 8..11 (registers 4..7), h = 1 rows 4..7 (registers 0..3).  Four half-wave swaps give every lane ONE output row of its
+            // slot -- h = 0: rows 0..5 = output row 2 sy (pixels 2 sx, 2 sx + 1 x 3 channels), h = 1: rows 6..11 = output row 2 sy + 1 -- six consecutive
+            // values in the label tile and in the dlogits tile, with the channel of value j a literal (j % 3): no per-value address arithmetic or selects.
+            float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3], v4 = acc[4], v5 = acc[5], v6 = acc[6], v7 = acc[7];
+            {
+                auto sw = [](float& x, float& y) {            // x.upper <- y.lower, y.lower <- x.upper
+                    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, x), __builtin_bit_cast(uint32_t, y), false, false);
+                    x = __builtin_bit_cast(float, (uint32_t)r[0]); y = __builtin_bit_cast(float, (uint32_t)r[1]);
+                };
+                sw(v0, v4); sw(v1, v5);                       // v0 = [row 0 | row 8], v4 = [row 4 | -];  v1 = [row 1 | row 9], v5 = [row 5 | -]
+                sw(v4, v6); sw(v5, v7);                       // v4 = [row 4 | row 10],                   v5 = [row 5 | row 11]
+            }
+            // lower half: rows 0..5 = v0 v1 v2 v3 v4 v5; upper half: rows 6..11 = v2 v3 v0 v1 v4 v5
+            const float xr[6] = {lgrp ? v2 : v0, lgrp ? v3 : v1, lgrp ? v0 : v2, lgrp ? v1 : v3, v4, v5};
             const bool slot_in = sv && y0 + sy < p.GH && x0 + sx < p.GW;
             const bool owned = slot_in && sy < DT_TY && sx < DT_TX;
+            const float* lrowp = lab + (2 * sy + lgrp) * DT_LBC + sx * 6;
+            float yv[6];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = lgrp ? 4 + (i & 3) : (i < 4 ? i : i + 4);
-                const bool act = lgrp == 0 || i < 4;
-                const int cls = row / 3, n = row - cls * 3;
-                const int ph = cls >> 1, pw = cls & 1;
-                const float xraw = acc[i] + (n == 0 ? bias0 : (n == 1 ? bias1 : bias2));
-                const bf16_t xq = f32_to_bf16(xraw);        // the loss reads the logits as they would have been STORED (same values as the unfused kernel)
-                const float xv = bf16_to_f32(xq);
-                const int oy = 2 * (y0 + sy) + ph, ox = 2 * (x0 + sx) + pw;
-                const long long li = ((long long)oy * p.OW + ox) * 3 + n;
-                float yv = 0.f;
-                if (slot_in && act) {
-                    if (p.lab_u8) yv = u8_to_unit_exact((float)((const unsigned char*)p.labels)[fr * p.lab_stride + li]);
-                    else yv = ((const float*)p.labels)[fr * p.lab_stride + li];
-                }
+            for (int j = 0; j < 3; ++j) { const PackN<float, 2> t = *(const PackN<float, 2>*)(lrowp + 2 * j); yv[2 * j] = t.v[0]; yv[2 * j + 1] = t.v[1]; }
+            bf16_t gq[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float xraw = xr[j] + (j % 3 == 0 ? bias0 : (j % 3 == 1 ? bias1 : bias2));
+                const float xv = bf16_to_f32(f32_to_bf16(xraw));   // the loss reads the logits as they would have been STORED (same values as the unfused kernel)
                 float l, gr;
                 if constexpr (FASTBCE) {                   // loss_kind 0 on the hardware transcendentals (gather_narrow_kernel, FASTBCE)
                     const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
                     const float s1 = 1.0f + e;
                     const float rr = __builtin_amdgcn_rcpf(s1);
                     const float sg = xv >= 0.f ? rr : e * rr;
-                    l = fmaf(__builtin_amdgcn_logf(s1), 0.69314718f, fmaf(-xv, yv, fmaxf(xv, 0.f)));
-                    gr = sg - yv;
+                    l = fmaf(__builtin_amdgcn_logf(s1), 0.69314718f, fmaf(-xv, yv[j], fmaxf(xv, 0.f)));
+                    gr = sg - yv[j];
                 } else {
                     const float e = __expf(-fabsf(xv));
                     const float rr = __frcp_rn(1.0f + e);
                     const float sg = xv >= 0.f ? rr : e * rr;
-                    if (p.loss_kind == 0) { l = fmaxf(xv, 0.f) - xv * yv + __logf(1.0f + e); gr = sg - yv; }
+                    if (p.loss_kind == 0) { l = fmaxf(xv, 0.f) - xv * yv[j] + __logf(1.0f + e); gr = sg - yv[j]; }
                     else if (p.loss_kind == 1) {
-                        l = -(yv * __logf(1e-10f + sg) + (1.0f - yv) * __logf(1e-10f + 1.0f - sg));
-                        gr = (-yv / (1e-10f + sg) + (1.0f - yv) / (1e-10f + 1.0f - sg)) * sg * (1.0f - sg);
-                    } else { const float dd = yv - sg; l = dd * dd; gr = -2.0f * dd * sg * (1.0f - sg); }
+                        l = -(yv[j] * __logf(1e-10f + sg) + (1.0f - yv[j]) * __logf(1e-10f + 1.0f - sg));
+                        gr = (-yv[j] / (1e-10f + sg) + (1.0f - yv[j]) / (1e-10f + 1.0f - sg)) * sg * (1.0f - sg);
+                    } else { const float dd = yv[j] - sg; l = dd * dd; gr = -2.0f * dd * sg * (1.0f - sg); }
                 }
-                const bf16_t gq = slot_in ? f32_to_bf16(gr * p.inv_b) : (bf16_t)0;
-                if (owned && act) {
-                    lsum += l;
-                    const float gst = bf16_to_f32(gq);      // the bias gradient sums the STORED (rounded) values, like BiasAddGrad of dlogits
-                    if (n == 0) gs0 += gst; else if (n == 1) gs1 += gst; else gs2 += gst;
-                }
-                if (sv && act) *(bf16_t*)(dl + (2 * sy + ph) * DT_DLPITCH + ((2 * sx + pw) * 3 + n) * 2) = gq;
+                gq[j] = slot_in ? f32_to_bf16(gr * p.inv_b) : (bf16_t)0;
+                lsum += owned ? l : 0.f;
+                const float gst = owned ? bf16_to_f32(gq[j]) : 0.f;     // the bias gradient sums the STORED (rounded) values, like BiasAddGrad of dlogits
+                if (j % 3 == 0) gs0 += gst; else if (j % 3 == 1) gs1 += gst; else gs2 += gst;
+            }
+            if (sv) {
+                uint32_t* drow = (uint32_t*)(dl + (2 * sy + lgrp) * DT_DLPITCH + sx * 12);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) drow[j] = (uint32_t)gq[2 * j] | ((uint32_t)gq[2 * j + 1] << 16);
             }
         }
-        __syncthreads();
+        dt_lds_barrier();                                 // dlogits tile complete (LDS only: the next tile's global loads stay in flight)
 
         // ---- phase 2: input gradient of this wave's 32 pixels: rows yl = 2 wave, 2 wave + 1, columns xl = 0 .. 15 ----
         const int yl = 2 * wave + (lrow >> 4), xl = lrow & 15;
@@ -267,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 accw[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr), __builtin_bit_cast(bf16x8, bfr), accw[mt], 0, 0, 0);
             }
         }
-        __syncthreads();                                  // every wave is done with the staged tiles before the next tile overwrites them
+        dt_lds_barrier();                                 // every wave is done with the staged tiles before the next tile overwrites them
     }
 
     // ---- block totals: dW (4 waves take turns on one 8 KB buffer) -> this block's slab; loss / bias partials ----

@@ -113,6 +113,7 @@ struct VaeEngine {
     int ns_heads, ns_dz, nchunks, partial_cap;
     int last_B;
     int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
+    int tail_sched;                     // the current backward pass started behind a fused decoder tail (stream placement of the encoder's filter gradients)
     int tail_fused;                     // ... and (decoder tail in one launch, dectail_tile.hpp) deconv4's filter gradient and deconv3's output gradient
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
@@ -407,6 +408,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     if (!eps) return mi_fail(MI_ERR_STATE, "mi_vae_backward: no sampling forward pass recorded");
     const int B = e->last_B;
     if (B < 1) return mi_fail(MI_ERR_STATE, "mi_vae_backward: no forward pass recorded");
+    if (part == 0 || part == 1) e->tail_sched = e->tail_fused;      // (remembered for the encoder parts of a split backward)
+    const bool tail_was_fused = e->tail_sched != 0;
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_vae_backward: engine created without a gradient buffer");
     const MiVaeDesc& d = e->d; const Geom& g = e->g; const Workspace& W = e->W;
     void* st = stream;
@@ -482,9 +485,12 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             // measured against 1 / 3 / 9 / 13 interleaved on one box: 1.068 vs 1.090 / 1.111 / 1.078 / 1.079 ms per step; moving a decoder layer's
             // filter gradient instead: no gain), without the shared split scratch, which the other stream may still be using (fp32 atomics into dW).
             // MI355_WGRAD_MAIN_MASK: bit i = conv(i+1).
-            static int main_mask = -1;
-            if (main_mask < 0) { const char* ev = getenv("MI355_WGRAD_MAIN_MASK"); main_mask = ev ? atoi(ev) : 5; }
-            const bool on_main = ((main_mask >> i) & 1) != 0;
+            // Round 3: with the decoder tail fused into the forward pass (its two gradient launches were the head of both streams) the filter-gradient
+            // stream is the shorter one again and takes conv3's filter gradient back: mask 1 (0.969 vs 0.984 / 0.988 / 0.992 / 1.014 ms for 5 / 3 / 0 / 4).
+            static int main_mask = -2;
+            if (main_mask == -2) { const char* ev = getenv("MI355_WGRAD_MAIN_MASK"); main_mask = ev ? atoi(ev) : -1; }
+            const int mm = main_mask >= 0 ? main_mask : (tail_was_fused ? 1 : 5);
+            const bool on_main = ((mm >> i) & 1) != 0;
             void* sg = on_main ? st : sw;
             if (!on_main) release();
             TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
