@@ -900,7 +900,7 @@ int mi_deconv2d_tail_blocks(void) { const int a = dectail_grid(0), b = dectail_g
 
 int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const void* w_t, const float* bias, int KH, int KW, int Cout,
                            const void* labels, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch,
-                           void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes) {
+                           void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes, int reduce_now) {
     if (!n_partial || !labels || !loss_partial || !bias_partial || !x || !w || !w_t || !dx || !dw) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_fused: missing buffers");
     *n_partial = 0;
     if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_fused: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
@@ -929,10 +929,17 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     else hipLaunchKernelGGL(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     int rc = mi_check_launch("dectail_kernel");
     if (rc != MI_OK) return rc;
-    hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(DT_SLAB, nblocks), dim3(256), 0, (hipStream_t)stream, q.slabs, (long long)DT_SLAB, nblocks, (long long)DT_SLAB, dw);
-    rc = mi_check_launch("reduce_slabs_kernel");
+    if (reduce_now) rc = mi_deconv2d_tail_reduce(stream, scratch, nblocks, dw);
     if (rc == MI_OK) *n_partial = nblocks;
     return rc;
+}
+
+// dw[1536] += the per-block partial filter gradients mi_deconv2d_tail_fused(reduce_now = 0) left in scratch (n_partial of them): any stream position
+// behind that launch and in front of the optimiser step (the VAE engine runs it where its stream would otherwise wait for the other one)
+int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw) {
+    if (!scratch || !dw || n_partial < 1) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_reduce: missing buffers");
+    hipLaunchKernelGGL(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
+    return mi_check_launch("dectail_reduce_kernel");
 }
 
 // conv2d_transpose input gradient = plain stride-2 conv of dy with the same kernel read as HWIO [kh,kw,I=co,O=ci]

@@ -66,6 +66,7 @@ struct Workspace {
     long long gdec[5];
     long long z, dheads;               // T
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
+    long long tail_slabs, tail_slab_bytes;   // per-block partial filter gradients of the fused decoder tail (dectail_tile.hpp)
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
@@ -113,6 +114,11 @@ struct VaeEngine {
     int ns_heads, ns_dz, nchunks, partial_cap;
     int last_B;
     int b4_fused;                       // the last forward already accumulated deconv4's bias gradient
+    int tail_nblk;                      // partial filter gradients of the fused decoder tail waiting in the workspace (reduced inside the backward pass)
+    // finalize_losses of the last forward, deferred (mi_vae_train_step only): nothing in the backward pass reads the loss scalars, so the one-block
+    // kernel runs where the caller's stream would otherwise wait for the filter-gradient stream instead of between forward and backward
+    struct { int pending, nblk, B; float kl_floor, inv_batch, metric_weight; float* metrics3; float* dbias; } fin;
+    int defer_fin;
     int tail_sched;                     // the current backward pass started behind a fused decoder tail (stream placement of the encoder's filter gradients)
     int tail_fused;                     // ... and (decoder tail in one launch, dectail_tile.hpp) deconv4's filter gradient and deconv3's output gradient
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
@@ -171,6 +177,8 @@ void make_workspace(VaeEngine& e) {
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
     W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
+    W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
+    W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
     W.bits_act1 = add(B * g.ih[1] * g.iw[1] * (g.c[1] / 16) * 4); W.bits_dec3 = add(B * g.dh[3] * g.dw[3] * (g.dc[3] / 16) * 4);
     {
         long long n = 0;
@@ -375,14 +383,23 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     if (tail_try) {
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                            tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, e->at(e->W.gdec[3]), e->gptr(18),
-                                           (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk, e->at(e->W.scratch), e->W.scratch_bytes / SCRATCH_REGIONS));
-        if (nblk > 0) e->tail_fused = 1;
+                                           (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk, e->at(e->W.tail_slabs), e->W.tail_slab_bytes, 0));
+        if (nblk > 0) { e->tail_fused = 1; e->tail_nblk = nblk; }      // (its slab reduce runs inside mi_vae_backward)
+        {
+            static int defer_on = -1;
+            if (defer_on < 0) { const char* ev = getenv("MI355_DEFER"); defer_on = (ev && ev[0] == '0') ? 0 : 1; }
+            if (nblk > 0 && !defer_on) { CK(mi_deconv2d_tail_reduce(stream, e->at(e->W.tail_slabs), nblk, e->gptr(18))); e->tail_nblk = 0; }
+        }
     }
     // (the fused forms never store the logits: only the loss partial sums and dlogits / the gradients leave the kernel)
     if (nblk == 0) TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_nhwc_fwd_bce_u8(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                             nullptr, tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, want_grad ? e->at(e->W.gdec[4]) : nullptr,
                                             (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk));
-    if (nblk > 0) {
+    e->fin.pending = 0;
+    if (nblk > 0 && e->defer_fin && want_grad) {
+        e->fin.pending = 1; e->fin.nblk = nblk; e->fin.B = B; e->fin.kl_floor = kl_floor; e->fin.inv_batch = inv_batch; e->fin.metric_weight = metric_weight;
+        e->fin.metrics3 = metrics3; e->fin.dbias = fuse_b4 ? e->gptr(19) : nullptr;
+    } else if (nblk > 0) {
         TOP(e, stream, OP_FINALIZE, mi_vae_finalize_losses_flat(stream, (const float*)e->at(e->W.partial), nblk, (const float*)e->at(e->W.kl_row), kl_floor, B, inv_batch,
                                        (float*)e->at(e->W.out2), metrics3, metric_weight, (const float*)e->at(e->W.bpart), nblk, d.ct, fuse_b4 ? e->gptr(19) : nullptr));
     } else {
@@ -457,6 +474,10 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
         }
         e->b4_fused = 0; e->tail_fused = 0;
+        if (e->tail_nblk > 0) {                              // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
+            CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));
+            e->tail_nblk = 0;
+        }
         // dense1: h = z W1 + b1
         release();
         TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
@@ -498,6 +519,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
+        }
+        if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
+            e->fin.pending = 0;
+            TOP(e, st, OP_FINALIZE, mi_vae_finalize_losses_flat(st, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
+                                           (float*)e->at(W.out2), e->fin.metrics3, e->fin.metric_weight, (const float*)e->at(W.bpart), e->fin.nblk, d.ct, e->fin.dbias));
         }
         join();
     }
@@ -552,6 +578,10 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
     // eager: on request; while per-op timing brackets single launches with events; and with injected noise (a parity-run pattern: the caller's
     // eps buffer usually changes every step, which would mean a new capture every step).  Eager launches take the caller's rows and Adam's step
     // size as they are (no staging kernel: 4.6 us at the head of the step's dependency chain)
+    struct FinGuard { VaeEngine* e; ~FinGuard() { e->defer_fin = 0; } } fin_guard{e};
+    static int defer_on = -1;                           // MI355_DEFER=0: loss finalisation and the tail's slab reduce right behind the forward pass (A/B runs)
+    if (defer_on < 0) { const char* ev = getenv("MI355_DEFER"); defer_on = (ev && ev[0] == '0') ? 0 : 1; }
+    e->defer_fin = defer_on;                            // forward + backward are issued together here: the loss scalars are finalised inside the backward pass
     if (!use_graph || e->tm.mode || eps) {
         CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
         CK(mi_vae_backward(h, stream, src, idx, eps, inv_batch, 0));

@@ -123,7 +123,10 @@ int mi_deconv2d_nhwc_fwd_bce_u8(void* stream, int dtype, const void* x, int B, i
  * bias_partial[][4] per block as there; scratch >= mi_deconv2d_tail_blocks() * 6144 bytes.  *n_partial = blocks written, or 0 when the layer is not
  * eligible (bf16 storage, 32 -> 3 channels, k = 4 only; nothing was launched: use the separate ops). */
 int mi_deconv2d_tail_blocks(void);
-int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const void* w_t, const float* bias, int KH, int KW, int Cout, const void* labels, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes);
+int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH, int IW, int Cin, const void* w, const void* w_t, const float* bias, int KH, int KW, int Cout, const void* labels, int labels_u8, const int* frame_idx, long long label_stride, int loss_kind, float inv_batch, void* dx, float* dw, float* loss_partial, float* bias_partial, int partial_capacity, int* n_partial, void* scratch, long long scratch_bytes, int reduce_now);
+/* reduce_now = 0 above leaves the per-block filter-gradient partial sums in scratch; this adds them to dw (anywhere behind that launch on the same
+ * stream order and in front of the optimiser step) */
+int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */

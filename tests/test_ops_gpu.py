@@ -707,7 +707,11 @@ def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     dw = torch.full((k, k, Co, Ci), 0.25, device="cuda")
     n2 = ctypes.c_int(0)
     L.mi_deconv2d_tail_fused(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), wt.data_ptr(), bd.data_ptr(), k, k, Co, labels.data_ptr(), int(u8), idxd.data_ptr(),
-                             OH * OW * Co, kind, inv_b, dx.data_ptr(), dw.data_ptr(), lp2.data_ptr(), bp2.data_ptr(), cap, ctypes.addressof(n2), scratch.data_ptr(), scratch.numel())
+                             OH * OW * Co, kind, inv_b, dx.data_ptr(), dw.data_ptr(), lp2.data_ptr(), bp2.data_ptr(), cap, ctypes.addressof(n2), scratch.data_ptr(), scratch.numel(), int(kind != 1))
+    if kind == 1:                                            # deferred form: the partial sums wait in scratch until the caller reduces them
+        torch.cuda.synchronize()
+        assert float((dw - 0.25).abs().max()) == 0.0
+        L.mi_deconv2d_tail_reduce(stream(), scratch.data_ptr(), n2.value, dw.data_ptr())
     torch.cuda.synchronize()
     assert 0 < n2.value <= nb
     assert abs(float(lp2[:n2.value].double().sum()) / loss_ref - 1) < 2e-6

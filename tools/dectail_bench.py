@@ -30,8 +30,10 @@ scratch = torch.empty(L.mi_deconv2d_tail_blocks() * 6144, device="cuda", dtype=t
 def fwd(): L.mi_deconv2d_nhwc_fwd_bce_u8(st, 1, x.data_ptr(), B, IH, IW, Ci, wb.data_ptr(), bias.data_ptr(), k, k, Co, None, frames.data_ptr(), 1, idx.data_ptr(), OH * OW * Co, 0, 1.0 / B, dl.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap, ctypes.addressof(n))
 def dgrad(): L.mi_deconv2d_nhwc_dgrad(st, 1, dl.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, x.data_ptr(), dx.data_ptr())
 def wgrad(): L.mi_deconv2d_nhwc_wgrad(st, 1, dl.data_ptr(), B, OH, OW, Co, x.data_ptr(), k, k, Ci, dw.data_ptr())
-def fused(): L.mi_deconv2d_tail_fused(st, 1, x.data_ptr(), B, IH, IW, Ci, wb.data_ptr(), wt.data_ptr(), bias.data_ptr(), k, k, Co, frames.data_ptr(), 1, idx.data_ptr(), OH * OW * Co, 0, 1.0 / B, dx.data_ptr(), dw.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap, ctypes.addressof(n), scratch.data_ptr(), scratch.numel())
-for name, fn in (("deconv4.fwd+loss", fwd), ("deconv4.dgrad", dgrad), ("deconv4.wgrad", wgrad), ("fused tail", fused)):
+def fused(): L.mi_deconv2d_tail_fused(st, 1, x.data_ptr(), B, IH, IW, Ci, wb.data_ptr(), wt.data_ptr(), bias.data_ptr(), k, k, Co, frames.data_ptr(), 1, idx.data_ptr(), OH * OW * Co, 0, 1.0 / B, dx.data_ptr(), dw.data_ptr(), lp.data_ptr(), bp.data_ptr(), cap, ctypes.addressof(n), scratch.data_ptr(), scratch.numel(), 0)
+def red(): L.mi_deconv2d_tail_reduce(st, scratch.data_ptr(), n.value, dw.data_ptr())
+fused()
+for name, fn in (("deconv4.fwd+loss", fwd), ("deconv4.dgrad", dgrad), ("deconv4.wgrad", wgrad), ("fused tail", fused), ("  its slab reduce", red)):
     for _ in range(5): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
