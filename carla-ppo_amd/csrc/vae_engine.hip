@@ -463,6 +463,9 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (fork) { hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent((hipStream_t)st, e->ev_done, 0); }
     };
     struct DeferGuard { bool on; ~DeferGuard() { if (on) mi_tapwgrad_defer(0); } } guard{defer};
+    static int late_on = -1;                              // MI355_LATE_DENSE=0: dense1 / heads filter gradients on the filter-gradient stream as in round 2
+    if (late_on < 0) { const char* ev = getenv("MI355_LATE_DENSE"); late_on = (ev && ev[0] == '0') ? 0 : 1; }
+    const bool late_dense = late_on && fork && part == 0;
     if (part == 0 || part == 1) {
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             if (i == 3 && e->tail_fused) continue;           // deconv4's two gradients were computed by the forward pass's decoder-tail kernel
@@ -478,10 +481,14 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));
             e->tail_nblk = 0;
         }
-        // dense1: h = z W1 + b1
-        release();
-        TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-        TOP(e, sw, OP_DENSE1_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+        // dense1: h = z W1 + b1.  Full two-stream backward (round 3): the four latent-side filter / bias gradients (dense1, heads: ~60 us of the
+        // filter-gradient stream, which is the longer one) are issued on the caller's stream at the very END of the pass, where that stream would
+        // otherwise wait ~100 us for the other one; their operands (gdec0, z, dheads, act4) stay intact until then and no event is needed for them.
+        if (!late_dense) {
+            release();
+            TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, sw, OP_DENSE1_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+        }
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
         if (part == 1) join();                               // a full backward joins once, at its end: nothing below reads a filter gradient
     }
@@ -491,9 +498,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
         TOP(e, st, OP_REPARAM_BWD, mi_vae_reparam_kl_bwd(st, d.dtype, (const float*)e->at(W.dz_slab), e->ns_dz, (const float*)e->at(W.mean), (const float*)e->at(W.logvar),
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
-        release();
-        TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-        TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+        if (!late_dense) {
+            release();
+            TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+        }
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
     }
     if (upper || lower) {
@@ -519,6 +528,12 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
+        }
+        if (late_dense) {
+            TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            TOP(e, st, OP_HEADS_BIAS, mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, st, OP_HEADS_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
             e->fin.pending = 0;
