@@ -477,8 +477,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
         }
         e->b4_fused = 0; e->tail_fused = 0;
-        if (e->tail_nblk > 0) {                              // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
-            CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));
+        if (e->tail_nblk > 0 && !late_dense) {               // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
+            CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));      // (full two-stream backward: at the tail of the caller's stream, below)
             e->tail_nblk = 0;
         }
         // dense1: h = z W1 + b1.  Full two-stream backward (round 3): the four latent-side filter / bias gradients (dense1, heads: ~60 us of the
@@ -529,11 +529,13 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
         }
-        if (late_dense) {
+        if (late_dense) {                                    // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
             TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
             TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
-            TOP(e, st, OP_HEADS_BIAS, mi_colsum(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, st, OP_HEADS_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
+            if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
+            TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
             e->fin.pending = 0;

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "full_batch or train_step_losses or captured_graph" 2>&1 | tail -3
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --steps 100 --warmup 10"
+run() { env "$@" timeout 200 python bench.py $X 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],4), 'ms')"; }
+for r in 1 2 3; do
+  run MI355_LATE_DENSE=0
+  run MI355_LATE_DENSE=1
+done
+bash tools/timeline.sh r03c; sed -n 28,45p gpurun_out/timeline_r03c.md
