@@ -210,6 +210,7 @@ extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode d
     g_npending = 0;
     return prev;
 }
+extern "C" int mi_tapwgrad_slab_bf16(int on) { const int prev = g_slab_bf16; g_slab_bf16 = on ? 1 : 0; return prev; }
 extern "C" int mi_tapwgrad_flush(void* stream) {
     const int n = g_npending;
     g_npending = 0;
@@ -238,6 +239,8 @@ int g_tapwgrad_split = 1;
 int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
+int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
+                                                           // partial sums), switched on by the VAE engine around its backward pass (mi_tapwgrad_slab_bf16); mi_set_tuning key 18
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
@@ -309,8 +312,8 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     // when it is large enough; otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
     const int kt_tiles = taps == 2 ? 4 : 2;
     const long long slab_floats = (long long)gy * q.npairs * kt_tiles * 1024;
-    q.slabs = nullptr; q.slab_stride = slab_floats;
-    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * 4 && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
+    q.slabs = nullptr; q.slab_stride = slab_floats; q.slab_bf16 = g_slab_bf16 ? 1 : 0;
+    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * (q.slab_bf16 ? 2 : 4) && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
     const bool split = g_tapwgrad_split && taps == 2 && q.npairs == 8;   // wave = (tap, position half): fewer LDS reads per MFMA
@@ -746,6 +749,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 15) { prev = mi_rwconv_conv_mode(value < 0 ? 0 : value); }
     else if (key == 16) { prev = mi_rwconv_blocks(value < 0 ? 0 : value); }
     else if (key == 17) { prev = g_gemm2_tile; g_gemm2_tile = value; }
+    else if (key == 18) { prev = g_slab_bf16; g_slab_bf16 = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

@@ -11,6 +11,7 @@ int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK /
 // deferred split reductions of the raw-staged filter-gradient kernel (conv_ops.hip; used by the VAE engine)
 extern "C" int mi_tapwgrad_defer(int on);        // returns the previous mode
 extern "C" int mi_tapwgrad_flush(void* stream);  // launches the recorded reduces on `stream`
+extern "C" int mi_tapwgrad_slab_bf16(int on);    // partial-sum slabs rounded to bf16 (the engine's bf16 backward); returns the previous setting
 
 // register-weight kernel of the thin gather-form layers (rwconv.hip): 1 launched, 0 not eligible, < 0 error
 int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,

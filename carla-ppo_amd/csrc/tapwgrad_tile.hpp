@@ -45,6 +45,9 @@ struct TapWgradParams {
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     float* out;
     float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
+    int slab_bf16;                   // the partial sums are stored ROUNDED TO BF16 (round 3; the bf16 engine's default, mi_set_tuning key 18): ~256 slabs per
+                                     // element, each 2^-9 relative with independent signs, add ~1e-4 of the element's own scale to a gradient whose operands
+                                     // were bf16 to begin with -- and halve the 211 MB written + 214 MB read per step that the slabs cost
     long long* trace; int trace_cap;   // debug stamps (mi_debug_set_trace)
     int dbg_cheap_addr;                // debug (mi_set_tuning key 2 == 2): trivial DMA addresses, wrong results, shows the cost of the address arithmetic
 };
@@ -53,6 +56,7 @@ struct TapWgradParams {
 // ds_read_b64_tr_b16 it cannot prove disjoint, which would serialise prefetch and compute; asm loads are invisible to that
 // pass, so the step barrier carries an explicit vmcnt(0).  m0 = LDS byte address of lane 0's 16 bytes (wave-uniform).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tw_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
     const unsigned long long b = (unsigned long long)base;
     u32x4 r;
@@ -369,7 +373,19 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     // Without scratch: fp32 atomics straight into dW.
     auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
         if (p.slabs) {
-            float* const dst = p.slabs + (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
+            const long long eoff = (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
+            if (p.slab_bf16) {
+                bf16_t* const dst = (bf16_t*)p.slabs + eoff;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float v[4] = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
+                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + (kt * 4 + g4) * 256));
+                    }
+                return;
+            }
+            float* const dst = p.slabs + eoff;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -613,7 +629,17 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const f32x16& t = acc[tb][kt];
-                float* const dst = p.slabs + (long long)bx * p.slab_stride + (((long long)(by * p.npairs + pi) * KT) + kt) * 1024 + lane * 4;
+                const long long eoff = (long long)bx * p.slab_stride + (((long long)(by * p.npairs + pi) * KT) + kt) * 1024 + lane * 4;
+                if (p.slab_bf16) {
+                    bf16_t* const dst = (bf16_t*)p.slabs + eoff;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float v[4] = {t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]};
+                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + g4 * 256));
+                    }
+                    continue;
+                }
+                float* const dst = p.slabs + eoff;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) __builtin_nontemporal_store(f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]}, (f32x4*)(dst + g4 * 256));
             }
@@ -642,10 +668,20 @@ __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int n
 #pragma unroll
         for (int t = 0; t < 4; ++t) ov[t] = p.out[base + t * stride];
     }
-    const float* src = p.slabs + (long long)gid * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (p.slab_bf16) {
+        const bf16_t* src = (const bf16_t*)p.slabs + (long long)gid * 4;
 #pragma unroll 16
-    for (int k = by; k < nslab; k += nby) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+        for (int k = by; k < nslab; k += nby) {
+            const tw_u32x2 w = __builtin_nontemporal_load((const tw_u32x2*)(src + k * p.slab_stride));
+            s[0] += __builtin_bit_cast(float, w[0] << 16); s[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
+            s[2] += __builtin_bit_cast(float, w[1] << 16); s[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
+        }
+    } else {
+        const float* src = p.slabs + (long long)gid * 4;
+#pragma unroll 16
+        for (int k = by; k < nslab; k += nby) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (nby == 1) p.out[base + t * stride] = ov[t] + s[t];

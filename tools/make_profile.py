@@ -55,7 +55,10 @@ NAMES_R02 = [("rwconv_gather_kernel<3, 5, true, 0, true, 0>", None, "deconv3.fwd
          ("narrow_conv48_kernel<unsigned char, 0>", None, "conv1.fwd"), ("narrow_conv48_kernel<bf16, 1>", None, "deconv4.dgrad"),
          ("gather_narrow_kernel<bf16, 2, 4, 3, true>", None, "deconv4.fwd + loss"), ("reduce_fused_kernel", None, "filter-gradient slab reduce (6 layers)"),
          ("adam_tf_kernel", None, "adam")]
-NAMES = NAMES_R01 if tag.startswith("r01") else NAMES_R02
+# round 3: the decoder tail is one kernel (deconv4 forward + loss + both of its gradients); deconv3's forward no longer writes ReLU bit words
+NAMES_R03 = [("dectail_kernel<true>", None, "deconv4.fwd (decoder tail: deconv4 fwd + loss + dgrad + wgrad)"), ("dectail_kernel<false>", None, "deconv4.fwd (decoder tail, library-math loss)"),
+             ("rwconv_gather_kernel<3, 5, true, 0, false, 0, 1>", None, "deconv3.fwd"), ("dectail_reduce_kernel", None, "decoder-tail slab reduce")] + NAMES_R02
+NAMES = NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else NAMES_R03)
 lines, traffic = [], {}
 for kern, grid, op in NAMES:
     keys = [k for k in sqr if k[0].strip("`") == kern and (grid is None or k[1] == grid)]
@@ -71,7 +74,7 @@ for kern, grid, op in NAMES:
 doc = """# %s
 
 ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  Sources: `rocprofv3 --kernel-trace --stats` of
-`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-replay` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
+`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
 `rocprofv3 --pmc` passes (`tools/pmc_pass.sh`: SQ/GRBM counters, FETCH_SIZE alone, WRITE_SIZE alone -- one TCC-derived counter per pass, no trace
 domains combined with --pmc).  Assembled by `tools/make_profile.py`.
 
@@ -112,5 +115,5 @@ conv1 kernels of round 1 may be over-counted) + WRITE_SIZE, both reported in KB 
 """ % (title, json.dumps(bench), "\n".join(lines), stats, timeline, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
 open(R + "profiles/%s.md" % outname, "w").write(doc)
 json.dump({"provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, batch 512 bf16; FETCH_SIZE doubled per MI355X_MICROARCH.md",
-           "ops": traffic}, open(R + "profiles/%s_pmc_traffic.json" % ("r01" if tag.startswith("r01") else "r02"), "w"), indent=1)
+           "ops": traffic}, open(R + "profiles/%s_pmc_traffic.json" % tag[:3], "w"), indent=1)
 print("\n".join(lines))
