@@ -927,6 +927,7 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     const int fast = loss_kind == 0 ? 1 : 0;
     int nblocks = dectail_grid(fast);
     if (nblocks > q.ntiles) nblocks = q.ntiles;
+    if (nblocks >= 16) nblocks &= ~7;                       // whole rounds of the eight XCDs (the kernel's tile order)
     if (nblocks > partial_capacity || scratch_bytes < (long long)nblocks * DT_SLAB * 4) return MI_OK;
     q.slabs = (float*)scratch;
     if (fast) hipLaunchKernelGGL(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);

@@ -181,11 +181,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     };
     Staged cur;
-    int t_nxt = min((int)blockIdx.x + (int)gridDim.x, p.ntiles - 1);     // (past the end: a valid tile is requested again -- no branch around the loads)
-    int fr_req = frame_of((int)blockIdx.x);
-    request((int)blockIdx.x, fr_req, cur);
+    // Tile order: block b runs on XCD b % 8 (observed placement; only speed depends on it), and neighbouring tiles share a third of their staged pixels.
+    // In every round of gridDim.x tiles XCD x takes the contiguous run [x G / 8, (x + 1) G / 8): the halo re-reads then hit that XCD's L2 (with tile =
+    // b + k G the eight neighbours of a tile sat on eight different L2s: 186 MB fetched from HBM for 121 MB of tensors).  The host launches G % 8 == 0.
+    const int G = (int)gridDim.x;
+    const int vb = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    int t_nxt = min(vb + G, p.ntiles - 1);                   // (past the end: a valid tile is requested again -- no branch around the loads)
+    int fr_req = frame_of(min(vb, p.ntiles - 1));
+    request(min(vb, p.ntiles - 1), fr_req, cur);
     fr_req = frame_of(t_nxt);
-    for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += (int)gridDim.x) {
+    for (int tile = vb; tile < p.ntiles; tile += G) {
         uint32_t b, rem, ty, tx;
         p.div_tpf.divmod((uint32_t)tile, b, rem);
         p.div_tx.divmod(rem, ty, tx);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         commit(cur);
         __syncthreads();
         request(t_nxt, fr_req, cur);
-        t_nxt = min(t_nxt + (int)gridDim.x, p.ntiles - 1);
+        t_nxt = min(t_nxt + G, p.ntiles - 1);
         fr_req = frame_of(t_nxt);
 
         // ---- phase 1: logits of the 9 x 17 slots, loss, dlogits into the LDS tile ----
