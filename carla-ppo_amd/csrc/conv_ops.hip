@@ -210,6 +210,8 @@ extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode d
     g_npending = 0;
     return prev;
 }
+int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
+                                                           // partial sums), switched on by the VAE engine around its backward pass (mi_tapwgrad_slab_bf16); mi_set_tuning key 18
 extern "C" int mi_tapwgrad_slab_bf16(int on) { const int prev = g_slab_bf16; g_slab_bf16 = on ? 1 : 0; return prev; }
 extern "C" int mi_tapwgrad_flush(void* stream) {
     const int n = g_npending;
@@ -239,8 +241,6 @@ int g_tapwgrad_split = 1;
 int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
-int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
-                                                           // partial sums), switched on by the VAE engine around its backward pass (mi_tapwgrad_slab_bf16); mi_set_tuning key 18
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
