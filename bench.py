@@ -214,13 +214,17 @@ def ppo_extra(tmp, steps=5):
     R = torch.from_numpy(rng.randn(T).astype(np.float32)).to(dev)
     A = torch.from_numpy(rng.randn(T).astype(np.float32)).to(dev)
 
+    lp = torch.empty(T, device=dev)
+
     def update():
+        # train.py:192-204 with the horizon batch resident on the device: theta_old <- theta, log pi_old(a|s) of the batch once, then 4 epochs x 4 shuffled
+        # minibatches of 32 whose rows are gathered INSIDE the step's kernels (mi_ppo_train_step_idx)
         m.update_old_policy()
+        m.dev.logp_old(s, a, T, lp)
         for _ in range(4):
-            perm = torch.from_numpy(np.random.RandomState(0).permutation(T)).to(dev)
+            perm = torch.from_numpy(np.random.RandomState(0).permutation(T).astype(np.int32)).to(dev)
             for i in range(4):
-                mb = perm[i * 32:(i + 1) * 32]
-                m._step_resident(s[mb].contiguous(), a[mb].contiguous(), R[mb].contiguous(), A[mb].contiguous(), 32, 32)
+                m._step_rows(s, a, R, A, lp, perm[i * 32:(i + 1) * 32], 32, 32)
     update()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -325,6 +325,30 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
     return mi_ppo_fused_step((hipStream_t)stream, q, 1);
 }
 
+// mi_ppo_train_step with the minibatch GATHER fused in: states / actions / returns / advantage / logp_old are the horizon-batch tables (n_rows rows;
+// device resident for the whole update, train.py:175-207) and row_idx [M] (int32, device) names the rows of this minibatch -- the reference's
+// `states[mb_idx]` fancy-indexing (train.py:199-204) happens inside the kernels that read the operands instead of as five gather launches per step.
+int mi_ppo_train_step_idx(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old,
+                          const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (M < 1 || M > e->d.max_batch || n_rows < 1) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step_idx: batch outside [1, max_batch] or empty tables");
+    if (!row_idx) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step_idx: missing row index (use mi_ppo_train_step for contiguous minibatches)");
+    if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step_idx: engine created without optimiser buffers");
+    if (!fused_enabled(e)) return mi_fail(MI_ERR_SHAPE, "mi_ppo_train_step_idx: needs the fused kernels (shape outside their range or MI355_PPO_FUSED=0): gather on the host side and call mi_ppo_train_step");
+    PpoFusedParams q; fill_fused(e, q, states, M);
+    q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
+    q.logp_old = logp_old; q.n_nets = logp_old ? 2 : 3;
+    q.row_idx = row_idx; q.n_rows = n_rows; q.s_gath = (float*)e->at(e->s_pad);
+    e->last_M = M;
+    if (M > 256) {
+        CK(mi_ppo_fused_step((hipStream_t)stream, q, 0));
+        return mi_ppo_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
+    }
+    q.alpha = alpha; q.omb1 = 1.0f - beta1; q.omb2 = 1.0f - beta2; q.epsilon = epsilon;
+    return mi_ppo_fused_step((hipStream_t)stream, q, 1);
+}
+
 // log pi_old(a | s) of M samples under theta_old -> out [M] (the per-horizon cache for mi_ppo_train_step)
 int mi_ppo_logp_old(void* h, void* stream, const float* states, const float* actions, int M, float* out) {
     PpoEngine* e = (PpoEngine*)h;

@@ -90,8 +90,15 @@ __global__ __launch_bounds__(256) void ppo_l1_kernel(const PpoFusedParams q) {
     const int n = n0 + lrow;
     // states rows are din long, W1 has kin >= din rows of which the last kin - din are zero (and stay zero: their gradient is never formed): a k past
     // din reads the next row's finite values against a zero weight row; past the tensors the range check returns 0.0
-    const __amdgpu_buffer_rsrc_t rsS = PF_RSRC(q.states, (long long)q.M * q.din * 4), rsW = PF_RSRC(W, (long long)q.kin * q.H1 * 4);
-    const unsigned arow = (unsigned)min(m0 + lrow, q.M - 1) * (unsigned)q.din, H1u = (unsigned)q.H1;
+    // (with a row index: the state table has n_rows rows and sample m is its row row_idx[m] -- one dependent load per lane in front of the operand loads)
+    const int mrow = min(m0 + lrow, q.M - 1);
+    const int srow = q.row_idx ? q.row_idx[mrow] : mrow;
+    const __amdgpu_buffer_rsrc_t rsS = PF_RSRC(q.states, (long long)(q.row_idx ? q.n_rows : q.M) * q.din * 4), rsW = PF_RSRC(W, (long long)q.kin * q.H1 * 4);
+    const unsigned arow = (unsigned)srow * (unsigned)q.din, H1u = (unsigned)q.H1;
+    if (q.row_idx && q.s_gath && net == 0 && blockIdx.x == 0) {      // the gathered minibatch for the layer-1 filter gradient: rows m0 .. m0 + 31, columns dealt to the 8 half-waves
+        const int m = m0 + lrow;
+        for (int k = wave * 2 + lgrp; k < q.din; k += 8) if (m < q.M) q.s_gath[(long long)m * q.din + k] = q.states[(long long)srow * q.din + k];
+    }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -197,14 +204,15 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
 #pragma unroll
     for (int i = 0; i < (PF_H2MAX + 255) / 256; ++i) { const int x = tid + 256 * i; stv[i] = x < H2 ? Wv[x] : 0.f; }
     float p_act[NA], p_adv_s = 0.f, p_ret_s = 0.f, p_lpo_s = 0.f, p_ls[NA], p_lso[NA], p_lo[NA], p_hi[NA];
+    const int mr = (q.row_idx && mok) ? q.row_idx[m] : m;     // the sample's row in the horizon-batch tables (actions / returns / advantages / cached log pi_old)
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const bool aok = a < A;
-        p_act[a] = (mok && aok) ? q.actions[(long long)m * A + a] : 0.f;
+        p_act[a] = (mok && aok) ? q.actions[(long long)mr * A + a] : 0.f;
         p_ls[a] = aok ? q.theta[q.off[6] + a] : 0.f; p_lso[a] = (aok && old_net) ? q.theta_old[q.off[6] + a] : 0.f;
         p_lo[a] = aok ? q.low[a] : 0.f; p_hi[a] = aok ? q.high[a] : 0.f;
     }
-    if (mok) { p_adv_s = q.adv[m]; p_ret_s = q.returns[m]; if (!old_net) p_lpo_s = q.logp_old[m]; }
+    if (mok) { p_adv_s = q.adv[mr]; p_ret_s = q.returns[mr]; if (!old_net) p_lpo_s = q.logp_old[mr]; }
 #pragma unroll
     for (int i = 0; i < NST; ++i) { const int x = tid + 256 * i; if (x < H2 * A) { sWm[x] = stm[i]; sWo[x] = sto[i]; } }
 #pragma unroll
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         oW = pf_off(q, net, 2); ob = pf_off(q, net, 3); ldw = H2; kvalid = H1;
     } else if (t < KT2 * NT2 + KT1 * NT1) {               // layer 1 (rows din .. kin-1 of W1 are the zero padding: their gradient stays 0)
         t -= KT2 * NT2; kt = t / NT1; nt = t - kt * NT1;
-        X = q.states; ldx = q.din; Kx = q.din; G = q.dh1 + (long long)net * M * H1; ldg = H1; Ng = H1;
+        X = q.row_idx ? q.s_gath : q.states; ldx = q.din; Kx = q.din; G = q.dh1 + (long long)net * M * H1; ldg = H1; Ng = H1;
         oW = pf_off(q, net, 0); ob = pf_off(q, net, 1); ldw = H1; kvalid = q.kin;
     } else {                                              // head kernel [H2, A]
         kt = t - KT2 * NT2 - KT1 * NT1; nt = 0;

@@ -14,6 +14,9 @@ struct PpoFusedParams {
     const float *states, *actions, *returns, *adv, *low, *high;
     float *h1, *h2, *dh1, *dh2;                           // h1/h2: 3 nets; dh1/dh2: 2 nets
     float *du, *dv, *partial, *losses, *mean_out;
+    // minibatch gather fused into the step (mi_ppo_train_step_idx): sample m of the minibatch is row row_idx[m] of the horizon-batch tables
+    // states / actions / returns / adv / logp_old (n_rows rows each); layer 1 also leaves the gathered states in s_gath [M, din] for the filter gradient
+    const int* row_idx; int n_rows; float* s_gath;
     const float* logp_old;                                // cached log pi_old(a|s) per sample (nullptr: recomputed from net 2)
     float* logp_out;                                      // when set: the loss kernel also stores log pi(a|s) (used to fill the cache)
     int n_nets;                                           // 3, or 2 with the cache

@@ -149,6 +149,13 @@ class PpoDevice:
         self.L.mi_ppo_train_step(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), int(M), float(inv_m), float(grad_scale),
                                  float(alpha), float(beta1), float(beta2), float(epsilon))
 
+    def train_step_idx(self, states, actions, returns, advantage, logp_old, row_idx, M, inv_m, grad_scale, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """train_step on rows `row_idx` (int32 device tensor [M]) of the horizon-batch tables: the gather happens inside the kernels."""
+        self.ensure_batch(M)
+        p = milib.ptr
+        self.L.mi_ppo_train_step_idx(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), p(row_idx), int(states.shape[0]), int(M),
+                                     float(inv_m), float(grad_scale), float(alpha), float(beta1), float(beta2), float(epsilon))
+
     def logp_old(self, states, actions, M, out):
         """log pi_old(a | s) of M samples under theta_old (computed once per horizon batch; theta_old only changes in update_old())."""
         self.ensure_batch(M)

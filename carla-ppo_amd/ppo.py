@@ -162,6 +162,20 @@ class PPO():
         self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
 
+    def _step_rows(self, s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, m_global):
+        """One SGD step on rows `rows` (int32 device tensor) of device-resident horizon-batch tables: the minibatch gather of train.py:199-204 runs inside
+        the step's kernels (single rank, fused kernels); otherwise the rows are gathered here and _step_resident takes over."""
+        dev = self.dev
+        if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0" and os.environ.get("MI355_PPO_IDX", "1") != "0":
+            alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
+            dev.train_step_idx(s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+            self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
+            self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
+            return
+        mb = rows.to("cuda" if rows.is_cuda else rows.device).long()
+        self._step_resident(s_all[mb].contiguous(), a_all[mb].contiguous(), r_all[mb].contiguous(), adv_all[mb].contiguous(), m_local, m_global,
+                            logp_old=None if logp_old_all is None else logp_old_all[mb].contiguous())
+
     def train(self, input_states, taken_actions, returns, advantage):
         """One SGD step on a minibatch + metric update + train_step_counter += 1; returns None (ppo.py:218-229)."""
         dev = self._need_dev()

@@ -117,16 +117,19 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
             hi_ = min(lo_ + 4096, n_loc)
             pdev.logp_old(s[lo_:hi_], a[lo_:hi_], hi_ - lo_, logp_old[lo_:hi_])
     records = []
+    fused_rows = world == 1 and hasattr(ppo, "_step_rows") and hasattr(pdev, "train_step_idx")
     for _ in range(num_epochs):
         indices = np.arange(n_loc)
         np.random.shuffle(indices)                                               # legacy numpy RNG, as train.py:194-195
-        perm = torch.from_numpy(indices).to(device)
+        perm = torch.from_numpy(indices.astype(np.int32) if fused_rows else indices).to(device)
         n_steps = int(np.ceil(n_loc / mb_loc)) if mb_loc > 0 else 0
         for i in range(n_steps):
             mb = perm[i * mb_loc:(i + 1) * mb_loc]                               # the last one may be partial (train.py:199-201)
             m_local = int(mb.numel())
             m_global = m_local * world if world > 1 else m_local                 # ranks hold equal shares (R divisible by world is the C5 layout)
-            if logp_old is not None:
+            if fused_rows:                                                       # the minibatch gather happens inside the step's kernels (a slice of the permutation is the row index)
+                ppo._step_rows(s, a, ret, adv_t, logp_old, mb, m_local, m_global)
+            elif logp_old is not None:
                 ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global, logp_old=logp_old[mb].contiguous())
             else:
                 ppo._step_resident(s[mb].contiguous(), a[mb].contiguous(), ret[mb].contiguous(), adv_t[mb].contiguous(), m_local, m_global)

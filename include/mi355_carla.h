@@ -271,6 +271,9 @@ int mi_ppo_apply_adam(void* h, void* stream, float alpha, float beta1, float bet
 /* PPO.train's device work in ONE call (single rank): fused forward / losses / backward / Adam, five launches — ppo.py:218-229; logp_old (optional):
  * log pi_old(a|s) of the samples from mi_ppo_logp_old, computed once per horizon batch (theta_old is constant between update_old_policy() calls) */
 int mi_ppo_train_step(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
+/* the same step with the minibatch gather fused in — train.py:199-204 (`states[mb_idx]`, ...): the five operands are the horizon-batch tables (n_rows rows,
+ * device resident for the whole update) and row_idx [M] (int32, device) names this minibatch's rows */
+int mi_ppo_train_step_idx(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
 int mi_ppo_logp_old(void* h, void* stream, const float* states, const float* actions, int M, float* out);
 
 #ifdef __cplusplus

@@ -279,3 +279,50 @@ def test_rollout_step_one_call_matches_encode_then_predict(tmp_path):
             a2, v2 = m.predict(np.append(z2, meas), greedy=True)
             a, v, state = step(frame, meas, greedy=True)
             assert rel_err(state[:64], z2) < 1e-5 and np.allclose(a, a2, atol=1e-5) and v == pytest.approx(float(v2), rel=1e-5, abs=1e-6)
+
+
+@pytest.mark.parametrize("M", [32, 77, 300])
+def test_step_with_fused_minibatch_gather_equals_gathered_step(tmp_path, M):
+    """mi_ppo_train_step_idx (the reference's `states[mb_idx]` ... `advantages[mb_idx]` fancy-indexing of train.py:199-204 done inside the step's kernels)
+    against mi_ppo_train_step on the rows gathered beforehand: same parameters after the step (bit for bit at M <= 256, where both run the same
+    summation order; M > 256 meets in fp32 atomics: 1e-6), same loss scalars -- with and without the cached log pi_old."""
+    import torch
+    T = 512
+    rng = np.random.RandomState(M)
+    s = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    R, A = rng.randn(T).astype(np.float32), rng.randn(T).astype(np.float32)
+    rows = rng.permutation(T)[:M].astype(np.int32)
+    outs = []
+    for fused in (False, True):
+        for cached in (False, True):
+            o, m = make_pair(tmp_path / ("f%d%d" % (fused, cached)))
+            for k in o.params:
+                o.params[k] = o.params[k] + (0.02 * np.random.RandomState(3).standard_normal(o.params[k].shape)).astype(np.float32)
+            m.set_weights(o.params)                      # theta != theta_old: ratio != 1
+            d = m.dev
+            d.ensure_batch(T)
+            sd, ad, Rd, Ad = (m._to_dev(x, x.shape) for x in (s, a, R, A))
+            lp = None
+            if cached:
+                lp = torch.empty(T, device=d.device)
+                d.logp_old(sd, ad, T, lp)
+            rd = torch.from_numpy(rows).to(d.device)
+            alpha = 1e-4
+            if fused:
+                d.train_step_idx(sd, ad, Rd, Ad, lp, rd, M, 1.0 / M, 1.0, alpha)
+            else:
+                mb = rd.long()
+                d.train_step(sd[mb].contiguous(), ad[mb].contiguous(), Rd[mb].contiguous(), Ad[mb].contiguous(), M, 1.0 / M, 1.0, alpha,
+                             logp_old=None if lp is None else lp[mb].contiguous())
+            outs.append((fused, cached, d.params.cpu().numpy().copy(), d.losses.cpu().numpy()[:5].copy()))
+    ref = {c: (p, l) for f, c, p, l in outs if not f}
+    for f, c, p, l in outs:
+        if not f:
+            continue
+        p0, l0 = ref[c]
+        if M <= 256:
+            assert np.array_equal(p, p0), (M, c, float(np.abs(p - p0).max()))
+        else:
+            assert np.abs(p - p0).max() <= 1e-6 * max(1.0, np.abs(p0).max()), (M, c)
+        assert np.allclose(l, l0, rtol=1e-6, atol=1e-7), (M, c, l, l0)
