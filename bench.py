@@ -337,6 +337,14 @@ def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
     return res
 
 
+def _library_stamp():
+    """ABI version + modification time of the loaded libmi355_carla.so: an A/B run states WHICH build it measured (DESIGN finding 28)."""
+    from mi355 import lib as milib
+    L = milib.get()
+    path = milib.LIB_PATH
+    return {"abi": int(L.mi_abi_version()), "built": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path))) if path and os.path.exists(path) else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -498,7 +506,8 @@ def main():
                        "frame_table": "uint8 camera bytes, k/255 in registers" if u8_pool else "float32 in [0,1]",
                        "noise": "N(0,1) drawn inside the reparameterisation kernel (Philox4x32-10)",
                        "launch": "hipGraph replay of the captured step" if (args.graph and world == 1) else "eager launches",
-                       "storage": "bf16 activations/weights, fp32 accumulate, fp32 master weights+Adam" if args.precision == "bf16" else "fp32"},
+                       "storage": "bf16 activations/weights, fp32 accumulate, fp32 master weights+Adam" if args.precision == "bf16" else "fp32",
+                       "library": _library_stamp()},
             "roofline": roofline,
             "step_model_flops_utilisation": {"algorithmic_tflops_per_step": step_flops / 1e12,
                                              "achieved_tflops": step_flops * args.steps / elapsed / 1e12,
