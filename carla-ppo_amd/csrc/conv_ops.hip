@@ -919,8 +919,13 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     q.labels = labels; q.lab_u8 = labels_u8 ? 1 : 0; q.lab_idx = frame_idx; q.lab_stride = label_stride; q.loss_kind = loss_kind; q.inv_b = inv_batch;
     q.dx = (bf16_t*)dx; q.lpart = loss_partial; q.bpart = bias_partial;
     q.OH = 2 * IH + 2; q.OW = 2 * IW + 2; q.GH = IH + 1; q.GW = IW + 1;
-    const int tiles_y = (q.GH + DT_TY - 1) / DT_TY;
-    q.tiles_x = (q.GW + DT_TX - 1) / DT_TX; q.tiles_per_frame = tiles_y * q.tiles_x;
+    static int edge = -1;                                 // A/B knob: tiles over the pixel grid, last slot row / column owned by the last tiles
+    if (edge < 0) { const char* e = getenv("MI355_DECTAIL_EDGE"); edge = (e && e[0] == '0') ? 0 : 1; }
+    q.edge_own = edge;
+    if ((long long)B * IH * IW * 64 >= 0x7fffff00ll || (long long)q.OH * q.OW * 12 >= 0x7fffff00ll) return MI_OK;      // 32-bit buffer offsets
+    q.x_bytes = (unsigned)((long long)B * IH * IW * 64);
+    const int tiles_y = ((edge ? IH : q.GH) + DT_TY - 1) / DT_TY;
+    q.tiles_x = ((edge ? IW : q.GW) + DT_TX - 1) / DT_TX; q.tiles_per_frame = tiles_y * q.tiles_x;
     const long long ntiles = (long long)B * q.tiles_per_frame;
     if (ntiles >= (1ll << 30) || (long long)B * q.OH * q.OW * 3 >= (1ll << 40)) return MI_OK;
     q.ntiles = (int)ntiles; q.div_tpf = make_fastdiv(q.tiles_per_frame); q.div_tx = make_fastdiv(q.tiles_x);

@@ -30,7 +30,10 @@ constexpr int DT_NSLOT = DT_SY * DT_SX;                   // 153
 constexpr int DT_DLC = 2 * DT_TX + 2;                     // dlogits tile: 18 rows x 34 pixels x 3 channels, bf16
 constexpr int DT_DLPITCH = DT_DLC * 6;                    // 204 bytes per row (4-byte aligned)
 constexpr int DT_DLBYTES = (2 * DT_TY + 2) * DT_DLPITCH;  // 3672
-constexpr int DT_XS = DT_NPIX * 64;                       // 11520: staged input pixels, 64 bytes each (32 bf16 channels), chunk-swizzled
+constexpr int DT_XP = 80;                                 // staged input pixels: 64 bytes (32 bf16 channels) at an 80-byte pitch -- 16 consecutive pixels start in 16
+                                                          // different bank quads, so the 16-byte fragment reads, the mask reads and the transposed reads need no swizzle
+                                                          // (and every tap of a slot is ONE base address + an immediate offset)
+constexpr int DT_XS = (DT_NPIX * DT_XP + 255) & ~255;      // 14592
 constexpr int DT_PT = 32 * 128;                           // per wave: transposed-read tile of its 32 patches, 64 columns (48 used)
 constexpr int DT_SLAB = 48 * 32;                          // floats of dW per block
 constexpr int DT_LBC = 104;                               // label tile: 18 rows x 102 values (34 pixels x 3) as fp32, 104-float pitch
@@ -38,6 +41,7 @@ constexpr int DT_LBBYTES = (2 * DT_TY + 2) * DT_LBC * 4;  // 7488
 
 struct DecTailParams {
     const bf16_t* x; int B, IH, IW;                      // deconv3's output [B, IH, IW, 32] (post-ReLU)
+    unsigned x_bytes;                                    // its size (< 2^31: read through a buffer descriptor with 32-bit offsets)
     const bf16_t* w;                                     // deconv4 kernel [4][4][3][32]  (kh, kw, out, in)
     const bf16_t* wt;                                    // the same K-contiguous: [32][48], k = (kh * 4 + kw) * 3 + out
     const float* bias;                                   // [3]
@@ -47,13 +51,21 @@ struct DecTailParams {
     float* slabs;                                        // [gridDim.x][DT_SLAB] partial filter gradients (reduce_slabs_kernel adds them to dW)
     float* lpart; float* bpart;                          // per block: loss partial sum; 4 floats of per-channel dlogits sums
     int OH, OW, GH, GW, tiles_x, tiles_per_frame, ntiles;
+    int edge_own;                                        // 1: tiles cover the PIXEL grid; the last slot row / column (index IH / IW) is owned by the last tile row / column
     FastDiv div_tpf, div_tx;
 };
+
+// two fp32 values -> two bf16 in one dword (low half = a): one v_cvt_pk_bf16_f32, round-to-nearest-even like f32_to_bf16
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_));
+}
 
 // block barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)), which would make the
 // software prefetch of the next tile wait at the first barrier it meets
 __device__ __forceinline__ void dt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ int dt_swz(int q) { return (q >> 2) & 3; }      // 64-byte rows read by 32 consecutive rows (gn_swz<4>)
 
 template <bool FASTBCE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dectail_kernel(const DecTailParams p) {
@@ -62,6 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     unsigned char* const pt = lds + DT_XS;                // 4 wave-private patch tiles (the cross-wave reduction at the very end reuses them)
     unsigned char* const dl = lds + DT_XS + 4 * DT_PT;    // dlogits tile (+ 16 floats of block reduction behind it)
     static_assert(DT_DLBYTES + 16 + 64 <= 3840, "dlogits tile + reduction words");
+    static_assert(DT_NSLOT > 128 && DT_NSLOT <= 160, "phase 1: four groups of 32 slots + one rotating fifth");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,68 +118,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // The staged data of a tile -- 720 sixteen-byte chunks of input pixels (3 per thread), 468 four-value label items (2 per thread) -- is REQUESTED one
     // tile ahead: the loads of tile t + 1 are issued right after the barrier that publishes tile t and land under its three phases (a block that stages,
     // waits, computes was a chain of one HBM latency per tile: with three blocks per CU that was half the kernel).  Per-thread roles are fixed:
-    int sq[3], spc[3]; bool sin3[3];                       // input chunk i: tile pixel, physical chunk
+    int sq[3], spc[3]; bool sin3[3];                       // input chunk i: tile pixel, 16-byte chunk
     int lr[2], ld4[2]; bool lin2[2];                       // label item i: tile row, item
+    int xrel[3], xr_[3], xc_[3];                           // input chunk i: byte offset relative to the tile origin's pixel, tile row / column
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const int id = tid + 256 * i; sin3[i] = id < DT_NPIX * 4; sq[i] = sin3[i] ? id >> 2 : 0; spc[i] = id & 3; }
+    for (int i = 0; i < 3; ++i) {
+        const int id = tid + 256 * i; sin3[i] = id < DT_NPIX * 4; sq[i] = sin3[i] ? id >> 2 : 0; spc[i] = id & 3;
+        xr_[i] = sq[i] / DT_PC; xc_[i] = sq[i] - xr_[i] * DT_PC;
+        xrel[i] = ((xr_[i] - 1) * p.IW + xc_[i] - 1) * 64 + spc[i] * 16;
+    }
+    int lrel[2];                                          // label item i: value offset relative to the tile's first label value
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int id = tid + 256 * i; lin2[i] = id < (2 * DT_TY + 2) * (DT_LBC / 4); lr[i] = lin2[i] ? id / (DT_LBC / 4) : 0; ld4[i] = lin2[i] ? id - lr[i] * (DT_LBC / 4) : 0; }
-    // the label frame of a tile (minibatch gather): looked up TWO tiles ahead, so that the requests of the next tile never wait for it
-    // (kept in a VECTOR register on purpose -- `vzero` is 0 in every lane but divergent to the compiler: a uniform value is moved to a scalar
-    //  register with v_readfirstlane right behind its load, i.e. behind an s_waitcnt vmcnt(0) that would also drain the prefetch just issued)
-    const int vzero = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
-    auto frame_of = [&](int tile) -> int { const int b = (int)p.div_tpf.div((uint32_t)tile) + vzero; return p.lab_idx ? p.lab_idx[b] : b; };
-    struct Staged { f32x4 x[3]; f32x4 l[2]; uint32_t ok; };   // (uint8 labels: the raw dword travels in l[i][0]); ok: bit i = item i lies inside the tensors
-    // Branch-free: an item outside the image / the frame reads a valid address anyway (the tensor base) and is zeroed when it is committed.  With
-    // exec-masked loads the compiler loses count of what is in flight and falls back to s_waitcnt vmcnt(0) -- which drains the prefetch.
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i; lin2[i] = id < (2 * DT_TY + 2) * (DT_LBC / 4); lr[i] = lin2[i] ? id / (DT_LBC / 4) : 0; ld4[i] = lin2[i] ? id - lr[i] * (DT_LBC / 4) : 0;
+        lrel[i] = lr[i] * (3 * p.OW) + 4 * ld4[i];
+    }
+    // Both tensors are read through buffer descriptors with 32-bit offsets (the host checks the sizes): an item outside the image / the frame is requested at
+    // an offset past the end and comes back as zeros from the range check -- no branch around a load (with exec-masked loads the compiler loses count of what is
+    // in flight and falls back to s_waitcnt vmcnt(0), which drains the prefetch), no select when it is committed, no 64-bit address arithmetic.
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const int lesz = p.lab_u8 ? 1 : 4;
+    constexpr int DT_OOB = 0x7ffffff0;
+    // the label frame of a tile (minibatch gather) is a SCALAR load (s_load_dword + its own lgkmcnt wait: the 2 KB index vector lives in the scalar cache).  As a
+    // vector load it was followed by v_readfirstlane behind an s_waitcnt vmcnt(0) -- which drains the prefetch just issued.  The scalar frame also gives the label
+    // descriptor an exact base and extent per tile: offsets inside one frame, range check = the frame.
+    auto frame_of = [&](int tile) -> int {
+        const int b = (int)p.div_tpf.div((uint32_t)tile);
+        int fr = b;
+        if (p.lab_idx) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fr) : "s"(p.lab_idx + b) : "memory");
+        return fr;
+    };
+    struct Staged { f32x4 x[3]; f32x4 l[2]; };             // (uint8 labels: the raw dword travels in l[i][0])
     auto request = [&](int tile, int frame, Staged& R) {
         uint32_t b, rem, ty, tx;
         p.div_tpf.divmod((uint32_t)tile, b, rem);
         p.div_tx.divmod(rem, ty, tx);
         const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
-        const long long fr = frame;                        // (its load was issued one tile ago: the only wait in front of the five requests below)
-        const bf16_t* xb = p.x + (long long)b * p.IH * p.IW * 32;
-        uint32_t ok = 0;
+        const int xbase = (((int)b * p.IH + y0) * p.IW + x0) * 64;                  // bytes; the host guarantees B IH IW 64 < 2^31
+        const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)p.labels + (long long)frame * p.lab_stride * lesz), 0,
+                                                                             p.OH * p.OW * 3 * lesz, 0x00020000);
+        const int lbase = 2 * y0 * (3 * p.OW) + 6 * x0;                             // values inside the frame
         // labels of the 18 x 34 output pixels the tile's slots cover: row r = output row 2 y0 + r, 102 consecutive values from column 2 x0 (4 values per
         // item; whole items only: the host guarantees 3 OW % 4 == 0, so a row's valid part ends on an item boundary; the rest reads 0)
-        const unsigned char* lsrc[2];
+        int loff[2], xoff[3];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int oy = 2 * y0 + lr[i], j0 = 6 * x0 + 4 * ld4[i];      // value offset inside the output row
-            const bool in = lin2[i] && oy < p.OH && j0 + 4 <= 3 * p.OW;
-            ok |= in ? 8u << i : 0u;
-            const long long off = in ? fr * p.lab_stride + (long long)oy * (3 * p.OW) + j0 : 0ll;
-            lsrc[i] = (const unsigned char*)p.labels + off * (p.lab_u8 ? 1 : 4);
+            const bool in = lin2[i] && 2 * y0 + lr[i] < p.OH && 6 * x0 + 4 * ld4[i] + 4 <= 3 * p.OW;
+            loff[i] = in ? (lbase + lrel[i]) * lesz : DT_OOB;
         }
-        const bf16_t* xsrc[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int r = sq[i] / DT_PC, c = sq[i] - r * DT_PC;
-            const int y = y0 - 1 + r, x = x0 - 1 + c;
-            const bool in = sin3[i] && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
-            ok |= in ? 1u << i : 0u;
-            const int lc = spc[i] ^ dt_swz(sq[i]);        // the logical chunk that lives in this physical one
-            xsrc[i] = in ? xb + ((long long)y * p.IW + x) * 32 + lc * 8 : p.x;
+            const bool in = sin3[i] && (unsigned)(y0 - 1 + xr_[i]) < (unsigned)p.IH && (unsigned)(x0 - 1 + xc_[i]) < (unsigned)p.IW;
+            xoff[i] = in ? xbase + xrel[i] : DT_OOB;
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) R.x[i] = *(const f32x4*)xsrc[i];
+        for (int i = 0; i < 3; ++i) R.x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[i], 0, 0));
         if (p.lab_u8) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) R.l[i][0] = __builtin_bit_cast(float, *(const uint32_t*)lsrc[i]);
+            for (int i = 0; i < 2; ++i) R.l[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, loff[i], 0, 0));
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) R.l[i] = *(const f32x4*)lsrc[i];
+            for (int i = 0; i < 2; ++i) R.l[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsL, loff[i], 0, 0));
         }
-        R.ok = ok;
     };
     auto commit = [&](const Staged& R) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            f32x4 v = R.x[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (R.ok >> i) & 1u ? v[e] : 0.f;
-            if (sin3[i]) *(f32x4*)(xs + sq[i] * 64 + spc[i] * 16) = v;
-        }
+        for (int i = 0; i < 3; ++i)
+            if (sin3[i]) *(f32x4*)(xs + sq[i] * DT_XP + spc[i] * 16) = R.x[i];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 v = R.l[i];
@@ -175,8 +193,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = u8_to_unit_exact((float)((u >> (8 * e)) & 255u));
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (R.ok >> (3 + i)) & 1u ? v[e] : 0.f;
             if (lin2[i]) *(f32x4*)(lab + lr[i] * DT_LBC + 4 * ld4[i]) = v;
         }
     };
@@ -187,9 +203,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int G = (int)gridDim.x;
     const int vb = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     int t_nxt = min(vb + G, p.ntiles - 1);                   // (past the end: a valid tile is requested again -- no branch around the loads)
-    int fr_req = frame_of(min(vb, p.ntiles - 1));
-    request(min(vb, p.ntiles - 1), fr_req, cur);
-    fr_req = frame_of(t_nxt);
+    request(min(vb, p.ntiles - 1), frame_of(min(vb, p.ntiles - 1)), cur);
+    // Phase 1 has FIVE groups of 32 slots for four waves (9 x 17 = 153 slots): wave w takes group w, wave 0 also the fifth.  (Rotating the fifth group over the
+    // waves from tile to tile changed nothing: 88.6 vs 90.3 us.)  The slot of a lane in its wave's own group never changes: its LDS addresses are set up once.
+    struct SlotLane { int sy, sx; uint32_t xa, la, da; bool sv; };       // slot; byte addresses of its first tap's fragment / its label row / its dlogits row
+    auto slot_lane = [&](int g) -> SlotLane {
+        SlotLane L;
+        const int sidx = min(g * 32 + lrow, DT_NSLOT - 1);
+        L.sv = g * 32 + lrow < DT_NSLOT;
+        L.sy = sidx / DT_SX; L.sx = sidx - L.sy * DT_SX;
+        L.xa = (uint32_t)((L.sy * DT_PC + L.sx) * DT_XP + lgrp * 16);
+        L.la = (uint32_t)(((2 * L.sy + lgrp) * DT_LBC + L.sx * 6) * 4);
+        L.da = (uint32_t)((2 * L.sy + lgrp) * DT_DLPITCH + L.sx * 12);
+        return L;
+    };
+    const SlotLane own = slot_lane(wave);
+    const uint32_t wa = (uint32_t)(wrow * 64 + lgrp * 16);
     for (int tile = vb; tile < p.ntiles; tile += G) {
         uint32_t b, rem, ty, tx;
         p.div_tpf.divmod((uint32_t)tile, b, rem);
@@ -197,29 +226,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
         commit(cur);
         __syncthreads();
-        request(t_nxt, fr_req, cur);
+        request(t_nxt, frame_of(t_nxt), cur);
         t_nxt = min(t_nxt + G, p.ntiles - 1);
-        fr_req = frame_of(t_nxt);
 
         // ---- phase 1: logits of the 9 x 17 slots, loss, dlogits into the LDS tile ----
-        for (int g = wave; g * 32 < DT_NSLOT; g += 4) {
-            const int sidx = min(g * 32 + lrow, DT_NSLOT - 1);
-            const bool sv = g * 32 + lrow < DT_NSLOT;
-            const int sy = sidx / DT_SX, sx = sidx - sy * DT_SX;
+        auto slot_group = [&](const SlotLane& L) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int tap = 0; tap < 4; ++tap) {
-                const int q = (sy + (tap >> 1)) * DT_PC + sx + (tap & 1);
-                const int sw = dt_swz(q);
+            for (int tap = 0; tap < 4; ++tap)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    const u16x8 af = *(const u16x8*)(xs + q * 64 + (((2 * kk + lgrp) ^ sw) << 4));
-                    const u32x4 wv = *(const u32x4*)(wl + (tap * 13 + wrow) * 64 + (2 * kk + lgrp) * 16);
+                    const u16x8 af = *(const u16x8*)(xs + L.xa + ((tap >> 1) * DT_PC + (tap & 1)) * DT_XP + kk * 32);
+                    const u32x4 wv = *(const u32x4*)(wl + wa + tap * 13 * 64 + kk * 32);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
                 }
-            }
             // D rows: register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h; rows 0 .. 11 = class * 3 + channel are live: h = 0 holds rows 0..3
             // (registers 0..3) and 8..11 (registers 4..7), h = 1 rows 4..7 (registers 0..3).  Four half-wave swaps give every lane ONE output row of its
             // slot -- h = 0: rows 0..5 = output row 2 sy (pixels 2 sx, 2 sx + 1 x 3 channels), h = 1: rows 6..11 = output row 2 sy + 1 -- six consecutive
@@ -235,46 +257,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
             // lower half: rows 0..5 = v0 v1 v2 v3 v4 v5; upper half: rows 6..11 = v2 v3 v0 v1 v4 v5
             const float xr[6] = {lgrp ? v2 : v0, lgrp ? v3 : v1, lgrp ? v0 : v2, lgrp ? v1 : v3, v4, v5};
-            const bool slot_in = sv && y0 + sy < p.GH && x0 + sx < p.GW;
-            const bool owned = slot_in && sy < DT_TY && sx < DT_TX;
-            const float* lrowp = lab + (2 * sy + lgrp) * DT_LBC + sx * 6;
+            // a tile owns the slots of its own 8 x 16 pixels; the slot grid is one row and one column larger than the pixel grid, and that last row /
+            // column -- the ninth / seventeenth of the last tiles, computed anyway for their pixels' patches -- belongs to them
+            // (bitwise on purpose: with && / || hipcc turned these into five branches per group)
+            const int ylast = p.GH - 1 - y0, xlast = p.GW - 1 - x0;
+            const bool eo = p.edge_own != 0;
+            const bool slot_in = L.sv & (L.sy <= ylast) & (L.sx <= xlast);
+            const bool owned = slot_in & ((L.sy < DT_TY) | (eo & (L.sy == ylast))) & ((L.sx < DT_TX) | (eo & (L.sx == xlast)));
+            // masks as DATA: a select per value made hipcc branch around each logit's gradient (six s_and_saveexec / s_cbranch_execz pairs per group)
+            const uint32_t inm = slot_in ? 0xffffffffu : 0u;
+            const float ownf = owned ? 1.0f : 0.0f;
             float yv[6];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const PackN<float, 2> t = *(const PackN<float, 2>*)(lrowp + 2 * j); yv[2 * j] = t.v[0]; yv[2 * j + 1] = t.v[1]; }
-            bf16_t gq[6];
+            for (int j = 0; j < 3; ++j) { const PackN<float, 2> t = *(const PackN<float, 2>*)((const unsigned char*)lab + L.la + 8 * j); yv[2 * j] = t.v[0]; yv[2 * j + 1] = t.v[1]; }
+            uint32_t gw[3];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float xraw = xr[j] + (j % 3 == 0 ? bias0 : (j % 3 == 1 ? bias1 : bias2));
-                const float xv = bf16_to_f32(f32_to_bf16(xraw));   // the loss reads the logits as they would have been STORED (same values as the unfused kernel)
-                float l, gr;
-                if constexpr (FASTBCE) {                   // loss_kind 0 on the hardware transcendentals (gather_narrow_kernel, FASTBCE)
-                    const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
-                    const float s1 = 1.0f + e;
-                    const float rr = __builtin_amdgcn_rcpf(s1);
-                    const float sg = xv >= 0.f ? rr : e * rr;
-                    l = fmaf(__builtin_amdgcn_logf(s1), 0.69314718f, fmaf(-xv, yv[j], fmaxf(xv, 0.f)));
-                    gr = sg - yv[j];
-                } else {
-                    const float e = __expf(-fabsf(xv));
-                    const float rr = __frcp_rn(1.0f + e);
-                    const float sg = xv >= 0.f ? rr : e * rr;
-                    if (p.loss_kind == 0) { l = fmaxf(xv, 0.f) - xv * yv[j] + __logf(1.0f + e); gr = sg - yv[j]; }
-                    else if (p.loss_kind == 1) {
-                        l = -(yv[j] * __logf(1e-10f + sg) + (1.0f - yv[j]) * __logf(1e-10f + 1.0f - sg));
-                        gr = (-yv[j] / (1e-10f + sg) + (1.0f - yv[j]) / (1e-10f + 1.0f - sg)) * sg * (1.0f - sg);
-                    } else { const float dd = yv[j] - sg; l = dd * dd; gr = -2.0f * dd * sg * (1.0f - sg); }
+            for (int jp = 0; jp < 3; ++jp) {                // two logits at a time: one v_cvt_pk_bf16_f32 rounds both (logits as STORED, dlogits as STORED)
+                const int ja = 2 * jp, jb = 2 * jp + 1;
+                const float xa_ = xr[ja] + (ja % 3 == 0 ? bias0 : (ja % 3 == 1 ? bias1 : bias2));
+                const float xb_ = xr[jb] + (jb % 3 == 0 ? bias0 : (jb % 3 == 1 ? bias1 : bias2));
+                const uint32_t xpk = pack2_bf16(xa_, xb_);
+                const float xv2[2] = {__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
+                float gr2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * jp + h;
+                    const float xv = xv2[h];
+                    float l, gr;
+                    if constexpr (FASTBCE) {               // loss_kind 0 on the hardware transcendentals (gather_narrow_kernel, FASTBCE)
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
+                        const float s1 = 1.0f + e;
+                        const float rr = __builtin_amdgcn_rcpf(s1);
+                        const float sg = xv >= 0.f ? rr : e * rr;
+                        l = fmaf(__builtin_amdgcn_logf(s1), 0.69314718f, fmaf(-xv, yv[j], fmaxf(xv, 0.f)));
+                        gr = sg - yv[j];
+                    } else {
+                        const float e = __expf(-fabsf(xv));
+                        const float rr = __frcp_rn(1.0f + e);
+                        const float sg = xv >= 0.f ? rr : e * rr;
+                        if (p.loss_kind == 0) { l = fmaxf(xv, 0.f) - xv * yv[j] + __logf(1.0f + e); gr = sg - yv[j]; }
+                        else if (p.loss_kind == 1) {
+                            l = -(yv[j] * __logf(1e-10f + sg) + (1.0f - yv[j]) * __logf(1e-10f + 1.0f - sg));
+                            gr = (-yv[j] / (1e-10f + sg) + (1.0f - yv[j]) / (1e-10f + 1.0f - sg)) * sg * (1.0f - sg);
+                        } else { const float dd = yv[j] - sg; l = dd * dd; gr = -2.0f * dd * sg * (1.0f - sg); }
+                    }
+                    gr2[h] = gr * p.inv_b;
+                    lsum = fmaf(l, ownf, lsum);
                 }
-                gq[j] = slot_in ? f32_to_bf16(gr * p.inv_b) : (bf16_t)0;
-                lsum += owned ? l : 0.f;
-                const float gst = owned ? bf16_to_f32(gq[j]) : 0.f;     // the bias gradient sums the STORED (rounded) values, like BiasAddGrad of dlogits
-                if (j % 3 == 0) gs0 += gst; else if (j % 3 == 1) gs1 += gst; else gs2 += gst;
+                gw[jp] = pack2_bf16(gr2[0], gr2[1]) & inm;
+                // the bias gradient sums the STORED (rounded) values, like BiasAddGrad of dlogits
+                const float ga = __builtin_bit_cast(float, gw[jp] << 16), gb = __builtin_bit_cast(float, gw[jp] & 0xffff0000u);
+                if (ja % 3 == 0) gs0 = fmaf(ga, ownf, gs0); else if (ja % 3 == 1) gs1 = fmaf(ga, ownf, gs1); else gs2 = fmaf(ga, ownf, gs2);
+                if (jb % 3 == 0) gs0 = fmaf(gb, ownf, gs0); else if (jb % 3 == 1) gs1 = fmaf(gb, ownf, gs1); else gs2 = fmaf(gb, ownf, gs2);
             }
-            if (sv) {
-                uint32_t* drow = (uint32_t*)(dl + (2 * sy + lgrp) * DT_DLPITCH + sx * 12);
+            if (L.sv) {
+                uint32_t* drow = (uint32_t*)(dl + L.da);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) drow[j] = (uint32_t)gq[2 * j] | ((uint32_t)gq[2 * j + 1] << 16);
+                for (int j = 0; j < 3; ++j) drow[j] = gw[j];
             }
-        }
+        };
+        slot_group(own);
+        if (wave == 0) slot_group(slot_lane(4));
         dt_lds_barrier();                                 // dlogits tile complete (LDS only: the next tile's global loads stay in flight)
 
         // ---- phase 2: input gradient of this wave's 32 pixels: rows yl = 2 wave, 2 wave + 1, columns xl = 0 .. 15 ----
@@ -309,8 +352,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};
             // ReluGrad: the staged activation row itself is the mask
             const int qm = (yl + 1) * DT_PC + xl + 1;
-            const PackN<uint32_t, 4> m0 = *(const PackN<uint32_t, 4>*)(xs + qm * 64 + (((2 * lgrp) ^ dt_swz(qm)) << 4));
-            const PackN<uint32_t, 4> m1 = *(const PackN<uint32_t, 4>*)(xs + qm * 64 + (((2 * lgrp + 1) ^ dt_swz(qm)) << 4));
+            const PackN<uint32_t, 4> m0 = *(const PackN<uint32_t, 4>*)(xs + qm * DT_XP + lgrp * 32);
+            const PackN<uint32_t, 4> m1 = *(const PackN<uint32_t, 4>*)(xs + qm * DT_XP + lgrp * 32 + 16);
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
                 uint32_t pos, nz;                          // per 16-bit half: x > 0 as a signed integer (negative floats are negative int16) -> 1, else 0
@@ -336,9 +379,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             u16x8 bfr;
             {
                 const int q0 = (2 * wave + ks + 1) * DT_PC + 1 + trow;      // staged-tile pixel of row trow (and trow + 4)
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(xs + q0 * 64 + (((tcol >> 3) ^ dt_swz(q0)) << 4) + (tcol & 7) * 2));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(xs + q0 * DT_XP + tcol * 2));
                 const int q1 = q0 + 4;
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(xs + q1 * 64 + (((tcol >> 3) ^ dt_swz(q1)) << 4) + (tcol & 7) * 2));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(xs + q1 * DT_XP + tcol * 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { bfr[e] = (unsigned short)lo[e]; bfr[4 + e] = (unsigned short)hi[e]; }
             }
