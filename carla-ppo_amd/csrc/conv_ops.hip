@@ -239,6 +239,8 @@ extern "C" int mi_tapwgrad_flush(void* stream) {
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
 int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
+static int nw_depth_env() { const char* e = getenv("MI355_NW_DEPTH"); return e ? atoi(e) : 3; }
+int g_nw_depth = nw_depth_env();                          // narrow_wgrad (uint8 conv1 shape): steps in flight per wave (3 | 5 | 6); mi_set_tuning key 19
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
@@ -444,7 +446,11 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
         if (g3 && q.dbias) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 1, NWV_>), g, t, 0, st, q); \
         else if (g3) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 0, NWV_>), g, t, 0, st, q); \
         else hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 0, -1, NWV_>), g, t, 0, st, q); } while (0)
-    if (narrow_f32 == 2) NW_LAUNCH(unsigned char, 12);
+    if (narrow_f32 == 2 && g3 && q.dbias && g_nw_depth == 6) {
+        hipLaunchKernelGGL((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 6>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
+    } else if (narrow_f32 == 2 && g3 && q.dbias && g_nw_depth == 5) {
+        hipLaunchKernelGGL((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 5>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
+    } else if (narrow_f32 == 2) NW_LAUNCH(unsigned char, 12);
     else if (narrow_f32) { if (g_nw_waves >= 12) NW_LAUNCH(float, 12); else if (g_nw_waves >= 8) NW_LAUNCH(float, 8); else NW_LAUNCH(float, 4); }
     else { if (g_nw_waves >= 12) NW_LAUNCH(bf16_t, 12); else if (g_nw_waves >= 8) NW_LAUNCH(bf16_t, 8); else NW_LAUNCH(bf16_t, 4); }
 #undef NW_LAUNCH
@@ -750,6 +756,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 16) { prev = mi_rwconv_blocks(value < 0 ? 0 : value); }
     else if (key == 17) { prev = g_gemm2_tile; g_gemm2_tile = value; }
     else if (key == 18) { prev = g_slab_bf16; g_slab_bf16 = value ? 1 : 0; }
+    else if (key == 19) { prev = g_nw_depth; g_nw_depth = value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }
@@ -948,7 +955,7 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
 // behind that launch and in front of the optimiser step (the VAE engine runs it where its stream would otherwise wait for the other one)
 int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw) {
     if (!scratch || !dw || n_partial < 1) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_reduce: missing buffers");
-    hipLaunchKernelGGL(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
+    hipLaunchKernelGGL(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
     return mi_check_launch("dectail_reduce_kernel");
 }
 

@@ -430,25 +430,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
 }
 
-// dW[1536] += sum over the n per-block slabs: a block owns 32 consecutive outputs (128 bytes per slab row), its 8 thread rows take every 8th slab,
-// eight loads in flight per thread; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void dectail_reduce_kernel(const float* __restrict__ slabs, int n, float* __restrict__ dw) {
-    __shared__ float red[8][32];
-    const int col = (int)blockIdx.x * 32 + (threadIdx.x & 31), r0 = threadIdx.x >> 5;
+// dW[1536] += sum over the n per-block slabs: a block owns 32 consecutive outputs (128 bytes per slab row), its 32 thread rows take every 32nd slab,
+// eight loads in flight per thread (768 slabs: three batches); fixed summation order (deterministic).  (256-thread blocks with 8 thread rows: 12 batches
+// of dependent-latency loads, 16 us at the very end of the step's critical path.)
+__global__ __launch_bounds__(1024) void dectail_reduce_kernel(const float* __restrict__ slabs, int n, float* __restrict__ dw) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    const int col = (int)blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int k0 = r0; k0 < n; k0 += 64) {
+    for (int k0 = r0; k0 < n; k0 += 256) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + 8 * u; v[u] = k < n ? slabs[(long long)k * DT_SLAB + col] : 0.f; }
+        for (int u = 0; u < 8; ++u) { const int k = k0 + 32 * u; v[u] = k < n ? __builtin_nontemporal_load(&slabs[(long long)k * DT_SLAB + col]) : 0.f; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
     }
-    red[r0][threadIdx.x & 31] = s;
+    red[r0][c] = s;
     __syncthreads();
     if (threadIdx.x < 32) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
         dw[col] += t;
     }
 }

@@ -301,7 +301,9 @@ constexpr int NW_BP = 16;            // pixels per wave step
 // add per block and address) queue up at the end: 18 us of a 73 us launch with 747 four-wave blocks; 12-wave blocks (one per CU) cut the
 // queue depth by three.
 constexpr int NW_WAVES = 12;
-template <typename TS, int NGRP = 0, int BIAS = -1, int NWV = NW_WAVES>
+// DEPTH: steps in flight per wave (register pipeline).  The kernel is latency-bound -- 75 % of its wave cycles wait, VALU 20 %, MFMA 5 % (profiles/r03_b) -- so
+// what a wave has in flight IS its speed: 3 steps = 5.3 KB per wave, 64 KB per CU.
+template <typename TS, int NGRP = 0, int BIAS = -1, int NWV = NW_WAVES, int DEPTH = 3>
 __global__ __launch_bounds__(NWV * 64) void narrow_wgrad_kernel(const NarrowWgradParams p) {
     constexpr int PA = 128, PS = 64;                      // LDS row pitch: im2col rows (64 bf16), wide rows (32 bf16)
     constexpr int WSTG = NW_BP * PA + NW_BP * PS;         // per wave: one im2col tile + one wide-row tile = 3 KB
@@ -415,14 +417,16 @@ __global__ __launch_bounds__(NWV * 64) void narrow_wgrad_kernel(const NarrowWgra
         if (BIAS > 0 || (BIAS < 0 && p.dbias)) acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, sf), acc[2], 0, 0, 0);
     };
 
-    // 3-deep register pipeline (steps s, s+1, s+2 in flight); out-of-range steps load nothing and store zeros
-    StepRegs R0, R1, R2;
-    load_step(0, R0); load_step(1, R1);
-    for (int step = 0; step < nsteps; step += 3) {       // steps past the range load nothing and add zeros: no branch in the body
-        load_step(step + 2, R2);
-        store_step(R0); compute();
-        load_step(step + 3, R0); store_step(R1); compute();
-        load_step(step + 4, R1); store_step(R2); compute();
+    // DEPTH-deep register pipeline (steps s .. s + DEPTH - 1 in flight); out-of-range steps load nothing and store zeros
+    StepRegs R[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load_step(d, R[d]);
+    for (int step = 0; step < nsteps; step += DEPTH) {   // steps past the range load nothing and add zeros: no branch in the body
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            load_step(step + u + DEPTH - 1, R[(u + DEPTH - 1) % DEPTH]);
+            store_step(R[u]); compute();
+        }
     }
 
     // cross-wave reduction (waves take turns on one 12 KB buffer), then one set of atomics per block:
