@@ -188,10 +188,11 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // Deferred split reductions.  The reduce that follows a tapwgrad launch is a small, bandwidth-trivial kernel, but on the filter-gradient
 // stream of the engine it shares the chip with a big input-gradient kernel and takes 15-30 us instead of 7.  In deferred mode the launch
 // is recorded instead (parameters by value; every layer then needs its OWN scratch region until the flush) and mi_tapwgrad_flush issues
-// all of them back to back.  Process-global like the tuning knobs; used by the VAE engine only.
+// all of them back to back.  Per host THREAD (thread_local): a backward pass is issued by one thread from defer(1) to flush, so two engines driven by two
+// threads keep separate lists (round 3; the tuning knobs stay process-global configuration).  Used by the VAE engine only.
 struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; };
-static PendingReduce g_pending[16];
-static int g_npending = 0, g_defer_reduces = 0;
+static thread_local PendingReduce g_pending[16];
+static thread_local int g_npending = 0, g_defer_reduces = 0;
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element: about 512 blocks in flight, at most ~16 slabs per thread
     unsigned ry = 1;
     while (((unsigned)(r.ngroups / 256 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4) ry *= 2;
@@ -212,7 +213,9 @@ extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode d
 }
 int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
                                                            // partial sums), switched on by the VAE engine around its backward pass (mi_tapwgrad_slab_bf16); mi_set_tuning key 18
-extern "C" int mi_tapwgrad_slab_bf16(int on) { const int prev = g_slab_bf16; g_slab_bf16 = on ? 1 : 0; return prev; }
+static thread_local int t_slab_bf16 = -1;                  // this thread's override for the pass it is issuing (-1: the process default above)
+static inline int slab_bf16_now() { return t_slab_bf16 >= 0 ? t_slab_bf16 : g_slab_bf16; }
+extern "C" int mi_tapwgrad_slab_bf16(int on) { const int prev = t_slab_bf16; t_slab_bf16 = on < 0 ? -1 : (on ? 1 : 0); return prev; }
 extern "C" int mi_tapwgrad_flush(void* stream) {
     const int n = g_npending;
     g_npending = 0;
@@ -221,7 +224,7 @@ extern "C" int mi_tapwgrad_flush(void* stream) {
         for (int i = 0; i < n; ++i) launch_tiled_reduce((hipStream_t)stream, g_pending[i]);
         return mi_check_launch("reduce_tiled_kernel");
     }
-    static FusedReduceParams f;                           // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
+    static thread_local FusedReduceParams f;              // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
     f.n = n; f.first[0] = 0;
     for (int i = 0; i < n; ++i) {
         const PendingReduce& r = g_pending[i];
@@ -314,7 +317,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     // when it is large enough; otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
     const int kt_tiles = taps == 2 ? 4 : 2;
     const long long slab_floats = (long long)gy * q.npairs * kt_tiles * 1024;
-    q.slabs = nullptr; q.slab_stride = slab_floats; q.slab_bf16 = g_slab_bf16 ? 1 : 0;
+    q.slabs = nullptr; q.slab_stride = slab_floats; q.slab_bf16 = slab_bf16_now() ? 1 : 0;
     if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * (q.slab_bf16 ? 2 : 4) && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)

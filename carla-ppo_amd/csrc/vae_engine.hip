@@ -72,7 +72,11 @@ struct Workspace {
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
     long long total;
+    // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
+    // finds the region a kernel wrote past (the bounds-checking debug mode of the new build)
+    int n_guards; long long guard_off[96];
 };
+constexpr uint32_t GUARD_WORD = 0xC0DEFA11u;
 
 // ---- per-op HIP-event timing (bench.py's live roofline numbers; off by default) ----
 enum {
@@ -157,8 +161,15 @@ void make_workspace(VaeEngine& e) {
     const MiVaeDesc& d = e.d; const Geom& g = e.g;
     const long long B = d.max_batch;
     long long o = 0;
-    auto add = [&](long long bytes) { long long r = o; o += (bytes + 255) / 256 * 256; return r; };
     Workspace& W = e.W;
+    const char* ge = getenv("MI355_DEBUG_GUARDS");
+    const bool guards = ge && ge[0] == '1';
+    W.n_guards = 0;
+    auto add = [&](long long bytes) {
+        long long r = o; o += (bytes + 255) / 256 * 256;
+        if (guards && W.n_guards < 96) { W.guard_off[W.n_guards++] = o; o += 256; }
+        return r;
+    };
     W.act[0] = W.gact[0] = 0;
     for (int i = 1; i <= NCONV; ++i) {
         const long long n = B * g.ih[i] * g.iw[i] * g.c[i];
@@ -317,7 +328,39 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
     if ((((uintptr_t)params) | ((uintptr_t)workspace) | ((uintptr_t)bf16_shadow) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: buffers must be 256-byte aligned"); return nullptr; }
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->wt = weights_t; e->ws = (char*)workspace;
     e->last_B = 0;
+    if (e->W.n_guards > 0) {                              // debug mode: arm the guard words (synchronous copies; never on the production path)
+        uint32_t pat[64];
+        for (int i = 0; i < 64; ++i) pat[i] = GUARD_WORD ^ (uint32_t)i;
+        for (int k = 0; k < e->W.n_guards; ++k)
+            if (hipMemcpy(e->ws + e->W.guard_off[k], pat, 256, hipMemcpyHostToDevice) != hipSuccess) { free(e); mi_fail(MI_ERR_STATE, "mi_vae_create: arming the debug guards failed"); return nullptr; }
+    }
     return e;
+}
+
+// Debug (MI355_DEBUG_GUARDS=1): *n_regions = guarded workspace regions (0: the mode is off), *n_bad = guards whose 256 bytes no longer hold the pattern,
+// i.e. regions some kernel wrote past; mi_last_error() names the first one.  Synchronises the device.  guard_index >= 0: also returns that guard's byte
+// offset in *guard_offset (tests corrupt one on purpose).
+int mi_vae_debug_check_guards(void* h, int* n_regions, int* n_bad, int guard_index, long long* guard_offset) {
+    VaeEngine* e = (VaeEngine*)h;
+    if (!e || !n_regions || !n_bad) return mi_fail(MI_ERR_ARG, "mi_vae_debug_check_guards: missing arguments");
+    *n_regions = e->W.n_guards; *n_bad = 0;
+    if (guard_offset) *guard_offset = (guard_index >= 0 && guard_index < e->W.n_guards) ? e->W.guard_off[guard_index] : -1;
+    if (e->W.n_guards == 0) return MI_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_debug_check_guards: device error before the check");
+    int first = -1;
+    for (int k = 0; k < e->W.n_guards; ++k) {
+        uint32_t got[64];
+        if (hipMemcpy(got, e->ws + e->W.guard_off[k], 256, hipMemcpyDeviceToHost) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_debug_check_guards: copy failed");
+        bool bad = false;
+        for (int i = 0; i < 64; ++i) bad |= got[i] != (GUARD_WORD ^ (uint32_t)i);
+        if (bad) { ++*n_bad; if (first < 0) first = k; }
+    }
+    if (first >= 0) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "workspace guard %d (byte offset %lld) overwritten: a kernel wrote past the region in front of it", first, e->W.guard_off[first]);
+        mi_fail(MI_OK, msg);
+    }
+    return MI_OK;
 }
 
 void mi_vae_destroy(void* h) {
@@ -469,7 +512,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     // Measured, three interleaved pairs on one box: 0.966 -> 0.943 ms per step.  MI355_SLAB_BF16=0: fp32 slabs.
     static int slab16 = -1;
     if (slab16 < 0) { const char* ev = getenv("MI355_SLAB_BF16"); slab16 = (ev && ev[0] == '0') ? 0 : 1; }
-    struct SlabGuard { int prev; bool on; ~SlabGuard() { if (on) mi_tapwgrad_slab_bf16(prev); } } slab_guard{0, false};
+    struct SlabGuard { int prev; bool on; ~SlabGuard() { if (on) mi_tapwgrad_slab_bf16(prev); } } slab_guard{-1, false};
     if (slab16 && d.dtype == MI_BF16) { slab_guard.prev = mi_tapwgrad_slab_bf16(1); slab_guard.on = true; }
     static int late_on = -1;                              // MI355_LATE_DENSE=0: dense1 / heads filter gradients on the filter-gradient stream as in round 2
     if (late_on < 0) { const char* ev = getenv("MI355_LATE_DENSE"); late_on = (ev && ev[0] == '0') ? 0 : 1; }

@@ -21,7 +21,24 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, asan=False):
+    """asan=True: the HOST side of the library with AddressSanitizer (-fsanitize=address is ignored for the gfx950 code objects) into build/asan/ -- the
+    checker build of tools/asan_host_check.sh (sanitizer row); never loaded by the product."""
+    global OBJ, LIB, FLAGS
+    if asan:
+        saved = (OBJ, LIB, FLAGS)
+        OBJ = os.path.join(ROOT, "build", "obj_asan")
+        os.makedirs(os.path.join(ROOT, "build", "asan"), exist_ok=True)
+        LIB = os.path.join(ROOT, "build", "asan", "libmi355_carla.so")
+        FLAGS = [f if f != "-O3" else "-O1" for f in FLAGS] + ["-g", "-fsanitize=address", "-shared-libsan", "-fno-omit-frame-pointer", "-Wno-option-ignored"]
+        try:
+            return _build(force, verbose, ["-fsanitize=address", "-shared-libsan"])
+        finally:
+            OBJ, LIB, FLAGS = saved
+    return _build(force, verbose, [])
+
+
+def _build(force, verbose, link_extra):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".hpp"))
@@ -44,7 +61,7 @@ def build(force=False, verbose=True):
                 print("[mi355.build] compiled", os.path.basename(done), flush=True)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
     if force or jobs or not os.path.exists(LIB):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], capture_output=True, text=True)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + link_extra + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
         if verbose:
@@ -53,4 +70,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv)

@@ -10,7 +10,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 HEADER = os.path.join(ROOT, "include", "mi355_carla.h")
-LIB_PATH = os.path.join(HERE, "libmi355_carla.so")
+LIB_PATH = os.environ.get("MI355_LIB") or os.path.join(HERE, "libmi355_carla.so")     # MI355_LIB: another build of the same library (tools/asan_host_check.sh)
 
 MI_F32, MI_BF16, MI_BF16X3 = 0, 1, 2              # MI_BF16X3: split storage (two bf16 halves hi | lo per 4-byte element), include/mi355_carla.h
 

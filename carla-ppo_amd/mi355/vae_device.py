@@ -184,6 +184,13 @@ class VaeDevice:
     def export_grads(self):
         return self._from_flat(self.grads.cpu().numpy())
 
+    def check_guards(self, guard_index=-1):
+        """Debug mode (MI355_DEBUG_GUARDS=1 when the engine was created): (guarded regions, overwritten guards, byte offset of guard `guard_index` or -1).
+        0 regions = the mode is off.  Synchronises the device."""
+        n, bad, off = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_longlong(-1)
+        self.L.mi_vae_debug_check_guards(self.handle, ctypes.addressof(n), ctypes.addressof(bad), int(guard_index), ctypes.addressof(off))
+        return n.value, bad.value, off.value
+
     # ---- steps (all asynchronous on the current torch stream) ----
     # Frame tables are float32 [N, feat] in [0, 1] or -- bf16 engine only -- raw uint8 camera frames [N, feat] (normalised to k / 255 inside
     # the kernels that read them: 4x less HBM traffic in conv1 forward / filter gradient and the loss); source and target share the format.

