@@ -53,11 +53,22 @@ long long* g_trace = nullptr; int g_trace_cap = 0;
 int g_wgrad_skip = 0;
 int g_tap_mask_prefetch = 1;                                // tapconv: touch the ReluGrad-mask lines in the last main-loop step; mi_set_tuning key 12
 int g_gemm2_on = -1;
+static int gemm2_stages_env() { const char* e = getenv("MI355_GEMM2_STAGES"); return e ? atoi(e) : 2; }
+int g_gemm2_stages = gemm2_stages_env();                    // gemm2 128 x 64 tiles: LDS stages of the K pipeline (2 | 3 | 4); mi_set_tuning key 20
 int g_gemm2_tile = 2;                                       // wide-output gemm2 layers: 0 auto (64 x 64 tiles on small grids), 1 always 64 x 64, 2 never; mi_set_tuning key 17
 int g_tap_min = -2;
 bool gemm2_enabled() {
     if (g_gemm2_on < 0) { const char* e = getenv("MI355_GEMM2"); g_gemm2_on = (e && e[0] == '0') ? 0 : 1; }
     return g_gemm2_on != 0;
+}
+
+template <typename T, int AMODE, int BMODE, bool UTAP>
+void launch_gemm2_128x64(hipStream_t st, dim3 g, const Gemm2Params& p) {
+    const int nk = (p.K * (int)sizeof(T) + 127) / 128;    // (upper bound for the gather form: its K depends on the parity class)
+    const int ns = nk >= 6 ? g_gemm2_stages : 2;           // a deeper ring needs steps to fill
+    if (ns >= 4) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 4>), g, dim3(GEMM_NT), 0, st, p);
+    else if (ns == 3) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 2>), g, dim3(GEMM_NT), 0, st, p);
 }
 
 template <typename T, int AMODE, int BMODE, bool UTAP>
@@ -68,7 +79,7 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
         hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 256, 32, UTAP>), g, dim3(GEMM_NT), 0, st, p);
     } else if (p.N <= 64) {
         dim3 g((M_for_grid + 127) / 128, 1, gz);
-        hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+        launch_gemm2_128x64<T, AMODE, BMODE, UTAP>(st, g, p);
     } else {
         if (g_gemm2_tile == 1 || (g_gemm2_tile == 0 && (long long)((M_for_grid + 127) / 128) * ((p.N + 63) / 64) * gz < 512)) {
             // small grids (conv4 forward / deconv1 input gradient at batch 512: 96 x 4 tiles of 128 x 64 = 1.5 blocks per CU, each a serial chain of
@@ -83,7 +94,7 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
             hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
         } else {                                          // few tiles: narrower blocks fill the 256 CUs
             dim3 g(gx, (p.N + 63) / 64, gz);
-            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+            launch_gemm2_128x64<T, AMODE, BMODE, UTAP>(st, g, p);
         }
     }
     return mi_check_launch("gemm2_kernel");
@@ -760,6 +771,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 17) { prev = g_gemm2_tile; g_gemm2_tile = value; }
     else if (key == 18) { prev = g_slab_bf16; g_slab_bf16 = value ? 1 : 0; }
     else if (key == 19) { prev = g_nw_depth; g_nw_depth = value; }
+    else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

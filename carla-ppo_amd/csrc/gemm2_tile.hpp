@@ -36,7 +36,11 @@ struct Gemm2Params {
 
 // BM x BN output tile (pixels x channels), 256 threads = 4 waves.  UTAP: every 128-byte stage lies inside one deconv tap
 // (C*sizeof(T) % 128 == 0), so the tap arithmetic is wave-uniform (scalar unit).
-template <typename T, int AMODE, int BMODE, int BM, int BN, bool UTAP>
+// NST: LDS stages of the K pipeline.  Round 3: with two stages the loads of step k + 1 are issued after the barrier of step k and must land before the barrier of
+// step k + 1 -- one step of MFMAs (0.1-0.2 us) to cover an L2 / HBM round trip (0.6-0.9 us): the small-grid layers (conv4 forward, deconv1's input gradient: 32
+// k-steps, 1.5 blocks per CU) ran as a chain of memory latencies, 30 us for 5 us of MFMAs.  With NST stages NST - 1 are in flight: the barrier of step k waits with
+// s_waitcnt vmcnt((NST - 2) x loads per stage) -- "all but the newest NST - 2 stages" (LDS-DMA returns in order) -- instead of __syncthreads()'s vmcnt(0).
+template <typename T, int AMODE, int BMODE, int BM, int BN, bool UTAP, int NST = 2>
 __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
     constexpr int RB = 128;
     constexpr int ESZ = (int)sizeof(T);
@@ -52,7 +56,8 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
     static_assert(BMODE == B_NK || BMODE == B_DECONV, "gemm2 wants K-contiguous weights");
     typedef typename Frag<T>::reg freg;
 
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    static_assert(NST >= 2 && NST <= 4 && (NST - 2) * (NJA + NJB) < 64, "stage ring");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -162,11 +167,25 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int xs = (lrow >> 1) & 7;                        // fragment-read swizzle term (same for every 32-row subtile)
-    if (nk > 0) issue(0, 0);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        __syncthreads();                                   // stage ks has landed (vmcnt(0) + barrier); buffer cur^1 is free
-        if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    if constexpr (NST == 2) { if (nk > 0) issue(0, 0); }
+    else {
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) issue(s_, s_);
+    }
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks, cur = (cur + 1 == NST ? 0 : cur + 1)) {
+        if constexpr (NST == 2) {
+            __syncthreads();                               // stage ks has landed (vmcnt(0) + barrier); buffer cur^1 is free
+            if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+        } else {
+            // every thread issues exactly NJA + NJB DMA instructions per stage, in stage order: "all but the newest (NST - 2) stages' worth" = stage ks is in LDS.
+            // (the last NST - 2 steps have fewer stages behind them: wait for everything there)
+            if (ks + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * (NJA + NJB)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // everybody's share of stage ks has landed, and everybody is done reading stage ks - 1 ...
+            const int nb = cur == 0 ? NST - 1 : cur - 1;   // ... whose buffer takes stage ks + NST - 1
+            if (ks + NST - 1 < nk) issue(ks + NST - 1, nb);
+        }
         const unsigned char* As = &lds[cur * STAGE];
         const unsigned char* Bs = As + BM * RB;
 #pragma unroll
