@@ -55,7 +55,8 @@ int g_tap_mask_prefetch = 1;                                // tapconv: touch th
 int g_gemm2_on = -1;
 static int gemm2_stages_env() { const char* e = getenv("MI355_GEMM2_STAGES"); return e ? atoi(e) : 2; }
 int g_gemm2_stages = gemm2_stages_env();                    // gemm2 128 x 64 tiles: LDS stages of the K pipeline (2 | 3 | 4); mi_set_tuning key 20
-int g_gemm2_tile = 2;                                       // wide-output gemm2 layers: 0 auto (64 x 64 tiles on small grids), 1 always 64 x 64, 2 never; mi_set_tuning key 17
+static int gemm2_tile_env() { const char* e = getenv("MI355_GEMM2_TILE"); return e ? atoi(e) : 2; }
+int g_gemm2_tile = gemm2_tile_env();                                       // wide-output gemm2 layers: 0 auto (64 x 64 tiles on small grids), 1 always 64 x 64, 2 never, 3 always 128 x 128 (64 x 64 wave tiles: 1 KB of LDS reads per MFMA instead of 1.5); mi_set_tuning key 17
 int g_tap_min = -2;
 bool gemm2_enabled() {
     if (g_gemm2_on < 0) { const char* e = getenv("MI355_GEMM2"); g_gemm2_on = (e && e[0] == '0') ? 0 : 1; }
@@ -89,9 +90,11 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
             return mi_check_launch("gemm2_kernel");
         }
         const int gx = (M_for_grid + 127) / 128;
-        if ((long long)gx * ((p.N + 127) / 128) * gz >= 384) {
+        if (g_gemm2_tile == 3 || (long long)gx * ((p.N + 127) / 128) * gz >= 384) {
             dim3 g(gx, (p.N + 127) / 128, gz);
-            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+            const int nk = (p.K * (int)sizeof(T) + 127) / 128;
+            if (g_gemm2_tile == 3 && g_gemm2_stages >= 3 && nk >= 6) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
+            else hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
         } else {                                          // few tiles: narrower blocks fill the 256 CUs
             dim3 g(gx, (p.N + 63) / 64, gz);
             launch_gemm2_128x64<T, AMODE, BMODE, UTAP>(st, g, p);
@@ -735,6 +738,14 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 }
 
 }  // namespace
+
+// internal entry points for the other translation units (mi_internal.hpp)
+int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(n, nslab), dim3(256), 0, st, slabs, stride, nslab, n, out);
+    return mi_check_launch("reduce_slabs_kernel");
+}
+
+bool mi_narrow_enabled() { return narrow_enabled(); }
 
 void mi_get_trace(long long** buf, int* cap) { *buf = g_trace; *cap = g_trace_cap; }
 

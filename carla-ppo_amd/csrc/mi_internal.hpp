@@ -22,3 +22,7 @@ int mi_rwconv_conv_mode(int set);                // mi_set_tuning key 15: 0 off,
 int mi_rwconv_blocks(int set);                   // mi_set_tuning key 16: persistent blocks per XCD (0 = resident maximum); set < 0 queries
 int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace
+
+// out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_slabs_kernel, tapwgrad_tile.hpp; fixed summation order) -- conv_ops.hip
+int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out);
+bool mi_narrow_enabled();                        // the narrow-layer kernels are switched on (mi_set_tuning key 4 / MI355_NARROW) -- conv_ops.hip

@@ -67,6 +67,7 @@ struct Workspace {
     long long z, dheads;               // T
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long tail_slabs, tail_slab_bytes;   // per-block partial filter gradients of the fused decoder tail (dectail_tile.hpp)
+    long long enc_slabs, enc_slab_bytes;     // per-block partial sums of the fused encoder-head backward kernel (enchead_tile.hpp)
     long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
@@ -190,6 +191,8 @@ void make_workspace(VaeEngine& e) {
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
     W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
     W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
+    W.enc_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 8320 : 0;                  // up to 8 resident blocks per CU x (64 x 32 + 32) floats
+    W.enc_slabs = add(W.enc_slab_bytes > 0 ? W.enc_slab_bytes : 256);
     W.bits_act1 = add(B * g.ih[1] * g.iw[1] * (g.c[1] / 16) * 4); W.bits_dec3 = add(B * g.dh[3] * g.dw[3] * (g.dc[3] / 16) * 4);
     {
         long long n = 0;
@@ -517,6 +520,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     static int late_on = -1;                              // MI355_LATE_DENSE=0: dense1 / heads filter gradients on the filter-gradient stream as in round 2
     if (late_on < 0) { const char* ev = getenv("MI355_LATE_DENSE"); late_on = (ev && ev[0] == '0') ? 0 : 1; }
     const bool late_dense = late_on && fork && part == 0;
+    static int heads_main = -1;                           // MI355_HEADS_MAIN=0: the heads' filter / bias gradient stay on the filter-gradient stream behind a fused encoder head
+    if (heads_main < 0) { const char* ev = getenv("MI355_HEADS_MAIN"); heads_main = (ev && ev[0] == '0') ? 0 : 1; }
     if (part == 0 || part == 1) {
         for (int i = 3; i >= 0; --i) {                       // deconv(i+1): input dec[i] -> output dec[i+1]
             if (i == 3 && e->tail_fused) continue;           // deconv4's two gradients were computed by the forward pass's decoder-tail kernel
@@ -557,6 +562,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
     }
     if (upper || lower) {
+        bool enc_fused = false;
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             if (i == NCONV - 1 ? !upper : !lower) continue;
             const void* gy = e->at(W.gact[i + 1]);
@@ -573,9 +579,17 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             const int mm = main_mask >= 0 ? main_mask : (tail_was_fused ? 1 : 5);
             const bool on_main = ((mm >> i) & 1) != 0;
             void* sg = on_main ? st : sw;
+            if (i == 0 && enc_fused) continue;               // conv1's filter / bias gradient came out of the fused encoder-head kernel below
             if (!on_main) release();
             TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
                                                                    (on_main && fork) ? nullptr : scratch_of(), (on_main && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
+            if (i == 1 && d.dtype == MI_BF16 && e->bits1_ok && e->W.enc_slab_bytes > 0 && g.c[0] == 3 && g.c[1] == 32 && g.c[2] == 64) {
+                // conv2's input gradient feeds nothing but conv1's filter gradient: both in one launch, the 99 MB tensor between them never exists (enchead_tile.hpp)
+                int nblk = 0;
+                TOP(e, st, OP_CONV_DGRAD + 1, mi_conv2d_head_bwd_fused(st, d.dtype, src, e->last_u8 ? 2 : 1, idx, B, d.ih, d.iw, gy, e->wptr(2), e->at(W.bits_act1),
+                                                                      e->gptr(0), e->gptr(1), e->at(W.enc_slabs), W.enc_slab_bytes, &nblk));
+                if (nblk > 0) { enc_fused = true; continue; }
+            }
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
@@ -585,8 +599,10 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
-            TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            // the heads' gradients: behind a fused encoder head the caller's stream is the one that ends early (conv1's filter gradient is no longer a launch of its own)
+            void* sh = (enc_fused && heads_main) ? st : sw;
+            TOP(e, sh, OP_HEADS_BIAS, mi_colsum(sh, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sh, OP_HEADS_WGRAD, mi_gemm_wgrad(sh, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
             e->fin.pending = 0;

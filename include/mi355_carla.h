@@ -127,6 +127,13 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
 /* reduce_now = 0 above leaves the per-block filter-gradient partial sums in scratch; this adds them to dw (anywhere behind that launch on the same
  * stream order and in front of the optimiser step) */
 int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw);
+/* The encoder head of a backward pass in ONE launch (csrc/enchead_tile.hpp; replaces Conv2DBackpropInput of conv2 + Conv2DBackpropFilter / BiasAddGrad of conv1,
+ * vae/models.py:250-251 behind :142): frames [*, FH, FW, 3] (frames_fmt 1 = fp32, 2 = uint8 camera bytes; optionally gathered through frame_idx) -conv1 k4 s2-> 32 ch
+ * -conv2 k4 s2-> 64 ch; dy2 = gradient wrt conv2's pre-activation [B, OH, OW, 64], w2 = conv2's kernel [4][4][32][64], bits_act1 = ReLU bit words of conv1's output.
+ * dw1 [4][4][3][32] += , db1 [32] += .  The gradient of conv1's output is never written.  *n_blocks = 0: not eligible (nothing launched; call
+ * mi_conv2d_nhwc_dgrad_bits and mi_conv2d_nhwc_wgrad_ws).  scratch: >= mi_conv2d_head_bwd_blocks() * 8320 bytes. */
+int mi_conv2d_head_bwd_blocks(void);
+int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* frames, int frames_fmt, const int* frame_idx, int B, int FH, int FW, const void* dy2, const void* w2, const void* bits_act1, float* dw1, float* db1, void* scratch, long long scratch_bytes, int* n_blocks);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */

@@ -720,3 +720,71 @@ def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), float((dx.float() - dx_ref.float()).abs().max())
     s = float(dw_ref.abs().max())
     assert_close(host(dw) - 0.25, host(dw_ref), 1e-5, 2e-5 * s, "filter gradient")
+
+
+@pytest.mark.parametrize("u8", [True, False])
+@pytest.mark.parametrize("B,FH,FW", [(3, 80, 160), (2, 38, 70), (1, 20, 132)])
+def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
+    """mi_conv2d_head_bwd_fused (conv2's input gradient + conv1's filter and bias gradient in one launch, enchead_tile.hpp; the gradient of conv1's output never
+    exists) against the two separately validated ops it replaces -- mi_conv2d_nhwc_dgrad_bits, then mi_conv2d_nhwc_wgrad_ws on its output -- on the model's geometry
+    and two ragged ones (8 x 16 tiles overhanging the image, odd slot counts), camera bytes and fp32 frames, gathered through a frame index, ACCUMULATING into the
+    gradient buffers; and against the float64 statement of the same two contractions (bf16 operands, the intermediate rounded to bf16 like the stored tensor)."""
+    import ctypes
+    L = milib.get()
+    code, td = DT["bf16"]
+    IH, IW = (FH - 4) // 2 + 1, (FW - 4) // 2 + 1
+    OH, OW = (IH - 4) // 2 + 1, (IW - 4) // 2 + 1
+    rng = np.random.RandomState(B * 10 + FH)
+    n_frames = B + 2
+    frames_u8 = rng.randint(0, 256, (n_frames, FH, FW, 3)).astype(np.uint8)
+    idx = rng.permutation(n_frames)[:B].astype(np.int32)
+    fr = dev(frames_u8, torch.uint8) if u8 else dev(frames_u8.astype(np.float32) / 255.0)
+    idxd = dev(idx, torch.int32)
+    w1 = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)
+    b1 = (0.1 * rng.randn(32)).astype(np.float32)
+    w1t = torch.from_numpy(w1).permute(3, 0, 1, 2).reshape(32, -1).contiguous()
+    w2 = (rng.randn(4, 4, 32, 64) / np.sqrt(512)).astype(np.float32)
+    dy = rng.randn(B, OH, OW, 64).astype(np.float32)
+    act1 = alloc(td, B, IH, IW, 32)
+    bits = torch.zeros(B * IH * IW * 2, device="cuda", dtype=torch.int32)
+    wrote = np.zeros(1, np.int32)
+    fmt = 2 if u8 else 1
+    L.mi_conv2d_nhwc_fwd_bits(stream(), code, fr.data_ptr(), idxd.data_ptr(), fmt, B, FH, FW, 3, P(dev(w1t, td)), 1, P(dev(b1)), 4, 4, 32, 1, act1.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
+    torch.cuda.synchronize()
+    if wrote[0] != 1:
+        pytest.skip("conv1 forward did not take the bit-word kernel on this geometry")
+    dyd, w2d = dev(dy, td), dev(w2, td)
+    # --- the two ops ---
+    g1 = alloc(td, B, IH, IW, 32, fill=7.0)
+    L.mi_conv2d_nhwc_dgrad_bits(stream(), code, dyd.data_ptr(), B, OH, OW, 64, w2d.data_ptr(), 4, 4, 32, IH, IW, act1.data_ptr(), bits.data_ptr(), g1.data_ptr())
+    dw_ref, db_ref = torch.zeros(4, 4, 3, 32, device="cuda"), torch.zeros(32, device="cuda")
+    ws = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    L.mi_conv2d_nhwc_wgrad_ws(stream(), code, fr.data_ptr(), idxd.data_ptr(), fmt, B, FH, FW, 3, g1.data_ptr(), 4, 4, 32, dw_ref.data_ptr(), ws.data_ptr(), ws.numel(), db_ref.data_ptr())
+    # --- one launch ---
+    nb = L.mi_conv2d_head_bwd_blocks()
+    scratch = torch.empty(nb * 8320, device="cuda", dtype=torch.uint8)
+    dw, db = torch.full((4, 4, 3, 32), 0.5, device="cuda"), torch.full((32,), -0.25, device="cuda")
+    n = ctypes.c_int(0)
+    L.mi_conv2d_head_bwd_fused(stream(), code, fr.data_ptr(), fmt, idxd.data_ptr(), B, FH, FW, dyd.data_ptr(), w2d.data_ptr(), bits.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                               scratch.data_ptr(), scratch.numel(), ctypes.addressof(n))
+    torch.cuda.synchronize()
+    assert 0 < n.value <= nb
+    sw, sb = float(dw_ref.abs().max()), float(db_ref.abs().max())
+    assert sw > 0 and sb > 0
+    # same bf16 operands, same rounding point of the intermediate; what differs is the fp32 summation order inside the K = 256 products (a last-bit flip of an
+    # intermediate value now and then) and across blocks
+    assert_close(host(dw) - 0.5, host(dw_ref), 1e-3, 2e-4 * sw, "conv1 filter gradient, fused vs two ops")
+    assert_close(host(db) + 0.25, host(db_ref), 1e-3, 2e-4 * sb, "conv1 bias gradient, fused vs two ops")
+    # --- float64 statement ---
+    t64 = lambda a: torch.from_numpy(np.asarray(a, np.float64))      # noqa: E731
+    dyb, w2b = host(dyd).astype(np.float64), host(w2d).astype(np.float64)
+    g = torch.nn.functional.conv_transpose2d(t64(dyb).permute(0, 3, 1, 2), t64(w2b).permute(3, 2, 0, 1), stride=2)      # [B, 32, IH', IW']
+    g = torch.nn.functional.pad(g, (0, IW - g.shape[3], 0, IH - g.shape[2]))
+    g = g.permute(0, 2, 3, 1) * t64(host(act1) > 0)
+    g = t64(host(dev(g.numpy().astype(np.float32), td)))                                                                   # rounded where the unfused path stores it
+    xs = t64(host(dev(frames_u8[idx].astype(np.float32) / 255.0, td)))                                                      # the bf16 value of k / 255 the kernels form
+    patches = xs.unfold(1, 4, 2).unfold(2, 4, 2)                                                                            # [B, IH, IW, 3, kh, kw]
+    dw64 = torch.einsum("byxckl,byxn->klcn", patches, g).numpy()
+    db64 = g.sum((0, 1, 2)).numpy()
+    assert_close(host(dw) - 0.5, dw64, 2e-3, 5e-4 * float(np.abs(dw64).max()), "conv1 filter gradient vs float64")
+    assert_close(host(db) + 0.25, db64, 2e-3, 5e-4 * float(np.abs(db64).max()), "conv1 bias gradient vs float64")

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -p no:cacheprovider -k "encoder_head" 2>&1 | tail -3
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --steps 100"
+for r in 1 2 3; do
+for v in "1 1" "1 0" "0 1"; do
+  set -- $v
+  MI355_ENCHEAD=$1 MI355_HEADS_MAIN=$2 timeout 300 python bench.py $X 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); po=d['per_op_ms']; print('ENCHEAD=$1 HEADS_MAIN=$2', round(d['ms_per_step'],4), ' '.join('%s %.1f'%(k,po.get(k,0)*1e3) for k in ('conv2.dgrad','conv1.wgrad','conv2.wgrad')))"
+done; done
