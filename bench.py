@@ -46,7 +46,7 @@ ENC = [(80, 160, 3, 32), (39, 79, 32, 64), (18, 38, 64, 128), (8, 18, 128, 256)]
 DEC = [(3, 8, 256, 128, 4), (8, 18, 128, 64, 4), (18, 38, 64, 32, 5), (39, 79, 32, 3, 4)]  # IH, IW, Cin, Cout, k
 
 
-def op_work(name, B, esz, n_params, frame_bytes=4, tail_fused=False):
+def op_work(name, B, esz, n_params, frame_bytes=4, tail_fused=False, enc_fused=False):
     """Algorithmic work of one launch of op `name` at batch B: (flops, bytes). SURVEY.md 8(d) per-frame figures x B; bytes = every operand
     read once + the result written once (+ the ReLU-grad mask tensor for input gradients), weights included.  frame_bytes: 4 = fp32 frame
     tables, 1 = uint8 tables."""
@@ -58,6 +58,11 @@ def op_work(name, B, esz, n_params, frame_bytes=4, tail_fused=False):
         xin = ih * iw * ci * (frame_bytes if layer == "conv1" else esz) * B
         yout = oh * ow * co * esz * B
         w = 16 * ci * co * (esz if kind != "wgrad" else 4)
+        if layer == "conv2" and kind == "dgrad" and enc_fused:
+            # the encoder head of backward in one launch (enchead_bwd_kernel): conv2's input gradient + conv1's filter / bias gradient; reads dy2, the ReLU bit words of
+            # conv1's output (8 bytes per pixel) and the frames once; the gradient of conv1's output stays on chip
+            f1 = 2.0 * ih * iw * ci * 48 * B
+            return flops + f1, float(yout + ih * iw * 8 * B + 80 * 160 * 3 * frame_bytes * B + w + 48 * 32 * 4)
         nbytes = {"fwd": xin + yout + w, "dgrad": yout + 2 * xin + w, "wgrad": xin + yout + w}[kind]     # dgrad: dy in, mask in, dx out
         return flops, float(nbytes)
     if layer.startswith("deconv") and kind in ("fwd", "dgrad", "wgrad"):
@@ -92,9 +97,9 @@ def op_work(name, B, esz, n_params, frame_bytes=4, tail_fused=False):
     return None, float(64 * 6 * 4 * B)                  # reparam / finalize: tiny
 
 
-def roofline_of(name, avg_s, B, esz, n_params, precision, frame_bytes, tail_fused=False):
+def roofline_of(name, avg_s, B, esz, n_params, precision, frame_bytes, tail_fused=False, enc_fused=False):
     """Roofline object of one op: the bound is decided by comparing the arithmetic intensity with the ridge point."""
-    flops, nbytes = op_work(name, B, esz, n_params, frame_bytes, tail_fused)
+    flops, nbytes = op_work(name, B, esz, n_params, frame_bytes, tail_fused, enc_fused)
     peak_f = PEAK[{"bf16": "mfma_bf16", "bf16x3": "mfma_bf16x3"}.get(precision, "mfma_f32")]
     t_hbm = nbytes / PEAK["hbm"]
     t_mfma = (flops or 0.0) / peak_f
@@ -455,7 +460,10 @@ def main():
         di = names.index(dominant)
         avg_s = float(ms_d[di] / max(cnt_d[di], 1)) * 1e-3
         tail_fused = "deconv4.dgrad" not in per_op and args.precision == "bf16"      # the decoder tail ran as one launch (timed as deconv4.fwd)
-        roofline = roofline_of(dominant, avg_s, B, esz, dev.n_flat, args.precision, frame_bytes, tail_fused)
+        enc_fused = "conv1.wgrad" not in per_op and args.precision == "bf16"         # conv2's input gradient + conv1's filter gradient ran as one launch (timed as conv2.dgrad)
+        roofline = roofline_of(dominant, avg_s, B, esz, dev.n_flat, args.precision, frame_bytes, tail_fused, enc_fused)
+        if dominant == "conv2.dgrad" and enc_fused:
+            roofline["kernel"] = "conv2.dgrad = encoder head of backward (enchead_bwd_kernel: conv2 input gradient + conv1 filter / bias gradient)"
         if dominant == "deconv4.fwd" and tail_fused:
             roofline["kernel"] = "deconv4.fwd = decoder tail (dectail_kernel: deconv4 forward + reconstruction loss + input gradient + filter gradient)"
         roofline["launches_timed"] = int(cnt_d[di])

@@ -57,7 +57,9 @@ NAMES_R02 = [("rwconv_gather_kernel<3, 5, true, 0, true, 0>", None, "deconv3.fwd
          ("adam_tf_kernel", None, "adam")]
 # round 3: the decoder tail is one kernel (deconv4 forward + loss + both of its gradients); deconv3's forward no longer writes ReLU bit words
 NAMES_R03 = [("dectail_kernel<true>", None, "deconv4.fwd (decoder tail: deconv4 fwd + loss + dgrad + wgrad)"), ("dectail_kernel<false>", None, "deconv4.fwd (decoder tail, library-math loss)"),
-             ("rwconv_gather_kernel<3, 5, true, 0, false, 0, 1>", None, "deconv3.fwd"), ("dectail_reduce_kernel", None, "decoder-tail slab reduce")] + NAMES_R02
+             ("rwconv_gather_kernel<3, 5, true, 0, false, 0, 1>", None, "deconv3.fwd"), ("dectail_reduce_kernel", None, "decoder-tail slab reduce"),
+             ("enchead_bwd_kernel<unsigned char>", None, "conv2.dgrad (encoder head of backward: conv2 dgrad + conv1 wgrad + bias)"), ("enchead_reduce_kernel", None, "encoder-head slab reduce"),
+             ("gemm2_kernel<bf16, 0, 1, 128, 64, false, 2>", "96x4x1", "conv4.fwd / deconv1.dgrad")] + NAMES_R02
 NAMES = NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else NAMES_R03)
 lines, traffic = [], {}
 for kern, grid, op in NAMES:
