@@ -153,13 +153,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int tg = lane >> 4, tc = lane & 15;
     const int trow = (tg >> 1) * 8 + (tc >> 2), tcol = (tg & 1) * 16 + (tc & 3) * 4;
 
+    // the frame patch + bit word of a tile are requested as soon as the previous tile has consumed its own (same registers): they fly under that tile's second
+    // half, the barrier, the commit and this tile's 16 MFMAs (requested at the top of their own tile they had 16 MFMAs = 0.2 us to land: every tile waited for them)
+    Raw raw;
+    request_patch(min(vb, p.ntiles - 1), raw);
     for (int tile = vb; tile < p.ntiles; tile += G) {
         commit(cur);
         __syncthreads();
-        Raw raw;
-        request_patch(tile, raw);                          // consumed behind the 16 MFMAs below
         request(t_nxt, cur);                               // the next tile's dy2 pixels: land under this tile's work (LDS-only barriers from here on)
-        t_nxt = min(t_nxt + G, p.ntiles - 1);
 
         // ---- g1 of this wave's 32 pixels: D[ci][pixel] = sum over taps, co ----
         f32x16 acc;
@@ -213,6 +214,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
             *(u16x8*)(ptw + lrow * 128 + (((2 * s + lgrp) ^ (lrow & 7)) << 4)) = xf;
         }
+        request_patch(t_nxt, raw);                         // (past the end: a valid tile again -- no branch around the loads)
+        t_nxt = min(t_nxt + G, p.ntiles - 1);
         __builtin_amdgcn_wave_barrier();                  // same wave, in-order LDS queue
         // ---- filter (+ bias) gradient: dW[k][ci] += sum over this wave's pixels of patch[pixel][k] * g1[pixel][ci]; k = 48 is the all-ones column ----
 #pragma unroll
