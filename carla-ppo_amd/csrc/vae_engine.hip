@@ -129,6 +129,9 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
+    hipEvent_t ev_lat, ev_third;
+    int third_ok;
     int bits1_ok, bits3_ok;             // the last forward pass wrote the ReLU bit words of act1 / dec3
     int rng_ready;                      // generator state in the workspace has been initialised (mi_vae_set_seed)
     const float* last_eps;              // the noise the last sampling forward used (caller's buffer or the engine's own draw)
@@ -371,6 +374,7 @@ void mi_vae_destroy(void* h) {
     if (e && e->gexec) hipGraphExecDestroy(e->gexec);
     if (e && e->cap_ok == 1) hipStreamDestroy(e->cap);
     if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
+    if (e && e->third_ok == 1) { hipStreamDestroy(e->third); hipEventDestroy(e->ev_lat); hipEventDestroy(e->ev_third); }
     free(h);
 }
 
@@ -487,6 +491,13 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
         else e->side_ok = -1;
     }
+    static int third_on = -1;                             // MI355_THIRD=1: the latent layers' filter / bias gradients, the tail's slab sum and the loss finalisation on a third stream
+    if (third_on < 0) { const char* ev = getenv("MI355_THIRD"); third_on = (ev && ev[0] == '1') ? 1 : 0; }
+    if (third_on && two_streams && !e->third_ok) {
+        if (hipStreamCreateWithFlags(&e->third, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_lat, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e->ev_third, hipEventDisableTiming) == hipSuccess) e->third_ok = 1;
+        else e->third_ok = -1;
+    }
     const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
     void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
     auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
@@ -520,6 +531,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     static int late_on = -1;                              // MI355_LATE_DENSE=0: dense1 / heads filter gradients on the filter-gradient stream as in round 2
     if (late_on < 0) { const char* ev = getenv("MI355_LATE_DENSE"); late_on = (ev && ev[0] == '0') ? 0 : 1; }
     const bool late_dense = late_on && fork && part == 0;
+    const bool use_third = late_dense && third_on && e->third_ok == 1;
     static int heads_main = -1;                           // MI355_HEADS_MAIN=0: the heads' filter / bias gradient stay on the filter-gradient stream behind a fused encoder head
     if (heads_main < 0) { const char* ev = getenv("MI355_HEADS_MAIN"); heads_main = (ev && ev[0] == '0') ? 0 : 1; }
     if (part == 0 || part == 1) {
@@ -560,6 +572,23 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
+        if (use_third) {
+            // everything the latent layers' gradients read exists from here on (gdec0, z, dheads, act4; the tail's slabs and loss partials since the forward pass): they run on
+            // their own stream under the encoder half instead of serialising ~70 us of small launches at the end of the caller's stream
+            hipStream_t s3 = e->third;
+            hipEventRecord(e->ev_lat, (hipStream_t)st); hipStreamWaitEvent(s3, e->ev_lat, 0);
+            TOP(e, s3, OP_DENSE1_BIAS, mi_colsum(s3, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, s3, OP_DENSE1_WGRAD, mi_gemm_wgrad(s3, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            TOP(e, s3, OP_HEADS_BIAS, mi_colsum(s3, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, s3, OP_HEADS_WGRAD, mi_gemm_wgrad(s3, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(s3, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
+            if (e->fin.pending) {
+                e->fin.pending = 0;
+                TOP(e, s3, OP_FINALIZE, mi_vae_finalize_losses_flat(s3, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
+                                               (float*)e->at(W.out2), e->fin.metrics3, e->fin.metric_weight, (const float*)e->at(W.bpart), e->fin.nblk, d.ct, e->fin.dbias));
+            }
+            hipEventRecord(e->ev_third, s3);
+        }
     }
     if (upper || lower) {
         bool enc_fused = false;
@@ -594,7 +623,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
         }
-        if (late_dense) {                                    // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
+        if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
             TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
             TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
@@ -604,6 +633,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, sh, OP_HEADS_BIAS, mi_colsum(sh, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
             TOP(e, sh, OP_HEADS_WGRAD, mi_gemm_wgrad(sh, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
+        if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
             e->fin.pending = 0;
             TOP(e, st, OP_FINALIZE, mi_vae_finalize_losses_flat(st, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
@@ -689,6 +719,14 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
             if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
             else e->side_ok = -1;
+        }
+        if (!e->third_ok) {
+            const char* ev3 = getenv("MI355_THIRD");
+            if (ev3 && ev3[0] == '1') {
+                if (hipStreamCreateWithFlags(&e->third, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_lat, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&e->ev_third, hipEventDisableTiming) == hipSuccess) e->third_ok = 1;
+                else e->third_ok = -1;
+            }
         }
         // the caller's stream may be the legacy null stream, which cannot be captured: the launch sequence is recorded on a stream of the
         // engine's own and the instantiated graph is then launched on the caller's stream
