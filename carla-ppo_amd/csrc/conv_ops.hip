@@ -205,6 +205,29 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // all of them back to back.  Per host THREAD (thread_local): a backward pass is issued by one thread from defer(1) to flush, so two engines driven by two
 // threads keep separate lists (round 3; the tuning knobs stay process-global configuration).  Used by the VAE engine only.
 struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; };
+// Split storage (MI_BF16X3) on the bf16 filter-gradient kernels: the tensors are handed over as bf16 tensors with TWICE the channels (channel 2c = lo half, 2c + 1 = hi half of
+// element c), the kernel produces dW'[t][2R][2Q] in a temporary, and the fold  dW[t][r][q] += dW'[t][2r][2q] + dW'[t][2r][2q+1] + dW'[t][2r+1][2q] + dW'[t][2r+1][2q+1]
+// (all four partial products of the two-term expansion) follows the slab reduce -- deferred with it when the reduces are deferred.
+struct PendingFold { const float* tmp; float* out; const float* tmp_bias; float* dbias; int T, R, Q, NB; };
+static thread_local PendingFold g_folds[16];
+static thread_local int g_nfolds = 0;
+__global__ __launch_bounds__(256) void fold_split_kernel(const PendingFold f) {
+    const long long n = (long long)f.T * f.R * f.Q;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int q = (int)(i % f.Q); const long long tr = i / f.Q; const int r = (int)(tr % f.R); const long long t = tr / f.R;
+        const float* s = f.tmp + ((t * 2 * f.R + 2 * r) * 2ll * f.Q + 2 * q);
+        f.out[i] += (s[0] + s[1]) + (s[2ll * f.Q] + s[2ll * f.Q + 1]);
+    } else if (f.dbias && i - n < f.NB) {
+        const int b = (int)(i - n);
+        f.dbias[b] += f.tmp_bias[2 * b] + f.tmp_bias[2 * b + 1];
+    }
+}
+static int launch_fold(hipStream_t st, const PendingFold& f) {
+    const long long n = (long long)f.T * f.R * f.Q + (f.dbias ? f.NB : 0);
+    hipLaunchKernelGGL(fold_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f);
+    return mi_check_launch("fold_split_kernel");
+}
 static thread_local PendingReduce g_pending[16];
 static thread_local int g_npending = 0, g_defer_reduces = 0;
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element: about 512 blocks in flight, at most ~16 slabs per thread
@@ -222,7 +245,7 @@ static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
 extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode drops whatever an aborted pass may have left in the list
     const int prev = g_defer_reduces;
     g_defer_reduces = on ? 1 : 0;
-    g_npending = 0;
+    g_npending = 0; g_nfolds = 0;
     return prev;
 }
 int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
@@ -230,7 +253,15 @@ int g_slab_bf16 = 0;                                       // tapwgrad partial-s
 static thread_local int t_slab_bf16 = -1;                  // this thread's override for the pass it is issuing (-1: the process default above)
 static inline int slab_bf16_now() { return t_slab_bf16 >= 0 ? t_slab_bf16 : g_slab_bf16; }
 extern "C" int mi_tapwgrad_slab_bf16(int on) { const int prev = t_slab_bf16; t_slab_bf16 = on < 0 ? -1 : (on ? 1 : 0); return prev; }
+static int tapwgrad_flush_reduces(void* stream);
 extern "C" int mi_tapwgrad_flush(void* stream) {
+    int rc = tapwgrad_flush_reduces(stream);
+    const int nf = g_nfolds;
+    g_nfolds = 0;
+    for (int i = 0; i < nf && rc == MI_OK; ++i) rc = launch_fold((hipStream_t)stream, g_folds[i]);
+    return rc;
+}
+static int tapwgrad_flush_reduces(void* stream) {
     const int n = g_npending;
     g_npending = 0;
     if (n == 0) return MI_OK;
@@ -356,6 +387,32 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
         if (g_defer_reduces && g_npending < 16) g_pending[g_npending++] = r;
         else { launch_tiled_reduce(st, r); rc = mi_check_launch("reduce_tiled_kernel"); }
     }
+    return rc == MI_OK ? 1 : rc;
+}
+
+// MI_BF16X3 filter gradients on the bf16 kernel (see PendingFold): scratch = [dW' (4 x the filter, fp32) | bias' (2 N) | slabs ...]
+int try_tapwgrad_split(hipStream_t st, int mode, const void* a, const void* d, int B, int IH, int IW, int C, int OH, int OW, int N,
+                       int KH, int KW, float* out, void* scratch, long long scratch_bytes, float* dbias) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_X3_TAPWGRAD"); on = e ? atoi(e) : 0; }     // off by default: the split engine's step is bound by its forward / input-gradient stream (2.742 ms either way)
+    if (!on || !scratch || (((uintptr_t)scratch) & 255)) return 0;
+    const long long nw = (long long)KH * KW * C * N;
+    const long long tmp_bytes = ((4 * nw + 2 * N) * 4 + 255) / 256 * 256;
+    if (scratch_bytes < tmp_bytes + (1 << 20)) return 0;
+    // cheap shape test first (the same conditions try_tapwgrad applies to the doubled channel counts): nothing is touched for a layer it will not take
+    const int taps = (KH + 1) / 2;
+    if (KH != KW || taps != 2) return 0;                    // (the k = 5 gather kernels are built for 32 output channels per parity class: 2 N = 64 does not fit)
+    if (mode == TC_CONV ? ((8 * C) % 128 != 0 || (2 * N) % 64 != 0) : ((2 * C) % 128 != 0 || (2 * N) % 64 != 0)) return 0;
+    // measured per layer at batch 512 (us, doubled-channel bf16 kernel vs the first-generation split kernel): conv2 125 / 164, conv3 122 / 136, deconv2 150 / 150, conv4 187 / 86,
+    // deconv1 227 / 91 -- the wide layers end up with 64 column blocks and four position splits.  MI355_X3_TAPWGRAD=2 takes every eligible layer (A/B).
+    if (on != 2 && (mode != TC_CONV || (long long)C * N > 64 * 128)) return 0;
+    float* tmp = (float*)scratch; float* tb = tmp + 4 * nw;
+    if (hipMemsetAsync(tmp, 0, (size_t)((4 * nw + 2 * N) * 4), st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "try_tapwgrad_split: memset failed");
+    const int r = try_tapwgrad(st, MI_BF16, mode, a, d, B, IH, IW, 2 * C, OH, OW, 2 * N, KH, KW, tmp, (char*)scratch + tmp_bytes, scratch_bytes - tmp_bytes, dbias ? tb : nullptr);
+    if (r <= 0) return r;
+    PendingFold f = {tmp, out, tb, dbias, KH * KW, mode == TC_CONV ? C : N, mode == TC_CONV ? N : C, N};
+    if (g_defer_reduces && g_nfolds < 16) { g_folds[g_nfolds++] = f; return 1; }
+    const int rc = launch_fold(st, f);
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -857,7 +914,8 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
     }
     if (x_is_f32 == 2) return mi_fail(MI_ERR_ARG, "mi_conv2d_nhwc_wgrad: uint8 frames are only read by the narrow-layer kernel (bf16 mode)");
     if (!frame_idx && !x_is_f32) {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
+        const int r3 = dtype == MI_BF16X3 ? try_tapwgrad_split((hipStream_t)stream, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias)
+                                          : try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass
@@ -1022,7 +1080,8 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     {
-        const int r3 = try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
+        const int r3 = dtype == MI_BF16X3 ? try_tapwgrad_split((hipStream_t)stream, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias)
+                                          : try_tapwgrad((hipStream_t)stream, dtype, TC_GATHER, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {

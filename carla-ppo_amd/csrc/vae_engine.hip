@@ -190,7 +190,7 @@ void make_workspace(VaeEngine& e) {
     e.partial_cap = (int)(B * 64 > B * e.nchunks ? B * 64 : B * e.nchunks);   // loss partial sums: per (frame, chunk) or per block of the fused decoder tail
     W.partial = add((long long)e.partial_cap * 4); W.bpart = add((long long)e.partial_cap * 16); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
-    W.scratch_bytes = d.dtype == MI_BF16 ? SCRATCH_REGIONS * (64ll << 20) : 0;   // one region per raw-staged filter gradient of a backward pass
+    W.scratch_bytes = d.dtype != MI_F32 ? SCRATCH_REGIONS * (64ll << 20) : 0;    // one region per raw-staged filter gradient of a backward pass (split storage: + the unfolded dW')
     W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
     W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
     W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
