@@ -284,6 +284,8 @@ static int tapwgrad_flush_reduces(void* stream) {
 // tapwgrad (tapwgrad_tile.hpp): bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles.
 // mi_set_tuning key 3 / MI355_TAPWGRAD=0 disables it.
 // ---------------------------------------------------------------------------------------------------------------
+static int x3_tapwgrad_env() { const char* e = getenv("MI355_X3_TAPWGRAD"); return e ? atoi(e) : 0; }
+int g_x3_tapwgrad = x3_tapwgrad_env();                   // split-storage filter gradients on the doubled-channel bf16 kernel: 0 off (default: the bf16x3 step is bound by its other stream, 2.742 ms either way), 1 conv2 / conv3, 2 every eligible layer; mi_set_tuning key 21
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
 int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
@@ -393,8 +395,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
 // MI_BF16X3 filter gradients on the bf16 kernel (see PendingFold): scratch = [dW' (4 x the filter, fp32) | bias' (2 N) | slabs ...]
 int try_tapwgrad_split(hipStream_t st, int mode, const void* a, const void* d, int B, int IH, int IW, int C, int OH, int OW, int N,
                        int KH, int KW, float* out, void* scratch, long long scratch_bytes, float* dbias) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MI355_X3_TAPWGRAD"); on = e ? atoi(e) : 0; }     // off by default: the split engine's step is bound by its forward / input-gradient stream (2.742 ms either way)
+    const int on = g_x3_tapwgrad;
     if (!on || !scratch || (((uintptr_t)scratch) & 255)) return 0;
     const long long nw = (long long)KH * KW * C * N;
     const long long tmp_bytes = ((4 * nw + 2 * N) * 4 + 255) / 256 * 256;
@@ -840,6 +841,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 18) { prev = g_slab_bf16; g_slab_bf16 = value ? 1 : 0; }
     else if (key == 19) { prev = g_nw_depth; g_nw_depth = value; }
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
+    else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

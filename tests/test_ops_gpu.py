@@ -749,7 +749,8 @@ def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     bits = torch.zeros(B * IH * IW * 2, device="cuda", dtype=torch.int32)
     wrote = np.zeros(1, np.int32)
     fmt = 2 if u8 else 1
-    L.mi_conv2d_nhwc_fwd_bits(stream(), code, fr.data_ptr(), idxd.data_ptr(), fmt, B, FH, FW, 3, P(dev(w1t, td)), 1, P(dev(b1)), 4, 4, 32, 1, act1.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
+    w1d, b1d = dev(w1t, td), dev(b1)                                        # (kept alive: temporaries inside the argument list may share one freed block)
+    L.mi_conv2d_nhwc_fwd_bits(stream(), code, fr.data_ptr(), idxd.data_ptr(), fmt, B, FH, FW, 3, w1d.data_ptr(), 1, b1d.data_ptr(), 4, 4, 32, 1, act1.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
     torch.cuda.synchronize()
     if wrote[0] != 1:
         pytest.skip("conv1 forward did not take the bit-word kernel on this geometry")
@@ -788,3 +789,46 @@ def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     db64 = g.sum((0, 1, 2)).numpy()
     assert_close(host(dw) - 0.5, dw64, 2e-3, 5e-4 * float(np.abs(dw64).max()), "conv1 filter gradient vs float64")
     assert_close(host(db) + 0.25, db64, 2e-3, 5e-4 * float(np.abs(db64).max()), "conv1 bias gradient vs float64")
+
+
+@pytest.mark.parametrize("form,geom", [("conv", (39, 79, 32, 64)), ("conv", (18, 38, 64, 128)), ("conv", (8, 18, 128, 256)), ("deconv", (8, 18, 128, 64)), ("deconv", (3, 8, 256, 128))])
+def test_split_storage_filter_gradient_on_the_doubled_channel_bf16_kernel(form, geom):
+    """DESIGN finding 32: a split tensor (MI_BF16X3) read as bf16 has twice the channels (2c = lo half, 2c + 1 = hi half); the bf16 raw-staged filter-gradient kernel run on the
+    doubled channel counts + fold_split_kernel (sum of every 2 x 2 block = the four partial products) must give the fp32-limit result of the split kernels: filter AND bias gradient
+    against float64 on the split-rounded operands, accumulated into a non-zero buffer.  (mi_set_tuning key 21 = 2: every eligible layer; the engine leaves it off.)"""
+    L = milib.get()
+    code, td = DT["x3"]
+    IH, IW, Ci, Co = geom
+    k, B = 4, 3
+    rng = np.random.RandomState(IH + Ci)
+    prev = L.mi_set_tuning(21, 2)
+    try:
+        ws = torch.empty(96 << 20, device="cuda", dtype=torch.uint8)
+        if form == "conv":
+            OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
+            x = rng.randn(B, IH, IW, Ci).astype(np.float32); dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+            xr, dyr = rounded(x, td), rounded(dy, td)
+            w = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+            F.conv2d(_nchw(xr), w, stride=2).backward(_nchw(dyr))
+            dwref = w.grad.permute(2, 3, 1, 0).numpy()                      # HWIO
+            dbref = dyr.sum((0, 1, 2)).numpy()
+            dw, db = torch.full((k, k, Ci, Co), 0.5, device="cuda"), torch.full((Co,), -1.0, device="cuda")
+            xd, dyd = dev(x, td), dev(dy, td)                                # (kept alive: the launch is asynchronous)
+            L.mi_conv2d_nhwc_wgrad_ws(stream(), code, xd.data_ptr(), None, 0, B, IH, IW, Ci, dyd.data_ptr(), k, k, Co, dw.data_ptr(), ws.data_ptr(), ws.numel(), db.data_ptr())
+        else:                                                              # transposed conv: x [B, IH, IW, Ci] -> y [B, OH, OW, Co], kernel [kh, kw, co, ci]
+            OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
+            x = rng.randn(B, IH, IW, Ci).astype(np.float32); dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+            xr, dyr = rounded(x, td), rounded(dy, td)
+            w = torch.zeros(Ci, Co, k, k, dtype=torch.float64, requires_grad=True)
+            F.conv_transpose2d(_nchw(xr), w, stride=2).backward(_nchw(dyr))
+            dwref = w.grad.permute(2, 3, 1, 0).numpy()                      # [kh, kw, co, ci]
+            dbref = dyr.sum((0, 1, 2)).numpy()
+            dw, db = torch.full((k, k, Co, Ci), 0.5, device="cuda"), torch.full((Co,), -1.0, device="cuda")
+            xd, dyd = dev(x, td), dev(dy, td)
+            L.mi_deconv2d_nhwc_wgrad_ws(stream(), code, dyd.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw.data_ptr(), ws.data_ptr(), ws.numel(), db.data_ptr())
+        torch.cuda.synchronize()
+        sw, sb = float(np.abs(dwref).max()), float(np.abs(dbref).max())
+        assert_close(host(dw) - 0.5, dwref, 2e-5, 2e-5 * sw, "filter gradient (split operands on the bf16 kernel)")
+        assert_close(host(db) + 1.0, dbref, 2e-5, 2e-5 * sb, "bias gradient")
+    finally:
+        L.mi_set_tuning(21, prev)
