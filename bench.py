@@ -477,6 +477,11 @@ def main():
                     if dominant in [x.strip().split(" ")[0] for x in op.split("/")]:
                         roofline["traffic"] = rec["hbm_bytes_per_launch"]
                         roofline["traffic_source"] = "profiles/%s: %s" % (fn, tj["provenance"])
+                        if rec.get("us"):
+                            # the same kernel ALONE on the GPU (the profile's counter pass serialises the launches): in the step it shares the CUs and HBM with
+                            # the kernel on the other backward stream, so the event time above is longer than its own (DESIGN finding 25)
+                            roofline["alone_in_profile"] = {"launch_ms": rec["us"] * 1e-3, "frac": (roofline["algorithmic_bytes_per_launch"] / (rec["us"] * 1e-6)) / PEAK["hbm"]
+                                                            if roofline["bound"] == "hbm" else None}
                 if roofline["traffic"] is not None:
                     break
             except Exception:
