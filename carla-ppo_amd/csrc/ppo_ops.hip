@@ -3,6 +3,7 @@
 //   Gaussian policy head (tanh squash, sample, clip), GAE reverse scan and advantage normalisation in fp64.
 #include "common.hpp"
 #include "mi_internal.hpp"
+#include "mi355_carla.h"
 
 using namespace mi;
 
@@ -156,6 +157,13 @@ __global__ void adv_normalize_f64_kernel(double* __restrict__ adv, const double*
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void relu_grad_kernel(const float* __restrict__ g, const float* __restrict__ h, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = h[i] > 0.f ? g[i] : 0.f;
+}
+}  // namespace
+
 extern "C" {
 
 int mi_ppo_loss_blocks(int M) { return (M + 255) / 256; }
@@ -183,6 +191,38 @@ int mi_policy_head(void* stream, const float* u, const float* logstd, const floa
 }
 
 // rewards [R,T], values [R,T+1] (last column = bootstrap), terminals [R,T] (0/1), all fp64 -> adv [R,T]
+// build_mlp trunk of the policy / value network as OP-level calls (SURVEY 8b names; the engines use the fused forms of ppo_fused.hip): utils.py:25-28 with
+// hidden sizes (H1, H2) and ReLU on both layers (ppo.py:42-44,51-53).  Exact fp32 (the same dense kernels the engine's unfused path runs).
+//   fwd: h1 = relu(x W1 + b1) [M, H1], h2 = relu(h1 W2 + b2) [M, H2]                       W1 [din, H1], W2 [H1, H2] (tf.layers.dense kernels)
+//   bwd: given g2 = dL/dh2 (post-activation) [M, H2]: dW2 += h1^T (g2 . relu'(h2)), db2 += column sums, dW1 += x^T dh1, db1 += ..., with
+//        dh1 = ((g2 . relu'(h2)) W2^T) . relu'(h1); scratch: M * (H1 + H2) floats.  The gradient wrt x is not produced (nothing upstream of the state trains).
+int mi_mlp_policy_fwd(void* stream, const float* x, int M, int din, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, float* h1, float* h2) {
+    if (!x || !W1 || !b1 || !W2 || !b2 || !h1 || !h2 || M < 1 || din < 1 || H1 < 1 || H2 < 1) return mi_fail(MI_ERR_ARG, "mi_mlp_policy_fwd: missing buffers or empty shape");
+    if (din % 4 != 0 || H1 % 4 != 0 || H2 % 4 != 0) return mi_fail(MI_ERR_SHAPE, "mi_mlp_policy_fwd: din, H1, H2 must be multiples of 4 (16-byte rows; pad the state with zero columns as the engine does)");
+    int rc = mi_gemm_bias_act(stream, MI_F32, x, M, din, W1, 0, H1, b1, 1, nullptr, h1, 1, 1);
+    if (rc != MI_OK) return rc;
+    return mi_gemm_bias_act(stream, MI_F32, h1, M, H1, W2, 0, H2, b2, 1, nullptr, h2, 1, 1);
+}
+int mi_mlp_policy_bwd(void* stream, const float* x, int M, int din, const float* W2, int H1, int H2, const float* h1, const float* h2, const float* g2,
+                      float* dW1, float* db1, float* dW2, float* db2, float* scratch) {
+    if (!x || !W2 || !h1 || !h2 || !g2 || !dW1 || !db1 || !dW2 || !db2 || !scratch || M < 1) return mi_fail(MI_ERR_ARG, "mi_mlp_policy_bwd: missing buffers or empty shape");
+    float* g2m = scratch; float* dh1 = scratch + (long long)M * H2;
+    if (din % 4 != 0 || H1 % 4 != 0 || H2 % 4 != 0) return mi_fail(MI_ERR_SHAPE, "mi_mlp_policy_bwd: din, H1, H2 must be multiples of 4 (16-byte rows; pad the state with zero columns as the engine does)");
+    {
+        const long long n = (long long)M * H2;
+        hipLaunchKernelGGL(relu_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g2, h2, n, g2m);
+        const int rc0 = mi_check_launch("relu_grad_kernel");
+        if (rc0 != MI_OK) return rc0;
+    }
+    int rc = MI_OK;
+    rc = mi_colsum(stream, MI_F32, g2m, M, H2, db2);
+    if (rc == MI_OK) rc = mi_gemm_wgrad(stream, MI_F32, h1, g2m, M, H1, H2, dW2);
+    if (rc == MI_OK) rc = mi_gemm_bias_act(stream, MI_F32, g2m, M, H2, W2, 1, H1, nullptr, 0, h1, dh1, 1, 1);      // x W^T with the ReluGrad mask of h1
+    if (rc == MI_OK) rc = mi_colsum(stream, MI_F32, dh1, M, H1, db1);
+    if (rc == MI_OK) rc = mi_gemm_wgrad(stream, MI_F32, x, dh1, M, din, H1, dW1);
+    return rc;
+}
+
 int mi_gae_scan(void* stream, const double* rewards, const double* values, const double* terminals, int R, int T, double gamma, double lam, double* adv) {
     if (R < 1 || T < 1) return mi_fail(MI_ERR_ARG, "mi_gae_scan: empty input");
     hipLaunchKernelGGL(gae_scan_f64_kernel, dim3((R + 63) / 64), dim3(64), 0, (hipStream_t)stream, rewards, values, terminals, R, T, gamma, gamma * lam, adv);

@@ -192,6 +192,11 @@ int mi_range_check(void* stream, const float* x, long long n, float lo, float hi
 int mi_ppo_loss_blocks(int M);
 int mi_ppo_loss_partial_floats(int M);
 int mi_ppo_loss_fwd_bwd(void* stream, const float* u, const float* u_old, const float* logstd, const float* logstd_old, const float* vraw, const float* actions, const float* returns, const float* advantage, const float* low, const float* high, int M, int A, float clip_eps, float value_scale, float entropy_scale, float inv_m, float grad_scale, float* du, float* dv, float* partial, float* losses5, float* dlogstd);
+/* build_mlp trunk (utils.py:25-28 with ppo.py:42-44,51-53: two dense layers, ReLU on both) as op-level calls; exact fp32.  din, H1, H2 multiples of 4 (pad the state).
+ * fwd: h1 = relu(x W1 + b1), h2 = relu(h1 W2 + b2).  bwd: from g2 = dL/dh2 [M, H2]: dW1, db1, dW2, db2 are ACCUMULATED into; scratch M * (H1 + H2) floats.
+ * (The engines run the fused forms: mi_ppo_train_step / mi_ppo_predict / mi_rollout_step.) */
+int mi_mlp_policy_fwd(void* stream, const float* x, int M, int din, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, float* h1, float* h2);
+int mi_mlp_policy_bwd(void* stream, const float* x, int M, int din, const float* W2, int H1, int H2, const float* h1, const float* h2, const float* g2, float* dW1, float* db1, float* dW2, float* db2, float* scratch);
 /* action_mean rescale, Normal.sample, clip_by_value — ppo.py:47,58-62 */
 int mi_policy_head(void* stream, const float* u, const float* logstd, const float* noise, const float* low, const float* high, int M, int A, int greedy, float* action, float* mean_out);
 /* compute_gae — utils.py:45-50 (fp64, rounding sequence of numpy + scipy.signal.lfilter) */

@@ -326,3 +326,37 @@ def test_step_with_fused_minibatch_gather_equals_gathered_step(tmp_path, M):
         else:
             assert np.abs(p - p0).max() <= 1e-6 * max(1.0, np.abs(p0).max()), (M, c)
         assert np.allclose(l, l0, rtol=1e-6, atol=1e-7), (M, c, l, l0)
+
+
+@pytest.mark.parametrize("M", [32, 77])
+def test_mlp_policy_op_level_forward_backward(M):
+    """SURVEY 8b names `mi_mlp_policy_fwd / _bwd`: the build_mlp trunk (utils.py:25-28; dense 500 ReLU, dense 300 ReLU: ppo.py:42-44) as op-level calls of the C ABI, against
+    the float64 statement of the same two layers: activations 1e-5 of max, the four gradient tensors 2e-5 of max, accumulated into non-zero buffers; bad shapes are refused."""
+    import torch
+    from mi355 import lib as milib
+    L = milib.get()
+    rng = np.random.RandomState(M)
+    din, H1, H2 = 68, 500, 300                                # the state padded to 68 columns as in the engine (column 67 is zero)
+    x = (0.5 * rng.standard_normal((M, din))).astype(np.float32); x[:, 67] = 0
+    W1 = (rng.standard_normal((din, H1)) / np.sqrt(din)).astype(np.float32); b1 = (0.1 * rng.standard_normal(H1)).astype(np.float32)
+    W2 = (rng.standard_normal((H1, H2)) / np.sqrt(H1)).astype(np.float32); b2 = (0.1 * rng.standard_normal(H2)).astype(np.float32)
+    g2 = rng.standard_normal((M, H2)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()                  # noqa: E731
+    xd, W1d, b1d, W2d, b2d, g2d = d(x), d(W1), d(b1), d(W2), d(b2), d(g2)
+    h1, h2 = torch.empty(M, H1, device="cuda"), torch.empty(M, H2, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    L.mi_mlp_policy_fwd(st, xd.data_ptr(), M, din, W1d.data_ptr(), b1d.data_ptr(), H1, W2d.data_ptr(), b2d.data_ptr(), H2, h1.data_ptr(), h2.data_ptr())
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float64)).requires_grad_(True)      # noqa: E731
+    x64, W164, b164, W264, b264 = t(x), t(W1), t(b1), t(W2), t(b2)
+    r1 = torch.relu(x64 @ W164 + b164); r2 = torch.relu(r1 @ W264 + b264)
+    (r2 * torch.from_numpy(g2.astype(np.float64))).sum().backward()
+    assert rel_err(h1.cpu().numpy(), r1.detach().numpy()) < 1e-5 and rel_err(h2.cpu().numpy(), r2.detach().numpy()) < 1e-5
+    dW1, db1 = torch.full((din, H1), 0.5, device="cuda"), torch.full((H1,), -1.0, device="cuda")
+    dW2, db2 = torch.full((H1, H2), 0.25, device="cuda"), torch.full((H2,), 2.0, device="cuda")
+    scratch = torch.empty(M * (H1 + H2), device="cuda")
+    L.mi_mlp_policy_bwd(st, xd.data_ptr(), M, din, W2d.data_ptr(), H1, H2, h1.data_ptr(), h2.data_ptr(), g2d.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(), scratch.data_ptr())
+    torch.cuda.synchronize()
+    for got, off, ref, name in ((dW1, 0.5, W164.grad, "dW1"), (db1, -1.0, b164.grad, "db1"), (dW2, 0.25, W264.grad, "dW2"), (db2, 2.0, b264.grad, "db2")):
+        assert rel_err(got.cpu().numpy() - off, ref.numpy()) < 2e-5, name
+    with pytest.raises(milib.MiError):
+        L.mi_mlp_policy_fwd(st, xd.data_ptr(), M, 67, W1d.data_ptr(), b1d.data_ptr(), H1, W2d.data_ptr(), b2d.data_ptr(), H2, h1.data_ptr(), h2.data_ptr())
