@@ -43,7 +43,7 @@ struct EncHeadParams {
 template <typename TS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void enchead_bwd_kernel(const EncHeadParams p) {
     constexpr int SSZ = (int)sizeof(TS), GSZ = 4 * SSZ, GDW = GSZ / 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[EH_DYS + 4 * EH_PT + 4 * EH_GT];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[EH_DYS + 4 * EH_PT + 4 * EH_GT + 4 * 4096];
     unsigned char* const dys = lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,15 +55,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
 
     // ---- per wave, once: the class's weights: tap (ta, tb) -> kernel (ph + 2 ta, pw + 2 tb); MFMA row = ci = lrow, this half-wave's 8 co of k-step kk ----
-    u16x8 wf[4][4];
+    // taps 0 .. 2 in registers (48 VGPRs); the fourth tap's four fragments live in a wave-private 4 KB LDS tile, lane-linear (one conflict-free ds_read_b128 each): with all
+    // 64 weight registers the kernel sat at the three-waves-per-SIMD limit with two fragments spilled, and their scratch reloads inside the tile loop drained every prefetch
+    unsigned char* const wlw = lds + EH_DYS + 4 * EH_PT + 4 * EH_GT + wave * 4096;
+    u16x8 wf[3][4];
     {
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 16 * 32 * 64 * 2, 0x00020000);
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {
             const int kh = ph + 2 * (tap >> 1), kw = pw + 2 * (tap & 1);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                wf[tap][kk] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (((kh * 4 + kw) * 32 + lrow) * 64 + kk * 16 + lgrp * 8) * 2, 0, 0));
+            for (int kk = 0; kk < 4; ++kk) {
+                const u16x8 f = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (((kh * 4 + kw) * 32 + lrow) * 64 + kk * 16 + lgrp * 8) * 2, 0, 0));
+                if (tap < 3) wf[tap][kk] = f; else *(u16x8*)(wlw + kk * 1024 + lane * 16) = f;
+            }
         }
     }
     // patch tile: column 48 = 1.0 in every row (the bias gradient rides along as row 48 of the filter gradient), columns 49 .. 63 = 0: chunks 6, 7 of the 128-byte row
@@ -81,13 +86,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bits, 0, (int)p.bits_bytes, 0x00020000);
     constexpr int EH_OOB = 0x7ffffff0;
 
-    // staging roles: 45 pixels x 8 sixteen-byte chunks = 360 items, two per thread (the second only for tid < 104)
-    int sp[2], sc[2], sr_[2], scol[2]; bool sin2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + 256 * i; sin2[i] = id < EH_NS * 8; sp[i] = sin2[i] ? id >> 3 : 0; sc[i] = id & 7;
-        sr_[i] = sp[i] / EH_SC; scol[i] = sp[i] - sr_[i] * EH_SC;
-    }
+    // staging roles: 45 pixels x 8 sixteen-byte chunks = 360 items, two per thread (the second only for tid < 104); recomputed where they are used (held in
+    // registers they were the difference between 168 VGPRs with two weight fragments spilled -- reloaded by scratch loads INSIDE the tile loop, whose s_waitcnt
+    // vmcnt drained every prefetch in front of them -- and no spill)
+    auto role = [&](int i, int& spix, int& schk, int& srow, int& scl, bool& sin) {
+        const int id = tid + 256 * i; sin = id < EH_NS * 8; spix = sin ? id >> 3 : 0; schk = id & 7;
+        srow = (spix * 57) >> 9; scl = spix - srow * EH_SC;            // spix / 9 for spix < 45
+    };
     struct Staged { f32x4 d[2]; };
     auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
         uint32_t bb, rem, ty, tx;
@@ -100,25 +105,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         tile_origin(tile, b, y0, x0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int oy = (y0 >> 1) - 1 + sr_[i], ox = (x0 >> 1) - 1 + scol[i];
-            const bool in = sin2[i] && (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
-            const int off = in ? (((b * p.OH + oy) * p.OW + ox) * 64 + sc[i] * 8) * 2 : EH_OOB;
+            int spix, schk, srow, scl; bool sin;
+            role(i, spix, schk, srow, scl, sin);
+            const int oy = (y0 >> 1) - 1 + srow, ox = (x0 >> 1) - 1 + scl;
+            const bool in = sin && (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
+            const int off = in ? (((b * p.OH + oy) * p.OW + ox) * 64 + schk * 8) * 2 : EH_OOB;
             R.d[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsD, off, 0, 0));
         }
     };
     auto commit = [&](const Staged& R) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (sin2[i]) *(f32x4*)(dys + sp[i] * EH_SP + sc[i] * 16) = R.d[i];
+        for (int i = 0; i < 2; ++i) {
+            int spix, schk, srow, scl; bool sin;
+            role(i, spix, schk, srow, scl, sin);
+            if (sin) *(f32x4*)(dys + spix * EH_SP + schk * 16) = R.d[i];
+        }
     };
     // frame patch of the lane's pixel: group j = 2 s + gi of this lane: q = 4 s + gi (+ 2 for the upper half-wave) -> kernel row q / 3, value offset (q % 3) * 4
     const uint32_t rowb = (uint32_t)(p.FW * 3 * SSZ);
-    uint32_t goff[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    auto goff = [&](int j) -> uint32_t {                  // (a select between two wave-uniform values per use instead of six registers held across the kernel)
         const int qa = 4 * (j >> 1) + (j & 1), qb = qa + 2;
-        goff[j] = lgrp ? (uint32_t)(qb / 3) * rowb + (uint32_t)((qb % 3) * GSZ) : (uint32_t)(qa / 3) * rowb + (uint32_t)((qa % 3) * GSZ);
-    }
+        const uint32_t oa = (uint32_t)(qa / 3) * rowb + (uint32_t)((qa % 3) * GSZ), ob = (uint32_t)(qb / 3) * rowb + (uint32_t)((qb % 3) * GSZ);
+        return lgrp ? ob : oa;
+    };
     struct Raw { uint32_t d[6][GDW]; uint32_t mw; };
     auto frame_of = [&](int b) -> int {                   // scalar load + its own wait (dectail_tile.hpp: a vector load of a uniform value drains the prefetch)
         int fr = b;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const unsigned char* pix = (const unsigned char*)p.frames + ((long long)frame_of(b) * p.frame_stride + (2ll * yc * p.FW + 2 * xc) * 3) * SSZ;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
+            const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff(j));
 #pragma unroll
             for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
         }
@@ -153,46 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const int tg = lane >> 4, tc = lane & 15;
     const int trow = (tg >> 1) * 8 + (tc >> 2), tcol = (tg & 1) * 16 + (tc & 3) * 4;
 
-    // the frame patch + bit word of a tile are requested as soon as the previous tile has consumed its own (same registers): they fly under that tile's second
-    // half, the barrier, the commit and this tile's 16 MFMAs (requested at the top of their own tile they had 16 MFMAs = 0.2 us to land: every tile waited for them)
+    // the frame patch + bit word of a tile are CONSUMED at the top of the tile (converted into the wave's patch tile, the bit word kept in one register) and the next
+    // tile's are requested right behind, into the same registers: a whole tile (~9 k cycles per block at three blocks per CU) to land.  Requested at the top of their own
+    // tile they had 16 MFMAs = 0.2 us; requested behind the conversion in the middle of the tile, half a tile: 57 % of the kernel's wave cycles were waits.
     Raw raw;
     request_patch(min(vb, p.ntiles - 1), raw);
     for (int tile = vb; tile < p.ntiles; tile += G) {
         commit(cur);
-        __syncthreads();
-        request(t_nxt, cur);                               // the next tile's dy2 pixels: land under this tile's work (LDS-only barriers from here on)
-
-        // ---- g1 of this wave's 32 pixels: D[ci][pixel] = sum over taps, co ----
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const u16x8 bf = *(const u16x8*)(dys + dya + ((1 - (tap >> 1)) * EH_SC + (1 - (tap & 1))) * EH_SP + kk * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[tap][kk]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
-            }
-        // ---- epilogue of narrow_conv48_kernel<., 1>: bf16, half-wave exchange (lane (pixel, g) then owns channels 16 g .. 16 g + 15), ReluGrad from the bit word ----
-        {
-            uint32_t R[4][2];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
-                const PackN<uint32_t, 2> w2 = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
-                R[qd][0] = w2.v[0]; R[qd][1] = w2.v[1];
-            }
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                auto r0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = r0[0]; R[2][d] = r0[1];
-                auto r1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = r1[0]; R[3][d] = r1[1];
-            }
-            uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
-#pragma unroll
-            for (int d = 0; d < 8; ++d) o[d] &= ((raw.mw >> d) & 0x00010001u) * 0xffffu;
-            *(PackN<uint32_t, 4>*)(gtw + lrow * EH_GP + lgrp * 32) = PackN<uint32_t, 4>{{o[0], o[1], o[2], o[3]}};
-            *(PackN<uint32_t, 4>*)(gtw + lrow * EH_GP + lgrp * 32 + 16) = PackN<uint32_t, 4>{{o[4], o[5], o[6], o[7]}};
-        }
         // ---- the lane's half of its pixel's frame patch -> row lrow of the wave's patch tile (k order (kh * 4 + kw) * 3 + c = conv1's HWIO rows) ----
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -214,9 +190,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             }
             *(u16x8*)(ptw + lrow * 128 + (((2 * s + lgrp) ^ (lrow & 7)) << 4)) = xf;
         }
+        const uint32_t mw = raw.mw;
         request_patch(t_nxt, raw);                         // (past the end: a valid tile again -- no branch around the loads)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the staged dy2 pixels are published; LDS-only: __syncthreads() would drain the requests just issued
+        request(t_nxt, cur);                               // the next tile's dy2 pixels: land under this tile's work (LDS-only barriers from here on)
         t_nxt = min(t_nxt + G, p.ntiles - 1);
-        __builtin_amdgcn_wave_barrier();                  // same wave, in-order LDS queue
+
+        // ---- g1 of this wave's 32 pixels: D[ci][pixel] = sum over taps, co ----
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u16x8 bf = *(const u16x8*)(dys + dya + ((1 - (tap >> 1)) * EH_SC + (1 - (tap & 1))) * EH_SP + kk * 32);
+                u16x8 wa;
+                if (tap < 3) wa = wf[tap][kk]; else wa = *(const u16x8*)(wlw + kk * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+            }
+        // ---- epilogue of narrow_conv48_kernel<., 1>: bf16, half-wave exchange (lane (pixel, g) then owns channels 16 g .. 16 g + 15), ReluGrad from the bit word ----
+        {
+            uint32_t R[4][2];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+                const PackN<uint32_t, 2> w2 = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+                R[qd][0] = w2.v[0]; R[qd][1] = w2.v[1];
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto r0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = r0[0]; R[2][d] = r0[1];
+                auto r1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = r1[0]; R[3][d] = r1[1];
+            }
+            uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o[d] &= ((mw >> d) & 0x00010001u) * 0xffffu;
+            *(PackN<uint32_t, 4>*)(gtw + lrow * EH_GP + lgrp * 32) = PackN<uint32_t, 4>{{o[0], o[1], o[2], o[3]}};
+            *(PackN<uint32_t, 4>*)(gtw + lrow * EH_GP + lgrp * 32 + 16) = PackN<uint32_t, 4>{{o[4], o[5], o[6], o[7]}};
+        }
+        __builtin_amdgcn_wave_barrier();                  // same wave, in-order LDS queue (g1 tile written above, patch tile at the top of the tile)
         // ---- filter (+ bias) gradient: dW[k][ci] += sum over this wave's pixels of patch[pixel][k] * g1[pixel][ci]; k = 48 is the all-ones column ----
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {                   // k-step = 16 pixels
