@@ -695,12 +695,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     // the raw patch of one tile: 6 groups per lane, requested one tile AHEAD of its use (a wave walks tiles tile, tile + nw, ...; the
     // persistent grid keeps 8 waves per SIMD resident, and within a wave the next tile's loads fly under this tile's arithmetic and stores)
     struct Raw { uint32_t d[6][GDW]; uint32_t mw; };
-    auto request = [&](int t, Raw& r) {
+    // the frame of a lane's pixel (minibatch gather) is looked up TWO tiles ahead: looked up inside request() its load was followed by s_waitcnt vmcnt(0) -- the address of the
+    // six patch loads depends on it -- which every tile drained the whole vector-memory queue, the previous tile's store acknowledgements included (round 3; dectail_tile.hpp)
+    auto frame_of = [&](int t) -> int {
+        const int m = min(t * 32 + lrow, p.M - 1);
+        const uint32_t b = p.div_ohw.div((uint32_t)m);
+        return p.frame_idx ? p.frame_idx[b] : (int)b;
+    };
+    auto request = [&](int t, int frame, Raw& r) {
         const int m = min(t * 32 + lrow, p.M - 1);       // pixels past M recompute the last one; their stores fall outside the descriptors
         uint32_t b, rem, y, x;
         p.div_ohw.divmod((uint32_t)m, b, rem);
         p.div_ow.divmod(rem, y, x);
-        const long long fr = p.frame_idx ? (long long)p.frame_idx[b] : (long long)b;
+        const long long fr = frame;
         const unsigned char* pix = (const unsigned char*)p.src + fr * p.frame_stride * SSZ + (2u * y * (uint32_t)p.IW + 2u * x) * (uint32_t)(p.Cs * SSZ);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -711,9 +718,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if constexpr (MODE == 1) r.mw = __builtin_amdgcn_raw_buffer_load_b32(rsBI, (t * 32 + lrow) * 8 + lgrp * 4, 0, 0);
     };
     Raw cur, nxt;
-    request(tile, cur);
+    request(tile, frame_of(tile), cur);
+    int fr_nxt = frame_of(min(tile + nw, ntiles - 1));
     for (; tile < ntiles; tile += nw) {
-        request(min(tile + nw, ntiles - 1), nxt);        // (the last iteration re-requests its own tile: no branch in the loop body)
+        const int fr_use = fr_nxt;
+        fr_nxt = frame_of(min(tile + 2 * nw, ntiles - 1));
+        request(min(tile + nw, ntiles - 1), fr_use, nxt);        // (the last iteration re-requests its own tile: no branch in the loop body)
         u16x8 xf[3];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
