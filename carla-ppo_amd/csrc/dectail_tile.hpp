@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         p.div_tx.divmod(rem, ty, tx);
         const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
         commit(cur);
-        __syncthreads();
+        dt_lds_barrier();                                 // LDS only: __syncthreads() also waited for the ACKNOWLEDGEMENTS of the previous tile's gradient stores (vmcnt counts stores too)
         request(t_nxt, frame_of(t_nxt), cur);
         t_nxt = min(t_nxt + G, p.ntiles - 1);
 
