@@ -204,7 +204,7 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // is recorded instead (parameters by value; every layer then needs its OWN scratch region until the flush) and mi_tapwgrad_flush issues
 // all of them back to back.  Per host THREAD (thread_local): a backward pass is issued by one thread from defer(1) to flush, so two engines driven by two
 // threads keep separate lists (round 3; the tuning knobs stay process-global configuration).  Used by the VAE engine only.
-struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; };
+struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; const float* bpart; float* bout; int bnslab, bN; };
 // Split storage (MI_BF16X3) on the bf16 filter-gradient kernels: the tensors are handed over as bf16 tensors with TWICE the channels (channel 2c = lo half, 2c + 1 = hi half of
 // element c), the kernel produces dW'[t][2R][2Q] in a temporary, and the fold  dW[t][r][q] += dW'[t][2r][2q] + dW'[t][2r][2q+1] + dW'[t][2r+1][2q] + dW'[t][2r+1][2q+1]
 // (all four partial products of the two-term expansion) follows the slab reduce -- deferred with it when the reduces are deferred.
@@ -229,25 +229,30 @@ static int launch_fold(hipStream_t st, const PendingFold& f) {
     return mi_check_launch("fold_split_kernel");
 }
 static thread_local PendingReduce g_pending[16];
-static thread_local int g_npending = 0, g_defer_reduces = 0;
-static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element: about 512 blocks in flight, at most ~16 slabs per thread
+static thread_local int g_npending = 0, g_defer_reduces = 0, g_defer_pause = 0;
+static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element (a power of two <= 64, from the shape only): about 512 blocks in flight, at most ~16 slabs per thread
     unsigned ry = 1;
-    while (((unsigned)(r.ngroups / 256 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4) ry *= 2;
+    while (((unsigned)(r.ngroups / 256 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
     return ry;
 }
+static unsigned reduce_blocks(const PendingReduce& r, unsigned ry) { const unsigned gpb = 256 / ry; return (unsigned)((r.ngroups + gpb - 1) / gpb); }
 static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
     const unsigned ry = reduce_ry(r);
-    const dim3 rg((unsigned)((r.ngroups + 255) / 256), ry, 1);
-    if (r.kind == 0) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
-    else if (r.kind == 1) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
-    else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups);
+    const dim3 rg(reduce_blocks(r, ry), 1, 1);
+    if (r.kind == 0) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    else if (r.kind == 1) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    if (r.bpart) hipLaunchKernelGGL(reduce_bias_kernel, dim3(1), dim3(256), 0, st, r.bpart, r.bnslab, r.bN, r.bout);
 }
 extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode drops whatever an aborted pass may have left in the list
     const int prev = g_defer_reduces;
     g_defer_reduces = on ? 1 : 0;
-    g_npending = 0; g_nfolds = 0;
+    g_npending = 0; g_nfolds = 0; g_defer_pause = 0;
     return prev;
 }
+// pause != 0: the next filter gradients reduce their slabs right behind their own launch although the pass defers (a layer issued on ANOTHER stream than the
+// one the deferred list will be flushed on); returns the previous setting
+extern "C" int mi_tapwgrad_defer_pause(int pause) { const int prev = g_defer_pause; g_defer_pause = pause ? 1 : 0; return prev; }
 int g_slab_bf16 = 0;                                       // tapwgrad partial-sum slabs rounded to bf16 (half the slab traffic): off for the layer-op entry points (exact fp32
                                                            // partial sums), switched on by the VAE engine around its backward pass (mi_tapwgrad_slab_bf16); mi_set_tuning key 18
 static thread_local int t_slab_bf16 = -1;                  // this thread's override for the pass it is issuing (-1: the process default above)
@@ -270,14 +275,15 @@ static int tapwgrad_flush_reduces(void* stream) {
         return mi_check_launch("reduce_tiled_kernel");
     }
     static thread_local FusedReduceParams f;              // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
-    f.n = n; f.first[0] = 0;
+    f.n = n; f.first[0] = 0; f.nbias = 0;
     for (int i = 0; i < n; ++i) {
         const PendingReduce& r = g_pending[i];
         f.q[i] = r.q; f.splits[i] = r.splits; f.ngroups[i] = r.ngroups; f.kind[i] = r.kind; f.ry[i] = (int)reduce_ry(r);
-        f.first[i + 1] = f.first[i] + ((r.ngroups + 255) / 256) * f.ry[i];
+        f.first[i + 1] = f.first[i] + (int)reduce_blocks(r, (unsigned)f.ry[i]);
+        if (r.bpart) { f.bpart[f.nbias] = r.bpart; f.bout[f.nbias] = r.bout; f.bnslab[f.nbias] = r.bnslab; f.bN[f.nbias] = r.bN; ++f.nbias; }
     }
     for (int i = n; i < TW_MAX_FUSED; ++i) f.first[i + 1] = f.first[n];
-    hipLaunchKernelGGL(reduce_fused_kernel, dim3((unsigned)f.first[n]), dim3(256), 0, (hipStream_t)stream, f);
+    hipLaunchKernelGGL(reduce_fused_kernel, dim3((unsigned)(f.first[n] + f.nbias)), dim3(256), 0, (hipStream_t)stream, f);
     return mi_check_launch("reduce_fused_kernel");
 }
 
@@ -365,10 +371,17 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     const int kt_tiles = taps == 2 ? 4 : 2;
     const long long slab_floats = (long long)gy * q.npairs * kt_tiles * 1024;
     q.slabs = nullptr; q.slab_stride = slab_floats; q.slab_bf16 = slab_bf16_now() ? 1 : 0;
-    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * slab_floats * (q.slab_bf16 ? 2 : 4) && slab_floats < (1ll << 29)) q.slabs = (float*)scratch;
+    const bool split = g_tapwgrad_split && taps == 2 && q.npairs == 8;   // wave = (tap, position half): fewer LDS reads per MFMA
+    // behind the slabs: the bias-gradient partial sums of every position split (x 2 position halves in the split layout), summed in a fixed order with the slabs
+    const long long slab_bytes = ((long long)splits * slab_floats * (q.slab_bf16 ? 2 : 4) + 255) / 256 * 256;
+    q.bias_part = nullptr; q.bias_nh = split ? 2 : 1;
+    const long long bias_bytes = dbias ? (long long)splits * q.bias_nh * q.NE * 4 : 0;
+    if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= slab_bytes + bias_bytes && slab_floats < (1ll << 29) && (!dbias || N <= 256)) {
+        q.slabs = (float*)scratch;
+        if (dbias) q.bias_part = (float*)((char*)scratch + slab_bytes);
+    }
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
-    const bool split = g_tapwgrad_split && taps == 2 && q.npairs == 8;   // wave = (tap, position half): fewer LDS reads per MFMA
     if (mode == TC_CONV) {
         if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
         else hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
@@ -386,7 +399,8 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     if (rc == MI_OK && q.slabs) {
         PendingReduce r;
         r.q = q; r.splits = splits; r.ngroups = (int)(slab_floats / 4); r.kind = mode == TC_CONV ? 0 : (taps == 2 ? 1 : 2);
-        if (g_defer_reduces && g_npending < 16) g_pending[g_npending++] = r;
+        r.bpart = q.bias_part; r.bout = dbias; r.bnslab = splits * q.bias_nh * (q.NE / N); r.bN = N;
+        if (g_defer_reduces && !g_defer_pause && g_npending < 16) g_pending[g_npending++] = r;
         else { launch_tiled_reduce(st, r); rc = mi_check_launch("reduce_tiled_kernel"); }
     }
     return rc == MI_OK ? 1 : rc;
@@ -412,7 +426,7 @@ int try_tapwgrad_split(hipStream_t st, int mode, const void* a, const void* d, i
     const int r = try_tapwgrad(st, MI_BF16, mode, a, d, B, IH, IW, 2 * C, OH, OW, 2 * N, KH, KW, tmp, (char*)scratch + tmp_bytes, scratch_bytes - tmp_bytes, dbias ? tb : nullptr);
     if (r <= 0) return r;
     PendingFold f = {tmp, out, tb, dbias, KH * KW, mode == TC_CONV ? C : N, mode == TC_CONV ? N : C, N};
-    if (g_defer_reduces && g_nfolds < 16) { g_folds[g_nfolds++] = f; return 1; }
+    if (g_defer_reduces && !g_defer_pause && g_nfolds < 16) { g_folds[g_nfolds++] = f; return 1; }
     const int rc = launch_fold(st, f);
     return rc == MI_OK ? 1 : rc;
 }
@@ -532,9 +546,9 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     int rc = mi_check_launch("narrow_wgrad_kernel");
     if (rc == MI_OK && q.slabs) {
         const long long n_out = (long long)KH * run * 32;
-        hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(n_out, blocks), dim3(256), 0, st, q.slabs, (long long)NW_SLAB, blocks, n_out, out);
-        if (dbias) hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(32, blocks), dim3(256), 0, st, q.slabs + 64 * 32, (long long)NW_SLAB, blocks, 32ll, dbias);
-        rc = mi_check_launch("reduce_slabs_kernel");
+        launch_reduce_slabs_ordered(st, q.slabs, (long long)NW_SLAB, blocks, n_out, out);
+        if (dbias) launch_reduce_slabs_ordered(st, q.slabs + 64 * 32, (long long)NW_SLAB, blocks, 32ll, dbias);
+        rc = mi_check_launch("reduce_slabs_ordered_kernel");
     }
     return rc == MI_OK ? 1 : rc;
 }
@@ -736,7 +750,9 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
     return launch_gemm_bn<bf16_t, bf16_t, A_DECONV, B_DECONV, 8, 16>(st, p, maxM, 4);
 }
 
-int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks) {
+// scratch (optional): the pixel splits store per-split slabs there and one ordered pass adds them to out -- two runs are bitwise equal; without
+// scratch (or with too little of it) the splits meet in fp32 atomics on out (run-to-run differences in the last bit)
+int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0) {
     const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : (dtype == MI_BF16X3 ? WgradCfg<split_t>::BP : WgradCfg<bf16_t>::BP);
     const bool wide = p.Kc > 64;                          // 128 kc rows per block: halves the re-reads of the small tensor
     const int gx = wide ? (p.Kc + 127) / 128 : 1, gy = (p.N + 63) / 64;
@@ -748,6 +764,8 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     splits = (p.M + mps - 1) / mps;
     p.m_per_split = mps;
     p.debug_skip_out = g_wgrad_skip;
+    p.slabs = nullptr; p.slab_stride = ((long long)p.Kc * p.N + 3) / 4 * 4;
+    if (splits > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * p.slab_stride * 4) p.slabs = (float*)scratch;
     dim3 g(gx, gy, splits);
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
@@ -778,7 +796,12 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
         else return mi_fail(MI_ERR_SHAPE, "wgrad (bf16): channel count / alignment not supported");
     }
 #undef WG_LAUNCH
-    return mi_check_launch("wgrad_kernel");
+    int rc = mi_check_launch("wgrad_kernel");
+    if (rc == MI_OK && p.slabs) {
+        launch_reduce_slabs_ordered(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out);
+        rc = mi_check_launch("reduce_slabs_ordered_kernel");
+    }
+    return rc;
 }
 
 void fill_wgrad_geom(WgradParams& p, int B, int IH, int IW, int C, int OH, int OW, int KH, int KW, int stride, bool merged) {
@@ -799,8 +822,8 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 
 // internal entry points for the other translation units (mi_internal.hpp)
 int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, reduce_slabs_grid(n, nslab), dim3(256), 0, st, slabs, stride, nslab, n, out);
-    return mi_check_launch("reduce_slabs_kernel");
+    launch_reduce_slabs_ordered(st, slabs, stride, nslab, n, out);
+    return mi_check_launch("reduce_slabs_ordered_kernel");
 }
 
 bool mi_narrow_enabled() { return narrow_enabled(); }
@@ -911,7 +934,7 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
                             float* dbias) {
     const int OH = (IH - KH) / 2 + 1, OW = (IW - KW) / 2 + 1;
     {
-        const int r4 = try_narrow_wgrad((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, dbias, nullptr, 0);   // atomics measured faster than slabs here (92 vs 119 us)
+        const int r4 = try_narrow_wgrad((hipStream_t)stream, dtype, x, x_is_f32 == 2 ? 2 : ((x_is_f32 || dtype == MI_F32) ? 1 : 0), frame_idx, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, dbias, scratch, scratch_bytes);   // per-block slabs + ordered reduce when the caller brings scratch (deterministic; atomics measured 92 vs 119 us -- the engines' default path is the fused encoder-head kernel anyway)
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     if (x_is_f32 == 2) return mi_fail(MI_ERR_ARG, "mi_conv2d_nhwc_wgrad: uint8 frames are only read by the narrow-layer kernel (bf16 mode)");
@@ -920,15 +943,15 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
                                           : try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
-    if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass
-        const int rcb = mi_colsum(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias);
+    if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass (same scratch, same stream: the filter gradient below reuses it in stream order)
+        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, scratch, scratch_bytes);
         if (rcb != MI_OK) return rcb;
     }
     WgradParams p = {};
     p.big = x; p.frame_idx = frame_idx;
     fill_wgrad_geom(p, B, IH, IW, Cin, OH, OW, KH, KW, 2, needs_merge(Cin, dtype, x_is_f32));
     p.N = Cout; p.small = dy; p.s_vec = vec_ok(dy, Cout, dtype); p.out = dw;
-    return launch_wgrad((hipStream_t)stream, dtype, x_is_f32, p, 1024);
+    return launch_wgrad((hipStream_t)stream, dtype, x_is_f32, p, 1024, scratch, scratch_bytes);
 }
 
 // conv2d_transpose NHWC stride-2 VALID forward, kernel [kh,kw,co,ci] (reference vae/models.py:261-264)
@@ -1078,7 +1101,7 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
                               const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes, float* dbias) {
     const int IH = (OH - KH) / 2 + 1, IW = (OW - KW) / 2 + 1;
     {   // deconv with a narrow OUTPUT: dW[kh,kw,co,ci] = sum patches(dy)[.,(kh,kw,co)] x[.,ci]; its bias gradient is not a by-product here
-        const int r4 = dbias ? 0 : try_narrow_wgrad((hipStream_t)stream, dtype, dy, 0, nullptr, x, B, OH, OW, Cout, IH, IW, Cin, KH, KW, dw, nullptr, nullptr, 0);
+        const int r4 = dbias ? 0 : try_narrow_wgrad((hipStream_t)stream, dtype, dy, 0, nullptr, x, B, OH, OW, Cout, IH, IW, Cin, KH, KW, dw, nullptr, scratch, scratch_bytes);
         if (r4 != 0) return r4 > 0 ? MI_OK : r4;
     }
     {
@@ -1087,14 +1110,14 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {
-        const int rcb = mi_colsum(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias);
+        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, scratch, scratch_bytes);
         if (rcb != MI_OK) return rcb;
     }
     WgradParams p = {};
     p.big = dy; p.frame_idx = nullptr;
     fill_wgrad_geom(p, B, OH, OW, Cout, IH, IW, KH, KW, 2, needs_merge(Cout, dtype, 0));
     p.N = Cin; p.small = x; p.s_vec = vec_ok(x, Cin, dtype); p.out = dw;
-    return launch_wgrad((hipStream_t)stream, dtype, 0, p, 1024);
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, 1024, scratch, scratch_bytes);
 }
 
 // Dense: out[M,N] = act(a[M,K] * W + bias).  w_layout 0: W[K,N] (tf dense kernel), 1: W[N,K] (used for x * W^T).
@@ -1140,15 +1163,26 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
     return conv_form_gemm<B_NK>((hipStream_t)stream, dtype, 0, p, gz);
 }
 
-// Dense filter gradient: dw[K,N] += a[M,K]^T * dy[M,N]   (fp32 atomics)
+// Dense filter gradient: dw[K,N] += a[M,K]^T * dy[M,N]   (row splits meet in fp32 atomics)
 int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw) {
+    return mi_gemm_wgrad_ws(stream, dtype, a, dy, M, K, N, dw, nullptr, 0);
+}
+
+// same with caller scratch (>= mi_gemm_wgrad_scratch_bytes): the row splits store per-split slabs that one ordered pass adds to dw -- deterministic
+long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N) {
+    (void)dtype; (void)M;
+    // splits x gx x gy <= the target block count, a block covers at most 128 x 64 outputs; + one 16-byte rounding per slab
+    return (long long)(g_dense_wgrad_blocks > 1024 ? g_dense_wgrad_blocks : 1024) * (128 * 64 + 4) * 4 + ((long long)K * N + 4) * 4;
+}
+
+int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes) {
     WgradParams p = {};
     p.big = a; p.frame_idx = nullptr;
     fill_wgrad_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
     const int vb = dtype == MI_BF16 ? 8 : 4;
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
-    return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks);
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks, scratch, scratch_bytes);
 }
 
 }  // extern "C"

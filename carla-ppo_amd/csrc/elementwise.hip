@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void u8_to_unit_kernel(const unsigned char* __
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ part, int part_stride) {
     __shared__ float cs[256];
     const int ntu = (256 / N) * N;                       // active threads: stride is a multiple of N -> fixed column per thread
     const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -392,14 +392,15 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__
     if ((int)threadIdx.x < N) {
         float s = 0.f;
         for (int t = threadIdx.x; t < ntu; t += N) s += cs[t];
-        atomicAdd(&out[threadIdx.x], s);
+        if (part) part[(long long)blockIdx.x * part_stride + threadIdx.x] = s;      // per-block partial sums, added up in a fixed order by the caller's reduce
+        else atomicAdd(&out[threadIdx.x], s);
     }
 }
 
 // vectorised variant for N % VEC == 0 (VEC = 16 B of T): each thread owns a fixed group of VEC columns
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, float* __restrict__ part, int part_stride) {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ float cs[256][VEC + 1];
     const int gpr = N / VEC;                             // vector groups per row
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x
         const int g = threadIdx.x / VEC, e = threadIdx.x % VEC;
         float s = 0.f;
         for (int t = g; t < ntu; t += gpr) s += cs[t][e];
-        atomicAdd(&out[threadIdx.x], s);
+        if (part) part[(long long)blockIdx.x * part_stride + threadIdx.x] = s;
+        else atomicAdd(&out[threadIdx.x], s);
     }
 }
 
@@ -466,13 +468,14 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __r
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, long long M, int N, int rows_per_block,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ part, int part_stride) {
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(M, r0 + (long long)rows_per_block);
     for (int c = blockIdx.y * 256 + threadIdx.x; c < N; c += gridDim.y * 256) {
         float acc = 0.f;
         for (long long r = r0; r < r1; ++r) acc += Elem<T>::to_f32(x[r * N + c]);
-        atomicAdd(&out[c], acc);
+        if (part) part[(long long)blockIdx.x * part_stride + c] = acc;
+        else atomicAdd(&out[c], acc);
     }
 }
 
@@ -662,30 +665,44 @@ int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, c
 
 // out[N] += column sums of x[M,N]   (BiasAddGrad)
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out) {
+    return mi_colsum_ws(stream, dtype, x, M, N, out, nullptr, 0);
+}
+
+// scratch for the deterministic form: at most 2,048 row blocks x N columns (rounded up to 4) of fp32 partial sums
+long long mi_colsum_scratch_bytes(long long M, int N) { (void)M; return 2048ll * ((N + 3) / 4 * 4) * 4; }
+
+// out[n] += sum_m x[m, n].  With scratch (>= mi_colsum_scratch_bytes) every row block stores its column sums and one ordered pass adds them to out:
+// two runs are bitwise equal (round 4).  Without it the row blocks meet in fp32 atomics on out.
+int mi_colsum_ws(void* stream, int dtype, const void* x, long long M, int N, float* out, void* scratch, long long scratch_bytes) {
     if (M <= 0 || N <= 0) return MI_OK;
     const int vec = dtype == MI_BF16 ? 8 : 4;
+    const int pstride = (N + 3) / 4 * 4;
+    auto part_of = [&](int gx) -> float* {
+        return (gx > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)gx * pstride * 4) ? (float*)scratch : nullptr;
+    };
+    int gx; float* part;
     if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
         // <= 512 blocks (2,048 for tensors beyond 32 MB): every block ends with N atomics on the same N addresses, so block count (not bytes) sets the floor of the small ones
         const long long nblk = (long long)M * N * (dtype == MI_BF16 ? 2 : 4) > (32ll << 20) ? 2048 : 512;
         long long rows = (M + nblk - 1) / nblk;
         if (rows * N < 32768) rows = (32768 + N - 1) / N;
-        const int gx = (int)((M + rows - 1) / rows);
-        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_vec_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
-        return mi_check_launch("colsum_vec");
-    }
-    if (N <= 256) {
+        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_vec_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
+    } else if (N <= 256) {
         long long rows = (M + 1023) / 1024;
         if (rows * N < 4096) rows = (4096 + N - 1) / N;
-        const int gx = (int)((M + rows - 1) / rows);
-        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_small_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
+        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_small_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
     } else {
         long long rows = (M + 63) / 64;
         if (rows < 8) rows = 8;
-        const int gx = (int)((M + rows - 1) / rows);
+        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
         const int gy = (N + 255) / 256;
-        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_wide_kernel<TT>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out));
+        BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_wide_kernel<TT>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
     }
-    return mi_check_launch("colsum");
+    int rc = mi_check_launch("colsum");
+    if (rc == MI_OK && part) rc = mi_reduce_slabs((hipStream_t)stream, part, pstride, gx, N, out);
+    return rc;
 }
 
 int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n) {

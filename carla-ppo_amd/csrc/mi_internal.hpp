@@ -11,6 +11,7 @@ int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK /
 // deferred split reductions of the raw-staged filter-gradient kernel (conv_ops.hip; used by the VAE engine)
 extern "C" int mi_tapwgrad_defer(int on);        // returns the previous mode
 extern "C" int mi_tapwgrad_flush(void* stream);  // launches the recorded reduces on `stream`
+extern "C" int mi_tapwgrad_defer_pause(int pause);   // != 0: reduce right behind the launch although the pass defers (a layer issued on another stream); returns the previous setting
 extern "C" int mi_tapwgrad_slab_bf16(int on);    // partial-sum slabs rounded to bf16 (the engine's bf16 backward); returns the previous setting
 
 // register-weight kernel of the thin gather-form layers (rwconv.hip): 1 launched, 0 not eligible, < 0 error
@@ -23,6 +24,6 @@ int mi_rwconv_blocks(int set);                   // mi_set_tuning key 16: persis
 int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace
 
-// out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_slabs_kernel, tapwgrad_tile.hpp; fixed summation order) -- conv_ops.hip
+// out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_slabs_ordered_kernel, tapwgrad_tile.hpp; fixed summation order, no atomics) -- conv_ops.hip
 int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out);
 bool mi_narrow_enabled();                        // the narrow-layer kernels are switched on (mi_set_tuning key 4 / MI355_NARROW) -- conv_ops.hip

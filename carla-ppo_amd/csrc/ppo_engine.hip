@@ -96,7 +96,7 @@ bool fused_switch() {                                    // MI355_PPO_FUSED=0: t
 // the fused kernels serve the shapes they were built for (the reference's 500 / 300 trunk, <= 8 actions); anything else takes the per-layer path
 bool fused_enabled(const PpoEngine* e);
 
-bool fused_enabled(const PpoEngine* e) { return fused_switch() && mi_ppo_fused_shape_ok(e->d.num_actions, e->d.h2, e->kin); }
+bool fused_enabled(const PpoEngine* e) { return fused_switch() && mi_ppo_fused_shape_in_range(e->d.num_actions, e->d.h2, e->kin); }
 
 void fill_fused(const PpoEngine* e, PpoFusedParams& q, const float* states, int M) {
     const MiPpoDesc& d = e->d;
@@ -323,6 +323,14 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
     q.alpha = alpha; q.omb1 = 1.0f - beta1; q.omb2 = 1.0f - beta2; q.epsilon = epsilon;
     e->last_M = M;
     return mi_ppo_fused_step((hipStream_t)stream, q, 1);
+}
+
+// 1: this engine's shape (num_actions, hidden sizes, input width) is inside the range of the fused kernels (csrc/ppo_fused.hip) and they are switched on, i.e.
+// mi_ppo_train_step_idx / mi_ppo_logp_old will run; 0: only the per-layer path (mi_ppo_train_step / mi_ppo_forward_backward fall back to it by themselves;
+// the _idx form has no per-layer equivalent: gather on the host side).  The host mirror asks before it picks the in-kernel gather.
+int mi_ppo_fused_shape_ok(void* h) {
+    PpoEngine* e = (PpoEngine*)h;
+    return (e && fused_enabled(e)) ? 1 : 0;
 }
 
 // mi_ppo_train_step with the minibatch GATHER fused in: states / actions / returns / advantage / logp_old are the horizon-batch tables (n_rows rows;

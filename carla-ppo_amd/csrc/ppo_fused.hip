@@ -83,6 +83,16 @@ __device__ __forceinline__ long long pf_off(const PpoFusedParams& q, int net, in
 __global__ __launch_bounds__(256) void ppo_l1_kernel(const PpoFusedParams q) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lrow = lane & 31, lgrp = lane >> 5;
     const int net = blockIdx.y, m0 = blockIdx.z * 32, n0 = (blockIdx.x * 4 + wave) * 32;
+    // the gathered minibatch for the layer-1 filter gradient (rows m0 .. m0 + 31, columns dealt to the 8 half-waves of block column 0) is written BEFORE the
+    // tile-range return: with H1 < 128 the waves whose column tile lies past H1 still own their share of the columns (a hidden size of 64 left
+    // three quarters of s_gath unwritten)
+    if (q.row_idx && q.s_gath && net == 0 && blockIdx.x == 0) {
+        const int m = m0 + lrow;
+        if (m < q.M) {
+            const long long srow_g = min(max(q.row_idx[m], 0), q.n_rows - 1);      // (rows are clamped into the table: a bad index reads a wrong row, never past the buffers)
+            for (int k = wave * 2 + lgrp; k < q.din; k += 8) q.s_gath[(long long)m * q.din + k] = q.states[srow_g * q.din + k];
+        }
+    }
     if (n0 >= q.H1) return;
     const float* th = pf_theta(q, net);
     const float* W = th + pf_off(q, net, 0);
@@ -92,13 +102,9 @@ __global__ __launch_bounds__(256) void ppo_l1_kernel(const PpoFusedParams q) {
     // din reads the next row's finite values against a zero weight row; past the tensors the range check returns 0.0
     // (with a row index: the state table has n_rows rows and sample m is its row row_idx[m] -- one dependent load per lane in front of the operand loads)
     const int mrow = min(m0 + lrow, q.M - 1);
-    const int srow = q.row_idx ? q.row_idx[mrow] : mrow;
+    const int srow = q.row_idx ? min(max(q.row_idx[mrow], 0), q.n_rows - 1) : mrow;
     const __amdgpu_buffer_rsrc_t rsS = PF_RSRC(q.states, (long long)(q.row_idx ? q.n_rows : q.M) * q.din * 4), rsW = PF_RSRC(W, (long long)q.kin * q.H1 * 4);
     const unsigned arow = (unsigned)srow * (unsigned)q.din, H1u = (unsigned)q.H1;
-    if (q.row_idx && q.s_gath && net == 0 && blockIdx.x == 0) {      // the gathered minibatch for the layer-1 filter gradient: rows m0 .. m0 + 31, columns dealt to the 8 half-waves
-        const int m = m0 + lrow;
-        for (int k = wave * 2 + lgrp; k < q.din; k += 8) if (m < q.M) q.s_gath[(long long)m * q.din + k] = q.states[(long long)srow * q.din + k];
-    }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256) void ppo_head_loss_kernel(const PpoFusedParams
 #pragma unroll
     for (int i = 0; i < (PF_H2MAX + 255) / 256; ++i) { const int x = tid + 256 * i; stv[i] = x < H2 ? Wv[x] : 0.f; }
     float p_act[NA], p_adv_s = 0.f, p_ret_s = 0.f, p_lpo_s = 0.f, p_ls[NA], p_lso[NA], p_lo[NA], p_hi[NA];
-    const int mr = (q.row_idx && mok) ? q.row_idx[m] : m;     // the sample's row in the horizon-batch tables (actions / returns / advantages / cached log pi_old)
+    const int mr = (q.row_idx && mok) ? min(max(q.row_idx[m], 0), q.n_rows - 1) : m;     // the sample's row in the horizon-batch tables (actions / returns / advantages / cached log pi_old)
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const bool aok = a < A;
@@ -580,9 +586,9 @@ __global__ __launch_bounds__(256) void ppo_predict_head_kernel(const PpoFusedPar
 using namespace mi;
 
 // shapes the fused kernels are built for (checked BEFORE anything is launched; the engine falls back to the per-layer path otherwise)
-bool mi_ppo_fused_shape_ok(int A, int H2, int kin) { return A >= 1 && A <= PF_MAX_ACT && H2 <= PF_H2MAX && H2 % 4 == 0 && kin <= 96; }
+bool mi_ppo_fused_shape_in_range(int A, int H2, int kin) { return A >= 1 && A <= PF_MAX_ACT && H2 <= PF_H2MAX && H2 % 4 == 0 && kin <= 96; }
 static int pf_check_shape(const PpoFusedParams& q, const char* who) {
-    if (mi_ppo_fused_shape_ok(q.A, q.H2, q.kin)) return MI_OK;
+    if (mi_ppo_fused_shape_in_range(q.A, q.H2, q.kin)) return MI_OK;
     static thread_local char msg[160];
     snprintf(msg, sizeof(msg), "%s: shape outside the fused kernels' range (1 <= num_actions <= 8, H2 <= 320 and a multiple of 4, inputs <= 96)", who);
     return mi_fail(MI_ERR_SHAPE, msg);

@@ -31,7 +31,7 @@ struct PpoFusedParams {
 
 int mi_ppo_fused_partial_floats(int M);
 int mi_ppo_fused_trunks(hipStream_t st, const mi::PpoFusedParams& q);
-bool mi_ppo_fused_shape_ok(int A, int H2, int kin);
+bool mi_ppo_fused_shape_in_range(int A, int H2, int kin);
 int mi_ppo_fused_step(hipStream_t st, mi::PpoFusedParams& q, int fuse_adam);
 int mi_ppo_fused_predict(hipStream_t st, mi::PpoFusedParams& q, const float* noise, int greedy, float* action, float* value);
 int mi_ppo_fused_logp_old(hipStream_t st, mi::PpoFusedParams& q, float* out);

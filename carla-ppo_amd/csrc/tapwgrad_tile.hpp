@@ -45,6 +45,8 @@ struct TapWgradParams {
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     float* out;
     float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
+    float* bias_part; int bias_nh;   // optional (with slabs): the bias-gradient partial sums of position split bx, half h go to bias_part[(bx * bias_nh + h) * NE + ne] (plain
+                                     // stores, every element exactly once) and the ordered reduce adds them to dbias; NULL: fp32 atomics on dbias
     int slab_bf16;                   // the partial sums are stored ROUNDED TO BF16 (round 3; the bf16 engine's default, mi_set_tuning key 18): ~256 slabs per
                                      // element, each 2^-9 relative with independent signs, add ~1e-4 of the element's own scale to a gradient whose operands
                                      // were bf16 to begin with -- and halve the 211 MB written + 214 MB read per step that the slabs cost
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         if (ne >= p.NE) continue;
         int n = ne;
         if constexpr (MODE == TC_GATHER) n = ne - (int)p.div_n.div((uint32_t)ne) * p.N;
-        atomicAdd(&p.dbias[n], accb[q][0]);
+        if (p.bias_part) p.bias_part[((long long)bx * p.bias_nh + (SPLIT ? half : 0)) * p.NE + ne] = accb[q][0];
+        else atomicAdd(&p.dbias[n], accb[q][0]);
     }
     // ---------------- dW: register r of a lane is row (r&3) + 8(r>>2) + 4 lgrp, column lcol; the row -> kernel-tap decode is done once
     // per group of 4 registers (4 consecutive rows share it: C and N are multiples of 4) ----------------
@@ -616,7 +619,10 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
         }
         if (bias_on && lane < 32) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
             const int ne = ne0 + cls * 32 + lane;
-            if (ne < p.NE) atomicAdd(&p.dbias[ne - (int)p.div_n.div((uint32_t)ne) * p.N], accb[0]);
+            if (ne < p.NE) {
+                if (p.bias_part) p.bias_part[(long long)bx * p.bias_nh * p.NE + ne] = accb[0];
+                else atomicAdd(&p.dbias[ne - (int)p.div_n.div((uint32_t)ne) * p.N], accb[0]);
+            }
         }
         if (!cls_live) return;
         // dW tiles: same accumulator order / slab layout as tapwgrad_kernel (pair index looked up in the host's (tap, output tile) list)
@@ -648,13 +654,42 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
     if (pw == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{});
 }
 
-// dW += sum over the position-split slabs written in accumulator order by tapwgrad_kernel.  One thread per 16-byte group
-// (block column, pair, kt, row group, lane); blockIdx.y takes every gridDim.y-th slab so that small filters still fill the chip:
-// gridDim.y == 1 is a plain read-modify-write in a fixed order (deterministic), otherwise the partial sums meet in atomics.
+// dW += sum over the position-split slabs written in accumulator order by tapwgrad_kernel, in a FIXED order (round 4: the ry slab chains of an element met in
+// atomics before).  A block owns 256 / ry 16-byte groups (block column, pair, kt, row group, lane); the ry threads of a group take every ry-th slab each, meet in
+// LDS in a fixed binary tree, and one of them does the filter-index decode and the read-modify-write of dW.  ry: a power of two <= 64, chosen from the layer's
+// shape only (conv_ops.hip, reduce_ry) so that small filters still fill the chip.
 template <int MODE, int TAPS, int KT, int NTB>
-__device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int nslab, int ngroups, int bx, int by, int nby) {
-    const int gid = bx * 256 + (int)threadIdx.x;
-    if (gid >= ngroups) return;
+__device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int nslab, int ngroups, int bx, int ry, f32x4* sm) {
+    const int gpb = 256 / ry;
+    const int gl = (int)threadIdx.x & (gpb - 1), by = (int)threadIdx.x / gpb;
+    const int gid = bx * gpb + gl;
+    const bool live = gid < ngroups;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (p.slab_bf16) {
+            const bf16_t* src = (const bf16_t*)p.slabs + (long long)gid * 4;
+#pragma unroll 16
+            for (int k = by; k < nslab; k += ry) {
+                const tw_u32x2 w = __builtin_nontemporal_load((const tw_u32x2*)(src + k * p.slab_stride));
+                s[0] += __builtin_bit_cast(float, w[0] << 16); s[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                s[2] += __builtin_bit_cast(float, w[1] << 16); s[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
+            }
+        } else {
+            const float* src = p.slabs + (long long)gid * 4;
+#pragma unroll 16
+            for (int k = by; k < nslab; k += ry) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+        }
+    }
+    if (ry > 1) {                                        // (block-uniform)
+        sm[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = ry >> 1; o > 0; o >>= 1) {
+            if (by < o) sm[threadIdx.x] += sm[threadIdx.x + o * gpb];
+            __syncthreads();
+        }
+        s = sm[threadIdx.x];
+    }
+    if (!live || by != 0) return;
     const int lane = gid & 63, g4 = (gid >> 6) & 3;
     const int slot = gid >> 8;                            // (block column * npairs + pair) * KT + kt
     const int kt = slot % KT, bp = slot / KT;
@@ -663,91 +698,119 @@ __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int n
     long long base, stride;
     const bool ok = tw_dw_index<MODE, TAPS>(p, kb * 32 * KT, nb * 32 * NTB, p.pair_tap[pi], kt, p.pair_nt[pi], 8 * g4 + 4 * (lane >> 5), lane & 31, base, stride);
     if (!ok) return;
-    float ov[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nby == 1) {                                       // the read half of the read-modify-write is requested before the slab loop
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ov[t] = p.out[base + t * stride];
-    }
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (p.slab_bf16) {
-        const bf16_t* src = (const bf16_t*)p.slabs + (long long)gid * 4;
-#pragma unroll 16
-        for (int k = by; k < nslab; k += nby) {
-            const tw_u32x2 w = __builtin_nontemporal_load((const tw_u32x2*)(src + k * p.slab_stride));
-            s[0] += __builtin_bit_cast(float, w[0] << 16); s[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
-            s[2] += __builtin_bit_cast(float, w[1] << 16); s[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
-        }
-    } else {
-        const float* src = p.slabs + (long long)gid * 4;
-#pragma unroll 16
-        for (int k = by; k < nslab; k += nby) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (nby == 1) p.out[base + t * stride] = ov[t] + s[t];
-        else atomicAdd(p.out + base + t * stride, s[t]);
-    }
+    for (int t = 0; t < 4; ++t) p.out[base + t * stride] += s[t];
 }
 template <int MODE, int TAPS, int KT, int NTB>
-__global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams p, int nslab, int ngroups) {
-    reduce_tiled_body<MODE, TAPS, KT, NTB>(p, nslab, ngroups, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+__global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams p, int nslab, int ngroups, int ry) {
+    __shared__ f32x4 sm[256];
+    reduce_tiled_body<MODE, TAPS, KT, NTB>(p, nslab, ngroups, (int)blockIdx.x, ry, sm);
+}
+
+// dbias[c] += sum over nslab rows of part[k * N + c], N <= 256, one block, fixed order (the bias-gradient partial sums of the position splits)
+__device__ __forceinline__ void reduce_bias_block(const float* __restrict__ part, int nslab, int N, float* __restrict__ dbias, f32x4* smv) {
+    float* sm = (float*)smv;
+    int np2 = 1; while (np2 < N) np2 <<= 1;
+    const int kl_n = 256 / np2;
+    const int col = (int)threadIdx.x & (np2 - 1), kl = (int)threadIdx.x / np2;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < N) {
+        int k = kl;
+        for (; k + 3 * kl_n < nslab; k += 4 * kl_n) {
+            a0 += part[(long long)k * N + col]; a1 += part[(long long)(k + kl_n) * N + col];
+            a2 += part[(long long)(k + 2 * kl_n) * N + col]; a3 += part[(long long)(k + 3 * kl_n) * N + col];
+        }
+        for (; k < nslab; k += kl_n) a0 += part[(long long)k * N + col];
+    }
+    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int o = kl_n >> 1; o > 0; o >>= 1) {
+        if (kl < o) sm[threadIdx.x] += sm[threadIdx.x + o * np2];
+        __syncthreads();
+    }
+    if (kl == 0 && col < N) dbias[col] += sm[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restrict__ part, int nslab, int N, float* __restrict__ dbias) {
+    __shared__ f32x4 sm[64];
+    reduce_bias_block(part, nslab, N, dbias, sm);
 }
 
 // All deferred reductions of one backward pass in ONE launch (six layers: ~190 MB of slabs, 35-40 us at HBM speed against 130 us as six
-// latency-bound launches): block b belongs to the layer l with first[l] <= b < first[l + 1]; inside the layer, b - first[l] = bx * ry + by.
+// latency-bound launches): block b belongs to the layer l with first[l] <= b < first[l + 1]; inside the layer, b - first[l] = the block of 256 / ry groups.
+// Blocks first[n] .. first[n] + nbias - 1: one per layer whose bias-gradient partial sums wait in its scratch.
 constexpr int TW_MAX_FUSED = 8;
 struct FusedReduceParams {
     TapWgradParams q[TW_MAX_FUSED];
     int splits[TW_MAX_FUSED], ngroups[TW_MAX_FUSED], kind[TW_MAX_FUSED], ry[TW_MAX_FUSED], first[TW_MAX_FUSED + 1];
     int n;
+    const float* bpart[TW_MAX_FUSED]; float* bout[TW_MAX_FUSED]; int bnslab[TW_MAX_FUSED], bN[TW_MAX_FUSED];
+    int nbias;
 };
 __global__ __launch_bounds__(256) void reduce_fused_kernel(const FusedReduceParams f) {
+    __shared__ f32x4 sm[256];
     const int b = (int)blockIdx.x;
+    if (b >= f.first[f.n]) {                              // (block-uniform)
+        const int j = b - f.first[f.n];
+        if (j < f.nbias) reduce_bias_block(f.bpart[j], f.bnslab[j], f.bN[j], f.bout[j], sm);
+        return;
+    }
     int l = 0;
 #pragma unroll
     for (int i = 1; i < TW_MAX_FUSED; ++i) l += (i < f.n && b >= f.first[i]) ? 1 : 0;
     const int local = b - f.first[l], ry = f.ry[l];
-    const int bx = local / ry, by = local - bx * ry;
     const TapWgradParams& p = f.q[l];
-    if (f.kind[l] == 0) reduce_tiled_body<TC_CONV, 2, 4, 2>(p, f.splits[l], f.ngroups[l], bx, by, ry);
-    else if (f.kind[l] == 1) reduce_tiled_body<TC_GATHER, 2, 4, 2>(p, f.splits[l], f.ngroups[l], bx, by, ry);
-    else reduce_tiled_body<TC_GATHER, 3, 2, 4>(p, f.splits[l], f.ngroups[l], bx, by, ry);
+    if (f.kind[l] == 0) reduce_tiled_body<TC_CONV, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
+    else if (f.kind[l] == 1) reduce_tiled_body<TC_GATHER, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
+    else reduce_tiled_body<TC_GATHER, 3, 2, 4>(p, f.splits[l], f.ngroups[l], local, ry, sm);
 }
 
-// dW[i] += sum over the split slabs.  blockIdx.y takes every gridDim.y-th slab so small outputs still fill the chip;
-// with gridDim.y == 1 the result is a plain read-modify-write in a fixed order (deterministic), otherwise the gridDim.y
-// partial sums meet in a handful of atomics per element.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, long long stride, int nslab, long long n, float* __restrict__ out) {
-    const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    const int k0 = blockIdx.y, kstep = gridDim.y;
-    if (i4 + 4 <= n) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+// out[i] += sum over the split slabs, in a FIXED order whatever the launch looks like (round 4: the gridDim.y partial sums of the first form met in
+// atomics).  A block owns 256 / KL groups of four consecutive elements; the KL threads of a group take every KL-th slab each (independent 16-byte loads),
+// their partial sums meet in LDS in a fixed binary tree, and one thread does the read-modify-write of out.  Rows need not be 16-byte aligned (scalar path).
+template <int KL>
+__global__ __launch_bounds__(256) void reduce_slabs_ordered_kernel(const float* __restrict__ slabs, long long stride, int nslab, long long n, float* __restrict__ out, int vec_ok) {
+    constexpr int QPB = 256 / KL;
+    __shared__ f32x4 sm[256];
+    const int q = (int)threadIdx.x % QPB, kl = (int)threadIdx.x / QPB;
+    const long long i4 = ((long long)blockIdx.x * QPB + q) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < n) {
+        if (vec_ok && i4 + 4 <= n) {
 #pragma unroll 8
-        for (int k = k0; k < nslab; k += kstep) s += *(const f32x4*)(slabs + k * stride + i4);
-        if (kstep == 1) {
-            f32x4 o = *(f32x4*)(out + i4);
-            o += s;
-            *(f32x4*)(out + i4) = o;
+            for (int k = kl; k < nslab; k += KL) s += *(const f32x4*)(slabs + k * stride + i4);
         } else {
+            for (int k = kl; k < nslab; k += KL)
+                for (int e = 0; e < 4; ++e) if (i4 + e < n) s[e] += slabs[k * stride + i4 + e];
+        }
+    }
+    if constexpr (KL > 1) {
+        sm[threadIdx.x] = s;
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(out + i4 + e, s[e]);
+        for (int o = KL / 2; o > 0; o >>= 1) {
+            if (kl < o) sm[threadIdx.x] += sm[threadIdx.x + o * QPB];
+            __syncthreads();
         }
-    } else {
-        for (long long i = i4; i < n; ++i) {
-            float a = 0.f;
-            for (int k = k0; k < nslab; k += kstep) a += slabs[k * stride + i];
-            if (kstep == 1) out[i] += a; else atomicAdd(out + i, a);
-        }
+        s = sm[threadIdx.x];
+    }
+    if (kl == 0 && i4 < n) {
+        if (vec_ok && i4 + 4 <= n) { f32x4 o = *(f32x4*)(out + i4); o += s; *(f32x4*)(out + i4) = o; }
+        else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] += s[e];
     }
 }
 
-// host helper: pick gridDim.y so that about 1024 blocks run
-inline dim3 reduce_slabs_grid(long long n, int nslab) {
-    const unsigned gx = (unsigned)((n / 4 + 255) / 256 + 1);
-    unsigned gy = 1;
-    while (gx * gy < 512 && (int)(gy * 2) <= nslab / 4) gy *= 2;
-    return dim3(gx, gy, 1);
+// host helper: the smallest KL in {1, 4, 16, 64} that puts >= 256 blocks in flight (never more slab lanes than slabs); the choice depends on the shape
+// only, so the summation order of a given layer is the same in every run
+inline void launch_reduce_slabs_ordered(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
+    const long long quads = (n + 3) / 4;
+    const int vec_ok = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
+    int kl = 1;
+    while (kl < 64 && (quads * kl + 255) / 256 < 256 && kl * 4 <= nslab) kl *= 4;
+    const unsigned g = (unsigned)((quads * kl + 255) / 256);
+    if (kl == 1) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<1>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
+    else if (kl == 4) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<4>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
+    else if (kl == 16) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<16>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
+    else hipLaunchKernelGGL(reduce_slabs_ordered_kernel<64>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
 }
 
 }  // namespace mi

@@ -68,7 +68,10 @@ struct Workspace {
     long long heads_slab, dz_slab, mean, logvar, kl_row, partial, bpart, out2, zf32;   // fp32
     long long tail_slabs, tail_slab_bytes;   // per-block partial filter gradients of the fused decoder tail (dectail_tile.hpp)
     long long enc_slabs, enc_slab_bytes;     // per-block partial sums of the fused encoder-head backward kernel (enchead_tile.hpp)
-    long long scratch, scratch_bytes;  // split-reduction slabs of the bf16 weight-gradient kernel
+    long long scratch, scratch_bytes;  // split-reduction slabs of the filter-gradient kernels on the filter-gradient stream (SCRATCH_REGIONS rotating regions)
+    long long scratch_main, scratch_main_bytes;    // ... of the filter / bias gradients issued on the caller's stream (one region, reused in stream order)
+    long long scratch_third, scratch_third_bytes;  // ... of the latent layers' gradients on the optional third stream
+    long long scratch_side, scratch_side_bytes;    // ... of the latent layers' gradients when they run on the filter-gradient stream (outside the rotating regions: those may hold deferred slabs)
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
@@ -190,8 +193,13 @@ void make_workspace(VaeEngine& e) {
     e.partial_cap = (int)(B * 64 > B * e.nchunks ? B * 64 : B * e.nchunks);   // loss partial sums: per (frame, chunk) or per block of the fused decoder tail
     W.partial = add((long long)e.partial_cap * 4); W.bpart = add((long long)e.partial_cap * 16); W.out2 = add(256); W.zf32 = add(B * d.z_dim * 4);
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
-    W.scratch_bytes = d.dtype != MI_F32 ? SCRATCH_REGIONS * (64ll << 20) : 0;    // one region per raw-staged filter gradient of a backward pass (split storage: + the unfolded dW')
-    W.scratch = add(W.scratch_bytes > 0 ? W.scratch_bytes : 256);
+    // one region per raw-staged filter gradient of a backward pass (split storage: + the unfolded dW').  Round 4: the fp32 engine has them too -- every
+    // filter / bias gradient of every engine reduces its position splits through slabs in a fixed order (two runs of a step are bitwise equal)
+    W.scratch_bytes = SCRATCH_REGIONS * (64ll << 20);
+    W.scratch = add(W.scratch_bytes);
+    W.scratch_main_bytes = 64ll << 20; W.scratch_main = add(W.scratch_main_bytes);
+    W.scratch_third_bytes = 16ll << 20; W.scratch_third = add(W.scratch_third_bytes);
+    W.scratch_side_bytes = 16ll << 20; W.scratch_side = add(W.scratch_side_bytes);
     W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
     W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
     W.enc_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 8320 : 0;                  // up to 8 resident blocks per CU x (64 x 32 + 32) floats
@@ -514,6 +522,21 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         return ptr;
     };
     const long long scratch_sz = defer ? region : W.scratch_bytes;
+    // latent-layer filter / bias gradients (dense1, heads): slabs of their row splits in the region that belongs to the stream they are issued on
+    // (reused in stream order: each call's ordered reduce is issued right behind its kernel)
+    auto small_ws = [&](void* s_, long long* bytes) -> void* {
+        if (fork && s_ == (void*)e->side) { *bytes = W.scratch_side_bytes; return e->at(W.scratch_side); }
+        if (e->third_ok == 1 && s_ == (void*)e->third) { *bytes = W.scratch_third_bytes; return e->at(W.scratch_third); }
+        *bytes = W.scratch_main_bytes; return e->at(W.scratch_main);
+    };
+    auto bias_grad = [&](void* s_, const void* x, long long M, int N, float* out) -> int {
+        long long nb = 0; void* ws_ = small_ws(s_, &nb);
+        return mi_colsum_ws(s_, d.dtype, x, M, N, out, ws_, nb);
+    };
+    auto dense_wgrad = [&](void* s_, const void* a, const void* dy, int M, int K, int N, float* dw) -> int {
+        long long nb = 0; void* ws_ = small_ws(s_, &nb);
+        return mi_gemm_wgrad_ws(s_, d.dtype, a, dy, M, K, N, dw, ws_, nb);
+    };
     if (defer) mi_tapwgrad_defer(1);
     auto join = [&]() {
         if (defer) mi_tapwgrad_flush(sw);
@@ -554,8 +577,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         // otherwise wait ~100 us for the other one; their operands (gdec0, z, dheads, act4) stay intact until then and no event is needed for them.
         if (!late_dense) {
             release();
-            TOP(e, sw, OP_DENSE1_BIAS, mi_colsum(sw, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, sw, OP_DENSE1_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            TOP(e, sw, OP_DENSE1_BIAS, bias_grad(sw, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, sw, OP_DENSE1_WGRAD, dense_wgrad(sw, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
         }
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
         if (part == 1) join();                               // a full backward joins once, at its end: nothing below reads a filter gradient
@@ -568,8 +591,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
         if (!late_dense) {
             release();
-            TOP(e, sw, OP_HEADS_BIAS, mi_colsum(sw, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sw, OP_HEADS_WGRAD, mi_gemm_wgrad(sw, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            TOP(e, sw, OP_HEADS_BIAS, bias_grad(sw, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sw, OP_HEADS_WGRAD, dense_wgrad(sw, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
         if (use_third) {
@@ -577,10 +600,10 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             // their own stream under the encoder half instead of serialising ~70 us of small launches at the end of the caller's stream
             hipStream_t s3 = e->third;
             hipEventRecord(e->ev_lat, (hipStream_t)st); hipStreamWaitEvent(s3, e->ev_lat, 0);
-            TOP(e, s3, OP_DENSE1_BIAS, mi_colsum(s3, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, s3, OP_DENSE1_WGRAD, mi_gemm_wgrad(s3, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
-            TOP(e, s3, OP_HEADS_BIAS, mi_colsum(s3, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, s3, OP_HEADS_WGRAD, mi_gemm_wgrad(s3, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            TOP(e, s3, OP_DENSE1_BIAS, bias_grad(s3, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, s3, OP_DENSE1_WGRAD, dense_wgrad(s3, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            TOP(e, s3, OP_HEADS_BIAS, bias_grad(s3, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, s3, OP_HEADS_WGRAD, dense_wgrad(s3, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(s3, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (e->fin.pending) {
                 e->fin.pending = 0;
@@ -610,8 +633,17 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             void* sg = on_main ? st : sw;
             if (i == 0 && enc_fused) continue;               // conv1's filter / bias gradient came out of the fused encoder-head kernel below
             if (!on_main) release();
-            TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
-                                                                   (on_main && fork) ? nullptr : scratch_of(), (on_main && fork) ? 0 : scratch_sz, e->gptr(2 * i + 1)));
+            // on the caller's stream next to a live filter-gradient stream: its own scratch region, and its slab reduce is issued right behind it on THIS stream
+            // (the deferred list is flushed on the other one)
+            const bool own = on_main && fork;
+            if (own) mi_tapwgrad_defer_pause(1);
+            const int rcw = [&]() -> int {
+                TOP(e, sg, OP_CONV_WGRAD + i, mi_conv2d_nhwc_wgrad_ws(sg, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (e->last_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i], gy, 4, 4, g.c[i + 1], e->gptr(2 * i),
+                                                                       own ? e->at(W.scratch_main) : scratch_of(), own ? W.scratch_main_bytes : scratch_sz, e->gptr(2 * i + 1)));
+                return MI_OK;
+            }();
+            if (own) mi_tapwgrad_defer_pause(0);
+            CK(rcw);
             if (i == 1 && d.dtype == MI_BF16 && e->bits1_ok && e->W.enc_slab_bytes > 0 && g.c[0] == 3 && g.c[1] == 32 && g.c[2] == 64) {
                 // conv2's input gradient feeds nothing but conv1's filter gradient: both in one launch, the 99 MB tensor between them never exists (enchead_tile.hpp)
                 int nblk = 0;
@@ -628,14 +660,14 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (late_dense && dbg_skip_tail) { if (defer) mi_tapwgrad_flush(sw); e->tail_nblk = 0; e->fin.pending = 0; }
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
-            TOP(e, st, OP_DENSE1_BIAS, mi_colsum(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
             // the heads' gradients: behind a fused encoder head the caller's stream is the one that ends early (conv1's filter gradient is no longer a launch of its own)
             void* sh = (enc_fused && heads_main) ? st : sw;
-            TOP(e, sh, OP_HEADS_BIAS, mi_colsum(sh, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sh, OP_HEADS_WGRAD, mi_gemm_wgrad(sh, d.dtype, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
         if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one

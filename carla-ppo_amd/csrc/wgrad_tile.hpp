@@ -5,7 +5,9 @@
 namespace mi {
 
 // =====================================================================================================
-// wgrad: out[kc, n] += sum_{m in this block's pixel range} A(m, kc) * S(m, n)       (fp32 atomics)
+// wgrad: out[kc, n] += sum_{m in this block's pixel range} A(m, kc) * S(m, n)
+//   the pixel splits (blockIdx.z) meet either in per-split slabs that reduce_slabs_ordered_kernel sums in a FIXED order
+//   (caller scratch: two runs are bitwise equal -- round 4) or, without scratch, in fp32 atomics on out
 //   A(m,kc) = im2col view (A_CONV map) of the BIG tensor, S = the SMALL tensor [M, N] (pixel-aligned rows)
 // Tile 64(kc) x 64(n), 2x2 waves of one 32x32 accumulator, BP pixels per step staged in LDS pixel-major;
 // MFMA operands are read "transposed" (k = pixel) with scalar LDS reads.
@@ -23,6 +25,7 @@ struct WgradParams {
     float* out;
     int m_per_split;                 // multiple of BP
     int debug_skip_out;              // debug (mi_set_tuning key 2): drop the atomic accumulation to time the main loop alone
+    float* slabs; long long slab_stride;   // optional: split z stores its partial sums at slabs[z * slab_stride + kc * N + n] (plain stores, every in-range element exactly once)
 };
 
 template <typename T> struct WgradCfg;
@@ -207,7 +210,10 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
         for (int r = 0; r < 16; ++r) {
             const int kc = kc0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lgrp;
             const int n = n0 + wn * 32 + lrow;
-            if (kc < p.Kc && n < p.N) atomicAdd(&p.out[(long long)kc * p.N + n], acc[i][r]);
+            if (kc < p.Kc && n < p.N) {
+                if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                else atomicAdd(&p.out[(long long)kc * p.N + n], acc[i][r]);
+            }
         }
     }
 }

@@ -156,6 +156,10 @@ class PpoDevice:
         self.L.mi_ppo_train_step_idx(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), p(row_idx), int(states.shape[0]), int(M),
                                      float(inv_m), float(grad_scale), float(alpha), float(beta1), float(beta2), float(epsilon))
 
+    def fused_ok(self):
+        """True when the fused kernels (in-kernel minibatch gather, cached log pi_old) take this engine's shape; else only the per-layer path runs."""
+        return bool(self.L.mi_ppo_fused_shape_ok(self.handle))
+
     def logp_old(self, states, actions, M, out):
         """log pi_old(a | s) of M samples under theta_old (computed once per horizon batch; theta_old only changes in update_old())."""
         self.ensure_batch(M)

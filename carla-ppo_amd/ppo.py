@@ -166,7 +166,9 @@ class PPO():
         """One SGD step on rows `rows` (int32 device tensor) of device-resident horizon-batch tables: the minibatch gather of train.py:199-204 runs inside
         the step's kernels (single rank, fused kernels); otherwise the rows are gathered here and _step_resident takes over."""
         dev = self.dev
-        if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0" and os.environ.get("MI355_PPO_IDX", "1") != "0":
+        # (shapes outside the fused kernels' range -- e.g. more than 8 actions -- have no in-kernel gather: mi_ppo_fused_shape_ok says so up front and the rows
+        #  are gathered here instead; row values themselves are clamped into the tables by the kernels, ADVICE r03)
+        if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0" and os.environ.get("MI355_PPO_IDX", "1") != "0" and dev.fused_ok():
             alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
             dev.train_step_idx(s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
             self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))

@@ -102,9 +102,10 @@ int mi_deconv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, int B, int
 int mi_deconv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, const void* mask_bits, void* dx);
 /* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
-/* Conv2DBackpropFilter: dw += im2col(x)^T dy (fp32 atomics) */
+/* Conv2DBackpropFilter: dw += im2col(x)^T dy (position splits meet in fp32 atomics; the _ws form with scratch is the deterministic one) */
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw);
-/* same, with caller scratch for the split reduction of the bf16 kernel (no atomics, deterministic; may be NULL) and, when dbias != NULL,
+/* same, with caller scratch for the split reduction (every kernel generation and storage type: per-split partial sums added in a fixed order, no atomics,
+ * bitwise reproducible; 64 MiB covers every layer of the model at any batch size; may be NULL) and, when dbias != NULL,
  * the BiasAddGrad of the same layer (dbias[n] += sum dy) fused into the kernel where it is eligible, else run as mi_colsum */
 int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw, void* scratch, long long scratch_bytes, float* dbias);
 /* tf.layers.conv2d_transpose k x k, s2, VALID + BiasAdd (+ Relu) — vae/models.py:261-264 */
@@ -145,8 +146,12 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
 /* the finishing pass of a split-K dense layer: out[m,n] = mask(act(sum_s slabs[s][m][n] + bias[n])) -- the bias / ReLU / ReluGrad epilogue mi_gemm_bias_act
  * cannot apply to raw slabs (MlpVAE, vae/models.py:271-299: the 38400-long reductions of its first layer and of its last layer's input gradient) */
 int mi_splitk_finish(void* stream, int dtype, const float* slabs, int nsplit, int M, int N, const float* bias, int relu, const void* mask, void* out, int out_f32);
-/* dense kernel gradient dw[K,N] += a^T dy */
+/* dense kernel gradient dw[K,N] += a^T dy (MatMul's weight gradient behind tf.gradients -- vae/models.py:142, ppo.py:143-144); the row splits meet in fp32 atomics */
 int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw);
+/* same with caller scratch (>= mi_gemm_wgrad_scratch_bytes; may be NULL = the form above): every row split stores its partial sums and one pass adds them to dw
+ * in a fixed order -- two runs are bitwise equal (round 4; the parity engines use only this form) */
+long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N);
+int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes);
 
 /* ---- VAE elementwise / reduction kernels ---- */
 /* Normal(mean, exp(.5 lv)).sample + kl_divergence — vae/models.py:7-9,101-105 (eps injected; TF RNG is unseeded) */
@@ -180,8 +185,11 @@ int mi_cast_split_to_f32(void* stream, const void* src, float* dst, long long n)
 int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n);
 /* K-contiguous copies of the [K,N] kernels for the MFMA B operand: dst[off + n*K + k] = (T) src[off + k*N + n], count <= 16 tensors */
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count);
-/* BiasAddGrad */
+/* BiasAddGrad: out[n] += sum_m x[m,n] (row blocks meet in fp32 atomics) */
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out);
+/* same with caller scratch (>= mi_colsum_scratch_bytes; NULL = the form above): per-block column sums added up in a fixed order -- bitwise reproducible */
+long long mi_colsum_scratch_bytes(long long M, int N);
+int mi_colsum_ws(void* stream, int dtype, const void* x, long long M, int N, float* out, void* scratch, long long scratch_bytes);
 /* tf.nn.sigmoid(reconstructed_logits) — vae/models.py:113 */
 int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n);
 /* verify_range — vae/models.py:24-30 */
@@ -291,6 +299,10 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
 /* the same step with the minibatch gather fused in — train.py:199-204 (`states[mb_idx]`, ...): the five operands are the horizon-batch tables (n_rows rows,
  * device resident for the whole update) and row_idx [M] (int32, device) names this minibatch's rows */
 int mi_ppo_train_step_idx(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
+/* 1: this engine's shape (1 <= num_actions <= 8, h2 <= 320 and a multiple of 4, padded input width <= 96) is inside the range of the fused kernels and they are
+ * switched on, i.e. mi_ppo_train_step_idx / mi_ppo_logp_old will run; 0: only the per-layer path exists for it (mi_ppo_train_step and mi_ppo_forward_backward fall
+ * back by themselves; gather the minibatch on the host side instead of calling the _idx form).  Row indices are clamped into [0, n_rows) by the kernels. */
+int mi_ppo_fused_shape_ok(void* h);
 int mi_ppo_logp_old(void* h, void* stream, const float* states, const float* actions, int M, float* out);
 
 #ifdef __cplusplus

@@ -45,7 +45,7 @@ def check_vae(g, args):
     tgt_shape = tuple(g.attr(g.nodes["vae/target_state_placeholder"], "shape", "shape")[1:])
     z_dim = g.variable_shape("vae/mean/kernel")[1]
     if "vae/encoder/conv1/kernel" not in g.nodes:
-        raise SystemExit("this VAE graph is not the ConvVAE (MlpVAE graphs: compare through tests/test_vae_gpu.py's oracle instead)")
+        raise SystemExit("this VAE graph is not the ConvVAE (MlpVAE graphs: compare through tests/test_f_mlp_vae_gpu.py's oracle instead)")
     training = any(n["op"] == "ApplyAdam" for n in g.nodes.values())
     beta = float(g.const("vae/mul_1/x")) if "vae/mul_1/x" in g.nodes else 1.0
     print("ConvVAE graph: source %s target %s z_dim %d beta %g  (%s)" % (src_shape, tgt_shape, z_dim, beta, "training" if training else "inference"))

@@ -1,4 +1,4 @@
-"""Worker for test_data_parallel_two_ranks_on_the_gpu (tests/test_vae_gpu.py): launched by torch.distributed.run with 2 ranks that SHARE
+"""Worker for test_data_parallel_two_ranks_on_the_gpu (tests/test_d_c4_dp_gpu.py): launched by torch.distributed.run with 2 ranks that SHARE
 cuda:0 over the gloo backend (RCCL refuses two ranks on one device; gloo all-reduces device tensors through the host).  Unlike
 tests/dp_worker.py (CPU, oracle gradients) this runs the PRODUCT's whole data-parallel path: the native engine's decoder / encoder
 halves of backward, the two asynchronous bucket all-reduces on slices of the flat gradient buffer, fused Adam, the per-epoch metric
@@ -87,7 +87,7 @@ def run_ppo(model_dir):
 def main(out, backend="gloo"):
     world, rank, local = midist.init_from_env(backend)
     torch.cuda.set_device(local if backend == "nccl" else 0)     # nccl: one device per rank (RCCL over xGMI); gloo: both ranks share cuda:0
-    import test_vae_gpu as T
+    import vae_gpu_common as T
     frames, eps = dataset()
     m = build(os.path.join(out, "model_rank%d" % rank), T.trained_like_params(2))
     grads, losses, params = run(m, frames, eps)

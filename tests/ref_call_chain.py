@@ -8,7 +8,7 @@ recorded TRACE, so that the drop-in can be driven exactly the way the unchanged 
   * restated_load_vae / restated_encode_state: the same chain restated here (test infrastructure, cites the reference lines).
   * tests/golden/vae_common_calls.json (written by tests/golden/make_call_trace.py from trace_reference()) pins the restatement to the
     reference: test_host_logic.py checks golden == trace(restatement) everywhere and golden == trace(reference) where the checkout exists;
-    test_vae_gpu.py then runs the restatement against the real drop-in on the GPU and compares with the oracle.
+    test_b_c1_epoch_gpu.py then runs the restatement against the real drop-in on the GPU and compares with the oracle.
 """
 import importlib.util
 import os

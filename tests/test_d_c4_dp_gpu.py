@@ -1,0 +1,114 @@
+"""BASELINE configs[3]-shaped data parallelism on what one GPU allows: the C-ABI communicator against the real RCCL at world size 1, the whole product path with two
+ranks sharing this GPU (gloo) or one device per rank (nccl, needs two devices), and bench.py's --gpus 2 launch exactly as the driver issues it.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_oracle as vo  # noqa: E402
+from vae.models import ConvVAE, MlpVAE, bce_loss, bce_loss_v2, mse_loss  # noqa: E402,F401
+from vae_gpu_common import synth_frames, make, rel_err, trained_like_params, _dev_table, _mlp_params  # noqa: E402,F401
+
+
+def test_comm_c_abi_one_rank_world():
+    """The collective half of the C ABI against the real RCCL on this box, world size 1 (what one GPU allows): rendezvous id, communicator,
+    in-stream and side-stream all-reduce (identity at one rank), the join, broadcast, destroy.  librccl.so.1 is bound at run time."""
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    assert L.mi_comm_id_bytes() == 128
+    idb = np.zeros(128, np.uint8)
+    L.mi_comm_unique_id(idb.ctypes.data)
+    assert idb.any()
+    h = ctypes.c_void_p()
+    L.mi_comm_init(ctypes.addressof(h), 0, 1, idb.ctypes.data)
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.randn(100003, device="cuda")
+        ref = x.clone()
+        L.mi_allreduce_sum_f32(h, st, x.data_ptr(), x.numel())
+        y = x * 2                                           # work queued behind the bucket on the caller's stream
+        L.mi_allreduce_sum_f32_async(h, st, x.data_ptr(), 4096)
+        L.mi_allreduce_sum_f32_async(h, st, x.data_ptr() + 4 * 4096, x.numel() - 4096)
+        L.mi_comm_wait(h, st)
+        L.mi_comm_wait(h, st)                               # nothing pending: no-op
+        L.mi_broadcast(h, st, x.data_ptr(), x.numel() * 4, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref) and torch.equal(y, ref * 2)
+        with pytest.raises(milib.MiError):
+            L.mi_broadcast(h, st, x.data_ptr(), 16, 3)      # root outside the communicator
+    finally:
+        L.mi_comm_destroy(h)
+
+
+def _run_two_ranks(tmp_path, backend, port):
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dp")
+    os.makedirs(out)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out, backend], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(os.path.join(out, "rank0.npz")), np.load(os.path.join(out, "rank1.npz"))
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_data_parallel_two_ranks_on_the_gpu(tmp_path, backend):
+    """The product's data-parallel path end to end with world_size 2 (tests/dp_gpu_worker.py): the all-reduced gradients of a global minibatch
+    equal the single-process gradients of the same minibatch, the epoch metrics agree, both ranks end with identical parameters, and those
+    equal the single-process result up to Adam's sensitivity where |g| ~ 1e-8.
+    gloo: two ranks share this GPU (RCCL refuses two ranks on one device; gloo reduces device tensors through the host).
+    nccl: one device per rank, gradients summed by the library's own communicator (mi_comm, RCCL through the C ABI); needs two devices."""
+    import dp_gpu_worker as W
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL run needs two devices; this box has %d" % torch.cuda.device_count())
+    r0, r1 = _run_two_ranks(tmp_path, backend, "29541" if backend == "gloo" else "29543")
+    assert int(r0["world"]) == 2
+    if backend == "nccl":
+        assert str(r0["comm"]).startswith("mi_comm"), str(r0["comm"])
+    frames, eps = W.dataset()
+    m = W.build(str(tmp_path / "single"), trained_like_params(2))
+    grads, losses, params = W.run(m, frames, eps)
+    for k, g in grads.items():
+        key = "g|" + k.replace("/", "|")
+        assert np.array_equal(r0[key], r1[key]), k                                   # the same reduced buffer on both ranks
+        assert rel_err(r0[key], g) < 2e-5, (k, rel_err(r0[key], g))
+    assert np.allclose(r0["losses"], losses, rtol=1e-5) and np.array_equal(r0["losses"], r1["losses"])
+    for k, v in params.items():
+        key = "p|" + k.replace("/", "|")
+        assert np.array_equal(r0[key], r1[key]), k                                   # replicas stay bit-identical
+        assert rel_err(r0[key], v) < 2e-2, (k, rel_err(r0[key], v))
+    # PPO.train under data parallelism (each rank passes its 16 of 32 rows): the global loss scalars and the replicas against one process on all 32
+    pl, pp = W.run_ppo(str(tmp_path / "ppo_single"))
+    assert np.array_equal(r0["ppo_params"], r1["ppo_params"]) and np.array_equal(r0["ppo_losses"], r1["ppo_losses"])
+    assert np.allclose(r0["ppo_losses"], pl, rtol=2e-4, atol=1e-6), (r0["ppo_losses"], pl)
+    assert rel_err(r0["ppo_params"], pp) < 1e-4, rel_err(r0["ppo_params"], pp)
+
+
+def test_bench_data_parallel_path_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, two ranks), with the two ranks sharing this GPU over gloo
+    (RCCL refuses two ranks on one device): the weak-scaling bookkeeping, the per-rank gather, the exposed all-reduce measurement and the
+    parameter re-broadcast run end to end and the one JSON line has the contract's fields."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", MI355_BENCH_BACKEND="gloo", MI355_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "64", "--pool", "256"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] == pytest.approx(128 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+    dp = d["data_parallel"]
+    assert len(dp["ms_per_step_by_rank"]) == 2 and dp["gradient_bytes_per_step"] > 0 and "transport" in dp
+    assert d["roofline"] is not None and d["cpu_baseline"] is None

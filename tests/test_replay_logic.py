@@ -1,7 +1,7 @@
 """Host logic of replay.replay_update (BASELINE configs[4]) on CPU: the orchestration -- row sharding, state assembly, value pass, per-row GAE,
 flattening, legacy-numpy minibatch schedule with a partial last minibatch, loss records -- is run with STAND-INS for the two device
 engines and for utils.compute_gae_batched that compute with the oracle, and compared with the reference trainer's own sequence
-(train.py:171-207) written out from the oracle's pieces.  The device arithmetic itself is covered by tests/test_zz_replay_gpu.py."""
+(train.py:171-207) written out from the oracle's pieces.  The device arithmetic itself is covered by tests/test_e_c5_replay_gpu.py."""
 import sys
 import types
 
