@@ -141,8 +141,8 @@ def cpu_baseline(batch, seed=0, warm=3, timed=10):
     u8, eps = cpu_inputs(batch)
     frames = u8.astype(np.float32) / 255.0
     params = vo.init_vae_params(seed)
-    (recon, kl, _), _, fw = vo.vae_loss_and_grads(params, frames, frames, eps)           # step-0 losses / posterior means for the parity object
-    ref = {"params": params, "recon": recon, "kl": kl, "mean": fw["mean"].numpy()}
+    (recon, kl, _), g32, fw = vo.vae_loss_and_grads(params, frames, frames, eps)         # step-0 losses / posterior means / gradients for the parity object
+    ref = {"params": params, "recon": recon, "kl": kl, "mean": fw["mean"].numpy(), "grads_fp32": g32}
     o = vo.OracleVAE(params={k: v.copy() for k, v in params.items()})
     for _ in range(warm):
         o.train_step(frames, frames, eps)
@@ -177,23 +177,57 @@ def cpu_baseline(batch, seed=0, warm=3, timed=10):
     return out, ref
 
 
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
 def parity_object(tmp, ref, batch):
-    """The HIP engines against the oracle on the cpu_baseline's inputs, measured in this run (forward losses + encode of one batch-512 pass)."""
+    """The HIP engines against the oracle on the cpu_baseline's inputs, measured in this run: forward losses + encode of one batch-512 pass, and (round 4,
+    VERDICT r03 item 2) the GRADIENTS and the TF-Adam update of that step under the criteria of tests/test_a_c2_b512_gpu.py -- `grad_worst` is the worst
+    per-tensor ratio measured / allowed (<= 1 passes), `adam_off_fraction` the largest per-tensor fraction of weights whose first Adam update differs from the
+    oracle's by more than `adam_lim_of_lr` x lr."""
+    from oracle import vae_oracle as vo
     from vae.models import ConvVAE
     u8, eps = cpu_inputs(batch)
     frames = u8.astype(np.float32) / 255.0
+    params = ref["params"]
     out = {"inputs": "batch %d, seeds 1234 / 4321 / 0 (SURVEY 8d), oracle = torch-CPU fp32 port of the reference graph" % batch}
+    g32 = ref["grads_fp32"]
+    _, g64, _ = vo.vae_loss_and_grads(params, frames, frames, eps, beta=1.0, dtype=torch.float64)          # exact gradients (float64 run of the same graph)
+    _, gemu, _ = vo.vae_loss_and_grads(params, frames, frames, eps, beta=1.0, storage="bf16")              # the oracle's bf16-STORAGE emulation (same rounding points as the bf16 engine)
+    e_o32 = {k: _rel(g32[k], g64[k]) for k in g32}                                                         # the fp32 oracle's own distance from exact
     for prec in ("bf16", "bf16x3", "fp32"):
         m = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=os.path.join(tmp, "parity_" + prec), precision=prec, seed=0)
-        m.set_weights(ref["params"])
+        m.set_weights(params)
         m.init_session(init_logging=False)
         src = m._frames(frames, 38400, "src")
         e = m._eps(batch, eps)
-        m.dev.forward(src, src, None, batch, 1.0 / batch, e, 1, 0)
-        got = m.dev.losses.cpu().numpy()
-        mean = m.dev._view(1, batch * 64).cpu().numpy().reshape(batch, 64)
+        m.dev.forward(src, src, None, batch, 1.0 / batch, e, 1, 1)
+        got = m.dev.losses.cpu().numpy().copy()
+        mean = m.dev._view(1, batch * 64).cpu().numpy().reshape(batch, 64).copy()
+        m.dev.backward(src, None, e, 1.0 / batch, 0)
+        g = m.dev.export_grads()
+        if prec == "bf16":        # as close to the exact-fp32 gradients as the emulation is: e_dev <= 1.25 e_emul + 2e-3 of the tensor max
+            ratios = {k: _rel(g[k], g32[k]) / (1.25 * _rel(gemu[k], g32[k]) + 2e-3) for k in g32}
+            crit, want_g, lim, frac_lim = "e_dev / (1.25 e_emul + 2e-3), distances to the exact-fp32 gradient in units of the tensor max", gemu, 0.5, 0.05
+        else:                     # distance to the float64 gradient: <= max(floor, factor x the fp32 oracle's own distance)
+            floor, factor = (2e-4, 2.0) if prec == "fp32" else (1e-3, 4.0)
+            ratios = {k: _rel(g[k], g64[k]) / max(floor, factor * e_o32[k]) for k in g32}
+            crit, want_g = "e_dev / max(%.0e, %.0f x the fp32 oracle's own distance), distances to the float64 gradient in units of the tensor max" % (floor, factor), g32
+            lim, frac_lim = (0.02, 5e-3) if prec == "fp32" else (0.05, 2e-2)
+        adam = vo.AdamTF({k: v.shape for k, v in params.items()})
+        want = {k: v.copy() for k, v in params.items()}
+        adam.step(want, want_g, 1e-4)
+        m._adam_step()
+        got_p = m.dev.export_params()
+        off = {k: float(np.mean(np.abs((got_p[k] - params[k]) - (want[k] - params[k])) > lim * 1e-4)) for k in want}
+        worst_k = max(ratios, key=ratios.get)
         out[prec] = {"recon_loss_rel": float(abs(got[0] / ref["recon"] - 1)), "kl_loss_rel": float(abs(got[1] / ref["kl"] - 1)),
-                     "encode_rel_of_max": float(np.abs(mean - ref["mean"]).max() / np.abs(ref["mean"]).max())}
+                     "encode_rel_of_max": float(np.abs(mean - ref["mean"]).max() / np.abs(ref["mean"]).max()),
+                     "grad_worst": float(ratios[worst_k]), "grad_worst_tensor": worst_k, "grad_criterion": crit,
+                     "grad_rel_of_max_vs_fp32_oracle": float(max(_rel(g[k], g32[k]) for k in g32)),
+                     "adam_off_fraction": float(max(off.values())), "adam_off_fraction_limit": frac_lim, "adam_lim_of_lr": lim}
         m.dev.close()
     out["note"] = ("fp32 = exact-fp32 MFMA engine (the drop-in's default; north_star's 1e-4); bf16x3 = split storage (every element two bf16 halves hi + lo, "
                    "products on the bf16 MFMA pipe as hi/lo partial products, fp32 accumulate): the fast mode that meets the 1e-4; bf16 = the benchmarked throughput mode (bf16 storage, fp32 "
@@ -331,14 +365,26 @@ def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
     n = rows * T
     res = {"config": "synthetic replay (BASELINE configs[4] on 1 GPU): %d trajectories x %d steps, bf16 VAE encode of %d uint8 frames, values, GAE + per-row "
                      "normalisation, PPO SGD %d epochs x minibatch %d (fp32)" % (rows, T, rows * (T + 1), epochs, batch),
-           "seconds": dt, "samples_per_s": n / dt, "sgd_steps": len(out["losses"]), "includes": "host->device upload of the uint8 frames (PCIe)",
-           "last_loss": out["losses"][-1]["loss"] if out["losses"] else None}
-    for k, v in stages.items():
-        res[k + "_s"] = v
-    if "encode" in stages:
-        res["encode_frames_per_s"] = rows * (T + 1) / stages["encode"]
-    if "sgd" in stages:
-        res["ppo_sgd_samples_per_s"] = n * epochs / stages["sgd"]
+           "sgd_steps": len(out["losses"]), "last_loss": out["losses"][-1]["loss"] if out["losses"] else None}
+    # the same update with the frame table already resident in HBM (uploaded outside the timed region: the bench contract's form) ...
+    table = torch.from_numpy(frames.reshape(rows * (T + 1), -1)).to("cuda").view(rows, T + 1, 80, 160, 3)
+    torch.cuda.synchronize()
+    stages_r = {}
+    t0 = time.perf_counter()
+    out_r = replay.replay_update(vae, ppo, table, meas, actions, rewards, dones, 0.99, 0.95, epochs, batch, stage_times=stages_r)
+    torch.cuda.synchronize()
+    dt_r = time.perf_counter() - t0
+    res["resident"] = {"seconds": dt_r, "samples_per_s": n / dt_r, "frames": "uint8 table resident in HBM before the timed region (%.2f GB)" % (table.numel() / 1e9),
+                       "encode_frames_per_s": rows * (T + 1) / stages_r["encode"] if "encode" in stages_r else None}
+    res["resident"].update({k + "_s": v for k, v in stages_r.items()})
+    # ... and handed over as a host array (what a caller that holds the recording in host memory pays: a PCIe figure)
+    res["from_host"] = {"seconds": dt, "samples_per_s": n / dt, "includes": "host->device upload of %.2f GB of uint8 frames over PCIe inside the encode stage" % (frames.nbytes / 1e9),
+                        "encode_frames_per_s": rows * (T + 1) / stages["encode"] if "encode" in stages else None}
+    res["from_host"].update({k + "_s": v for k, v in stages.items()})
+    res["seconds"], res["samples_per_s"] = dt_r, n / dt_r
+    if "sgd" in stages_r:
+        res["ppo_sgd_samples_per_s"] = n * epochs / stages_r["sgd"]
+    del out_r
     return res
 
 

@@ -19,13 +19,13 @@ int launch_gemm_bn(hipStream_t st, const GemmParams& p, int M_for_grid, int gz) 
     if (gx <= 0) return MI_OK;
     if (p.N <= 32) {
         dim3 g(gx, 1, gz);
-        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 32>), g, dim3(GEMM_NT), 0, st, p);
+        MI_LAUNCH((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 32>), g, dim3(GEMM_NT), 0, st, p);
     } else if (p.N <= 64) {
         dim3 g(gx, 1, gz);
-        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 64>), g, dim3(GEMM_NT), 0, st, p);
+        MI_LAUNCH((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 64>), g, dim3(GEMM_NT), 0, st, p);
     } else {
         dim3 g(gx, (p.N + 127) / 128, gz);
-        hipLaunchKernelGGL((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 128>), g, dim3(GEMM_NT), 0, st, p);
+        MI_LAUNCH((gemm_kernel<T, TIn, AMODE, BMODE, VA, AALIGN, 128>), g, dim3(GEMM_NT), 0, st, p);
     }
     return mi_check_launch("gemm_kernel");
 }
@@ -67,9 +67,9 @@ template <typename T, int AMODE, int BMODE, bool UTAP>
 void launch_gemm2_128x64(hipStream_t st, dim3 g, const Gemm2Params& p) {
     const int nk = (p.K * (int)sizeof(T) + 127) / 128;    // (upper bound for the gather form: its K depends on the parity class)
     const int ns = nk >= 6 ? g_gemm2_stages : 2;           // a deeper ring needs steps to fill
-    if (ns >= 4) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 4>), g, dim3(GEMM_NT), 0, st, p);
-    else if (ns == 3) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 2>), g, dim3(GEMM_NT), 0, st, p);
+    if (ns >= 4) MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 4>), g, dim3(GEMM_NT), 0, st, p);
+    else if (ns == 3) MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
+    else MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 128, 64, UTAP, 2>), g, dim3(GEMM_NT), 0, st, p);
 }
 
 template <typename T, int AMODE, int BMODE, bool UTAP>
@@ -77,7 +77,7 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
     if (M_for_grid <= 0) return MI_OK;
     if (p.N <= 32) {
         dim3 g((M_for_grid + 255) / 256, 1, gz);
-        hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 256, 32, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+        MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 256, 32, UTAP>), g, dim3(GEMM_NT), 0, st, p);
     } else if (p.N <= 64) {
         dim3 g((M_for_grid + 127) / 128, 1, gz);
         launch_gemm2_128x64<T, AMODE, BMODE, UTAP>(st, g, p);
@@ -86,15 +86,15 @@ int launch_gemm2_tiles(hipStream_t st, const Gemm2Params& p, int M_for_grid, int
             // small grids (conv4 forward / deconv1 input gradient at batch 512: 96 x 4 tiles of 128 x 64 = 1.5 blocks per CU, each a serial chain of
             // 32 latency-bound k-steps): 64 x 64 tiles double the blocks in flight (32 KB of LDS each: four resident per CU cover each other's waits)
             dim3 g((M_for_grid + 63) / 64, (p.N + 63) / 64, gz);
-            hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 64, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+            MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 64, 64, UTAP>), g, dim3(GEMM_NT), 0, st, p);
             return mi_check_launch("gemm2_kernel");
         }
         const int gx = (M_for_grid + 127) / 128;
         if (g_gemm2_tile == 3 || (long long)gx * ((p.N + 127) / 128) * gz >= 384) {
             dim3 g(gx, (p.N + 127) / 128, gz);
             const int nk = (p.K * (int)sizeof(T) + 127) / 128;
-            if (g_gemm2_tile == 3 && g_gemm2_stages >= 3 && nk >= 6) hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
-            else hipLaunchKernelGGL((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
+            if (g_gemm2_tile == 3 && g_gemm2_stages >= 3 && nk >= 6) MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP, 3>), g, dim3(GEMM_NT), 0, st, p);
+            else MI_LAUNCH((gemm2_kernel<T, AMODE, BMODE, 128, 128, UTAP>), g, dim3(GEMM_NT), 0, st, p);
         } else {                                          // few tiles: narrower blocks fill the 256 CUs
             dim3 g(gx, (p.N + 63) / 64, gz);
             launch_gemm2_128x64<T, AMODE, BMODE, UTAP>(st, g, p);
@@ -130,10 +130,10 @@ int launch_tapconv_v(hipStream_t st, const TapParams& q) {
     const int gx = (q.MP + BMT - 1) / BMT;
     if (q.NE >= 128) {
         dim3 g(gx, (q.NE + 127) / 128, 1);
-        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
+        MI_LAUNCH((tapconv_kernel<T, MODE, 128, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
     } else {
         dim3 g(gx, (q.NE + 63) / 64, 1);
-        hipLaunchKernelGGL((tapconv_kernel<T, MODE, 64, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
+        MI_LAUNCH((tapconv_kernel<T, MODE, 64, TAPS, BMT, MAXHALO>), g, dim3(BMT * 2), 0, st, q);
     }
     return mi_check_launch("tapconv_kernel");
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void fold_split_kernel(const PendingFold f) {
 }
 static int launch_fold(hipStream_t st, const PendingFold& f) {
     const long long n = (long long)f.T * f.R * f.Q + (f.dbias ? f.NB : 0);
-    hipLaunchKernelGGL(fold_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f);
+    MI_LAUNCH(fold_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f);
     return mi_check_launch("fold_split_kernel");
 }
 static thread_local PendingReduce g_pending[16];
@@ -239,10 +239,10 @@ static unsigned reduce_blocks(const PendingReduce& r, unsigned ry) { const unsig
 static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
     const unsigned ry = reduce_ry(r);
     const dim3 rg(reduce_blocks(r, ry), 1, 1);
-    if (r.kind == 0) hipLaunchKernelGGL((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
-    else if (r.kind == 1) hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
-    else hipLaunchKernelGGL((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
-    if (r.bpart) hipLaunchKernelGGL(reduce_bias_kernel, dim3(1), dim3(256), 0, st, r.bpart, r.bnslab, r.bN, r.bout);
+    if (r.kind == 0) MI_LAUNCH((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    else if (r.kind == 1) MI_LAUNCH((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    else MI_LAUNCH((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
+    if (r.bpart) MI_LAUNCH(reduce_bias_kernel, dim3(1), dim3(256), 0, st, r.bpart, r.bnslab, r.bN, r.bout);
 }
 extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode drops whatever an aborted pass may have left in the list
     const int prev = g_defer_reduces;
@@ -283,7 +283,7 @@ static int tapwgrad_flush_reduces(void* stream) {
         if (r.bpart) { f.bpart[f.nbias] = r.bpart; f.bout[f.nbias] = r.bout; f.bnslab[f.nbias] = r.bnslab; f.bN[f.nbias] = r.bN; ++f.nbias; }
     }
     for (int i = n; i < TW_MAX_FUSED; ++i) f.first[i + 1] = f.first[n];
-    hipLaunchKernelGGL(reduce_fused_kernel, dim3((unsigned)(f.first[n] + f.nbias)), dim3(256), 0, (hipStream_t)stream, f);
+    MI_LAUNCH(reduce_fused_kernel, dim3((unsigned)(f.first[n] + f.nbias)), dim3(256), 0, (hipStream_t)stream, f);
     return mi_check_launch("reduce_fused_kernel");
 }
 
@@ -383,17 +383,17 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
     if (mode == TC_CONV) {
-        if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
-        else hipLaunchKernelGGL((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+        if (split) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        else MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     } else if (taps == 2) {
-        if (split) hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
-        else hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
+        if (split) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     }
     else {
         if (q.npairs > 32) return 0;
         // k = 5 with caller scratch: a wave per (parity class, tap row), the shifted slot fragments formed in registers (mi_set_tuning key 14 = 0: the pair layout)
-        if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) hipLaunchKernelGGL(tapwgrad_cw_kernel, g, dim3(TWC_NT), 0, st, q);
-        else hipLaunchKernelGGL((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
+        if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) MI_LAUNCH(tapwgrad_cw_kernel, g, dim3(TWC_NT), 0, st, q);
+        else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
     int rc = mi_check_launch("tapwgrad_kernel");
     if (rc == MI_OK && q.slabs) {
@@ -441,10 +441,10 @@ static bool narrow_lean_enabled() {                       // MI355_NARROW_LEAN=0
 template <typename T, int TAPS, int CPR>
 int launch_gather_narrow(hipStream_t st, const TapParams& q) {
     dim3 g((q.MP + GN_BMT - 1) / GN_BMT);
-    if (q.N == 3 && sizeof(T) == 2 && q.labels && q.loss_kind == 0 && narrow_lean_enabled()) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3, true>), g, dim3(GN_NT), 0, st, q);
-    else if (q.N == 3) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 3>), g, dim3(GN_NT), 0, st, q);
-    else if (q.N == 1) hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 1>), g, dim3(GN_NT), 0, st, q);
-    else hipLaunchKernelGGL((gather_narrow_kernel<T, TAPS, CPR, 0>), g, dim3(GN_NT), 0, st, q);
+    if (q.N == 3 && sizeof(T) == 2 && q.labels && q.loss_kind == 0 && narrow_lean_enabled()) MI_LAUNCH((gather_narrow_kernel<T, TAPS, CPR, 3, true>), g, dim3(GN_NT), 0, st, q);
+    else if (q.N == 3) MI_LAUNCH((gather_narrow_kernel<T, TAPS, CPR, 3>), g, dim3(GN_NT), 0, st, q);
+    else if (q.N == 1) MI_LAUNCH((gather_narrow_kernel<T, TAPS, CPR, 1>), g, dim3(GN_NT), 0, st, q);
+    else MI_LAUNCH((gather_narrow_kernel<T, TAPS, CPR, 0>), g, dim3(GN_NT), 0, st, q);
     return mi_check_launch("gather_narrow_kernel");
 }
 
@@ -532,13 +532,13 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     const bool g3 = KW * q.Cs == 12;                     // the 4 x 4 x 3-channel layers: fixed-shape loop body (one basic block)
 #define NW_LAUNCH(TS_, NWV_) do { \
         const dim3 g((unsigned)((nwave + NWV_ - 1) / NWV_)), t(NWV_ * 64); \
-        if (g3 && q.dbias) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 1, NWV_>), g, t, 0, st, q); \
-        else if (g3) hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 3, 0, NWV_>), g, t, 0, st, q); \
-        else hipLaunchKernelGGL((narrow_wgrad_kernel<TS_, 0, -1, NWV_>), g, t, 0, st, q); } while (0)
+        if (g3 && q.dbias) MI_LAUNCH((narrow_wgrad_kernel<TS_, 3, 1, NWV_>), g, t, 0, st, q); \
+        else if (g3) MI_LAUNCH((narrow_wgrad_kernel<TS_, 3, 0, NWV_>), g, t, 0, st, q); \
+        else MI_LAUNCH((narrow_wgrad_kernel<TS_, 0, -1, NWV_>), g, t, 0, st, q); } while (0)
     if (narrow_f32 == 2 && g3 && q.dbias && g_nw_depth == 6) {
-        hipLaunchKernelGGL((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 6>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
+        MI_LAUNCH((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 6>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
     } else if (narrow_f32 == 2 && g3 && q.dbias && g_nw_depth == 5) {
-        hipLaunchKernelGGL((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 5>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
+        MI_LAUNCH((narrow_wgrad_kernel<unsigned char, 3, 1, 12, 5>), dim3((unsigned)((nwave + 11) / 12)), dim3(768), 0, st, q);
     } else if (narrow_f32 == 2) NW_LAUNCH(unsigned char, 12);
     else if (narrow_f32) { if (g_nw_waves >= 12) NW_LAUNCH(float, 12); else if (g_nw_waves >= 8) NW_LAUNCH(float, 8); else NW_LAUNCH(float, 4); }
     else { if (g_nw_waves >= 12) NW_LAUNCH(bf16_t, 12); else if (g_nw_waves >= 8) NW_LAUNCH(bf16_t, 8); else NW_LAUNCH(bf16_t, 4); }
@@ -594,19 +594,19 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
             }
             return dim3((unsigned)(tiles4 < resident[si][mi] ? tiles4 : resident[si][mi]));
         };
-#define NC48(TS, SI) do { if (lean == 1) hipLaunchKernelGGL((narrow_conv48_kernel<TS, 0>), grid_of((const void*)narrow_conv48_kernel<TS, 0>, SI, 0), dim3(256), 0, st, q); \
-                          else hipLaunchKernelGGL((narrow_conv48_kernel<TS, 1>), grid_of((const void*)narrow_conv48_kernel<TS, 1>, SI, 1), dim3(256), 0, st, q); } while (0)
+#define NC48(TS, SI) do { if (lean == 1) MI_LAUNCH((narrow_conv48_kernel<TS, 0>), grid_of((const void*)narrow_conv48_kernel<TS, 0>, SI, 0), dim3(256), 0, st, q); \
+                          else MI_LAUNCH((narrow_conv48_kernel<TS, 1>), grid_of((const void*)narrow_conv48_kernel<TS, 1>, SI, 1), dim3(256), 0, st, q); } while (0)
         if (src_f32 == 2) NC48(unsigned char, 0); else if (src_f32) NC48(float, 1); else NC48(bf16_t, 2);
 #undef NC48
         const int rc = mi_check_launch("narrow_conv48_kernel");
         return rc == MI_OK ? 1 : rc;
     }
-    if (dtype == MI_F32) hipLaunchKernelGGL((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
-    else if (dtype == MI_BF16X3 && src_f32 == 1) hipLaunchKernelGGL((narrow_conv_kernel<split_t, float>), g, dim3(256), 0, st, q);
-    else if (dtype == MI_BF16X3) hipLaunchKernelGGL((narrow_conv_kernel<split_t, split_t>), g, dim3(256), 0, st, q);
-    else if (src_f32 == 2) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
-    else if (src_f32) hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
-    else hipLaunchKernelGGL((narrow_conv_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, q);
+    if (dtype == MI_F32) MI_LAUNCH((narrow_conv_kernel<float, float>), g, dim3(256), 0, st, q);
+    else if (dtype == MI_BF16X3 && src_f32 == 1) MI_LAUNCH((narrow_conv_kernel<split_t, float>), g, dim3(256), 0, st, q);
+    else if (dtype == MI_BF16X3) MI_LAUNCH((narrow_conv_kernel<split_t, split_t>), g, dim3(256), 0, st, q);
+    else if (src_f32 == 2) MI_LAUNCH((narrow_conv_kernel<bf16_t, unsigned char>), g, dim3(256), 0, st, q);
+    else if (src_f32) MI_LAUNCH((narrow_conv_kernel<bf16_t, float>), g, dim3(256), 0, st, q);
+    else MI_LAUNCH((narrow_conv_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, q);
     const int rc = mi_check_launch("narrow_conv_kernel");
     return rc == MI_OK ? 1 : rc;
 }
@@ -770,8 +770,8 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
 #define WG_LAUNCH(T_, TIn_, VA_, AL_) do { \
-        if (wide) hipLaunchKernelGGL((wgrad_kernel<T_, TIn_, VA_, AL_, 128>), g, dim3(GEMM_NT), 0, st, p); \
-        else hipLaunchKernelGGL((wgrad_kernel<T_, TIn_, VA_, AL_, 64>), g, dim3(GEMM_NT), 0, st, p); } while (0)
+        if (wide) MI_LAUNCH((wgrad_kernel<T_, TIn_, VA_, AL_, 128>), g, dim3(GEMM_NT), 0, st, p); \
+        else MI_LAUNCH((wgrad_kernel<T_, TIn_, VA_, AL_, 64>), g, dim3(GEMM_NT), 0, st, p); } while (0)
     if (dtype == MI_F32) {
         if (!p.merged && p.C % 4 == 0 && a16) WG_LAUNCH(float, float, 4, 16);
         else if (mergedok) WG_LAUNCH(float, float, 4, 8);
@@ -1051,8 +1051,8 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     if (nblocks >= 16) nblocks &= ~7;                       // whole rounds of the eight XCDs (the kernel's tile order)
     if (nblocks > partial_capacity || scratch_bytes < (long long)nblocks * DT_SLAB * 4) return MI_OK;
     q.slabs = (float*)scratch;
-    if (fast) hipLaunchKernelGGL(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    if (fast) MI_LAUNCH(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    else MI_LAUNCH(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     int rc = mi_check_launch("dectail_kernel");
     if (rc != MI_OK) return rc;
     if (reduce_now) rc = mi_deconv2d_tail_reduce(stream, scratch, nblocks, dw);
@@ -1064,7 +1064,7 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
 // behind that launch and in front of the optimiser step (the VAE engine runs it where its stream would otherwise wait for the other one)
 int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw) {
     if (!scratch || !dw || n_partial < 1) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_reduce: missing buffers");
-    hipLaunchKernelGGL(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
+    MI_LAUNCH(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
     return mi_check_launch("dectail_reduce_kernel");
 }
 
@@ -1127,7 +1127,7 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
     if (dtype == MI_F32 && w_layout == 0 && nsplit <= 1 && !mask && M <= 256 && K % 4 == 0 && gemm2_enabled() &&
         ((((uintptr_t)a) | ((uintptr_t)out)) & 15) == 0) {                 // small-M fp32 dense layer (PPO): K split across the waves of a block
         DenseSmallParams q = {(const float*)a, (const float*)w, bias, (float*)out, M, N, K, relu};
-        hipLaunchKernelGGL(dense_smallm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, q);
+        MI_LAUNCH(dense_smallm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, q);
         return mi_check_launch("dense_smallm_kernel");
     }
     // long reduction into a narrow output, K-contiguous weights, raw split-K slabs wanted (the latent-side layers): tallk_tile.hpp
@@ -1137,9 +1137,9 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
         if (nsplit % kp == 0) {
             TallKParams q = {a, w, (float*)out, M, N, K, K / nsplit, (unsigned)((long long)M * K * 2), (unsigned)((long long)N * K * 2)};
             const dim3 g((M + 31) / 32, nsplit / kp);
-            if (nt == 4) hipLaunchKernelGGL(tallk_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, q);
-            else if (nt == 2) hipLaunchKernelGGL(tallk_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL(tallk_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, q);
+            if (nt == 4) MI_LAUNCH(tallk_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, q);
+            else if (nt == 2) MI_LAUNCH(tallk_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, q);
+            else MI_LAUNCH(tallk_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, q);
             return mi_check_launch("tallk_kernel");
         }
     }

@@ -86,11 +86,11 @@ extern "C" int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* fra
     if (scratch_bytes < (long long)nblocks * EH_SLAB * 4) return MI_OK;
     q.slabs = (float*)scratch;
     hipStream_t st = (hipStream_t)stream;
-    if (frames_fmt == 2) hipLaunchKernelGGL(enchead_bwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, st, q);
-    else hipLaunchKernelGGL(enchead_bwd_kernel<float>, dim3(nblocks), dim3(256), 0, st, q);
+    if (frames_fmt == 2) MI_LAUNCH(enchead_bwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, st, q);
+    else MI_LAUNCH(enchead_bwd_kernel<float>, dim3(nblocks), dim3(256), 0, st, q);
     int rc = mi_check_launch("enchead_bwd_kernel");
     if (rc != MI_OK) return rc;
-    hipLaunchKernelGGL(enchead_reduce_kernel, dim3(49), dim3(1024), 0, st, (const float*)q.slabs, nblocks, dw1, db1);
+    MI_LAUNCH(enchead_reduce_kernel, dim3(49), dim3(1024), 0, st, (const float*)q.slabs, nblocks, dw1, db1);
     rc = mi_check_launch("enchead_reduce_kernel");
     if (rc == MI_OK) *n_blocks = nblocks;
     return rc;

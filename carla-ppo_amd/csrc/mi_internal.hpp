@@ -1,9 +1,20 @@
 // mi_internal.hpp — error plumbing shared by the launchers (not part of the public C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 enum { MI_F32 = 0, MI_BF16 = 1, MI_BF16X3 = 2 };   // MI_BF16X3: split storage (hi | lo bf16 halves per 4-byte element), common.hpp
 enum { MI_OK = 0, MI_ERR_ARG = -1, MI_ERR_SHAPE = -2, MI_ERR_LAUNCH = -3, MI_ERR_STATE = -4 };
+
+// A kernel launch that carries the caller's completion event ON ITS OWN DISPATCH PACKET (hipExtLaunchKernelGGL's stop event) instead of a separate
+// hipEventRecord marker behind it: the VAE engine's backward pass hands every gradient tensor from the caller's stream to the filter-gradient stream, and each
+// marker packet cost the producing queue ~6-8 us of bubble (profiles/r03_d, dispatch timeline; round 4).  The engine sets mi_tl_stop_event right before the
+// layer call whose (single) kernel produces the tensor; the first MI_LAUNCH of that call consumes it.  Unset (the default): a plain launch.
+extern thread_local hipEvent_t mi_tl_stop_event;
+#define MI_LAUNCH(kernel, grid, block, shmem, stream, ...) do { \
+        if (mi_tl_stop_event) { const hipEvent_t ev__ = mi_tl_stop_event; mi_tl_stop_event = nullptr; \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev__, 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
 int mi_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK / MI_ERR_LAUNCH

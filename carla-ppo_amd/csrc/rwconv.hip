@@ -671,25 +671,25 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     const dim3 g((unsigned)(8 * per_xcd));
 #define RW_LAUNCH(TAPS_, KH_) do { \
         const dim3 t_(TAPS_ == 2 ? 256 : 512); \
-        if (relu && q.bits_out && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 0, true>), g, t_, 0, st, q, nchunks); \
+        if (relu && q.bits_out && !mask) MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, true, 0, true>), g, t_, 0, st, q, nchunks); \
         else if (bits_out) return 0; \
-        else if (relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 1, false>), g, t_, 0, st, q, nchunks); \
-        else if (relu) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, true, 0, false>), g, t_, 0, st, q, nchunks); \
-        else if (q.mask_bits) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 2, false>), g, t_, 0, st, q, nchunks); \
-        else if (mask) hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 1, false>), g, t_, 0, st, q, nchunks); \
-        else hipLaunchKernelGGL((rwconv_gather_kernel<TAPS_, KH_, false, 0, false>), g, t_, 0, st, q, nchunks); } while (0)
+        else if (relu && mask) MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, true, 1, false>), g, t_, 0, st, q, nchunks); \
+        else if (relu) MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, true, 0, false>), g, t_, 0, st, q, nchunks); \
+        else if (q.mask_bits) MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, false, 2, false>), g, t_, 0, st, q, nchunks); \
+        else if (mask) MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, false, 1, false>), g, t_, 0, st, q, nchunks); \
+        else MI_LAUNCH((rwconv_gather_kernel<TAPS_, KH_, false, 0, false>), g, t_, 0, st, q, nchunks); } while (0)
     if (KH == 5 && relu && !mask && !bits_out && g_rwconv_dbg > 0) {  // debug variants of the deconv3-forward instantiation (MI355_RWCONV_DBG: 1 no stores, 2 no LDS reads, 3 no MFMAs)
-        if (g_rwconv_dbg == 1) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 1>), g, dim3(512), 0, st, q, nchunks);
-        else if (g_rwconv_dbg == 2) hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 2>), g, dim3(512), 0, st, q, nchunks);
-        else hipLaunchKernelGGL((rwconv_gather_kernel<3, 5, true, 0, false, 3>), g, dim3(512), 0, st, q, nchunks);
+        if (g_rwconv_dbg == 1) MI_LAUNCH((rwconv_gather_kernel<3, 5, true, 0, false, 1>), g, dim3(512), 0, st, q, nchunks);
+        else if (g_rwconv_dbg == 2) MI_LAUNCH((rwconv_gather_kernel<3, 5, true, 0, false, 2>), g, dim3(512), 0, st, q, nchunks);
+        else MI_LAUNCH((rwconv_gather_kernel<3, 5, true, 0, false, 3>), g, dim3(512), 0, st, q, nchunks);
     } else if (KH == 4 && ck == 2) {
         const dim3 t_(512);
-        if (relu && q.bits_out && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, true, 0, true, 0, 2>), g, t_, 0, st, q, nchunks);
+        if (relu && q.bits_out && !mask) MI_LAUNCH((rwconv_gather_kernel<2, 4, true, 0, true, 0, 2>), g, t_, 0, st, q, nchunks);
         else if (bits_out) return 0;
-        else if (relu && !mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, true, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
-        else if (!relu && q.mask_bits) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 2, false, 0, 2>), g, t_, 0, st, q, nchunks);
-        else if (!relu && mask) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 1, false, 0, 2>), g, t_, 0, st, q, nchunks);
-        else if (!relu) hipLaunchKernelGGL((rwconv_gather_kernel<2, 4, false, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (relu && !mask) MI_LAUNCH((rwconv_gather_kernel<2, 4, true, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu && q.mask_bits) MI_LAUNCH((rwconv_gather_kernel<2, 4, false, 2, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu && mask) MI_LAUNCH((rwconv_gather_kernel<2, 4, false, 1, false, 0, 2>), g, t_, 0, st, q, nchunks);
+        else if (!relu) MI_LAUNCH((rwconv_gather_kernel<2, 4, false, 0, false, 0, 2>), g, t_, 0, st, q, nchunks);
         else return 0;
     } else if (KH == 4) RW_LAUNCH(2, 4); else RW_LAUNCH(3, 5);
 #undef RW_LAUNCH
@@ -745,10 +745,10 @@ int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, 
     if (nblk > nchunks) nblk = nchunks;
     const dim3 g((unsigned)nblk), t(256);
 #define RC_LAUNCH(KH_, CK_) do { \
-        if (relu && mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, true, true>), g, t, 0, st, q, nchunks); \
-        else if (relu) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, true, false>), g, t, 0, st, q, nchunks); \
-        else if (mask) hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, false, true>), g, t, 0, st, q, nchunks); \
-        else hipLaunchKernelGGL((rwconv_conv_kernel<KH_, CK_, false, false>), g, t, 0, st, q, nchunks); } while (0)
+        if (relu && mask) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, true, true>), g, t, 0, st, q, nchunks); \
+        else if (relu) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, true, false>), g, t, 0, st, q, nchunks); \
+        else if (mask) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, true>), g, t, 0, st, q, nchunks); \
+        else MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, false>), g, t, 0, st, q, nchunks); } while (0)
     if (KH == 5) RC_LAUNCH(5, 1); else if (ck == 1) RC_LAUNCH(4, 1); else RC_LAUNCH(4, 2);
 #undef RC_LAUNCH
     const int rc = mi_check_launch("rwconv_conv_kernel");

@@ -132,6 +132,8 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int capturing;                      // the launch sequence is being recorded into a hipGraph (plain event records only)
+    int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
     hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
     hipEvent_t ev_lat, ev_third;
     int third_ok;
@@ -245,6 +247,11 @@ int check_batch(const VaeEngine* e, int B) {
     if (!e) return mi_fail(MI_ERR_STATE, "vae engine: null handle");
     if (B < 1 || B > e->d.max_batch) return mi_fail(MI_ERR_ARG, "vae engine: batch outside [1, max_batch]");
     return MI_OK;
+}
+
+unsigned ready_event_flags() {                         // MI355_KEVENT=2: the hand-over event with timing enabled (A/B: what hipExtLaunchKernelGGL's stop event wants)
+    const char* ev = getenv("MI355_KEVENT");
+    return (ev && atoi(ev) == 2) ? hipEventDefault : hipEventDisableTiming;
 }
 
 bool relu_bits_enabled() {                             // MI355_RELU_BITS=0: the input gradients read the activation tensors as ReluGrad masks (A/B runs)
@@ -438,10 +445,16 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     e->tail_fused = 0;
     CK(run_decoder(e, stream, B, 3, want_grad && !tail_try));
     int nblk = 0;
+    e->fwd_produced = 0;
     if (tail_try) {
+        static int kev = -1;
+        if (kev < 0) { const char* ev = getenv("MI355_KEVENT"); kev = ev ? atoi(ev) : 0; }
+        const bool carry = kev && !e->capturing && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
+        if (carry) mi_tl_stop_event = e->ev_ready;
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                            tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, e->at(e->W.gdec[3]), e->gptr(18),
                                            (float*)e->at(e->W.partial), (float*)e->at(e->W.bpart), e->partial_cap, &nblk, e->at(e->W.tail_slabs), e->W.tail_slab_bytes, 0));
+        if (carry) { e->fwd_produced = (nblk > 0 && mi_tl_stop_event == nullptr) ? 1 : 0; mi_tl_stop_event = nullptr; }
         if (nblk > 0) { e->tail_fused = 1; e->tail_nblk = nblk; }      // (its slab reduce runs inside mi_vae_backward)
         {
             static int defer_on = -1;
@@ -495,7 +508,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     static int two_streams = -1;
     if (two_streams < 0) { const char* ev = getenv("MI355_BWD_STREAMS"); two_streams = (ev && ev[0] == '0') ? 0 : 1; }
     if (two_streams && !e->side_ok) {
-        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
             hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
         else e->side_ok = -1;
     }
@@ -508,9 +521,22 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     }
     const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
     void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
+    // Hand-over of a gradient tensor from the caller's stream to the filter-gradient stream.  Round 3 form: hipEventRecord behind the producing kernel -- a marker
+    // packet of its own that costs the PRODUCING queue a 6-8 us bubble each time (six per step on the critical queue, profiles/r03_d).  MI355_KEVENT=1 (round 4):
+    // the producing kernel itself carries the event as the completion signal of its dispatch packet (hipExtLaunchKernelGGL's stop event, mi_internal.hpp MI_LAUNCH):
+    // no marker on the caller's queue, and the other queue's wait resolves the moment that kernel retires.
+    static int kev_env = -1;
+    if (kev_env < 0) { const char* ev = getenv("MI355_KEVENT"); kev_env = ev ? atoi(ev) : 0; }
+    const int kev = e->capturing ? 0 : kev_env;
+    bool produced = fork && kev && e->fwd_produced && (part == 0 || part == 1);      // ev_ready already rides on the last kernel issued on st
+    e->fwd_produced = 0;
     auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
-        if (fork) { hipEventRecord(e->ev_ready, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_ready, 0); }
+        if (fork) { if (!produced) hipEventRecord(e->ev_ready, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_ready, 0); }
+        produced = false;
     };
+    // call(): a layer op whose single kernel produces the tensor the NEXT release() hands over
+    auto arm = [&]() { produced = false; if (fork && kev) mi_tl_stop_event = e->ev_ready; };
+    auto armed_ok = [&]() { if (fork && kev) { produced = mi_tl_stop_event == nullptr; mi_tl_stop_event = nullptr; } };
     // In two-stream mode the split reductions of the filter gradients are deferred to the end of the side stream's work (they are tiny, but
     // next to a big input-gradient kernel each takes 15-30 us instead of ~7): every layer writes its slabs into its own scratch region.
     const bool defer = fork && W.scratch_bytes > 0;
@@ -564,8 +590,10 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             release();                                       // gy is complete on st (loss pass / previous input gradient)
             // BiasAddGrad is fused into the filter-gradient call
             TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), scratch_of(), scratch_sz, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
+            if (i > 0) arm();                                // its output is the next layer's filter-gradient operand
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
+            if (i > 0) armed_ok();
         }
         e->b4_fused = 0; e->tail_fused = 0;
         if (e->tail_nblk > 0 && !late_dense) {               // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
@@ -594,7 +622,9 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             TOP(e, sw, OP_HEADS_BIAS, bias_grad(sw, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
             TOP(e, sw, OP_HEADS_WGRAD, dense_wgrad(sw, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
         }
+        if (!use_third) arm();                               // gact4: conv4's filter-gradient operand
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
+        if (!use_third) armed_ok();
         if (use_third) {
             // everything the latent layers' gradients read exists from here on (gdec0, z, dheads, act4; the tail's slabs and loss partials since the forward pass): they run on
             // their own stream under the encoder half instead of serialising ~70 us of small launches at the end of the caller's stream
@@ -651,9 +681,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                                                                       e->gptr(0), e->gptr(1), e->at(W.enc_slabs), W.enc_slab_bytes, &nblk));
                 if (nblk > 0) { enc_fused = true; continue; }
             }
+            if (i > 1) arm();
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));
+            if (i > 1) armed_ok();
         }
         static int dbg_skip_tail = -1;                       // MI355_DBG_SKIP_TAIL=1 (wrong results): how much of the step the small launches at the end of the caller's stream are
         if (dbg_skip_tail < 0) { const char* ev = getenv("MI355_DBG_SKIP_TAIL"); dbg_skip_tail = (ev && ev[0] == '1') ? 1 : 0; }
@@ -752,7 +784,7 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
             hipGraphExecDestroy(e->gexec); e->gexec = nullptr;
         }
         if (!e->side_ok) {                                // the second stream and its events are created outside the capture
-            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, hipEventDisableTiming) == hipSuccess &&
+            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
                 hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
             else e->side_ok = -1;
         }
@@ -770,7 +802,9 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
         if (e->cap_ok != 1) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: could not create the capture stream");
         const hipError_t be = hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal);
         if (be != hipSuccess) { (void)hipGetLastError(); return mi_fail(MI_ERR_STATE, hipGetErrorString(be)); }
+        e->capturing = 1;
         const int rc = body((void*)e->cap);
+        e->capturing = 0;
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(e->cap, &graph);
         if (rc != MI_OK) { if (graph) hipGraphDestroy(graph); return rc; }

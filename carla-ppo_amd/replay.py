@@ -22,16 +22,27 @@ from mi355 import dist as midist
 
 
 def encode_resident(vae, frames, chunk=512):
-    """frames: uint8 or float [N, H, W, C] / [N, H*W*C] host array (uint8 is normalised on the device, bit-exact with /255) ->
-    device tensor [N, z_dim] of posterior means, encoded `chunk` frames per launch."""
+    """frames: uint8 or float [N, H, W, C] / [N, H*W*C] host array (uint8 is normalised on the device, bit-exact with /255), or the same table as a
+    device-resident torch tensor (uint8 / float32, contiguous: read where it lies) -> device tensor [N, z_dim] of posterior means, `chunk` frames per launch."""
     import torch
     dev = vae._need_dev()
     n = len(frames)
     feat = vae._src_feat()
     out = torch.empty(n, int(vae.z_dim), device=dev.device)
+    resident = torch.is_tensor(frames) and frames.is_cuda          # a frame table that already lives in HBM (recorded there, or uploaded once by the caller): no PCIe in this call
+    if resident:
+        if frames.dtype == torch.uint8 and not getattr(dev, "accepts_u8", False):
+            raise ValueError("encode_resident: a device-resident uint8 frame table needs the bf16 engine (the fp32 / bf16x3 engines read float frames)")
+        if frames.dtype not in (torch.uint8, torch.float32):
+            raise ValueError("encode_resident: device-resident frames must be uint8 camera bytes or float32 in [0, 1]")
+        table = frames.reshape(n, -1)
+        if table.shape[1] != feat or not table.is_contiguous():
+            raise ValueError("encode_resident: expected a contiguous table of %d values per frame, got shape %s" % (feat, tuple(frames.shape)))
+        if table.dtype == torch.float32 and not dev.range_ok(table):
+            raise ValueError("verify_range: device-resident frames outside [0, 1]")
     for lo in range(0, n, chunk):
         hi = min(lo + chunk, n)
-        src = vae._frames(frames[lo:hi], feat, "frames", keep_u8_ok=True)      # uint8 stays uint8 in HBM on the bf16 engine (conv1 normalises in registers)
+        src = table[lo:hi] if resident else vae._frames(frames[lo:hi], feat, "frames", keep_u8_ok=True)      # uint8 stays uint8 in HBM on the bf16 engine (conv1 normalises in registers)
         dev.encode(src, None, hi - lo, out[lo:hi])
     return out
 
@@ -40,7 +51,7 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
                   local_rows=False, stage_times=None, return_z=False):
     """One PPO update over R recorded trajectories (see the module docstring).
 
-    frames [R, T+1, H, W, C] (uint8 or float in [0,1]; the last frame of a row is the state after its last step), measurements [R, T+1, k],
+    frames [R, T+1, H, W, C] (uint8 or float in [0,1], host array or device-resident torch tensor; the last frame of a row is the state after its last step), measurements [R, T+1, k],
     actions [R, T, A] (the actions that were taken), rewards [R, T], dones [R, T].  batch_size is the GLOBAL minibatch size.
     local_rows=True: the arrays already hold only this rank's trajectories (each rank loaded / generated its own shard; every rank must
     hold the same number of them, so that all ranks run the same number of SGD steps).
@@ -52,10 +63,13 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     import torch
     import utils
 
-    frames, measurements = np.asarray(frames), np.asarray(measurements, np.float32)
+    import torch as _torch
+    if not (_torch.is_tensor(frames) and frames.is_cuda):      # (device-resident frame tables are read where they lie: encode_resident)
+        frames = np.asarray(frames)
+    measurements = np.asarray(measurements, np.float32)
     actions, rewards, dones = np.asarray(actions, np.float32), np.asarray(rewards, np.float64), np.asarray(dones, np.float64)
     R, T = rewards.shape
-    if frames.shape[:2] != (R, T + 1) or measurements.shape[:2] != (R, T + 1) or actions.shape[:2] != (R, T) or dones.shape != (R, T):
+    if tuple(frames.shape[:2]) != (R, T + 1) or measurements.shape[:2] != (R, T + 1) or actions.shape[:2] != (R, T) or dones.shape != (R, T):
         raise ValueError("replay_update: frames / measurements [R, T+1, ...], actions [R, T, A], rewards / dones [R, T]")
     world, rank = midist.world_size(), midist.rank()
     if world > 1 and not local_rows and R % world != 0:

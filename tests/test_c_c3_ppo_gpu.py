@@ -328,6 +328,50 @@ def test_step_with_fused_minibatch_gather_equals_gathered_step(tmp_path, M):
         assert np.allclose(l, l0, rtol=1e-6, atol=1e-7), (M, c, l, l0)
 
 
+@pytest.mark.parametrize("hidden", [(64, 64), (96, 32)])
+def test_fused_gather_with_narrow_hidden_layers(hidden):
+    """with H1 < 128 the layer-1 waves whose column tile lies past H1 return early -- the gathered minibatch they leave for the layer-1 filter
+    gradient must be complete all the same.  mi_ppo_train_step_idx against mi_ppo_train_step on host-gathered rows for hidden sizes the reference does not
+    use: identical parameters after the step (same kernels, same summation order), and out-of-range row values are clamped instead of read past the tables."""
+    import torch
+    from mi355.ppo_device import PpoDevice
+    from mi355.init import init_ppo
+    T, M = 256, 48
+    rng = np.random.RandomState(5)
+    s = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    R, A = rng.randn(T).astype(np.float32), rng.randn(T).astype(np.float32)
+    rows = rng.permutation(T)[:M].astype(np.int32)
+    res = []
+    for fused in (False, True):
+        d = PpoDevice(67, 2, [-1.0, 0.0], [1.0, 1.0], 0.2, 1.0, 0.01, hidden=hidden, max_batch=T)
+        assert d.fused_ok()
+        vals = init_ppo(3, 67, 2, 1.0, hidden=hidden)
+        for i, k in enumerate(vals):
+            if k.endswith("bias"):
+                vals[k] = (0.05 * np.random.RandomState(i).standard_normal(vals[k].shape)).astype(np.float32)
+        old = {k.replace("policy/", "policy_old/", 1): (v + 0.02 * np.random.RandomState(9).standard_normal(v.shape)).astype(np.float32) for k, v in vals.items()}
+        d.load_params(vals, old)
+        dev = d.device
+        sd, ad, Rd, Ad = (torch.from_numpy(x).to(dev) for x in (s, a, R, A))
+        rd = torch.from_numpy(rows).to(dev)
+        if fused:
+            d.train_step_idx(sd, ad, Rd, Ad, None, rd, M, 1.0 / M, 1.0, 1e-4)
+        else:
+            mb = rd.long()
+            d.train_step(sd[mb].contiguous(), ad[mb].contiguous(), Rd[mb].contiguous(), Ad[mb].contiguous(), M, 1.0 / M, 1.0, 1e-4)
+        res.append((d.params.cpu().numpy().copy(), d.losses.cpu().numpy()[:5].copy()))
+        if fused:                                           # rows outside the table: clamped (row -7 -> 0, row T + 5 -> T - 1), no fault, finite result
+            bad_rows = rows.copy(); bad_rows[0] = -7; bad_rows[1] = T + 5
+            d.train_step_idx(sd, ad, Rd, Ad, None, torch.from_numpy(bad_rows).to(dev), M, 1.0 / M, 1.0, 1e-4)
+            torch.cuda.synchronize()
+            assert np.isfinite(d.params.cpu().numpy()).all()
+    (p0, l0), (p1, l1) = res
+    assert np.array_equal(p0, p1), float(np.abs(p0 - p1).max())
+    assert np.allclose(l0, l1, rtol=1e-6, atol=1e-7)
+    assert not np.array_equal(p0[:64], np.zeros(64, np.float32))
+
+
 @pytest.mark.parametrize("M", [32, 77])
 def test_mlp_policy_op_level_forward_backward(M):
     """SURVEY 8b names `mi_mlp_policy_fwd / _bwd`: the build_mlp trunk (utils.py:25-28; dense 500 ReLU, dense 300 ReLU: ppo.py:42-44) as op-level calls of the C ABI, against

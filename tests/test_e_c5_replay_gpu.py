@@ -6,7 +6,7 @@ normalised advantages bit-exact / 1e-12 against the oracle's fp64 statements on 
 value loss and mean probability ratio 1e-4 relative; the policy term -mean(min(r A, clip(r) A)) is a cancelling sum over NORMALISED
 advantages (mean 0, std 1 per row), so its error is bounded relative to mean|A| = O(1): 1e-4 absolute.  Every stage is compared on the
 stage's own inputs as the device produced them (the oracle's SGD consumes the device's states / returns / advantages), so the stage
-tolerances do not compound.  File name: runs last."""
+tolerances do not compound."""
 import numpy as np
 import pytest
 
@@ -84,3 +84,32 @@ def test_synthetic_replay_matches_oracle_pipeline(tmp_path, R, T, batch, epochs)
         assert got["prob_ratio"] == pytest.approx(want["ratio_mean"], rel=1e-4), (i, got, want)
     assert out["losses"][0]["prob_ratio"] == pytest.approx(1.0, abs=1e-5)              # theta_old == theta at the first step
     assert m.get_train_step_idx() == n_steps
+
+
+def test_replay_reads_a_device_resident_frame_table_where_it_lies(tmp_path):
+    """Round 4: `replay_update(frames=<cuda uint8 tensor>)` -- the recording already in HBM, no PCIe in the call -- gives exactly the numbers of the host-array
+    form (same kernels on the same bytes); the fp32 engine refuses a uint8 device table (it reads float frames) instead of reinterpreting it."""
+    import torch
+    R, T = 3, 8
+    rng = np.random.RandomState(4)
+    frames = rng.randint(0, 256, (R, T + 1, 80, 160, 3), dtype=np.uint8)
+    meas = rng.uniform(0, 1, (R, T + 1, 3)).astype(np.float32)
+    actions = rng.uniform(0, 1, (R, T, 2)).astype(np.float32)
+    rewards, dones = rng.uniform(0, 1, (R, T)), np.zeros((R, T))
+    outs = []
+    for resident in (False, True):
+        vae = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / ("v%d" % resident)), precision="bf16", training=False, seed=0)
+        vae.set_weights(vo.init_vae_params(3))
+        vae.init_session(init_logging=False)
+        hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
+        m = PPO(np.array([67]), po.ActionSpace(), model_dir=str(tmp_path / ("p%d" % resident)), seed=2, **hp)
+        m.init_session(init_logging=False)
+        np.random.seed(5)
+        f = torch.from_numpy(frames).to("cuda") if resident else frames
+        outs.append(replay.replay_update(vae, m, f, meas, actions, rewards, dones, 0.99, 0.95, num_epochs=1, batch_size=8, return_z=True))
+    assert np.array_equal(outs[0]["z"], outs[1]["z"]) and np.array_equal(outs[0]["returns"], outs[1]["returns"])
+    assert [l["loss"] for l in outs[0]["losses"]] == [l["loss"] for l in outs[1]["losses"]]
+    v32 = ConvVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "v32"), precision="fp32", training=False, seed=0)
+    v32.init_session(init_logging=False)
+    with pytest.raises(ValueError, match="bf16 engine"):
+        replay.encode_resident(v32, torch.from_numpy(frames.reshape(-1, 38400)).to("cuda"))
