@@ -546,9 +546,8 @@ int try_narrow_wgrad(hipStream_t st, int dtype, const void* narrow, int narrow_f
     int rc = mi_check_launch("narrow_wgrad_kernel");
     if (rc == MI_OK && q.slabs) {
         const long long n_out = (long long)KH * run * 32;
-        launch_reduce_slabs_ordered(st, q.slabs, (long long)NW_SLAB, blocks, n_out, out);
-        if (dbias) launch_reduce_slabs_ordered(st, q.slabs + 64 * 32, (long long)NW_SLAB, blocks, 32ll, dbias);
-        rc = mi_check_launch("reduce_slabs_ordered_kernel");
+        rc = mi_reduce_slabs(st, q.slabs, (long long)NW_SLAB, blocks, n_out, out);
+        if (rc == MI_OK && dbias) rc = mi_reduce_slabs(st, q.slabs + 64 * 32, (long long)NW_SLAB, blocks, 32ll, dbias);
     }
     return rc == MI_OK ? 1 : rc;
 }
@@ -750,18 +749,26 @@ int deconv_form_gemm(hipStream_t st, int dtype, GemmParams& p, int B, int IH, in
     return launch_gemm_bn<bf16_t, bf16_t, A_DECONV, B_DECONV, 8, 16>(st, p, maxM, 4);
 }
 
+// pixel splits of a gen-1 filter-gradient launch (and the rows each takes): a function of the shape only
+static int wgrad_splits(int dtype, int M, int Kc, int N, int target_blocks, int* m_per_split) {
+    const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : (dtype == MI_BF16X3 ? WgradCfg<split_t>::BP : WgradCfg<bf16_t>::BP);
+    const int gx = Kc > 64 ? (Kc + 127) / 128 : 1, gy = (N + 63) / 64;
+    int splits = target_blocks / (gx * gy);
+    if (splits < 1) splits = 1;
+    int mps = (M + splits - 1) / splits;
+    mps = ((mps + BP - 1) / BP) * BP;
+    if (mps < BP) mps = BP;
+    if (m_per_split) *m_per_split = mps;
+    return (M + mps - 1) / mps;
+}
+
 // scratch (optional): the pixel splits store per-split slabs there and one ordered pass adds them to out -- two runs are bitwise equal; without
 // scratch (or with too little of it) the splits meet in fp32 atomics on out (run-to-run differences in the last bit)
 int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0) {
-    const int BP = dtype == MI_F32 ? WgradCfg<float>::BP : (dtype == MI_BF16X3 ? WgradCfg<split_t>::BP : WgradCfg<bf16_t>::BP);
     const bool wide = p.Kc > 64;                          // 128 kc rows per block: halves the re-reads of the small tensor
     const int gx = wide ? (p.Kc + 127) / 128 : 1, gy = (p.N + 63) / 64;
-    int splits = target_blocks / (gx * gy);
-    if (splits < 1) splits = 1;
-    int mps = (p.M + splits - 1) / splits;
-    mps = ((mps + BP - 1) / BP) * BP;
-    if (mps < BP) mps = BP;
-    splits = (p.M + mps - 1) / mps;
+    int mps = 0;
+    const int splits = wgrad_splits(dtype, p.M, p.Kc, p.N, target_blocks, &mps);
     p.m_per_split = mps;
     p.debug_skip_out = g_wgrad_skip;
     p.slabs = nullptr; p.slab_stride = ((long long)p.Kc * p.N + 3) / 4 * 4;
@@ -798,8 +805,7 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
 #undef WG_LAUNCH
     int rc = mi_check_launch("wgrad_kernel");
     if (rc == MI_OK && p.slabs) {
-        launch_reduce_slabs_ordered(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out);
-        rc = mi_check_launch("reduce_slabs_ordered_kernel");
+        rc = mi_reduce_slabs(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out);
     }
     return rc;
 }
@@ -821,10 +827,47 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 }  // namespace
 
 // internal entry points for the other translation units (mi_internal.hpp)
-int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
-    launch_reduce_slabs_ordered(st, slabs, stride, nslab, n, out);
-    return mi_check_launch("reduce_slabs_ordered_kernel");
+// Ordered slab sums: out[0 .. n) += sum_k slabs[k * stride + i], fixed order.  Deferred mode (per host thread; the VAE engine around the end of a full backward pass):
+// the jobs are recorded and mi_small_reduce_flush issues all of them as ONE launch -- every job's slabs must stay untouched until then and be complete on the
+// flush stream (the engine gives each its own piece of scratch and flushes on the stream that produced them).
+static thread_local SmallReduceParams t_sr;
+static thread_local int t_sr_defer = 0;
+static int sr_kl(long long n, int nslab) {                // slab lanes per element group: a power of two from the shape only, >= ~96 blocks per job where the slabs allow
+    const long long quads = (n + 3) / 4;
+    int kl = 1;
+    while (kl < 256 && kl * 2 <= nslab && (quads * kl + 255) / 256 < 96) kl *= 2;
+    return kl;
 }
+static int sr_launch(hipStream_t st) {
+    SmallReduceParams& f = t_sr;
+    if (f.njobs == 0) return MI_OK;
+    for (int i = f.njobs; i < SR_MAX; ++i) f.first[i + 1] = f.first[f.njobs];
+    MI_LAUNCH(reduce_small_fused_kernel, dim3((unsigned)f.first[f.njobs]), dim3(256), 0, st, f);
+    f.njobs = 0;
+    return mi_check_launch("reduce_small_fused_kernel");
+}
+int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
+    if (nslab < 1 || n < 1) return MI_OK;
+    SmallReduceParams& f = t_sr;
+    if (!t_sr_defer) f.njobs = 0;
+    if (f.njobs == SR_MAX) { const int rc = sr_launch(st); if (rc != MI_OK) return rc; }      // (a full list is issued as it is: still one fixed order per job)
+    const int j = f.njobs++;
+    if (j == 0) f.first[0] = 0;
+    f.slabs[j] = slabs; f.out[j] = out; f.stride[j] = stride; f.n[j] = n; f.nslab[j] = nslab;
+    f.kl[j] = sr_kl(n, nslab);
+    f.vec[j] = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
+    const long long quads = (n + 3) / 4;
+    f.first[j + 1] = f.first[j] + (int)((quads * f.kl[j] + 255) / 256);
+    return t_sr_defer ? MI_OK : sr_launch(st);
+}
+extern "C" int mi_small_reduce_defer(int on) {              // returns the previous mode; switching drops what an aborted pass may have left in the list
+    const int prev = t_sr_defer;
+    t_sr_defer = on ? 1 : 0;
+    t_sr.njobs = 0;
+    return prev;
+}
+extern "C" int mi_small_reduce_flush(void* stream) { return sr_launch((hipStream_t)stream); }
+extern "C" int mi_small_reduce_deferring(void) { return t_sr_defer; }
 
 bool mi_narrow_enabled() { return narrow_enabled(); }
 
@@ -943,9 +986,12 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
                                           : try_tapwgrad((hipStream_t)stream, dtype, TC_CONV, x, dy, B, IH, IW, Cin, OH, OW, Cout, KH, KW, dw, scratch, scratch_bytes, dbias);
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
-    if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass (same scratch, same stream: the filter gradient below reuses it in stream order)
-        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, scratch, scratch_bytes);
+    if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass, with the first piece of the scratch (its reduce may be deferred: the filter gradient below must not reuse it)
+        long long cb = (mi_colsum_scratch_bytes((long long)B * OH * OW, Cout) + 255) / 256 * 256;
+        if (!scratch || cb > scratch_bytes) cb = 0;
+        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, cb ? scratch : nullptr, cb);
         if (rcb != MI_OK) return rcb;
+        if (cb) { scratch = (char*)scratch + cb; scratch_bytes -= cb; }
     }
     WgradParams p = {};
     p.big = x; p.frame_idx = frame_idx;
@@ -1064,6 +1110,7 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
 // behind that launch and in front of the optimiser step (the VAE engine runs it where its stream would otherwise wait for the other one)
 int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, float* dw) {
     if (!scratch || !dw || n_partial < 1) return mi_fail(MI_ERR_ARG, "mi_deconv2d_tail_reduce: missing buffers");
+    if (t_sr_defer) return mi_reduce_slabs((hipStream_t)stream, (const float*)scratch, (long long)DT_SLAB, n_partial, (long long)DT_SLAB, dw);      // one of the jobs of the pass's fused small reduce
     MI_LAUNCH(dectail_reduce_kernel, dim3(DT_SLAB / 32), dim3(1024), 0, (hipStream_t)stream, (const float*)scratch, n_partial, dw);
     return mi_check_launch("dectail_reduce_kernel");
 }
@@ -1110,8 +1157,11 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {
-        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, scratch, scratch_bytes);
+        long long cb = (mi_colsum_scratch_bytes((long long)B * OH * OW, Cout) + 255) / 256 * 256;
+        if (!scratch || cb > scratch_bytes) cb = 0;
+        const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, cb ? scratch : nullptr, cb);
         if (rcb != MI_OK) return rcb;
+        if (cb) { scratch = (char*)scratch + cb; scratch_bytes -= cb; }
     }
     WgradParams p = {};
     p.big = dy; p.frame_idx = nullptr;
@@ -1170,9 +1220,9 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
 
 // same with caller scratch (>= mi_gemm_wgrad_scratch_bytes): the row splits store per-split slabs that one ordered pass adds to dw -- deterministic
 long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N) {
-    (void)dtype; (void)M;
-    // splits x gx x gy <= the target block count, a block covers at most 128 x 64 outputs; + one 16-byte rounding per slab
-    return (long long)(g_dense_wgrad_blocks > 1024 ? g_dense_wgrad_blocks : 1024) * (128 * 64 + 4) * 4 + ((long long)K * N + 4) * 4;
+    if (M < 1 || K < 1 || N < 1) return 0;
+    const int splits = wgrad_splits(dtype, M, K, N, g_dense_wgrad_blocks, nullptr);
+    return splits > 1 ? (long long)splits * (((long long)K * N + 3) / 4 * 4) * 4 : 0;      // (one row split: a single block per element adds straight into dw)
 }
 
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes) {

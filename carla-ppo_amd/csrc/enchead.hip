@@ -90,8 +90,13 @@ extern "C" int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* fra
     else MI_LAUNCH(enchead_bwd_kernel<float>, dim3(nblocks), dim3(256), 0, st, q);
     int rc = mi_check_launch("enchead_bwd_kernel");
     if (rc != MI_OK) return rc;
-    MI_LAUNCH(enchead_reduce_kernel, dim3(49), dim3(1024), 0, st, (const float*)q.slabs, nblocks, dw1, db1);
-    rc = mi_check_launch("enchead_reduce_kernel");
+    if (mi_small_reduce_deferring()) {                       // two jobs of the pass's fused small reduce: the 48 x 32 filter-gradient sums and the 32 bias sums at slab offset 2048
+        rc = mi_reduce_slabs(st, q.slabs, (long long)EH_SLAB, nblocks, 48ll * 32, dw1);
+        if (rc == MI_OK) rc = mi_reduce_slabs(st, q.slabs + 64 * 32, (long long)EH_SLAB, nblocks, 32ll, db1);
+    } else {
+        MI_LAUNCH(enchead_reduce_kernel, dim3(49), dim3(1024), 0, st, (const float*)q.slabs, nblocks, dw1, db1);
+        rc = mi_check_launch("enchead_reduce_kernel");
+    }
     if (rc == MI_OK) *n_blocks = nblocks;
     return rc;
 }

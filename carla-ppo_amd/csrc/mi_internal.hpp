@@ -35,6 +35,10 @@ int mi_rwconv_blocks(int set);                   // mi_set_tuning key 16: persis
 int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off, 1 auto, 2 whenever eligible; set < 0 queries
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace
 
-// out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_slabs_ordered_kernel, tapwgrad_tile.hpp; fixed summation order, no atomics) -- conv_ops.hip
+// out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_small_fused_kernel, tapwgrad_tile.hpp; fixed summation order, no atomics) -- conv_ops.hip
 int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out);
+// deferred mode of mi_reduce_slabs (per host thread): jobs are recorded and mi_small_reduce_flush(stream) issues all of them as ONE launch -- conv_ops.hip
+extern "C" int mi_small_reduce_defer(int on);
+extern "C" int mi_small_reduce_flush(void* stream);
+extern "C" int mi_small_reduce_deferring(void);
 bool mi_narrow_enabled();                        // the narrow-layer kernels are switched on (mi_set_tuning key 4 / MI355_NARROW) -- conv_ops.hip

@@ -764,15 +764,29 @@ __global__ __launch_bounds__(256) void reduce_fused_kernel(const FusedReducePara
     else reduce_tiled_body<TC_GATHER, 3, 2, 4>(p, f.splits[l], f.ngroups[l], local, ry, sm);
 }
 
-// out[i] += sum over the split slabs, in a FIXED order whatever the launch looks like (round 4: the gridDim.y partial sums of the first form met in
-// atomics).  A block owns 256 / KL groups of four consecutive elements; the KL threads of a group take every KL-th slab each (independent 16-byte loads),
-// their partial sums meet in LDS in a fixed binary tree, and one thread does the read-modify-write of out.  Rows need not be 16-byte aligned (scalar path).
-template <int KL>
-__global__ __launch_bounds__(256) void reduce_slabs_ordered_kernel(const float* __restrict__ slabs, long long stride, int nslab, long long n, float* __restrict__ out, int vec_ok) {
-    constexpr int QPB = 256 / KL;
+// out[i] += sum over split slabs in a FIXED order, whatever the launch looks like (round 4: the gridDim.y partial sums of the first form met in atomics).
+// Several ordered slab sums in ONE launch (round 4: the small reductions at the end of a backward pass -- encoder-head / decoder-tail slabs, the latent layers'
+// filter- and bias-gradient splits -- were seven latency-bound launches in a row on the caller's stream).  Job j owns blocks first[j] .. first[j + 1) - 1; inside a
+// job the block is 256 / kl[j] groups of four elements x kl[j] slab lanes (kl: a power of two chosen from the job's shape only), LDS tree, one read-modify-write.
+constexpr int SR_MAX = 12;
+struct SmallReduceParams {
+    const float* slabs[SR_MAX]; float* out[SR_MAX]; long long stride[SR_MAX], n[SR_MAX];
+    int nslab[SR_MAX], kl[SR_MAX], vec[SR_MAX], first[SR_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void reduce_small_fused_kernel(const SmallReduceParams f) {
     __shared__ f32x4 sm[256];
-    const int q = (int)threadIdx.x % QPB, kl = (int)threadIdx.x / QPB;
-    const long long i4 = ((long long)blockIdx.x * QPB + q) * 4;
+    const int b = (int)blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < SR_MAX; ++i) j += (i < f.njobs && b >= f.first[i]) ? 1 : 0;
+    const float* __restrict__ slabs = f.slabs[j];
+    float* __restrict__ out = f.out[j];
+    const long long stride = f.stride[j], n = f.n[j];
+    const int nslab = f.nslab[j], KL = f.kl[j], vec_ok = f.vec[j];
+    const int QPB = 256 / KL;
+    const int q = (int)threadIdx.x & (QPB - 1), kl = (int)threadIdx.x / QPB;
+    const long long i4 = ((long long)(b - f.first[j]) * QPB + q) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i4 < n) {
         if (vec_ok && i4 + 4 <= n) {
@@ -783,11 +797,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_ordered_kernel(const float* 
                 for (int e = 0; e < 4; ++e) if (i4 + e < n) s[e] += slabs[k * stride + i4 + e];
         }
     }
-    if constexpr (KL > 1) {
+    if (KL > 1) {                                        // (block-uniform)
         sm[threadIdx.x] = s;
         __syncthreads();
-#pragma unroll
-        for (int o = KL / 2; o > 0; o >>= 1) {
+        for (int o = KL >> 1; o > 0; o >>= 1) {
             if (kl < o) sm[threadIdx.x] += sm[threadIdx.x + o * QPB];
             __syncthreads();
         }
@@ -797,20 +810,6 @@ __global__ __launch_bounds__(256) void reduce_slabs_ordered_kernel(const float* 
         if (vec_ok && i4 + 4 <= n) { f32x4 o = *(f32x4*)(out + i4); o += s; *(f32x4*)(out + i4) = o; }
         else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] += s[e];
     }
-}
-
-// host helper: the smallest KL in {1, 4, 16, 64} that puts >= 256 blocks in flight (never more slab lanes than slabs); the choice depends on the shape
-// only, so the summation order of a given layer is the same in every run
-inline void launch_reduce_slabs_ordered(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
-    const long long quads = (n + 3) / 4;
-    const int vec_ok = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
-    int kl = 1;
-    while (kl < 64 && (quads * kl + 255) / 256 < 256 && kl * 4 <= nslab) kl *= 4;
-    const unsigned g = (unsigned)((quads * kl + 255) / 256);
-    if (kl == 1) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<1>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
-    else if (kl == 4) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<4>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
-    else if (kl == 16) hipLaunchKernelGGL(reduce_slabs_ordered_kernel<16>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
-    else hipLaunchKernelGGL(reduce_slabs_ordered_kernel<64>, dim3(g), dim3(256), 0, st, slabs, stride, nslab, n, out, vec_ok);
 }
 
 }  // namespace mi

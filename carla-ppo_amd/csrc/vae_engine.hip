@@ -71,6 +71,7 @@ struct Workspace {
     long long scratch, scratch_bytes;  // split-reduction slabs of the filter-gradient kernels on the filter-gradient stream (SCRATCH_REGIONS rotating regions)
     long long scratch_main, scratch_main_bytes;    // ... of the filter / bias gradients issued on the caller's stream (one region, reused in stream order)
     long long scratch_third, scratch_third_bytes;  // ... of the latent layers' gradients on the optional third stream
+    long long scratch_tail, scratch_tail_bytes;    // ... of the small reductions at the end of a full backward pass that run as ONE deferred launch (bump-allocated: every job keeps its slabs until the flush)
     long long scratch_side, scratch_side_bytes;    // ... of the latent layers' gradients when they run on the filter-gradient stream (outside the rotating regions: those may hold deferred slabs)
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
@@ -202,6 +203,7 @@ void make_workspace(VaeEngine& e) {
     W.scratch_main_bytes = 64ll << 20; W.scratch_main = add(W.scratch_main_bytes);
     W.scratch_third_bytes = 16ll << 20; W.scratch_third = add(W.scratch_third_bytes);
     W.scratch_side_bytes = 16ll << 20; W.scratch_side = add(W.scratch_side_bytes);
+    W.scratch_tail_bytes = 32ll << 20; W.scratch_tail = add(W.scratch_tail_bytes);
     W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
     W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
     W.enc_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 8320 : 0;                  // up to 8 resident blocks per CU x (64 x 32 + 32) floats
@@ -448,7 +450,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     e->fwd_produced = 0;
     if (tail_try) {
         static int kev = -1;
-        if (kev < 0) { const char* ev = getenv("MI355_KEVENT"); kev = ev ? atoi(ev) : 0; }
+        if (kev < 0) { const char* ev = getenv("MI355_KEVENT"); kev = ev ? atoi(ev) : 1; }
         const bool carry = kev && !e->capturing && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
         if (carry) mi_tl_stop_event = e->ev_ready;
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
@@ -522,11 +524,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
     void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
     // Hand-over of a gradient tensor from the caller's stream to the filter-gradient stream.  Round 3 form: hipEventRecord behind the producing kernel -- a marker
-    // packet of its own that costs the PRODUCING queue a 6-8 us bubble each time (six per step on the critical queue, profiles/r03_d).  MI355_KEVENT=1 (round 4):
+    // packet of its own that costs the PRODUCING queue a 6-8 us bubble each time (six per step on the critical queue, profiles/r03_d).  Round 4 (MI355_KEVENT=0: the record form; measured 0.913 -> 0.896 ms per step, two interleaved pairs on one box):
     // the producing kernel itself carries the event as the completion signal of its dispatch packet (hipExtLaunchKernelGGL's stop event, mi_internal.hpp MI_LAUNCH):
     // no marker on the caller's queue, and the other queue's wait resolves the moment that kernel retires.
     static int kev_env = -1;
-    if (kev_env < 0) { const char* ev = getenv("MI355_KEVENT"); kev_env = ev ? atoi(ev) : 0; }
+    if (kev_env < 0) { const char* ev = getenv("MI355_KEVENT"); kev_env = ev ? atoi(ev) : 1; }
     const int kev = e->capturing ? 0 : kev_env;
     bool produced = fork && kev && e->fwd_produced && (part == 0 || part == 1);      // ev_ready already rides on the last kernel issued on st
     e->fwd_produced = 0;
@@ -550,17 +552,35 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     const long long scratch_sz = defer ? region : W.scratch_bytes;
     // latent-layer filter / bias gradients (dense1, heads): slabs of their row splits in the region that belongs to the stream they are issued on
     // (reused in stream order: each call's ordered reduce is issued right behind its kernel)
-    auto small_ws = [&](void* s_, long long* bytes) -> void* {
+    // End of a full two-stream pass (round 4, MI355_TAIL_FUSE=0 switches it off): the slab sums of the encoder head, the decoder tail and the latent layers' filter /
+    // bias gradients -- seven to eleven latency-bound launches in a row on the caller's stream -- are recorded and issued as ONE launch (mi_small_reduce_flush);
+    // every job then keeps its own piece of the tail scratch until that launch.
+    static int tail_fuse_on = -1;
+    if (tail_fuse_on < 0) { const char* ev = getenv("MI355_TAIL_FUSE"); tail_fuse_on = (ev && ev[0] == '0') ? 0 : 1; }
+    bool tail_defer = false;
+    long long tail_bump = 0;
+    struct SrGuard { bool* on; ~SrGuard() { if (*on) mi_small_reduce_defer(0); } } sr_guard{&tail_defer};
+    auto small_ws = [&](void* s_, long long need, long long* bytes) -> void* {
+        if (tail_defer && s_ == st) {
+            need = (need + 255) / 256 * 256;
+            if (need <= W.scratch_tail_bytes) {
+                if (tail_bump + need > W.scratch_tail_bytes) { mi_small_reduce_flush(st); tail_bump = 0; }      // (the jobs recorded so far read their slabs before anything below overwrites them: same stream)
+                void* ptr = (char*)e->at(W.scratch_tail) + tail_bump;
+                tail_bump += need; *bytes = need;
+                return ptr;
+            }
+            mi_small_reduce_flush(st);
+        }
         if (fork && s_ == (void*)e->side) { *bytes = W.scratch_side_bytes; return e->at(W.scratch_side); }
         if (e->third_ok == 1 && s_ == (void*)e->third) { *bytes = W.scratch_third_bytes; return e->at(W.scratch_third); }
         *bytes = W.scratch_main_bytes; return e->at(W.scratch_main);
     };
     auto bias_grad = [&](void* s_, const void* x, long long M, int N, float* out) -> int {
-        long long nb = 0; void* ws_ = small_ws(s_, &nb);
+        long long nb = 0; void* ws_ = small_ws(s_, mi_colsum_scratch_bytes(M, N), &nb);
         return mi_colsum_ws(s_, d.dtype, x, M, N, out, ws_, nb);
     };
     auto dense_wgrad = [&](void* s_, const void* a, const void* dy, int M, int K, int N, float* dw) -> int {
-        long long nb = 0; void* ws_ = small_ws(s_, &nb);
+        long long nb = 0; void* ws_ = small_ws(s_, mi_gemm_wgrad_scratch_bytes(d.dtype, M, K, N), &nb);
         return mi_gemm_wgrad_ws(s_, d.dtype, a, dy, M, K, N, dw, ws_, nb);
     };
     if (defer) mi_tapwgrad_defer(1);
@@ -674,6 +694,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             }();
             if (own) mi_tapwgrad_defer_pause(0);
             CK(rcw);
+            if (i == 1 && late_dense && !use_third && tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }      // from here to the end of the pass every small slab sum on st is one job of the fused launch
             if (i == 1 && d.dtype == MI_BF16 && e->bits1_ok && e->W.enc_slab_bytes > 0 && g.c[0] == 3 && g.c[1] == 32 && g.c[2] == 64) {
                 // conv2's input gradient feeds nothing but conv1's filter gradient: both in one launch, the 99 MB tensor between them never exists (enchead_tile.hpp)
                 int nblk = 0;
@@ -692,14 +713,17 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (late_dense && dbg_skip_tail) { if (defer) mi_tapwgrad_flush(sw); e->tail_nblk = 0; e->fin.pending = 0; }
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
+            if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }
             TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
             TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
             // the heads' gradients: behind a fused encoder head the caller's stream is the one that ends early (conv1's filter gradient is no longer a launch of its own)
             void* sh = (enc_fused && heads_main) ? st : sw;
+            if (tail_defer && sh != st) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }      // (what follows is issued on the other stream: nothing of it may land in st's list)
             TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
             TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (tail_defer) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }
         }
         if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one

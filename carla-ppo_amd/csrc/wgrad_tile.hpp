@@ -6,7 +6,7 @@ namespace mi {
 
 // =====================================================================================================
 // wgrad: out[kc, n] += sum_{m in this block's pixel range} A(m, kc) * S(m, n)
-//   the pixel splits (blockIdx.z) meet either in per-split slabs that reduce_slabs_ordered_kernel sums in a FIXED order
+//   the pixel splits (blockIdx.z) meet either in per-split slabs that reduce_small_fused_kernel (mi_reduce_slabs) sums in a FIXED order
 //   (caller scratch: two runs are bitwise equal -- round 4) or, without scratch, in fp32 atomics on out
 //   A(m,kc) = im2col view (A_CONV map) of the BIG tensor, S = the SMALL tensor [M, N] (pixel-aligned rows)
 // Tile 64(kc) x 64(n), 2x2 waves of one 32x32 accumulator, BP pixels per step staged in LDS pixel-major;
