@@ -51,6 +51,12 @@ template <> struct is_split<split_t> { static constexpr bool value = true; };
 // the zero element of a storage type (split_t is a struct: no (T)0)
 template <typename T> __host__ __device__ __forceinline__ T zero_of() { return (T)0; }
 template <> __host__ __device__ __forceinline__ split_t zero_of<split_t>() { split_t s; s.u = 0u; return s; }
+// the value 1.0 in a storage type
+template <typename T> __host__ __device__ __forceinline__ T one_of();
+template <> __host__ __device__ __forceinline__ float one_of<float>() { return 1.0f; }
+template <> __host__ __device__ __forceinline__ bf16_t one_of<bf16_t>() { return (bf16_t)0x3F80; }
+template <> __host__ __device__ __forceinline__ split_t one_of<split_t>() { split_t s; s.u = 0x3F800000u; return s; }
+template <> __host__ __device__ __forceinline__ unsigned char one_of<unsigned char>() { return 1; }
 
 // ---- raw camera bytes -> [0, 1] (the reference's host preprocessing `frame.astype(np.float32) / 255.0`, vae/train_vae.py:15-18) ----
 // exact: q = k * fl(1/255), one Newton correction with two FMAs gives the correctly rounded float32(k) / float32(255) for every k in 0..255

@@ -204,6 +204,22 @@ int try_tapconv(hipStream_t st, int dtype, int mode, const void* a, const void* 
 // is recorded instead (parameters by value; every layer then needs its OWN scratch region until the flush) and mi_tapwgrad_flush issues
 // all of them back to back.  Per host THREAD (thread_local): a backward pass is issued by one thread from defer(1) to flush, so two engines driven by two
 // threads keep separate lists (round 3; the tuning knobs stay process-global configuration).  Used by the VAE engine only.
+// one more job of a fused ordered slab sum (kernel: tapwgrad_tile.hpp, sr_job_body); the lane count depends on the job's shape only
+static int sr_kl(long long n, int nslab) {                // slab lanes per element group: a power of two, >= ~96 blocks per job where the slabs allow
+    const long long quads = (n + 3) / 4;
+    int kl = 1;
+    while (kl < 256 && kl * 2 <= nslab && (quads * kl + 255) / 256 < 96) kl *= 2;
+    return kl;
+}
+static void sr_add(SmallReduceParams& f, const float* slabs, long long stride, int nslab, long long n, float* out) {
+    const int j = f.njobs++;
+    if (j == 0) f.first[0] = 0;
+    f.slabs[j] = slabs; f.out[j] = out; f.stride[j] = stride; f.n[j] = n; f.nslab[j] = nslab;
+    f.kl[j] = sr_kl(n, nslab);
+    f.vec[j] = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
+    const long long quads = (n + 3) / 4;
+    f.first[j + 1] = f.first[j] + (int)((quads * f.kl[j] + 255) / 256);
+}
 struct PendingReduce { TapWgradParams q; int splits, ngroups, kind; const float* bpart; float* bout; int bnslab, bN; };
 // Split storage (MI_BF16X3) on the bf16 filter-gradient kernels: the tensors are handed over as bf16 tensors with TWICE the channels (channel 2c = lo half, 2c + 1 = hi half of
 // element c), the kernel produces dW'[t][2R][2Q] in a temporary, and the fold  dW[t][r][q] += dW'[t][2r][2q] + dW'[t][2r][2q+1] + dW'[t][2r+1][2q] + dW'[t][2r+1][2q+1]
@@ -242,7 +258,7 @@ static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
     if (r.kind == 0) MI_LAUNCH((reduce_tiled_kernel<TC_CONV, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
     else if (r.kind == 1) MI_LAUNCH((reduce_tiled_kernel<TC_GATHER, 2, 4, 2>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
     else MI_LAUNCH((reduce_tiled_kernel<TC_GATHER, 3, 2, 4>), rg, dim3(256), 0, st, r.q, r.splits, r.ngroups, (int)ry);
-    if (r.bpart) MI_LAUNCH(reduce_bias_kernel, dim3(1), dim3(256), 0, st, r.bpart, r.bnslab, r.bN, r.bout);
+    if (r.bpart) mi_reduce_slabs(st, r.bpart, (long long)r.bN, r.bnslab, (long long)r.bN, r.bout);
 }
 extern "C" int mi_tapwgrad_defer(int on) {               // switching the mode drops whatever an aborted pass may have left in the list
     const int prev = g_defer_reduces;
@@ -275,15 +291,16 @@ static int tapwgrad_flush_reduces(void* stream) {
         return mi_check_launch("reduce_tiled_kernel");
     }
     static thread_local FusedReduceParams f;              // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
-    f.n = n; f.first[0] = 0; f.nbias = 0;
+    f.n = n; f.first[0] = 0; f.bias.njobs = 0; f.bias.first[0] = 0;
     for (int i = 0; i < n; ++i) {
         const PendingReduce& r = g_pending[i];
         f.q[i] = r.q; f.splits[i] = r.splits; f.ngroups[i] = r.ngroups; f.kind[i] = r.kind; f.ry[i] = (int)reduce_ry(r);
         f.first[i + 1] = f.first[i] + (int)reduce_blocks(r, (unsigned)f.ry[i]);
-        if (r.bpart) { f.bpart[f.nbias] = r.bpart; f.bout[f.nbias] = r.bout; f.bnslab[f.nbias] = r.bnslab; f.bN[f.nbias] = r.bN; ++f.nbias; }
+        if (r.bpart && f.bias.njobs < SR_MAX) sr_add(f.bias, r.bpart, (long long)r.bN, r.bnslab, (long long)r.bN, r.bout);
     }
     for (int i = n; i < TW_MAX_FUSED; ++i) f.first[i + 1] = f.first[n];
-    MI_LAUNCH(reduce_fused_kernel, dim3((unsigned)(f.first[n] + f.nbias)), dim3(256), 0, (hipStream_t)stream, f);
+    for (int i = f.bias.njobs; i < SR_MAX; ++i) f.bias.first[i + 1] = f.bias.first[f.bias.njobs];
+    MI_LAUNCH(reduce_fused_kernel, dim3((unsigned)(f.first[n] + f.bias.first[f.bias.njobs])), dim3(256), 0, (hipStream_t)stream, f);
     return mi_check_launch("reduce_fused_kernel");
 }
 
@@ -765,13 +782,14 @@ static int wgrad_splits(int dtype, int M, int Kc, int N, int target_blocks, int*
 // scratch (optional): the pixel splits store per-split slabs there and one ordered pass adds them to out -- two runs are bitwise equal; without
 // scratch (or with too little of it) the splits meet in fp32 atomics on out (run-to-run differences in the last bit)
 int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0) {
-    const bool wide = p.Kc > 64;                          // 128 kc rows per block: halves the re-reads of the small tensor
-    const int gx = wide ? (p.Kc + 127) / 128 : 1, gy = (p.N + 63) / 64;
+    const int Kce = p.Kc + (p.ones_row ? 1 : 0);          // rows of the result incl. the bias row
+    const bool wide = Kce > 64;                           // 128 kc rows per block: halves the re-reads of the small tensor
+    const int gx = wide ? (Kce + 127) / 128 : 1, gy = (p.N + 63) / 64;
     int mps = 0;
-    const int splits = wgrad_splits(dtype, p.M, p.Kc, p.N, target_blocks, &mps);
+    const int splits = wgrad_splits(dtype, p.M, Kce, p.N, target_blocks, &mps);
     p.m_per_split = mps;
     p.debug_skip_out = g_wgrad_skip;
-    p.slabs = nullptr; p.slab_stride = ((long long)p.Kc * p.N + 3) / 4 * 4;
+    p.slabs = nullptr; p.slab_stride = ((long long)Kce * p.N + 3) / 4 * 4;
     if (splits > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * p.slab_stride * 4) p.slabs = (float*)scratch;
     dim3 g(gx, gy, splits);
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
@@ -806,6 +824,7 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     int rc = mi_check_launch("wgrad_kernel");
     if (rc == MI_OK && p.slabs) {
         rc = mi_reduce_slabs(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out);
+        if (rc == MI_OK && p.ones_row) rc = mi_reduce_slabs(st, p.slabs + (long long)p.Kc * p.N, p.slab_stride, splits, (long long)p.N, p.dbias);
     }
     return rc;
 }
@@ -832,12 +851,6 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 // flush stream (the engine gives each its own piece of scratch and flushes on the stream that produced them).
 static thread_local SmallReduceParams t_sr;
 static thread_local int t_sr_defer = 0;
-static int sr_kl(long long n, int nslab) {                // slab lanes per element group: a power of two from the shape only, >= ~96 blocks per job where the slabs allow
-    const long long quads = (n + 3) / 4;
-    int kl = 1;
-    while (kl < 256 && kl * 2 <= nslab && (quads * kl + 255) / 256 < 96) kl *= 2;
-    return kl;
-}
 static int sr_launch(hipStream_t st) {
     SmallReduceParams& f = t_sr;
     if (f.njobs == 0) return MI_OK;
@@ -851,13 +864,7 @@ int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int ns
     SmallReduceParams& f = t_sr;
     if (!t_sr_defer) f.njobs = 0;
     if (f.njobs == SR_MAX) { const int rc = sr_launch(st); if (rc != MI_OK) return rc; }      // (a full list is issued as it is: still one fixed order per job)
-    const int j = f.njobs++;
-    if (j == 0) f.first[0] = 0;
-    f.slabs[j] = slabs; f.out[j] = out; f.stride[j] = stride; f.n[j] = n; f.nslab[j] = nslab;
-    f.kl[j] = sr_kl(n, nslab);
-    f.vec[j] = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
-    const long long quads = (n + 3) / 4;
-    f.first[j + 1] = f.first[j] + (int)((quads * f.kl[j] + 255) / 256);
+    sr_add(f, slabs, stride, nslab, n, out);
     return t_sr_defer ? MI_OK : sr_launch(st);
 }
 extern "C" int mi_small_reduce_defer(int on) {              // returns the previous mode; switching drops what an aborted pass may have left in the list
@@ -987,7 +994,7 @@ int mi_conv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* x, const int* f
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {                                          // not fused on this path: BiasAddGrad as its own pass, with the first piece of the scratch (its reduce may be deferred: the filter gradient below must not reuse it)
-        long long cb = (mi_colsum_scratch_bytes((long long)B * OH * OW, Cout) + 255) / 256 * 256;
+        long long cb = (mi_colsum_scratch_bytes(dtype, (long long)B * OH * OW, Cout) + 255) / 256 * 256;
         if (!scratch || cb > scratch_bytes) cb = 0;
         const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, cb ? scratch : nullptr, cb);
         if (rcb != MI_OK) return rcb;
@@ -1157,7 +1164,7 @@ int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, in
         if (r3 != 0) return r3 > 0 ? MI_OK : r3;
     }
     if (dbias) {
-        long long cb = (mi_colsum_scratch_bytes((long long)B * OH * OW, Cout) + 255) / 256 * 256;
+        long long cb = (mi_colsum_scratch_bytes(dtype, (long long)B * OH * OW, Cout) + 255) / 256 * 256;
         if (!scratch || cb > scratch_bytes) cb = 0;
         const int rcb = mi_colsum_ws(stream, dtype, dy, (long long)B * OH * OW, Cout, dbias, cb ? scratch : nullptr, cb);
         if (rcb != MI_OK) return rcb;
@@ -1221,12 +1228,19 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
 // same with caller scratch (>= mi_gemm_wgrad_scratch_bytes): the row splits store per-split slabs that one ordered pass adds to dw -- deterministic
 long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N) {
     if (M < 1 || K < 1 || N < 1) return 0;
-    const int splits = wgrad_splits(dtype, M, K, N, g_dense_wgrad_blocks, nullptr);
-    return splits > 1 ? (long long)splits * (((long long)K * N + 3) / 4 * 4) * 4 : 0;      // (one row split: a single block per element adds straight into dw)
+    const int splits = wgrad_splits(dtype, M, K + 1, N, g_dense_wgrad_blocks, nullptr);      // (+ 1: room for the bias row of mi_gemm_wgrad_bias_ws)
+    return splits > 1 ? (long long)splits * (((long long)(K + 1) * N + 3) / 4 * 4) * 4 : 0;  // (one row split: a single block per element adds straight into dw)
 }
 
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes) {
+    return mi_gemm_wgrad_bias_ws(stream, dtype, a, dy, M, K, N, dw, nullptr, scratch, scratch_bytes);
+}
+
+// same; dbias != NULL: dbias[n] += sum_m dy[m, n] as well -- the layer's BiasAddGrad as one more row of the same product (a column of ones appended to `a` inside
+// the kernel's loader): no separate column-sum launch
+int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes) {
     WgradParams p = {};
+    p.ones_row = dbias ? 1 : 0; p.dbias = dbias;
     p.big = a; p.frame_idx = nullptr;
     fill_wgrad_geom(p, M, 1, 1, K, 1, 1, 1, 1, 1, false);
     const int vb = dtype == MI_BF16 ? 8 : 4;

@@ -668,35 +668,56 @@ int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float*
     return mi_colsum_ws(stream, dtype, x, M, N, out, nullptr, 0);
 }
 
-// scratch for the deterministic form: at most 2,048 row blocks x N columns (rounded up to 4) of fp32 partial sums
-long long mi_colsum_scratch_bytes(long long M, int N) { (void)M; return 2048ll * ((N + 3) / 4 * 4) * 4; }
+// row blocks (and rows per block) of a column-sum launch: a function of the shape and storage type only
+static int colsum_plan(int dtype, const void* x, long long M, int N, int* kind, long long* rows_out) {
+    const int vec = dtype == MI_BF16 ? 8 : 4;
+    long long rows;
+    if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
+        // <= 512 blocks (2,048 for tensors beyond 32 MB): block count (not bytes) sets the floor of the small ones
+        const long long nblk = (long long)M * N * (dtype == MI_BF16 ? 2 : 4) > (32ll << 20) ? 2048 : 512;
+        rows = (M + nblk - 1) / nblk;
+        if (rows * N < 32768) rows = (32768 + N - 1) / N;
+        *kind = 0;
+    } else if (N <= 256) {
+        rows = (M + 1023) / 1024;
+        if (rows * N < 4096) rows = (4096 + N - 1) / N;
+        *kind = 1;
+    } else {
+        rows = (M + 63) / 64;
+        if (rows < 8) rows = 8;
+        *kind = 2;
+    }
+    *rows_out = rows;
+    return (int)((M + rows - 1) / rows);
+}
+
+// scratch of the deterministic form: one row of N (rounded up to 4) fp32 partial sums per row block of the launch
+long long mi_colsum_scratch_bytes(int dtype, long long M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    int kind; long long rows;
+    int gx = colsum_plan(dtype, nullptr, M, N, &kind, &rows);
+    if (kind == 0) {                                      // a tensor of this shape that is not 16-byte aligned takes the scalar kernel and its row blocks
+        long long r1 = (M + 1023) / 1024;
+        if (r1 * N < 4096) r1 = (4096 + N - 1) / N;
+        const int g1 = (int)((M + r1 - 1) / r1);
+        if (g1 > gx) gx = g1;
+    }
+    return (long long)gx * ((N + 3) / 4 * 4) * 4;
+}
 
 // out[n] += sum_m x[m, n].  With scratch (>= mi_colsum_scratch_bytes) every row block stores its column sums and one ordered pass adds them to out:
 // two runs are bitwise equal (round 4).  Without it the row blocks meet in fp32 atomics on out.
 int mi_colsum_ws(void* stream, int dtype, const void* x, long long M, int N, float* out, void* scratch, long long scratch_bytes) {
     if (M <= 0 || N <= 0) return MI_OK;
-    const int vec = dtype == MI_BF16 ? 8 : 4;
     const int pstride = (N + 3) / 4 * 4;
-    auto part_of = [&](int gx) -> float* {
-        return (gx > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)gx * pstride * 4) ? (float*)scratch : nullptr;
-    };
-    int gx; float* part;
-    if (N <= 256 && N % vec == 0 && ((((uintptr_t)x) & 15) == 0)) {
-        // <= 512 blocks (2,048 for tensors beyond 32 MB): every block ends with N atomics on the same N addresses, so block count (not bytes) sets the floor of the small ones
-        const long long nblk = (long long)M * N * (dtype == MI_BF16 ? 2 : 4) > (32ll << 20) ? 2048 : 512;
-        long long rows = (M + nblk - 1) / nblk;
-        if (rows * N < 32768) rows = (32768 + N - 1) / N;
-        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
+    int kind; long long rows;
+    const int gx = colsum_plan(dtype, x, M, N, &kind, &rows);
+    float* part = (gx > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)gx * pstride * 4) ? (float*)scratch : nullptr;
+    if (kind == 0) {
         BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_vec_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
-    } else if (N <= 256) {
-        long long rows = (M + 1023) / 1024;
-        if (rows * N < 4096) rows = (4096 + N - 1) / N;
-        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
+    } else if (kind == 1) {
         BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_small_kernel<TT>, dim3(gx), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
     } else {
-        long long rows = (M + 63) / 64;
-        if (rows < 8) rows = 8;
-        gx = (int)((M + rows - 1) / rows); part = part_of(gx);
         const int gy = (N + 255) / 256;
         BY_DTYPE(dtype, hipLaunchKernelGGL(colsum_wide_kernel<TT>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const TT*)x, M, N, (int)rows, out, part, pstride));
     }

@@ -680,26 +680,26 @@ __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int n
             for (int k = by; k < nslab; k += ry) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
         }
     }
-    if (ry > 1) {                                        // (block-uniform)
-        sm[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = ry >> 1; o > 0; o >>= 1) {
-            if (by < o) sm[threadIdx.x] += sm[threadIdx.x + o * gpb];
-            __syncthreads();
-        }
-        s = sm[threadIdx.x];
+    // the ry partial sums of a group meet in LDS: ONE barrier, then thread (group, element) adds its ry values in slab-lane order and does the
+    // read-modify-write of its element of dW (a binary tree cost four barriers per block: reduce_fused 37 -> 53 us)
+    float* const smf = (float*)sm;
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int idx = (int)threadIdx.x; idx < 4 * gpb; idx += 256) {
+        const int g2 = idx >> 2, e = idx & 3;
+        const int gid2 = bx * gpb + g2;
+        if (gid2 >= ngroups) continue;
+        float v = smf[g2 * 4 + e];
+        for (int k = 1; k < ry; ++k) v += smf[(k * gpb + g2) * 4 + e];
+        const int lane = gid2 & 63, g4 = (gid2 >> 6) & 3;
+        const int slot = gid2 >> 8;                       // (block column * npairs + pair) * KT + kt
+        const int kt = slot % KT, bp = slot / KT;
+        const int pi = bp % p.npairs, bcol = bp / p.npairs;
+        const int kb = bcol % p.nkb, nb = bcol / p.nkb;
+        long long base, stride;
+        const bool ok = tw_dw_index<MODE, TAPS>(p, kb * 32 * KT, nb * 32 * NTB, p.pair_tap[pi], kt, p.pair_nt[pi], 8 * g4 + 4 * (lane >> 5), lane & 31, base, stride);
+        if (ok) p.out[base + e * stride] += v;
     }
-    if (!live || by != 0) return;
-    const int lane = gid & 63, g4 = (gid >> 6) & 3;
-    const int slot = gid >> 8;                            // (block column * npairs + pair) * KT + kt
-    const int kt = slot % KT, bp = slot / KT;
-    const int pi = bp % p.npairs, bcol = bp / p.npairs;
-    const int kb = bcol % p.nkb, nb = bcol / p.nkb;
-    long long base, stride;
-    const bool ok = tw_dw_index<MODE, TAPS>(p, kb * 32 * KT, nb * 32 * NTB, p.pair_tap[pi], kt, p.pair_nt[pi], 8 * g4 + 4 * (lane >> 5), lane & 31, base, stride);
-    if (!ok) return;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p.out[base + t * stride] += s[t];
 }
 template <int MODE, int TAPS, int KT, int NTB>
 __global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams p, int nslab, int ngroups, int ry) {
@@ -707,86 +707,13 @@ __global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams 
     reduce_tiled_body<MODE, TAPS, KT, NTB>(p, nslab, ngroups, (int)blockIdx.x, ry, sm);
 }
 
-// dbias[c] += sum over nslab rows of part[k * N + c], N <= 256, one block, fixed order (the bias-gradient partial sums of the position splits)
-__device__ __forceinline__ void reduce_bias_block(const float* __restrict__ part, int nslab, int N, float* __restrict__ dbias, f32x4* smv) {
-    float* sm = (float*)smv;
-    int np2 = 1; while (np2 < N) np2 <<= 1;
-    const int kl_n = 256 / np2;
-    const int col = (int)threadIdx.x & (np2 - 1), kl = (int)threadIdx.x / np2;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (col < N) {
-        int k = kl;
-        for (; k + 3 * kl_n < nslab; k += 4 * kl_n) {
-            a0 += part[(long long)k * N + col]; a1 += part[(long long)(k + kl_n) * N + col];
-            a2 += part[(long long)(k + 2 * kl_n) * N + col]; a3 += part[(long long)(k + 3 * kl_n) * N + col];
-        }
-        for (; k < nslab; k += kl_n) a0 += part[(long long)k * N + col];
-    }
-    sm[threadIdx.x] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    for (int o = kl_n >> 1; o > 0; o >>= 1) {
-        if (kl < o) sm[threadIdx.x] += sm[threadIdx.x + o * np2];
-        __syncthreads();
-    }
-    if (kl == 0 && col < N) dbias[col] += sm[threadIdx.x];
-}
-__global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restrict__ part, int nslab, int N, float* __restrict__ dbias) {
-    __shared__ f32x4 sm[64];
-    reduce_bias_block(part, nslab, N, dbias, sm);
-}
-
-// All deferred reductions of one backward pass in ONE launch (six layers: ~190 MB of slabs, 35-40 us at HBM speed against 130 us as six
-// latency-bound launches): block b belongs to the layer l with first[l] <= b < first[l + 1]; inside the layer, b - first[l] = the block of 256 / ry groups.
-// Blocks first[n] .. first[n] + nbias - 1: one per layer whose bias-gradient partial sums wait in its scratch.
-constexpr int TW_MAX_FUSED = 8;
-struct FusedReduceParams {
-    TapWgradParams q[TW_MAX_FUSED];
-    int splits[TW_MAX_FUSED], ngroups[TW_MAX_FUSED], kind[TW_MAX_FUSED], ry[TW_MAX_FUSED], first[TW_MAX_FUSED + 1];
-    int n;
-    const float* bpart[TW_MAX_FUSED]; float* bout[TW_MAX_FUSED]; int bnslab[TW_MAX_FUSED], bN[TW_MAX_FUSED];
-    int nbias;
-};
-__global__ __launch_bounds__(256) void reduce_fused_kernel(const FusedReduceParams f) {
-    __shared__ f32x4 sm[256];
-    const int b = (int)blockIdx.x;
-    if (b >= f.first[f.n]) {                              // (block-uniform)
-        const int j = b - f.first[f.n];
-        if (j < f.nbias) reduce_bias_block(f.bpart[j], f.bnslab[j], f.bN[j], f.bout[j], sm);
-        return;
-    }
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < TW_MAX_FUSED; ++i) l += (i < f.n && b >= f.first[i]) ? 1 : 0;
-    const int local = b - f.first[l], ry = f.ry[l];
-    const TapWgradParams& p = f.q[l];
-    if (f.kind[l] == 0) reduce_tiled_body<TC_CONV, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
-    else if (f.kind[l] == 1) reduce_tiled_body<TC_GATHER, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
-    else reduce_tiled_body<TC_GATHER, 3, 2, 4>(p, f.splits[l], f.ngroups[l], local, ry, sm);
-}
-
-// out[i] += sum over split slabs in a FIXED order, whatever the launch looks like (round 4: the gridDim.y partial sums of the first form met in atomics).
-// Several ordered slab sums in ONE launch (round 4: the small reductions at the end of a backward pass -- encoder-head / decoder-tail slabs, the latent layers'
-// filter- and bias-gradient splits -- were seven latency-bound launches in a row on the caller's stream).  Job j owns blocks first[j] .. first[j + 1) - 1; inside a
-// job the block is 256 / kl[j] groups of four elements x kl[j] slab lanes (kl: a power of two chosen from the job's shape only), LDS tree, one read-modify-write.
-constexpr int SR_MAX = 12;
-struct SmallReduceParams {
-    const float* slabs[SR_MAX]; float* out[SR_MAX]; long long stride[SR_MAX], n[SR_MAX];
-    int nslab[SR_MAX], kl[SR_MAX], vec[SR_MAX], first[SR_MAX + 1];
-    int njobs;
-};
-__global__ __launch_bounds__(256) void reduce_small_fused_kernel(const SmallReduceParams f) {
-    __shared__ f32x4 sm[256];
-    const int b = (int)blockIdx.x;
-    int j = 0;
-#pragma unroll
-    for (int i = 1; i < SR_MAX; ++i) j += (i < f.njobs && b >= f.first[i]) ? 1 : 0;
-    const float* __restrict__ slabs = f.slabs[j];
-    float* __restrict__ out = f.out[j];
-    const long long stride = f.stride[j], n = f.n[j];
-    const int nslab = f.nslab[j], KL = f.kl[j], vec_ok = f.vec[j];
+// One job of an ordered slab sum: out[i] += sum_k slabs[k * stride + i], i < n.  The block is 256 / KL groups of four elements x KL slab lanes (KL: a power of
+// two chosen from the job's shape only); the lanes' partial sums meet in LDS (one barrier) and are added in lane order.
+__device__ __forceinline__ void sr_job_body(const float* __restrict__ slabs, float* __restrict__ out, long long stride, long long n, int nslab, int KL, int vec_ok,
+                                            int local_block, f32x4* sm) {
     const int QPB = 256 / KL;
     const int q = (int)threadIdx.x & (QPB - 1), kl = (int)threadIdx.x / QPB;
-    const long long i4 = ((long long)(b - f.first[j]) * QPB + q) * 4;
+    const long long i4 = ((long long)local_block * QPB + q) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i4 < n) {
         if (vec_ok && i4 + 4 <= n) {
@@ -800,16 +727,65 @@ __global__ __launch_bounds__(256) void reduce_small_fused_kernel(const SmallRedu
     if (KL > 1) {                                        // (block-uniform)
         sm[threadIdx.x] = s;
         __syncthreads();
-        for (int o = KL >> 1; o > 0; o >>= 1) {
-            if (kl < o) sm[threadIdx.x] += sm[threadIdx.x + o * QPB];
+        if (KL > 16) {                                   // two levels: lanes kl < 16 add every 16th lane's sum, then lane 0 adds those sixteen
+            if (kl < 16) { s = sm[kl * QPB + q]; for (int k = kl + 16; k < KL; k += 16) s += sm[k * QPB + q]; }
             __syncthreads();
-        }
-        s = sm[threadIdx.x];
+            if (kl < 16) sm[kl * QPB + q] = s;
+            __syncthreads();
+            if (kl == 0) { s = sm[q]; for (int k = 1; k < 16; ++k) s += sm[k * QPB + q]; }
+        } else if (kl == 0) for (int k = 1; k < KL; ++k) s += sm[k * QPB + q];
     }
     if (kl == 0 && i4 < n) {
         if (vec_ok && i4 + 4 <= n) { f32x4 o = *(f32x4*)(out + i4); o += s; *(f32x4*)(out + i4) = o; }
         else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] += s[e];
     }
+}
+constexpr int SR_MAX = 12;
+struct SmallReduceParams {
+    const float* slabs[SR_MAX]; float* out[SR_MAX]; long long stride[SR_MAX], n[SR_MAX];
+    int nslab[SR_MAX], kl[SR_MAX], vec[SR_MAX], first[SR_MAX + 1];
+    int njobs;
+};
+__device__ __forceinline__ void sr_dispatch(const SmallReduceParams& f, int b, f32x4* sm) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < SR_MAX; ++i) j += (i < f.njobs && b >= f.first[i]) ? 1 : 0;
+    sr_job_body(f.slabs[j], f.out[j], f.stride[j], f.n[j], f.nslab[j], f.kl[j], f.vec[j], b - f.first[j], sm);
+}
+
+// All deferred reductions of one backward pass in ONE launch (six layers: ~190 MB of slabs, 35-40 us at HBM speed against 130 us as six
+// latency-bound launches): block b belongs to the layer l with first[l] <= b < first[l + 1]; inside the layer, b - first[l] = the block of 256 / ry groups.
+// Blocks from first[n] on: the layers' bias-gradient partial sums as generic ordered jobs (several blocks each: a single block per layer summed up to 2,048
+// rows by itself and was the long pole of the launch).
+constexpr int TW_MAX_FUSED = 8;
+struct FusedReduceParams {
+    TapWgradParams q[TW_MAX_FUSED];
+    int splits[TW_MAX_FUSED], ngroups[TW_MAX_FUSED], kind[TW_MAX_FUSED], ry[TW_MAX_FUSED], first[TW_MAX_FUSED + 1];
+    int n;
+    SmallReduceParams bias;
+};
+__global__ __launch_bounds__(256) void reduce_fused_kernel(const FusedReduceParams f) {
+    __shared__ f32x4 sm[256];
+    const int b = (int)blockIdx.x;
+    if (b >= f.first[f.n]) {                              // (block-uniform)
+        sr_dispatch(f.bias, b - f.first[f.n], sm);
+        return;
+    }
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < TW_MAX_FUSED; ++i) l += (i < f.n && b >= f.first[i]) ? 1 : 0;
+    const int local = b - f.first[l], ry = f.ry[l];
+    const TapWgradParams& p = f.q[l];
+    if (f.kind[l] == 0) reduce_tiled_body<TC_CONV, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
+    else if (f.kind[l] == 1) reduce_tiled_body<TC_GATHER, 2, 4, 2>(p, f.splits[l], f.ngroups[l], local, ry, sm);
+    else reduce_tiled_body<TC_GATHER, 3, 2, 4>(p, f.splits[l], f.ngroups[l], local, ry, sm);
+}
+
+// Several ordered slab sums in ONE launch (round 4: the small reductions at the end of a backward pass -- encoder-head / decoder-tail slabs, the latent layers'
+// filter- and bias-gradient splits -- were seven latency-bound launches in a row on the caller's stream).  Job j owns blocks first[j] .. first[j + 1) - 1.
+__global__ __launch_bounds__(256) void reduce_small_fused_kernel(const SmallReduceParams f) {
+    __shared__ f32x4 sm[256];
+    sr_dispatch(f, (int)blockIdx.x, sm);
 }
 
 }  // namespace mi

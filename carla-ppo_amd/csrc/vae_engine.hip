@@ -576,12 +576,16 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         *bytes = W.scratch_main_bytes; return e->at(W.scratch_main);
     };
     auto bias_grad = [&](void* s_, const void* x, long long M, int N, float* out) -> int {
-        long long nb = 0; void* ws_ = small_ws(s_, mi_colsum_scratch_bytes(M, N), &nb);
+        long long nb = 0; void* ws_ = small_ws(s_, mi_colsum_scratch_bytes(d.dtype, M, N), &nb);
         return mi_colsum_ws(s_, d.dtype, x, M, N, out, ws_, nb);
     };
-    auto dense_wgrad = [&](void* s_, const void* a, const void* dy, int M, int K, int N, float* dw) -> int {
+    // round 4: the latent layers' BiasAddGrad rides on their filter gradient as one more row of the same product (mi_gemm_wgrad_bias_ws: a column of ones in the
+    // loader) -- two launches less at the end of the pass; MI355_DENSE_BIAS_FUSED=0: the separate column sums
+    static int bias_fused = -1;
+    if (bias_fused < 0) { const char* ev = getenv("MI355_DENSE_BIAS_FUSED"); bias_fused = (ev && ev[0] == '0') ? 0 : 1; }
+    auto dense_wgrad = [&](void* s_, const void* a, const void* dy, int M, int K, int N, float* dw, float* db) -> int {
         long long nb = 0; void* ws_ = small_ws(s_, mi_gemm_wgrad_scratch_bytes(d.dtype, M, K, N), &nb);
-        return mi_gemm_wgrad_ws(s_, d.dtype, a, dy, M, K, N, dw, ws_, nb);
+        return mi_gemm_wgrad_bias_ws(s_, d.dtype, a, dy, M, K, N, dw, bias_fused ? db : nullptr, ws_, nb);
     };
     if (defer) mi_tapwgrad_defer(1);
     auto join = [&]() {
@@ -625,8 +629,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         // otherwise wait ~100 us for the other one; their operands (gdec0, z, dheads, act4) stay intact until then and no event is needed for them.
         if (!late_dense) {
             release();
-            TOP(e, sw, OP_DENSE1_BIAS, bias_grad(sw, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, sw, OP_DENSE1_WGRAD, dense_wgrad(sw, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            if (!bias_fused) TOP(e, sw, OP_DENSE1_BIAS, bias_grad(sw, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, sw, OP_DENSE1_WGRAD, dense_wgrad(sw, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
         }
         TOP(e, st, OP_DENSE1_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.gdec[0]), B, g.flat, e->wptr(10), 1, d.z_dim, nullptr, 0, nullptr, e->at(W.dz_slab), 1, e->ns_dz));
         if (part == 1) join();                               // a full backward joins once, at its end: nothing below reads a filter gradient
@@ -639,8 +643,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                                  eps, (const float*)e->at(W.kl_row), d.beta, kl_floor, inv_batch, B, d.z_dim, e->at(W.dheads)));
         if (!late_dense) {
             release();
-            TOP(e, sw, OP_HEADS_BIAS, bias_grad(sw, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sw, OP_HEADS_WGRAD, dense_wgrad(sw, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (!bias_fused) TOP(e, sw, OP_HEADS_BIAS, bias_grad(sw, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sw, OP_HEADS_WGRAD, dense_wgrad(sw, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9)));
         }
         if (!use_third) arm();                               // gact4: conv4's filter-gradient operand
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
@@ -650,10 +654,10 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             // their own stream under the encoder half instead of serialising ~70 us of small launches at the end of the caller's stream
             hipStream_t s3 = e->third;
             hipEventRecord(e->ev_lat, (hipStream_t)st); hipStreamWaitEvent(s3, e->ev_lat, 0);
-            TOP(e, s3, OP_DENSE1_BIAS, bias_grad(s3, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, s3, OP_DENSE1_WGRAD, dense_wgrad(s3, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
-            TOP(e, s3, OP_HEADS_BIAS, bias_grad(s3, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, s3, OP_HEADS_WGRAD, dense_wgrad(s3, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (!bias_fused) TOP(e, s3, OP_DENSE1_BIAS, bias_grad(s3, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, s3, OP_DENSE1_WGRAD, dense_wgrad(s3, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
+            if (!bias_fused) TOP(e, s3, OP_HEADS_BIAS, bias_grad(s3, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, s3, OP_HEADS_WGRAD, dense_wgrad(s3, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(s3, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (e->fin.pending) {
                 e->fin.pending = 0;
@@ -714,15 +718,15 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
             if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }
-            TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10)));
+            if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+            TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
             // the heads' gradients: behind a fused encoder head the caller's stream is the one that ends early (conv1's filter gradient is no longer a launch of its own)
             void* sh = (enc_fused && heads_main) ? st : sw;
             if (tail_defer && sh != st) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }      // (what follows is issued on the other stream: nothing of it may land in st's list)
-            TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8)));
+            if (!bias_fused) TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+            TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9)));
             if (tail_defer) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }
         }
         if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }

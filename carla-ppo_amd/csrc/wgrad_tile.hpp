@@ -26,6 +26,8 @@ struct WgradParams {
     int m_per_split;                 // multiple of BP
     int debug_skip_out;              // debug (mi_set_tuning key 2): drop the atomic accumulation to time the main loop alone
     float* slabs; long long slab_stride;   // optional: split z stores its partial sums at slabs[z * slab_stride + kc * N + n] (plain stores, every in-range element exactly once)
+    int ones_row; float* dbias;      // ones_row != 0: the big tensor carries a virtual column kc == Kc of ones, so row Kc of the result is the column sum of S -- the layer's
+                                     // BiasAddGrad rides on the filter gradient (dense layers: one launch less per layer; slab row Kc, or atomics on dbias without slabs)
 };
 
 template <typename T> struct WgradCfg;
@@ -87,11 +89,12 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
 
     // this thread's fixed kc-vector offsets
     long long a_koff[NVA];
-    bool a_kok[NVA];
+    bool a_kok[NVA], a_one[NVA];
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
         const int kc = kc0 + (tsub + i * TPP) * VA;
         a_kok[i] = kc < p.Kc;
+        a_one[i] = p.ones_row && kc == p.Kc;              // (Kc is a multiple of VA: the ones column is element 0 of its vector)
         uint32_t seg, j;
         p.div_run.divmod((uint32_t)(a_kok[i] ? kc : 0), seg, j);
         if (p.merged) a_koff[i] = (long long)seg * p.IW * p.C + j;
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             const PackU<TIn, VA, AALIGN> t = *(const PackU<TIn, VA, AALIGN>*)src;
 #pragma unroll
             for (int e = 0; e < VA; ++e) a_reg[i].v[e] = ok ? t.v[e] : zero_of<TIn>();
+            if (a_one[i] && mok) a_reg[i].v[0] = one_of<TIn>();
         }
         const T* srow = Sg + (long long)(mok ? m : 0) * p.N;
 #pragma unroll
@@ -213,6 +217,9 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             if (kc < p.Kc && n < p.N) {
                 if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
                 else atomicAdd(&p.out[(long long)kc * p.N + n], acc[i][r]);
+            } else if (p.ones_row && kc == p.Kc && n < p.N) {
+                if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                else atomicAdd(&p.dbias[n], acc[i][r]);
             }
         }
     }

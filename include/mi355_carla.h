@@ -152,6 +152,8 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
  * in a fixed order -- two runs are bitwise equal (round 4; the parity engines use only this form) */
 long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N);
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes);
+/* same + the layer's BiasAddGrad in the same launch: dbias[n] += sum_m dy[m,n] (a column of ones appended to `a` inside the kernel's loader; dbias may be NULL) */
+int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes);
 
 /* ---- VAE elementwise / reduction kernels ---- */
 /* Normal(mean, exp(.5 lv)).sample + kl_divergence — vae/models.py:7-9,101-105 (eps injected; TF RNG is unseeded) */
@@ -188,7 +190,7 @@ int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, c
 /* BiasAddGrad: out[n] += sum_m x[m,n] (row blocks meet in fp32 atomics) */
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out);
 /* same with caller scratch (>= mi_colsum_scratch_bytes; NULL = the form above): per-block column sums added up in a fixed order -- bitwise reproducible */
-long long mi_colsum_scratch_bytes(long long M, int N);
+long long mi_colsum_scratch_bytes(int dtype, long long M, int N);
 int mi_colsum_ws(void* stream, int dtype, const void* x, long long M, int N, float* out, void* scratch, long long scratch_bytes);
 /* tf.nn.sigmoid(reconstructed_logits) — vae/models.py:113 */
 int mi_sigmoid(void* stream, int dtype, const void* x, float* out, long long n);

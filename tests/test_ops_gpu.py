@@ -276,6 +276,45 @@ def test_dense_wgrad(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(512, 64, 6144), (512, 6144, 128), (40, 72, 500), (2100, 64, 64), (300, 304, 1)])
+def test_ordered_dense_wgrad_with_bias_row_and_colsum(dt, shape):
+    """Round 4: mi_gemm_wgrad_bias_ws (row splits through per-split slabs + ONE ordered reduce; the layer's BiasAddGrad as one more row of the same product:
+    a column of ones appended to `a` in the kernel's loader) and mi_colsum_ws (per-block column sums + ordered reduce) against float64 -- and run three times
+    into zeroed buffers: bitwise identical results (no fp32 atomics on this path).  Shapes: the latent layers at batch 512, the PPO trunk, odd row counts."""
+    L = milib.get()
+    code, td = DT[dt]
+    M, K, N = shape
+    if dt == "bf16" and (K % 8):
+        pytest.skip("bf16 vectors need K % 8 == 0 (callers pad K)")
+    rng = np.random.RandomState(K + N)
+    a, dy = rng.randn(M, K).astype(np.float32), rng.randn(M, N).astype(np.float32)
+    ref = rounded(a, td).T @ rounded(dy, td)
+    refb = rounded(dy, td).sum(0)
+    ad, dyd = dev(a, td), dev(dy, td)
+    nb = int(L.mi_gemm_wgrad_scratch_bytes(code, M, K, N))
+    nc = int(L.mi_colsum_scratch_bytes(code, M, N))
+    assert nb < (64 << 20) and nc < (8 << 20)
+    ws = torch.empty(max(nb, 256), device="cuda", dtype=torch.uint8)
+    wc = torch.empty(max(nc, 256), device="cuda", dtype=torch.uint8)
+    runs = []
+    for _ in range(3):
+        dw, db, db2 = torch.zeros(K, N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        L.mi_gemm_wgrad_bias_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb)
+        L.mi_colsum_ws(stream(), code, dyd.data_ptr(), M, N, db2.data_ptr(), wc.data_ptr(), nc)
+        torch.cuda.synchronize()
+        runs.append((dw.cpu().numpy().copy(), db.cpu().numpy().copy(), db2.cpu().numpy().copy()))
+    assert_close(runs[0][0], ref.numpy(), 1e-5, 3e-5 * float(ref.abs().max()), "dense wgrad (slabs)")
+    assert_close(runs[0][1], refb.numpy(), 1e-5, 3e-5 * float(refb.abs().max()), "bias row")
+    assert_close(runs[0][2], refb.numpy(), 1e-5, 3e-5 * float(refb.abs().max()), "colsum (ordered)")
+    for r in runs[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(r, runs[0]))
+    # accumulating call without a bias row; dbias = NULL leaves nothing behind the filter rows
+    dw = torch.from_numpy(runs[0][0]).cuda()
+    L.mi_gemm_wgrad_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), ws.data_ptr(), nb)
+    assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_reparam_kl_fwd_bwd(dt):
     L = milib.get()
     code, td = DT[dt]
