@@ -416,8 +416,6 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--pool", type=int, default=2048, help="synthetic frames resident in HBM per GPU")
     ap.add_argument("--frames", default="u8", choices=["u8", "f32"], help="format of the HBM-resident frame pool (bf16 engine: uint8 camera bytes by default)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("MI355_BENCH_GRAPH", "0")),
-                    help="1: the timed steps replay the captured hipGraph of the step (the dominant kernel is then timed in an eager pass after the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true")
     ap.add_argument("--no-fp32", action="store_true")
@@ -439,7 +437,6 @@ def main():
 
     tmp = tempfile.mkdtemp(prefix="mi355_bench_")
     B = args.batch
-    os.environ["MI355_GRAPH"] = "1" if args.graph else "0"
     model = ConvVAE(np.array([80, 160, 3]), z_dim=64, beta=1.0, learning_rate=1e-4, model_dir=os.path.join(tmp, "vae"), precision=args.precision, seed=0)
     model.init_session(init_logging=False)
     dev = model.dev
@@ -481,13 +478,9 @@ def main():
     ms_all, cnt_all = collect_timing(dev, n_ops)
     per_op = {names[i]: float(ms_all[i] / cnt_all[i]) for i in range(n_ops) if cnt_all[i] > 0}
     dominant = max(per_op, key=per_op.get) if per_op else None
-    if args.graph and world == 1:                         # capture + first replays belong to the warm-up
-        for i in range(3):
-            step(total + i)
-        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides; (eager mode) the dominant op keeps its two HIP events ----
-    events_live = dominant is not None and not (args.graph and world == 1)
+    events_live = dominant is not None
     if events_live:
         dev.L.mi_vae_timing_begin(dev.handle, 2, names.index(dominant), args.steps + 4)
     midist.barrier()
@@ -507,12 +500,6 @@ def main():
     roofline = None
     if dominant is not None:
         how = "HIP events on the launch stream around every launch of this op inside the timed region"
-        if not events_live:                               # graph replays cannot carry per-launch events: a short eager pass right after the timed region
-            dev.L.mi_vae_timing_begin(dev.handle, 2, names.index(dominant), 64)
-            for i in range(min(args.steps, 50)):
-                step(i)
-            torch.cuda.synchronize()
-            how = "HIP events around every launch of this op in an eager pass of %d steps right after the graph-replayed timed region" % min(args.steps, 50)
         ms_d, cnt_d = collect_timing(dev, n_ops)
         di = names.index(dominant)
         avg_s = float(ms_d[di] / max(cnt_d[di], 1)) * 1e-3
@@ -575,7 +562,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world if world > 1 else "single", "frames_resident_in_hbm": args.pool,
                        "frame_table": "uint8 camera bytes, k/255 in registers" if u8_pool else "float32 in [0,1]",
                        "noise": "N(0,1) drawn inside the reparameterisation kernel (Philox4x32-10)",
-                       "launch": "hipGraph replay of the captured step" if (args.graph and world == 1) else "eager launches",
+                       "launch": "eager launches: one C call per step (mi_vae_train_step)",
                        "storage": "bf16 activations/weights, fp32 accumulate, fp32 master weights+Adam" if args.precision == "bf16" else "fp32",
                        "library": _library_stamp()},
             "roofline": roofline,

@@ -248,10 +248,10 @@ static thread_local PendingReduce g_pending[16];
 static thread_local int g_npending = 0, g_defer_reduces = 0, g_defer_pause = 0;
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element (a power of two <= 64, from the shape only): about 512 blocks in flight, at most ~16 slabs per thread
     unsigned ry = 1;
-    while (((unsigned)(r.ngroups / 256 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
+    while (((unsigned)(r.ngroups / 512 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
     return ry;
 }
-static unsigned reduce_blocks(const PendingReduce& r, unsigned ry) { const unsigned gpb = 256 / ry; return (unsigned)((r.ngroups + gpb - 1) / gpb); }
+static unsigned reduce_blocks(const PendingReduce& r, unsigned ry) { const unsigned upb = 256 / ry, nunits = (unsigned)r.ngroups / 2; return (nunits + upb - 1) / upb; }      // units = pairs of 16-byte groups
 static void launch_tiled_reduce(hipStream_t st, const PendingReduce& r) {
     const unsigned ry = reduce_ry(r);
     const dim3 rg(reduce_blocks(r, ry), 1, 1);
@@ -311,7 +311,8 @@ static int x3_tapwgrad_env() { const char* e = getenv("MI355_X3_TAPWGRAD"); retu
 int g_x3_tapwgrad = x3_tapwgrad_env();                   // split-storage filter gradients on the doubled-channel bf16 kernel: 0 off (default: the bf16x3 step is bound by its other stream, 2.742 ms either way), 1 conv2 / conv3, 2 every eligible layer; mi_set_tuning key 21
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
-int g_dense_wgrad_blocks = 256;                            // dense filter gradients: target block count (split-M atomics); mi_set_tuning key 11
+static int dense_wgrad_blocks_env() { const char* e = getenv("MI355_DENSE_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }
+int g_dense_wgrad_blocks = dense_wgrad_blocks_env();       // dense filter gradients: target block count (row splits); mi_set_tuning key 11
 static int nw_depth_env() { const char* e = getenv("MI355_NW_DEPTH"); return e ? atoi(e) : 3; }
 int g_nw_depth = nw_depth_env();                          // narrow_wgrad (uint8 conv1 shape): steps in flight per wave (3 | 5 | 6); mi_set_tuning key 19
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10

@@ -655,55 +655,76 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
 }
 
 // dW += sum over the position-split slabs written in accumulator order by tapwgrad_kernel, in a FIXED order (round 4: the ry slab chains of an element met in
-// atomics before).  A block owns 256 / ry 16-byte groups (block column, pair, kt, row group, lane); the ry threads of a group take every ry-th slab each, meet in
-// LDS in a fixed binary tree, and one of them does the filter-index decode and the read-modify-write of dW.  ry: a power of two <= 64, chosen from the layer's
-// shape only (conv_ops.hip, reduce_ry) so that small filters still fill the chip.
+// atomics before).  The unit of work is a PAIR of adjacent 16-byte groups = 8 consecutive slab values (block column, pair, kt, row group, two lanes): one 16-byte
+// load per bf16 slab (8-byte accesses run at 0.54-0.70 x the 16-byte rate, MI355X_MICROARCH.md).  A block owns 256 / ry units; the ry threads of a unit take
+// every ry-th slab each and meet in LDS behind ONE barrier; thread (value, part) then adds its share of the ry partial sums in slab-lane order (parts combined by
+// a fixed shuffle tree), does the filter-index decode and the read-modify-write of dW.  ry: a power of two <= 64, chosen from the layer's shape only
+// (conv_ops.hip, reduce_ry) so that small filters still fill the chip.
 template <int MODE, int TAPS, int KT, int NTB>
 __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int nslab, int ngroups, int bx, int ry, f32x4* sm) {
-    const int gpb = 256 / ry;
-    const int gl = (int)threadIdx.x & (gpb - 1), by = (int)threadIdx.x / gpb;
-    const int gid = bx * gpb + gl;
-    const bool live = gid < ngroups;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
+    const int upb = 256 / ry;                             // units per block
+    const int nunits = ngroups >> 1;                      // (ngroups is a multiple of 256)
+    const int ul = (int)threadIdx.x & (upb - 1), by = (int)threadIdx.x / upb;
+    const int uid = bx * upb + ul;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (uid < nunits) {
         if (p.slab_bf16) {
-            const bf16_t* src = (const bf16_t*)p.slabs + (long long)gid * 4;
-#pragma unroll 16
+            const bf16_t* src = (const bf16_t*)p.slabs + (long long)uid * 8;
+#pragma unroll 8
             for (int k = by; k < nslab; k += ry) {
-                const tw_u32x2 w = __builtin_nontemporal_load((const tw_u32x2*)(src + k * p.slab_stride));
-                s[0] += __builtin_bit_cast(float, w[0] << 16); s[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
-                s[2] += __builtin_bit_cast(float, w[1] << 16); s[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                const u32x4 w = __builtin_nontemporal_load((const u32x4*)(src + k * p.slab_stride));
+                s0[0] += __builtin_bit_cast(float, w[0] << 16); s0[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                s0[2] += __builtin_bit_cast(float, w[1] << 16); s0[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                s1[0] += __builtin_bit_cast(float, w[2] << 16); s1[1] += __builtin_bit_cast(float, w[2] & 0xffff0000u);
+                s1[2] += __builtin_bit_cast(float, w[3] << 16); s1[3] += __builtin_bit_cast(float, w[3] & 0xffff0000u);
             }
         } else {
-            const float* src = p.slabs + (long long)gid * 4;
-#pragma unroll 16
-            for (int k = by; k < nslab; k += ry) s += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+            const float* src = p.slabs + (long long)uid * 8;
+#pragma unroll 8
+            for (int k = by; k < nslab; k += ry) {
+                s0 += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+                s1 += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride + 4));
+            }
         }
     }
-    // the ry partial sums of a group meet in LDS: ONE barrier, then thread (group, element) adds its ry values in slab-lane order and does the
-    // read-modify-write of its element of dW (a binary tree cost four barriers per block: reduce_fused 37 -> 53 us)
-    float* const smf = (float*)sm;
-    sm[threadIdx.x] = s;
+    float* const smf = (float*)sm;                        // [by][unit][8]
+    sm[2 * threadIdx.x] = s0; sm[2 * threadIdx.x + 1] = s1;
     __syncthreads();
-    for (int idx = (int)threadIdx.x; idx < 4 * gpb; idx += 256) {
-        const int g2 = idx >> 2, e = idx & 3;
-        const int gid2 = bx * gpb + g2;
-        if (gid2 >= ngroups) continue;
-        float v = smf[g2 * 4 + e];
-        for (int k = 1; k < ry; ++k) v += smf[(k * gpb + g2) * 4 + e];
-        const int lane = gid2 & 63, g4 = (gid2 >> 6) & 3;
-        const int slot = gid2 >> 8;                       // (block column * npairs + pair) * KT + kt
+    const int nval = upb * 8;                             // values of this block: 2048 / ry
+    auto emit = [&](int vi, float v) {
+        const int u2 = vi >> 3, e = vi & 7;
+        const int gid = 2 * (bx * upb + u2) + (e >> 2);
+        const int lane = gid & 63, g4 = (gid >> 6) & 3;
+        const int slot = gid >> 8;                        // (block column * npairs + pair) * KT + kt
         const int kt = slot % KT, bp = slot / KT;
         const int pi = bp % p.npairs, bcol = bp / p.npairs;
         const int kb = bcol % p.nkb, nb = bcol / p.nkb;
         long long base, stride;
         const bool ok = tw_dw_index<MODE, TAPS>(p, kb * 32 * KT, nb * 32 * NTB, p.pair_tap[pi], kt, p.pair_nt[pi], 8 * g4 + 4 * (lane >> 5), lane & 31, base, stride);
-        if (ok) p.out[base + e * stride] += v;
+        if (ok) p.out[base + (e & 3) * stride] += v;
+    };
+    if (ry >= 8) {                                        // 256 = nval x P threads: part `part` adds slab lanes 8 part .. 8 part + 7, the P parts meet in a shuffle tree
+        const int P = ry >> 3;
+        const int part = (int)threadIdx.x & (P - 1), vi = (int)threadIdx.x / P;
+        const int u2 = vi >> 3, e = vi & 7;
+        float v = smf[((part * 8) * upb + u2) * 8 + e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += smf[((part * 8 + k) * upb + u2) * 8 + e];
+        for (int o = 1; o < P; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (part == 0 && bx * upb + u2 < nunits) emit(vi, v);
+    } else {
+        for (int vi = (int)threadIdx.x; vi < nval; vi += 256) {
+            const int u2 = vi >> 3, e = vi & 7;
+            if (bx * upb + u2 >= nunits) continue;
+            float v = smf[u2 * 8 + e];
+            for (int k = 1; k < ry; ++k) v += smf[(k * upb + u2) * 8 + e];
+            emit(vi, v);
+        }
     }
 }
 template <int MODE, int TAPS, int KT, int NTB>
 __global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams p, int nslab, int ngroups, int ry) {
-    __shared__ f32x4 sm[256];
+    __shared__ f32x4 sm[512];
     reduce_tiled_body<MODE, TAPS, KT, NTB>(p, nslab, ngroups, (int)blockIdx.x, ry, sm);
 }
 
@@ -765,7 +786,7 @@ struct FusedReduceParams {
     SmallReduceParams bias;
 };
 __global__ __launch_bounds__(256) void reduce_fused_kernel(const FusedReduceParams f) {
-    __shared__ f32x4 sm[256];
+    __shared__ f32x4 sm[512];
     const int b = (int)blockIdx.x;
     if (b >= f.first[f.n]) {                              // (block-uniform)
         sr_dispatch(f.bias, b - f.first[f.n], sm);

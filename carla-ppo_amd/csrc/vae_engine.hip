@@ -75,7 +75,7 @@ struct Workspace {
     long long scratch_side, scratch_side_bytes;    // ... of the latent layers' gradients when they run on the filter-gradient stream (outside the rotating regions: those may hold deferred slabs)
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
-    long long eps_buf, rng, idx_stage, scalars;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64); staged minibatch indices; alpha
+    long long eps_buf, rng;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64)
     long long total;
     // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
     // finds the region a kernel wrote past (the bounds-checking debug mode of the new build)
@@ -133,7 +133,6 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
-    int capturing;                      // the launch sequence is being recorded into a hipGraph (plain event records only)
     int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
     hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
     hipEvent_t ev_lat, ev_third;
@@ -142,10 +141,6 @@ struct VaeEngine {
     int rng_ready;                      // generator state in the workspace has been initialised (mi_vae_set_seed)
     const float* last_eps;              // the noise the last sampling forward used (caller's buffer or the engine's own draw)
     int last_u8;                        // frame-table format of the last forward (backward reads the same source table)
-    // one captured SGD step (mi_vae_train_step with use_graph): replayed while the call's pointer arguments stay the same
-    hipGraphExec_t gexec;
-    hipStream_t cap; int cap_ok;        // engine-owned stream the step is recorded on
-    struct GraphKey { const void *src, *tgt, *eps, *metrics, *stream; int u8, has_idx, B; float inv_batch, b1, b2, epsilon, mw; } gkey;
     // weights as the MFMA kernels read them: the fp32 masters (MI_F32) or the shadow copy Adam keeps in the engine's storage type (bf16 / split)
     const void* wptr(int t) const { return d.dtype == MI_F32 ? (const void*)(params + L.off[t]) : (const void*)((const char*)shadow + L.off[t] * esz); }
     const void* wtptr(int t) const { return (const void*)((const char*)wt + L.off[t] * esz); }
@@ -215,7 +210,7 @@ void make_workspace(VaeEngine& e) {
         W.roll_bytes = (n + d.z_dim + 64) * 4;
         W.roll = add(W.roll_bytes);
     }
-    W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256); W.idx_stage = add(B * 4); W.scalars = add(256);
+    W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256);
     W.total = o;
 }
 
@@ -388,8 +383,6 @@ int mi_vae_debug_check_guards(void* h, int* n_regions, int* n_bad, int guard_ind
 
 void mi_vae_destroy(void* h) {
     VaeEngine* e = (VaeEngine*)h;
-    if (e && e->gexec) hipGraphExecDestroy(e->gexec);
-    if (e && e->cap_ok == 1) hipStreamDestroy(e->cap);
     if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
     if (e && e->third_ok == 1) { hipStreamDestroy(e->third); hipEventDestroy(e->ev_lat); hipEventDestroy(e->ev_third); }
     free(h);
@@ -451,7 +444,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     if (tail_try) {
         static int kev = -1;
         if (kev < 0) { const char* ev = getenv("MI355_KEVENT"); kev = ev ? atoi(ev) : 1; }
-        const bool carry = kev && !e->capturing && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
+        const bool carry = kev && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
         if (carry) mi_tl_stop_event = e->ev_ready;
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                            tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, e->at(e->W.gdec[3]), e->gptr(18),
@@ -529,7 +522,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     // no marker on the caller's queue, and the other queue's wait resolves the moment that kernel retires.
     static int kev_env = -1;
     if (kev_env < 0) { const char* ev = getenv("MI355_KEVENT"); kev_env = ev ? atoi(ev) : 1; }
-    const int kev = e->capturing ? 0 : kev_env;
+    const int kev = kev_env;
     bool produced = fork && kev && e->fwd_produced && (part == 0 || part == 1);      // ev_ready already rides on the last kernel issued on st
     e->fwd_produced = 0;
     auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
@@ -764,87 +757,23 @@ int mi_vae_set_seed(void* h, unsigned long long seed) {
     return MI_OK;
 }
 
-namespace {
-// the per-step values of a (captured) step travel through device memory: this rank's rows of the minibatch and Adam's step size
-__global__ void stage_step_kernel(const int* __restrict__ idx, int B, int* __restrict__ idx_stage, float alpha, float* __restrict__ scalars) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx && i < B) idx_stage[i] = idx[i];
-    if (i == 0) scalars[0] = alpha;
-}
-}  // namespace
 
-// One whole SGD step (the reference's sess.run([train_step, ...]), vae/models.py:213-216): forward + ELBO, backward, TF-Adam, on ONE call.
-// use_graph != 0: the launch sequence (38 dispatches on two streams) is captured into a hipGraph the first time and replayed while the
-// pointer arguments, batch size and hyper-parameters stay the same; what changes every step -- the minibatch rows and Adam's bias-corrected
-// step size -- is staged into the workspace by one small kernel in front of the replay, and the noise stream continues from its device-side
-// offset.  Single-rank path: the data-parallel host drives mi_vae_forward / _backward(parts) / _apply_adam around its bucket all-reduces.
+// One whole SGD step (the reference's sess.run([train_step, ...]), vae/models.py:213-216): forward + ELBO, backward, TF-Adam, in ONE call; nothing synchronises the
+// host.  Single-rank path: the data-parallel host drives mi_vae_forward / _backward(parts) / _apply_adam around its bucket all-reduces.
+// (Rounds 2-3 could also capture this launch sequence into a hipGraph and replay it; replay measured slower than the eager launches every time -- 1.26 vs 1.19 ms in
+//  round 2, 0.991 vs 0.878 ms in round 3: ROCm 7.2 executes the captured fork / join of the two backward streams without their overlap, and the host is nowhere near
+//  launch-bound at ~36 launches per 0.9 ms -- so round 4 removed the path instead of shipping a flag that loses 13 %: DESIGN finding 15.)
 int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps,
-                      float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight, int use_graph) {
+                      float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight) {
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
-    hipStream_t st = (hipStream_t)stream;
-    int* idx_stage = (int*)e->at(e->W.idx_stage);
-    float* scalars = (float*)e->at(e->W.scalars);
-    // eager: on request; while per-op timing brackets single launches with events; and with injected noise (a parity-run pattern: the caller's
-    // eps buffer usually changes every step, which would mean a new capture every step).  Eager launches take the caller's rows and Adam's step
-    // size as they are (no staging kernel: 4.6 us at the head of the step's dependency chain)
     struct FinGuard { VaeEngine* e; ~FinGuard() { e->defer_fin = 0; } } fin_guard{e};
     static int defer_on = -1;                           // MI355_DEFER=0: loss finalisation and the tail's slab reduce right behind the forward pass (A/B runs)
     if (defer_on < 0) { const char* ev = getenv("MI355_DEFER"); defer_on = (ev && ev[0] == '0') ? 0 : 1; }
     e->defer_fin = defer_on;                            // forward + backward are issued together here: the loss scalars are finalised inside the backward pass
-    if (!use_graph || e->tm.mode || eps) {
-        CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
-        CK(mi_vae_backward(h, stream, src, idx, eps, inv_batch, 0));
-        return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
-    }
-    hipLaunchKernelGGL(stage_step_kernel, dim3((B + 255) / 256), dim3(256), 0, st, idx, B, idx_stage, alpha, scalars);
-    CK(mi_check_launch("stage_step"));
-    const int* idx_in = idx ? idx_stage : nullptr;
-    auto body = [&](void* s) -> int {
-        CK(mi_vae_forward(h, s, src, tgt, frames_u8, idx_in, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
-        CK(mi_vae_backward(h, s, src, idx_in, eps, inv_batch, 0));
-        return apply_adam(e, s, 0.f, scalars, beta1, beta2, epsilon);
-    };
-    const VaeEngine::GraphKey key = {src, tgt, eps, metrics3, stream, frames_u8 ? 1 : 0, idx ? 1 : 0, B, inv_batch, beta1, beta2, epsilon, metric_weight};
-    if (!e->gexec || memcmp(&key, &e->gkey, sizeof(key)) != 0) {
-        if (e->gexec) {                                   // the previous graph may still be running on the caller's stream
-            if (hipStreamSynchronize(st) != hipSuccess) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: stream synchronisation failed");
-            hipGraphExecDestroy(e->gexec); e->gexec = nullptr;
-        }
-        if (!e->side_ok) {                                // the second stream and its events are created outside the capture
-            if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
-                hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
-            else e->side_ok = -1;
-        }
-        if (!e->third_ok) {
-            const char* ev3 = getenv("MI355_THIRD");
-            if (ev3 && ev3[0] == '1') {
-                if (hipStreamCreateWithFlags(&e->third, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_lat, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&e->ev_third, hipEventDisableTiming) == hipSuccess) e->third_ok = 1;
-                else e->third_ok = -1;
-            }
-        }
-        // the caller's stream may be the legacy null stream, which cannot be captured: the launch sequence is recorded on a stream of the
-        // engine's own and the instantiated graph is then launched on the caller's stream
-        if (!e->cap_ok) e->cap_ok = hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking) == hipSuccess ? 1 : -1;
-        if (e->cap_ok != 1) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: could not create the capture stream");
-        const hipError_t be = hipStreamBeginCapture(e->cap, hipStreamCaptureModeThreadLocal);
-        if (be != hipSuccess) { (void)hipGetLastError(); return mi_fail(MI_ERR_STATE, hipGetErrorString(be)); }
-        e->capturing = 1;
-        const int rc = body((void*)e->cap);
-        e->capturing = 0;
-        hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(e->cap, &graph);
-        if (rc != MI_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-        if (ce != hipSuccess || !graph) return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipStreamEndCapture failed");
-        const hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (ie != hipSuccess) { e->gexec = nullptr; return mi_fail(MI_ERR_STATE, "mi_vae_train_step: hipGraphInstantiate failed"); }
-        memset(&e->gkey, 0, sizeof(e->gkey));
-        e->gkey = key;
-    }
-    if (hipGraphLaunch(e->gexec, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_vae_train_step: hipGraphLaunch failed");
-    return MI_OK;
+    CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+    CK(mi_vae_backward(h, stream, src, idx, eps, inv_batch, 0));
+    return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
 }
 
 // One environment step of the rollout loop in ONE call (callers vae_common.py:45-61, train.py:142, run_eval.py:54):

@@ -224,12 +224,12 @@ class VaeDevice:
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.L.mi_vae_apply_adam(self.handle, self.stream(), float(alpha), float(beta1), float(beta2), float(epsilon))
 
-    def train_step(self, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, graph=True, accumulate_metrics=True):
-        """One whole SGD step in one C call; graph=True replays the captured hipGraph of the step (single-rank path)."""
+    def train_step(self, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, accumulate_metrics=True):
+        """One whole SGD step in one C call (single-rank path)."""
         self.ensure_batch(B)
         p = milib.ptr
         self.L.mi_vae_train_step(self.handle, self.stream(), p(src), p(tgt), self._u8(src, tgt), p(idx), int(B), float(inv_batch), p(eps), float(alpha),
-                                 float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch), 1 if graph else 0)
+                                 float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)

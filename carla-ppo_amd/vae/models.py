@@ -293,11 +293,9 @@ class VAE():
         then conv3..conv1: each bucket's gradient all-reduce overlaps the next part), fused Adam."""
         dev = self.dev
         if midist.world_size() == 1 and hasattr(dev, "train_step"):
-            # single rank: the whole step is one C call.  MI355_GRAPH=1 replays the captured hipGraph of the step instead of launching eagerly:
-            # measured SLOWER on ROCm 7.2 (1.26 vs 1.19 ms per step at batch 512: the graph loses the overlap of the two backward streams and
-            # gains nothing at same-stream kernel boundaries, profiles/r02_*), so eager launches are the default
+            # single rank: the whole step is one C call (eager launches; the hipGraph replay of rounds 2-3 was slower every time it was measured and is gone)
             dev.train_step(src, tgt, idx, n_local, inv_batch, eps, adam_alpha(self.learning_rate_value, self.beta1_power, self.beta2_power),
-                           ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON, graph=os.environ.get("MI355_GRAPH", "0") == "1")
+                           ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
             self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
             self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
             return

@@ -239,8 +239,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
 int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
 /* seed of the engine's own N(0,1) source (TF's graph-level seed, train.py:50-51) */
 int mi_vae_set_seed(void* h, unsigned long long seed);
-/* one whole SGD step = the reference's sess.run([train_step, ...]) (vae/models.py:213-216) in ONE call; use_graph != 0: captured once as a hipGraph and replayed */
-int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight, int use_graph);
+/* one whole SGD step = the reference's sess.run([train_step, ...]) (vae/models.py:213-216) in ONE call (eager launches on the caller's stream + the engine's filter-gradient stream; nothing synchronises the host) */
+int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
 /* VAE.encode / generate_from_latent (= north_star "decode") / reconstruct — vae/models.py:188-202 */
 int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
