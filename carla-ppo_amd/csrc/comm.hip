@@ -27,8 +27,6 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
-    ncclResult_t (*GroupStart)(void);
-    ncclResult_t (*GroupEnd)(void);
     const char* (*GetErrorString)(ncclResult_t);
 };
 
@@ -49,8 +47,6 @@ int load_rccl() {
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
     r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(lib, "ncclReduceScatter");      // optional: the two-phase schedule below is skipped without them
     r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
-    r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
-    r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GetErrorString)
         return mi_fail(MI_ERR_STATE, "mi_comm: librccl.so.1 lacks an entry point");
     r.lib = lib;
@@ -64,17 +60,24 @@ struct MiComm {
     hipStream_t side;                                     // the all-reduce stream of the `_async` form
     hipEvent_t ready, done;
     int pending;                                          // buckets queued on `side` since the last mi_comm_wait
+    int algo;                                             // gradient-bucket schedule: 0 ncclAllReduce, 1 reduce-scatter + all-gather (mi_comm_set_algo: the SAME value on every rank)
 };
 
 // Gradient-bucket schedule: 0 = ncclAllReduce (RCCL picks ring / tree / one-shot itself), 1 = reduce-scatter + all-gather: on the
 // fully connected xGMI mesh of one node every rank owns 1/W of the bucket, receives the other ranks' pieces of ITS slice over the seven direct
 // links in one hop, sums, and sends its finished slice back over the same links -- 2 (W-1)/W of the bucket per link direction, no multi-hop ring.
-// MI355_COMM_ALGO=rsag selects it; both forms sit behind mi_allreduce_sum_f32 so callers never see the difference.  (Validated at world size 1
-// only -- no multi-GPU box in this build environment -- hence off by default.)
-int comm_algo() {
-    static int algo = -1;
-    if (algo < 0) { const char* e = getenv("MI355_COMM_ALGO"); algo = (e && strcmp(e, "rsag") == 0) ? 1 : 0; }
-    return algo;
+// Both forms sit behind mi_allreduce_sum_f32 so callers never see the difference.  The schedule is a property of the COMMUNICATOR, set by
+// mi_comm_set_algo after the ranks have agreed on it (mi355/dist.py: MI355_COMM_ALGO is read per process and a mismatch would pair one rank's
+// reduce-scatter with another's all-reduce -- a hang).  (Never timed: no multi-GPU box in this build environment -- hence off by default.)
+// What one call issues is a pure function of (algo, world, rank, n): mi_comm_allreduce_plan, checked on the CPU for every rank of 2 / 4 / 8.
+struct Plan { int rsag; long long chunk, mine, tail_off, tail_n; };
+Plan plan_of(int algo, int world, int rank, long long n) {
+    Plan p = {0, 0, 0, 0, 0};
+    const long long chunk = world > 0 ? n / world : 0;
+    if (algo == 1 && world > 1 && chunk >= 1024) {
+        p.rsag = 1; p.chunk = chunk; p.mine = (long long)rank * chunk; p.tail_off = chunk * world; p.tail_n = n - chunk * world;
+    }
+    return p;
 }
 
 int rccl_fail(const char* what, ncclResult_t r) {
@@ -85,17 +88,16 @@ int rccl_fail(const char* what, ncclResult_t r) {
 
 // in-place sum of buf[0..n) over the ranks on stream `st`
 int allreduce_on(MiComm* c, float* buf, long long n, hipStream_t st) {
-    const long long chunk = n / c->world;
-    if (comm_algo() == 1 && c->world > 1 && chunk >= 1024 && g_rccl.ReduceScatter && g_rccl.AllGather && g_rccl.GroupStart && g_rccl.GroupEnd) {
+    const Plan p = plan_of(c->algo, c->world, c->rank, n);
+    if (p.rsag && g_rccl.ReduceScatter && g_rccl.AllGather) {
         // slice r of the first chunk * W elements belongs to rank r (both calls in RCCL's in-place form); the n % W tail rides along as a tiny all-reduce
-        float* mine = buf + (long long)c->rank * chunk;
-        ncclResult_t r = g_rccl.ReduceScatter(buf, mine, (size_t)chunk, ncclFloat, ncclSum, c->comm, st);
+        float* mine = buf + p.mine;
+        ncclResult_t r = g_rccl.ReduceScatter(buf, mine, (size_t)p.chunk, ncclFloat, ncclSum, c->comm, st);
         if (r != ncclSuccess) return rccl_fail("ncclReduceScatter", r);
-        r = g_rccl.AllGather(mine, buf, (size_t)chunk, ncclFloat, c->comm, st);
+        r = g_rccl.AllGather(mine, buf, (size_t)p.chunk, ncclFloat, c->comm, st);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-        const long long tail = n - chunk * c->world;
-        if (tail > 0) {
-            r = g_rccl.AllReduce(buf + chunk * c->world, buf + chunk * c->world, (size_t)tail, ncclFloat, ncclSum, c->comm, st);
+        if (p.tail_n > 0) {
+            r = g_rccl.AllReduce(buf + p.tail_off, buf + p.tail_off, (size_t)p.tail_n, ncclFloat, ncclSum, c->comm, st);
             if (r != ncclSuccess) return rccl_fail("ncclAllReduce (tail)", r);
         }
         return MI_OK;
@@ -144,6 +146,25 @@ int mi_comm_init(void** comm_out, int rank, int world, const unsigned char* id) 
         return mi_fail(MI_ERR_STATE, "mi_comm_init: stream / event creation failed");
     }
     *comm_out = c;
+    return MI_OK;
+}
+
+// the gradient-bucket schedule of this communicator: 0 = ncclAllReduce, 1 = reduce-scatter + all-gather (needs both entry points in the bound library).  Every rank
+// must set the SAME value (the caller agrees on it first: mi355/dist.py); returns the previous one
+int mi_comm_set_algo(void* comm, int algo) {
+    MiComm* c = (MiComm*)comm;
+    if (!c || algo < 0 || algo > 1) return mi_fail(MI_ERR_ARG, "mi_comm_set_algo: bad arguments");
+    if (algo == 1 && !(g_rccl.ReduceScatter && g_rccl.AllGather)) return mi_fail(MI_ERR_STATE, "mi_comm_set_algo: the bound RCCL lacks ncclReduceScatter / ncclAllGather");
+    c->algo = algo;
+    return MI_OK;
+}
+
+// what one all-reduce of n floats issues on rank `rank` of `world` under schedule `algo` (no GPU, no RCCL needed): out[0] = 1 reduce-scatter + all-gather / 0 one
+// ncclAllReduce of n; out[1] = floats per rank slice; out[2] = this rank's slice offset; out[3], out[4] = offset and length of the tail all-reduce (n % world floats)
+int mi_comm_allreduce_plan(int algo, int world, int rank, long long n, long long* out5) {
+    if (!out5 || world < 1 || rank < 0 || rank >= world || n < 0 || algo < 0 || algo > 1) return mi_fail(MI_ERR_ARG, "mi_comm_allreduce_plan: bad arguments");
+    const Plan p = plan_of(algo, world, rank, n);
+    out5[0] = p.rsag; out5[1] = p.chunk; out5[2] = p.mine; out5[3] = p.tail_off; out5[4] = p.tail_n;
     return MI_OK;
 }
 

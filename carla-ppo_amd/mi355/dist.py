@@ -113,23 +113,31 @@ def mi_comm():
     try:
         L.mi_comm_init(ctypes.addressof(handle), r, W, idt.data_ptr())
         c = _MiComm(handle, L)
-        probe = torch.full((4096,), float(r + 1), dtype=torch.float32, device=dev)
+        # the bucket schedule is a property of the communicator and must be the same everywhere: every rank states what its environment asks for, the
+        # minimum wins (one rank without MI355_COMM_ALGO=rsag keeps all of them on ncclAllReduce), and only then is it set
+        want_algo = torch.tensor([1 if os.environ.get("MI355_COMM_ALGO") == "rsag" else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(want_algo, op=dist.ReduceOp.MIN)
+        algo = int(want_algo.item())
+        if algo:
+            L.mi_comm_set_algo(handle, algo)
+        # known sums through BOTH entry points, sized so that the selected schedule is the one exercised (rank slices of >= 1024 floats at any world size)
+        n_probe = 4096 * W
+        probe = torch.full((n_probe,), float(r + 1), dtype=torch.float32, device=dev)
         c.all_reduce(probe)
-        c.all_reduce(probe[:1024], async_op=True).wait()
+        c.all_reduce(probe[:n_probe // 2], async_op=True).wait()
         torch.cuda.synchronize(dev)
         want = W * (W + 1) / 2.0
-        ok = bool((probe[1024:] == want).all().item()) and bool((probe[:1024] == want * W).all().item())
+        ok = bool((probe[n_probe // 2:] == want).all().item()) and bool((probe[:n_probe // 2] == want * W).all().item())
         b = torch.full((256,), float(r), dtype=torch.float32, device=dev)
         c.broadcast(b, 0)
         torch.cuda.synchronize(dev)
         ok = ok and bool((b == 0).all().item())
     except Exception:
-        ok, c = False, None
+        ok, c, algo = False, None, 0
     if not _all_agree(ok, dev):
         return None
     _mi_comm = c
-    comm_note = "mi_comm (RCCL through the C ABI, on the engine's stream%s)" % (
-        "; reduce-scatter + all-gather schedule" if os.environ.get("MI355_COMM_ALGO") == "rsag" else "")
+    comm_note = "mi_comm (RCCL through the C ABI, on the engine's stream%s)" % ("; reduce-scatter + all-gather schedule" if algo else "")
     if not _atexit_registered[0]:
         import atexit
         atexit.register(shutdown)

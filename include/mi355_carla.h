@@ -261,8 +261,14 @@ int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char*
  *   mi_broadcast                rank `root`'s bytes to every rank (the initial parameter replica, vae/models.py / ppo.py init_session)
  *   mi_comm_probe               binds librccl (dlopen + entry points) and nothing else: called on EVERY rank before the collective mi_comm_init so that
  *                               a rank that cannot load RCCL is agreed on while everybody can still fall back together
- * MI355_COMM_ALGO=rsag: the all-reduce of a bucket as reduce-scatter + all-gather (one hop per phase on the fully connected xGMI mesh). */
+ *   mi_comm_set_algo            gradient-bucket schedule of this communicator: 0 = ncclAllReduce (default), 1 = reduce-scatter + all-gather (one hop per phase on the
+ *                               fully connected xGMI mesh).  The SAME value on every rank: the host agrees on it first (mi355/dist.py reads
+ *                               MI355_COMM_ALGO=rsag per process and takes the minimum over the ranks)
+ *   mi_comm_allreduce_plan      what one all-reduce of n floats issues on a given rank under a schedule (pure function, no GPU: checked on the CPU for every rank):
+ *                               out5 = {rsag?, floats per rank slice, this rank's slice offset, tail offset, tail floats} */
 int mi_comm_probe(void);
+int mi_comm_set_algo(void* comm, int algo);
+int mi_comm_allreduce_plan(int algo, int world, int rank, long long n, long long* out5);
 int mi_comm_id_bytes(void);
 int mi_comm_unique_id(unsigned char* id_out);
 int mi_comm_init(void** comm_out, int rank, int world, const unsigned char* id);

@@ -421,6 +421,25 @@ def test_dp_collective_schedule_is_identical_on_every_rank(tmp_path, monkeypatch
         assert len(per_step) == 6 and sum(c[1] for c in per_step[:3]) == 2584392      # 3 buckets x 2 steps; the buckets tile the flat gradient buffer
         assert seqs[0][-1] == ("all_reduce_sum", 3, False)                            # the epoch's metric sums
         per_rank.append(seqs[0])
+        # what each of those bucket all-reduces becomes INSIDE the library under either schedule (mi_comm_allreduce_plan: the pure function csrc/comm.hip's
+        # allreduce_on executes): the same ops with the same element counts on every rank -- a rank that scattered while another all-reduced would hang.
+        # rsag: W equal rank slices tiling the bucket's first chunk * W floats (slice r at offset r * chunk), the n % W tail as one small all-reduce.
+        from mi355 import lib as milib
+        L = milib.get()
+        for (_, n, _async) in per_step[:3]:
+            for algo in (0, 1):
+                plans = []
+                for r in range(world):
+                    out = np.zeros(5, np.int64)
+                    assert L.mi_comm_allreduce_plan(algo, world, r, n, out.ctypes.data) == 0
+                    plans.append(out.copy())
+                assert all(pl[0] == plans[0][0] and pl[1] == plans[0][1] and pl[3] == plans[0][3] and pl[4] == plans[0][4] for pl in plans), (n, algo)
+                rsag, chunk, _, tail_off, tail_n = (int(x) for x in plans[0])
+                if algo == 0 or n // world < 1024:
+                    assert rsag == 0                       # one ncclAllReduce of n floats everywhere
+                else:
+                    assert rsag == 1 and chunk == n // world and [int(pl[2]) for pl in plans] == [r * chunk for r in range(world)]
+                    assert tail_off == chunk * world and tail_n == n - chunk * world and 0 <= tail_n < world
     assert all(len(s) == len(per_rank[0]) for s in per_rank)
 
 
