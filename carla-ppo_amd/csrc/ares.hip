@@ -1,0 +1,65 @@
+// ares.hip — host side of the activation-resident kernels (ares_tile.hpp) for the four small-grid layers of the ConvVAE: conv4 forward / deconv1 input
+// gradient (conv form) and deconv1 forward / conv4 input gradient (gather form).  bf16 storage, the model's geometry only; anything else returns
+// "not launched" and the caller takes the general kernels (gemm2 / tapconv).
+#include <stdlib.h>
+#include "ares_tile.hpp"
+#include "mi_internal.hpp"
+#include "mi355_carla.h"
+
+using namespace mi;
+
+static bool ares_on() {                                     // MI355_ARES=0: the general tile kernels (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_ARES"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+extern "C" {
+
+// bytes of one fragment-ordered weight copy (either form: 16 x 128 x 256 bf16)
+long long mi_ares_weight_bytes(void) { return 16ll * 128 * 256 * 2; }
+
+// fp32 master kernel -> fragment order (bf16).  form 0 (conv form): w is [kh][kw][128][256] -- conv4's HWIO kernel for its forward pass, or deconv1's
+// [kh,kw,out = 128,in = 256] kernel for deconv1's INPUT gradient.  form 1 (gather form): w is [kh][kw][128][256] read as [kh][kw][n][c] -- deconv1's kernel
+// for its forward pass, or conv4's HWIO kernel for conv4's INPUT gradient.  (vae/models.py:253,261 and their gradients behind :142)
+int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out) {
+    if (!w_fp32 || !wf_out || form < 0 || form > 1) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
+    if ((((uintptr_t)w_fp32) | ((uintptr_t)wf_out)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(ares_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_fp32, (bf16_t*)wf_out, form);
+    return mi_check_launch("ares_pack_kernel");
+}
+
+// form 0: x [B,8,18,128] -> out [B,3,8,256] (k4 s2 conv: out = relu?(conv(x) + bias), masked by `mask` [B,3,8,256] when given);
+// form 1: x [B,3,8,256] -> out [B,8,18,128] (k4 s2 transposed conv in gather form, same epilogue, mask [B,8,18,128]).
+// wf: the fragment-ordered weights of mi_ares_pack_weights(form).  *launched = 0: not eligible (nothing was launched; use the general ops).
+int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched) {
+    if (!launched) return mi_fail(MI_ERR_ARG, "mi_ares_conv: missing arguments");
+    *launched = 0;
+    if (!ares_on() || dtype != MI_BF16 || form < 0 || form > 1 || !x || !wf || !out || B < 1) return MI_OK;
+    if ((((uintptr_t)x) | ((uintptr_t)wf) | ((uintptr_t)out) | ((uintptr_t)mask) | ((uintptr_t)bias)) & 15) return MI_OK;
+    const long long xb = (long long)B * 36864;             // 8 x 18 x 128 = 3 x 8 x 256 bf16 per frame... (both forms: 18,432 elements)
+    if (xb >= (long long)G2_OOB || (long long)B * 144 * 128 >= (1ll << 31)) return MI_OK;
+    AresParams p = {};
+    p.x = x; p.x_bytes = (uint32_t)xb; p.wf = wf; p.B = B;
+    p.out = out; p.bias = bias; p.mask = mask; p.relu = relu; p.out_f32 = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (form == 0) {
+        p.M = B * 24; p.N = AC_N; p.OH = AC_OH; p.OW = AC_OW;
+        const int groups = (B + AC_F - 1) / AC_F;
+        const int nb = (groups + 7) / 8 * 16;                // block b: frame group (b & 7) + 8 (b >> 4), column half (b >> 3) & 1
+        MI_LAUNCH(ares_conv_kernel, dim3(nb), dim3(256), 0, st, p);
+        const int rc = mi_check_launch("ares_conv_kernel");
+        if (rc != MI_OK) return rc;
+    } else {
+        p.M = B * AG_RPF; p.N = AG_N; p.OH = AG_OH; p.OW = AG_OW;
+        for (int c = 0; c < 4; ++c) { p.dc_ohw[c] = make_fastdiv(AG_RPF); p.dc_ow[c] = make_fastdiv(9); }
+        const int groups = (B + AG_F - 1) / AG_F;
+        MI_LAUNCH(ares_gather_kernel, dim3(groups * 4), dim3(256), 0, st, p);
+        const int rc = mi_check_launch("ares_gather_kernel");
+        if (rc != MI_OK) return rc;
+    }
+    *launched = 1;
+    return MI_OK;
+}
+
+}  // extern "C"

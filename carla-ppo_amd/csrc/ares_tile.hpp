@@ -1,0 +1,264 @@
+// ares_tile.hpp — "activation-resident" kernels for the four SMALL-GRID layers of the ConvVAE (round 4).
+//
+// conv4 forward / deconv1 input gradient (conv form, k4 s2: [B,8,18,128] -> [B,3,8,256]) and deconv1 forward / conv4 input gradient (gather form,
+// k4 s2: [B,3,8,256] -> [B,8,18,128]) are GEMMs with a LONG reduction (K = 2048 / 1024 per parity class) and FEW output rows (24 / 144 per frame).
+// As im2col tiles (gemm2: 96 x 4 blocks of 128 x 64; tapconv: 100 x 4 blocks) they ran 29.5 + 29.5 + 41.4 + 41.4 us at 15-24 % MFMA: 1.5 blocks per CU
+// (two rounds of 32 latency-bound k-steps), every A row re-fetched once per column tile, and ~1,100 cycles per k-step for 256 cycles of MFMA because a
+// 128 x 64 x 64 stage costs each wave six LDS-DMA instructions (~150 issue cycles apiece next to MFMAs, MI355X_MICROARCH.md).
+//
+// Here the roles are swapped.  A whole FRAME of input is tiny (36,864 B conv form, 12,288 B gather form), so a block keeps the complete inputs of a GROUP
+// of frames resident in LDS -- loaded ONCE, contiguously, no im2col duplication, no per-step DMA -- and streams the WEIGHTS through registers:
+//   * the weights live in HBM/L2 in FRAGMENT ORDER (mi_ares_pack_weights: [n tile][k16 step][lane][8 bf16] = one contiguous 1 KiB wave load per MFMA
+//     operand), so a wave walks its 32 output channels' weights as a purely sequential stream with eight loads in flight; 1 MB per layer: L2 resident;
+//   * a wave owns 32 output channels and ALL rows of the block (3 / 9 accumulator tiles of 32 x 32): one weight fragment feeds 3 / 9 MFMAs;
+//   * the A operand of every (tap, channel step) is a 16-byte LDS read per lane at pixel(tap) + chunk; pixels are stored with their 16-byte chunks
+//     ROTATED by a per-pixel amount that is linear in the pixel coordinates, chosen so that the 16 lanes of every ds_read_b128 service group hit 16 different
+//     chunk positions for every tap (conflict-free; a per-tap constant shifts all lanes alike);
+//   * grid = exactly one block per CU at batch 512: conv form 128 frame groups (4 frames = 96 rows) x 2 column halves; gather form 64 frame groups
+//     (8 frames = 288 rows per parity class) x 4 classes.
+// MFMA work per block: conv form 3 x 128 = 384, gather form 9 x 64 = 576 v_mfma_f32_32x32x16_bf16 per wave = 5.1 / 7.7 us at full issue rate.
+#pragma once
+#include "gemm_tile.hpp"
+#include "gemm2_tile.hpp"
+
+namespace mi {
+
+struct AresParams {
+    const void* x; uint32_t x_bytes;                      // input tensor [B, IH, IW, C] (bf16)
+    const void* wf;                                       // fragment-ordered weights (mi_ares_pack_weights)
+    int B, M;                                             // frames; output rows (conv form: B * 24; gather form: B * 36 per parity class)
+    // epilogue (store_tile)
+    void* out; const float* bias; const void* mask; int relu, out_f32;
+    int N, OH, OW;
+    FastDiv dc_ohw[4], dc_ow[4];
+};
+
+// ---- conv form: [B,8,18,128] -> [B,3,8,256], k = 4, s = 2 ----
+constexpr int AC_F = 4, AC_IH = 8, AC_IW = 18, AC_C = 128, AC_OH = 3, AC_OW = 8, AC_N = 256;
+constexpr int AC_PIX = AC_IH * AC_IW;                     // 144 pixels per frame, 256 B each
+constexpr int AC_KS = 16 * AC_C / 16;                     // 128 k16-steps (16 taps x 8)
+constexpr int AC_LDS = AC_F * AC_PIX * 256;               // 147,456 B
+constexpr int AR_D = 8;                                   // weight fragments in flight per wave
+
+__global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[AC_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, g = lane >> 5;
+    // blocks b and b + 8 (same XCD: b % 8) are the two column halves of one frame group: its frames come out of that XCD's L2 the second time
+    const int b = (int)blockIdx.x;
+    const int nh = (b >> 3) & 1, fg = (b & 7) + 8 * (b >> 4);
+    const int f0 = fg * AC_F;
+    if (f0 >= p.B) return;
+
+    // ---- stage the group's frames: 144 LDS-DMA instructions of 1 KiB (4 pixels x 16 chunks), source-side chunk rotation ----
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    {
+        const int pq = lane >> 4, pc = lane & 15;         // pixel of the quad, PHYSICAL chunk this lane fills
+#pragma unroll 4
+        for (int t = wave; t < AC_F * AC_PIX / 4; t += 4) {
+            const int q = 4 * t + pq;                     // block-local pixel
+            const int f = q / AC_PIX, rem = q - f * AC_PIX;
+            const int y = rem / AC_IW, x = rem - y * AC_IW;
+            const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
+            const int jc = (pc - s) & 15;                 // logical chunk that lives at physical position pc
+            const int frame = f0 + f;
+            const uint32_t vo = frame < p.B ? (uint32_t)((frame * AC_PIX + rem) * 256 + jc * 16) : G2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)vo, 0, 0, 0);
+        }
+    }
+
+    // ---- this wave's weight stream: 32 output channels, 128 fragments of 1 KiB, AR_D in flight ----
+    const int nt = nh * 4 + wave;                         // 32-channel tile of the 256 outputs
+    const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)nt * AC_KS) * 64 + lane;
+    u16x8 bq[AR_D];
+#pragma unroll
+    for (int d = 0; d < AR_D; ++d) bq[d] = wl[d * 64];
+
+    // ---- per-lane A addressing: row r = 32 i + lrow of the block = (frame f, output pixel (oy, ox)) ----
+    uint32_t pixbase[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = i * 32 + lrow;
+        const int f = r / 24, rem = r - f * 24;
+        const int oy = rem >> 3, ox = rem & 7;
+        pixbase[i] = (uint32_t)((f * AC_PIX + 2 * oy * AC_IW + 2 * ox) * 256);
+    }
+    const int s0 = lrow & 15;                             // (8 f + 8 oy + ox) & 15 = r & 15: the row's share of the chunk rotation
+
+    f32x16 acc[3][1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    __syncthreads();                                      // (s_waitcnt vmcnt(0) + barrier: the frames are in LDS -- and so are the first weight fragments)
+
+    auto a_off = [&](int ks) -> uint32_t {                // byte offset (same for the three tiles) of step ks' chunk relative to pixbase
+        const int tap = ks >> 3, ky = tap >> 2, kx = tap & 3;
+        const int j = (ks & 7) * 2 + g;
+        const int phys = (j + s0 + 8 * (ky >> 1) + (kx >> 1)) & 15;
+        return (uint32_t)((ky * AC_IW + kx) * 256 + phys * 16);
+    };
+    u16x8 an[3];
+    {
+        const uint32_t o = a_off(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
+    }
+    for (int k8 = 0; k8 < AC_KS; k8 += AR_D) {
+#pragma unroll
+        for (int d = 0; d < AR_D; ++d) {
+            const int ks = k8 + d;
+            u16x8 a[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[i] = an[i];
+            if (ks + 1 < AC_KS) {                         // next step's A fragments are requested before this step's MFMAs
+                const uint32_t o = a_off(ks + 1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
+            }
+            const u16x8 bw = bq[d];
+            if (ks + AR_D < AC_KS) bq[d] = wl[(ks + AR_D) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);      // D[row = channel][col = pixel]
+        }
+    }
+    store_tile<bf16_t, A_CONV, 3, 1>(p, acc, fg * (AC_F * 24), nt * 32, 0, 0, lrow, g, p.M, 0, 0, 0, 0);
+}
+
+// ---- gather form: [B,3,8,256] -> [B,8,18,128], k = 4, s = 2 (stride-2 transposed conv; one GEMM per output parity class) ----
+constexpr int AG_F = 8, AG_IH = 3, AG_IW = 8, AG_C = 256, AG_OH = 8, AG_OW = 18, AG_N = 128;
+constexpr int AG_PIX = AG_IH * AG_IW;                     // 24 pixels per frame, 512 B each
+constexpr int AG_KS = 4 * AG_C / 16;                      // 64 k16-steps (2 x 2 taps x 16)
+constexpr int AG_ZERO = AG_F * AG_PIX * 512;              // byte offset of the all-zero pixel (taps that fall outside the input)
+constexpr int AG_LDS = AG_ZERO + 512;
+constexpr int AG_RPF = 36;                                // output pixels of one parity class per frame (4 x 9)
+
+__global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[AG_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, g = lane >> 5;
+    const int b = (int)blockIdx.x;
+    const int cls = b & 3, fg = b >> 2;
+    const int ph = cls >> 1, pw = cls & 1;
+    const int f0 = fg * AG_F;
+    if (f0 >= p.B) return;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    {
+        const int pq = lane >> 5, pc = lane & 31;         // pixel of the pair, PHYSICAL chunk (two 256-byte halves of 16 chunks, each rotated by itself)
+#pragma unroll 4
+        for (int t = wave; t < AG_F * AG_PIX / 2; t += 4) {
+            const int q = 2 * t + pq;
+            const int f = q / AG_PIX, rem = q - f * AG_PIX;
+            const int y = rem >> 3, x = rem & 7;
+            const int s = (4 * f + 9 * y + x) & 15;
+            const int jc = (pc & 16) | ((pc - s) & 15);
+            const int frame = f0 + f;
+            const uint32_t vo = frame < p.B ? (uint32_t)((frame * AG_PIX + rem) * 512 + jc * 16) : G2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)vo, 0, 0, 0);
+        }
+        if (tid < 32) *(f32x4*)(lds + AG_ZERO + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)(cls * 4 + wave) * AG_KS) * 64 + lane;
+    u16x8 bq[AR_D];
+#pragma unroll
+    for (int d = 0; d < AR_D; ++d) bq[d] = wl[d * 64];
+
+    // row r = 32 i + lrow of the block = (frame f, class pixel (j, ii)); tap (th, tw) reads input pixel (j - th, ii - tw) or the zero pixel
+    int rf[9], rj[9], ri[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = i * 32 + lrow;
+        rf[i] = r / AG_RPF;
+        const int rem = r - rf[i] * AG_RPF;
+        rj[i] = rem / 9; ri[i] = rem - rj[i] * 9;
+    }
+    const int s0 = lrow & 15;                             // (4 f + 9 j + ii) & 15 = r & 15
+    uint32_t abase[9];
+    auto set_tap = [&](int tap) {
+        const int th = tap >> 1, tw = tap & 1;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int y = rj[i] - th, x = ri[i] - tw;
+            const bool ok = y >= 0 && y < AG_IH && x >= 0 && x < AG_IW;
+            abase[i] = ok ? (uint32_t)((rf[i] * AG_PIX + y * AG_IW + x) * 512) : (uint32_t)AG_ZERO;
+        }
+    };
+    auto a_off = [&](int ks) -> uint32_t {                // offset inside the pixel (same for all nine tiles; the zero pixel is zero at every offset)
+        const int tap = ks >> 4, th = tap >> 1, tw = tap & 1;
+        const int j = (ks & 15) * 2 + g;
+        return (uint32_t)((j & 16) * 16 + ((j + s0 - 9 * th - tw) & 15) * 16);
+    };
+
+    f32x16 acc[9][1];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    __syncthreads();
+
+    for (int tap = 0; tap < 4; ++tap) {
+        set_tap(tap);
+        u16x8 an[9];
+        {
+            const uint32_t o = a_off(tap * 16);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
+        }
+#pragma unroll 1
+        for (int k8 = 0; k8 < 16; k8 += AR_D) {
+#pragma unroll
+            for (int d = 0; d < AR_D; ++d) {
+                const int ks = tap * 16 + k8 + d;
+                u16x8 a[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) a[i] = an[i];
+                if (k8 + d + 1 < 16) {
+                    const uint32_t o = a_off(ks + 1);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
+                }
+                const u16x8 bw = bq[d];
+                if (ks + AR_D < AG_KS) bq[d] = wl[(ks + AR_D) * 64];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);
+            }
+        }
+    }
+    store_tile<bf16_t, A_DECONV, 9, 1>(p, acc, fg * (AG_F * AG_RPF), wave * 32, 0, 0, lrow, g, p.M, cls, ph, pw, 0);
+}
+
+// ---- weights -> fragment order (bf16), from the fp32 master tensor ----
+// form 0 (conv form): src is [K = 16 x 128][N = 256] (HWIO conv kernel, or a [kh,kw,out,in] transposed-conv kernel read as HWIO for its input gradient):
+//     dst[((nt * 128 + ks) * 64 + l) * 8 + e] = src[(ks * 16 + (l >> 5) * 8 + e) * 256 + nt * 32 + (l & 31)]
+// form 1 (gather form): src is [kh][kw][n = 128][c = 256] ([kh,kw,out,in] transposed-conv kernel, or an HWIO conv kernel read that way for its input gradient):
+//     dst[(((cls * 4 + nt) * 64 + ks) * 64 + l) * 8 + e] = src[((kh * 4 + kw) * 128 + nt * 32 + (l & 31)) * 256 + (ks & 15) * 16 + (l >> 5) * 8 + e],
+//     tap = ks >> 4 = (th, tw), (kh, kw) = (ph + 2 th, pw + 2 tw), cls = (ph, pw)
+__global__ __launch_bounds__(256) void ares_pack_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int form) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;                   // one thread per (fragment, lane): 8 values
+    if (gid >= 65536) return;                                                   // 65,536 threads x 8 = 524,288 weights = 1 MB of bf16
+    const int l = gid & 63, frag = gid >> 6;
+    float v[8];
+    if (form == 0) {
+        const int ks = frag & 127, nt = frag >> 7;
+        const int k = ks * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 256 + n];
+    } else {
+        const int ks = frag & 63, nt = (frag >> 6) & 3, cls = frag >> 8;
+        const int tap = ks >> 4, th = tap >> 1, tw = tap & 1;
+        const int kh = (cls >> 1) + 2 * th, kw = (cls & 1) + 2 * tw;
+        const float* s = src + ((long long)((kh * 4 + kw) * 128 + nt * 32 + (l & 31))) * 256 + (ks & 15) * 16 + (l >> 5) * 8;
+        const f32x4 a = *(const f32x4*)s, c = *(const f32x4*)(s + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+    }
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(v[e]);
+    *(u16x8*)(dst + (long long)gid * 8) = o;
+}
+
+}  // namespace mi

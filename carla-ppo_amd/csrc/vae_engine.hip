@@ -76,6 +76,8 @@ struct Workspace {
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64)
+    long long wfrag[4];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
+                              // gradient, deconv1 forward, deconv1 input gradient (1 MB each; rewritten behind every optimiser step with the K-contiguous copies)
     long long total;
     // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
     // finds the region a kernel wrote past (the bounds-checking debug mode of the new build)
@@ -133,6 +135,7 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int ares_ok;                        // the fragment-ordered weight copies exist (bf16 engine, the model's geometry): the four small-grid layers run on the activation-resident kernels
     int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
     hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
     hipEvent_t ev_lat, ev_third;
@@ -211,6 +214,7 @@ void make_workspace(VaeEngine& e) {
         W.roll = add(W.roll_bytes);
     }
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256);
+    for (int i = 0; i < 4; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());
     W.total = o;
 }
 
@@ -266,6 +270,11 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
         const void* x = i == 0 ? frames : e->at(e->W.act[i]);
         // conv1 (training pass, bf16): also writes the ReLU bit words conv2's input gradient reads instead of the 101 MB activation tensor
         const bool bits = i == 0 && want_bits && relu_bits_enabled() && d.dtype == MI_BF16 && g.c[1] == 32;
+        if (i == 3 && e->ares_ok) {                           // conv4: activation-resident kernel (frames of the group in LDS, fragment-ordered weights streamed)
+            int launched = 0;
+            TOP(e, st, OP_CONV_FWD + i, mi_ares_conv(st, d.dtype, 0, x, B, e->at(e->W.wfrag[0]), e->bptr(7), 1, nullptr, e->at(e->W.act[4]), &launched));
+            if (launched) continue;
+        }
         TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd_bits(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (frames_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i],
                               e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1]), bits ? e->at(e->W.bits_act1) : nullptr, bits ? &e->bits1_ok : nullptr));
     }
@@ -288,6 +297,11 @@ int run_decoder(VaeEngine* e, void* st, int B, int last = 4, int want_bits = 0) 
     TOP(e, st, OP_DENSE1_FWD, mi_gemm_bias_act(st, d.dtype, e->at(e->W.z), B, d.z_dim, e->wtptr(10), 1, g.flat, e->bptr(11), 0, nullptr, e->at(e->W.dec[0]), 0, 1));
     for (int i = 0; i < last; ++i) {
         const bool bits = i == 2 && want_bits && relu_bits_enabled() && d.dtype == MI_BF16 && g.dc[3] == 32;   // deconv3: ReLU bit words for deconv4's input gradient
+        if (i == 0 && e->ares_ok) {
+            int launched = 0;
+            TOP(e, st, OP_DECONV_FWD + i, mi_ares_conv(st, d.dtype, 1, e->at(e->W.dec[0]), B, e->at(e->W.wfrag[2]), e->bptr(13), 1, nullptr, e->at(e->W.dec[1]), &launched));
+            if (launched) continue;
+        }
         TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd_bits(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1]), bits ? e->at(e->W.bits_dec3) : nullptr, bits ? &e->bits3_ok : nullptr));
     }
@@ -303,7 +317,19 @@ int refresh_transposed(VaeEngine* e, void* st) {
     off[n] = e->L.off[8]; K[n] = g.flat; N[n] = 2 * d.z_dim; ++n;
     off[n] = e->L.off[10]; K[n] = d.z_dim; N[n] = g.flat; ++n;
     for (int i = 0; i < 4; ++i) { off[n] = e->L.off[12 + 2 * i]; K[n] = DEC_K[i] * DEC_K[i] * g.dc[i + 1]; N[n] = g.dc[i]; ++n; }
-    return mi_transpose_weights(st, d.dtype, e->params, e->wt, off, K, N, n);
+    CK(mi_transpose_weights(st, d.dtype, e->params, e->wt, off, K, N, n));
+    e->ares_ok = 0;
+    static int ares_on = -1;
+    if (ares_on < 0) { const char* ev = getenv("MI355_ARES"); ares_on = (ev && ev[0] == '0') ? 0 : 1; }
+    if (ares_on && d.dtype == MI_BF16 && g.ih[3] == 8 && g.iw[3] == 18 && g.c[3] == 128 && g.c[4] == 256 && g.dh[0] == 3 && g.dw[0] == 8 && g.dc[0] == 256 && g.dc[1] == 128 && DEC_K[0] == 4) {
+        // conv4's kernel: HWIO [4][4][128][256]; deconv1's kernel: [kh][kw][out = 128][in = 256] -- the same [16][128][256] shape, read either way (ares.hip)
+        CK(mi_ares_pack_weights(st, 0, e->params + e->L.off[6], e->at(e->W.wfrag[0])));        // conv4 forward
+        CK(mi_ares_pack_weights(st, 1, e->params + e->L.off[6], e->at(e->W.wfrag[1])));        // conv4 input gradient
+        CK(mi_ares_pack_weights(st, 1, e->params + e->L.off[12], e->at(e->W.wfrag[2])));       // deconv1 forward
+        CK(mi_ares_pack_weights(st, 0, e->params + e->L.off[12], e->at(e->W.wfrag[3])));       // deconv1 input gradient
+        e->ares_ok = 1;
+    }
+    return MI_OK;
 }
 
 }  // namespace
@@ -607,6 +633,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             release();                                       // gy is complete on st (loss pass / previous input gradient)
             // BiasAddGrad is fused into the filter-gradient call
             TOP(e, sw, OP_DECONV_WGRAD + i, mi_deconv2d_nhwc_wgrad_ws(sw, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->at(W.dec[i]), DEC_K[i], DEC_K[i], g.dc[i], e->gptr(12 + 2 * i), scratch_of(), scratch_sz, (i == 3 && e->b4_fused) ? nullptr : e->gptr(13 + 2 * i)));
+            if (i == 0 && e->ares_ok) {                      // deconv1's input gradient: conv form on the activation-resident kernel (no mask: dense1 has no ReLU)
+                int launched = 0;
+                TOP(e, st, OP_DECONV_DGRAD + i, mi_ares_conv(st, d.dtype, 0, gy, B, e->at(W.wfrag[3]), nullptr, 0, nullptr, e->at(W.gdec[0]), &launched));
+                if (launched) continue;
+            }
             if (i > 0) arm();                                // its output is the next layer's filter-gradient operand
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
@@ -700,6 +731,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                 if (nblk > 0) { enc_fused = true; continue; }
             }
             if (i > 1) arm();
+            if (i == 3 && e->ares_ok) {                      // conv4's input gradient: gather form on the activation-resident kernel, ReluGrad mask = conv3's output
+                int launched = 0;
+                TOP(e, st, OP_CONV_DGRAD + i, mi_ares_conv(st, d.dtype, 1, gy, B, e->at(W.wfrag[1]), nullptr, 0, e->at(W.act[3]), e->at(W.gact[3]), &launched));
+                if (launched) { armed_ok(); continue; }
+            }
             if (i > 0)                                       // conv1's input gradient is never used
                 TOP(e, st, OP_CONV_DGRAD + i, mi_conv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.ih[i + 1], g.iw[i + 1], g.c[i + 1], e->wptr(2 * i), 4, 4, g.c[i], g.ih[i], g.iw[i],
                                         e->at(W.act[i]), (i == 1 && e->bits1_ok) ? e->at(W.bits_act1) : nullptr, e->at(W.gact[i])));

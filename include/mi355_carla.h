@@ -135,6 +135,15 @@ int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, fl
  * mi_conv2d_nhwc_dgrad_bits and mi_conv2d_nhwc_wgrad_ws).  scratch: >= mi_conv2d_head_bwd_blocks() * 8320 bytes. */
 int mi_conv2d_head_bwd_blocks(void);
 int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* frames, int frames_fmt, const int* frame_idx, int B, int FH, int FW, const void* dy2, const void* w2, const void* bits_act1, float* dw1, float* db1, void* scratch, long long scratch_bytes, int* n_blocks);
+/* The four SMALL-GRID layers of the ConvVAE on the activation-resident kernels (round 4, csrc/ares_tile.hpp): a block keeps the whole inputs of a group of frames
+ * in LDS and streams fragment-ordered weights through registers.  form 0 (conv form, k4 s2, [B,8,18,128] -> [B,3,8,256]): conv4 forward (vae/models.py:253) and
+ * deconv1's input gradient (Conv2D of dy behind :142); form 1 (gather form, [B,3,8,256] -> [B,8,18,128]): deconv1 forward (:261) and conv4's input gradient
+ * (Conv2DBackpropInput).  mi_ares_pack_weights rewrites a [4][4][128][256] fp32 master kernel into the form's fragment order (mi_ares_weight_bytes() of bf16;
+ * once per optimiser step); mi_ares_conv: out = mask(relu?(op(x) + bias)), *launched = 0 when the call is not eligible (bf16 storage and this geometry only;
+ * nothing was launched: use the general ops above / below). */
+long long mi_ares_weight_bytes(void);
+int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out);
+int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
 /* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */

@@ -206,6 +206,64 @@ def test_deconv_fwd_dgrad_wgrad(dt, geom, kernels):
     assert_close(host(dw), dwref.numpy(), 1e-5 if dt != "bf16" else 1e-4, (2e-5 if dt != "bf16" else 1e-4) * s, "deconv wgrad")
 
 
+@pytest.mark.parametrize("B", [1, 3, 8, 37, 512])
+def test_activation_resident_small_grid_layers(B):
+    """Round 4 (csrc/ares_tile.hpp): conv4 forward / deconv1 input gradient (conv form) and deconv1 forward / conv4 input gradient (gather
+    form) with the frames of a group resident in LDS and fragment-ordered weights streamed through registers, against float64 statements of the four ops on the
+    bf16-rounded operands (bias + ReLU / ReluGrad mask as the model uses them) -- at batch sizes below, at and across the frame-group sizes (4 / 8), with the
+    last group ragged, and at the benchmarked 512 -- and bit for bit against the general kernels' results where both run the same products in fp32."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    rng = np.random.RandomState(B)
+    nb = int(L.mi_ares_weight_bytes())
+    assert nb == 16 * 128 * 256 * 2
+    # ---- conv form: [B,8,18,128] -> [B,3,8,256] ----
+    x = rng.randn(B, 8, 18, 128).astype(np.float32)
+    w = (rng.randn(4, 4, 128, 256) / np.sqrt(16 * 128)).astype(np.float32)          # HWIO (conv4) == [kh,kw,out=128,in=256] (deconv1) as stored
+    bias = (0.1 * rng.randn(256)).astype(np.float32)
+    mask = rng.randn(B, 3, 8, 256).astype(np.float32)
+    y0 = _nhwc(F.conv2d(_nchw(rounded(x, td)), rounded(w, td).permute(3, 2, 0, 1), None, stride=2))
+    wf = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    L.mi_ares_pack_weights(stream(), 0, P(dev(w)), wf.data_ptr())
+    xd = dev(x, td)
+    launched = np.zeros(1, np.int32)
+    out = alloc(td, B, 3, 8, 256, fill=7.0)
+    L.mi_ares_conv(stream(), code, 0, xd.data_ptr(), B, wf.data_ptr(), P(dev(bias)), 1, None, out.data_ptr(), launched.ctypes.data)
+    assert launched[0] == 1
+    ref = F.relu(y0 + torch.from_numpy(bias).double()).numpy()
+    rt, at = tols("bf16", float(np.abs(ref).max()))
+    assert_close(host(out), ref, rt, at, "conv form: conv4 forward (bias + relu)")
+    out2 = alloc(td, B, 3, 8, 256, fill=7.0)
+    L.mi_ares_conv(stream(), code, 0, xd.data_ptr(), B, wf.data_ptr(), None, 0, P(dev(mask, td)), out2.data_ptr(), launched.ctypes.data)
+    ref2 = (y0 * (rounded(mask, td) > 0)).numpy()
+    rt, at = tols("bf16", float(np.abs(ref2).max()))
+    assert_close(host(out2), ref2, rt, at, "conv form: input gradient of a transposed conv (mask)")
+    # ---- gather form: [B,3,8,256] -> [B,8,18,128] ----
+    xg = rng.randn(B, 3, 8, 256).astype(np.float32)
+    wg = (rng.randn(4, 4, 128, 256) / np.sqrt(4 * 256)).astype(np.float32)          # [kh,kw,out=128,in=256] (deconv1) == HWIO [kh,kw,ci=128,co=256] (conv4)
+    biasg = (0.1 * rng.randn(128)).astype(np.float32)
+    maskg = rng.randn(B, 8, 18, 128).astype(np.float32)
+    yg = _nhwc(F.conv_transpose2d(_nchw(rounded(xg, td)), rounded(wg, td).permute(3, 2, 0, 1), None, stride=2))
+    assert tuple(yg.shape) == (B, 8, 18, 128)
+    wfg = torch.empty(nb, device="cuda", dtype=torch.uint8)
+    L.mi_ares_pack_weights(stream(), 1, P(dev(wg)), wfg.data_ptr())
+    xgd = dev(xg, td)
+    og = alloc(td, B, 8, 18, 128, fill=7.0)
+    L.mi_ares_conv(stream(), code, 1, xgd.data_ptr(), B, wfg.data_ptr(), P(dev(biasg)), 1, None, og.data_ptr(), launched.ctypes.data)
+    assert launched[0] == 1
+    refg = F.relu(yg + torch.from_numpy(biasg).double()).numpy()
+    rt, at = tols("bf16", float(np.abs(refg).max()))
+    assert_close(host(og), refg, rt, at, "gather form: deconv1 forward (bias + relu)")
+    og2 = alloc(td, B, 8, 18, 128, fill=7.0)
+    L.mi_ares_conv(stream(), code, 1, xgd.data_ptr(), B, wfg.data_ptr(), None, 0, P(dev(maskg, td)), og2.data_ptr(), launched.ctypes.data)
+    refg2 = (yg * (rounded(maskg, td) > 0)).numpy()
+    rt, at = tols("bf16", float(np.abs(refg2).max()))
+    assert_close(host(og2), refg2, rt, at, "gather form: input gradient of a conv (mask)")
+    # not eligible: other storage types -> nothing launched, the caller takes the general kernels
+    L.mi_ares_conv(stream(), DT["f32"][0], 0, xd.data_ptr(), B, wf.data_ptr(), None, 0, None, out.data_ptr(), launched.ctypes.data)
+    assert launched[0] == 0
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_dgrad_into_larger_input(dt, kernels):
     """conv2 reads a 39x79 map but its VALID s2 windows never touch the last row/col: their gradient must be 0."""
