@@ -25,7 +25,25 @@ long long mi_ares_weight_bytes(void) { return 16ll * 128 * 256 * 2; }
 int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out) {
     if (!w_fp32 || !wf_out || form < 0 || form > 1) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
     if ((((uintptr_t)w_fp32) | ((uintptr_t)wf_out)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(ares_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_fp32, (bf16_t*)wf_out, form);
+    AresPackJobs j = {};
+    j.src[0] = w_fp32; j.dst[0] = (bf16_t*)wf_out; j.form[0] = form; j.n = 1;
+    hipLaunchKernelGGL(ares_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, j);
+    return mi_check_launch("ares_pack_kernel");
+}
+
+// the four copies an engine keeps (conv4 forward, conv4 input gradient, deconv1 forward, deconv1 input gradient) in ONE launch: conv4_w / deconv1_w are the two
+// [4][4][128][256] fp32 master kernels, wf_out[0..3] the four 1 MB destinations in that order
+int mi_ares_pack_weights4(void* stream, const float* conv4_w, const float* deconv1_w, void* wf0, void* wf1, void* wf2, void* wf3) {
+    if (!conv4_w || !deconv1_w || !wf0 || !wf1 || !wf2 || !wf3) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights4: bad arguments");
+    if ((((uintptr_t)conv4_w) | ((uintptr_t)deconv1_w) | ((uintptr_t)wf0) | ((uintptr_t)wf1) | ((uintptr_t)wf2) | ((uintptr_t)wf3)) & 15)
+        return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights4: buffers must be 16-byte aligned");
+    AresPackJobs j = {};
+    j.n = 4;
+    j.src[0] = conv4_w; j.dst[0] = (bf16_t*)wf0; j.form[0] = 0;
+    j.src[1] = conv4_w; j.dst[1] = (bf16_t*)wf1; j.form[1] = 1;
+    j.src[2] = deconv1_w; j.dst[2] = (bf16_t*)wf2; j.form[2] = 1;
+    j.src[3] = deconv1_w; j.dst[3] = (bf16_t*)wf3; j.form[3] = 0;
+    hipLaunchKernelGGL(ares_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, j);
     return mi_check_launch("ares_pack_kernel");
 }
 

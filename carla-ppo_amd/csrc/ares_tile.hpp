@@ -237,9 +237,14 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
 // form 1 (gather form): src is [kh][kw][n = 128][c = 256] ([kh,kw,out,in] transposed-conv kernel, or an HWIO conv kernel read that way for its input gradient):
 //     dst[(((cls * 4 + nt) * 64 + ks) * 64 + l) * 8 + e] = src[((kh * 4 + kw) * 128 + nt * 32 + (l & 31)) * 256 + (ks & 15) * 16 + (l >> 5) * 8 + e],
 //     tap = ks >> 4 = (th, tw), (kh, kw) = (ph + 2 th, pw + 2 tw), cls = (ph, pw)
-__global__ __launch_bounds__(256) void ares_pack_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int form) {
-    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;                   // one thread per (fragment, lane): 8 values
-    if (gid >= 65536) return;                                                   // 65,536 threads x 8 = 524,288 weights = 1 MB of bf16
+struct AresPackJobs { const float* src[4]; bf16_t* dst[4]; int form[4]; int n; };      // up to four copies in one launch: job = blockIdx.x >> 8
+__global__ __launch_bounds__(256) void ares_pack_kernel(const AresPackJobs jobs) {
+    const int job = (int)blockIdx.x >> 8;
+    if (job >= jobs.n) return;
+    const float* __restrict__ src = jobs.src[job];
+    bf16_t* __restrict__ dst = jobs.dst[job];
+    const int form = jobs.form[job];
+    const int gid = ((int)blockIdx.x & 255) * 256 + (int)threadIdx.x;           // one thread per (fragment, lane): 8 values; 65,536 threads x 8 = 524,288 weights = 1 MB of bf16
     const int l = gid & 63, frag = gid >> 6;
     float v[8];
     if (form == 0) {

@@ -323,10 +323,8 @@ int refresh_transposed(VaeEngine* e, void* st) {
     if (ares_on < 0) { const char* ev = getenv("MI355_ARES"); ares_on = (ev && ev[0] == '0') ? 0 : 1; }
     if (ares_on && d.dtype == MI_BF16 && g.ih[3] == 8 && g.iw[3] == 18 && g.c[3] == 128 && g.c[4] == 256 && g.dh[0] == 3 && g.dw[0] == 8 && g.dc[0] == 256 && g.dc[1] == 128 && DEC_K[0] == 4) {
         // conv4's kernel: HWIO [4][4][128][256]; deconv1's kernel: [kh][kw][out = 128][in = 256] -- the same [16][128][256] shape, read either way (ares.hip)
-        CK(mi_ares_pack_weights(st, 0, e->params + e->L.off[6], e->at(e->W.wfrag[0])));        // conv4 forward
-        CK(mi_ares_pack_weights(st, 1, e->params + e->L.off[6], e->at(e->W.wfrag[1])));        // conv4 input gradient
-        CK(mi_ares_pack_weights(st, 1, e->params + e->L.off[12], e->at(e->W.wfrag[2])));       // deconv1 forward
-        CK(mi_ares_pack_weights(st, 0, e->params + e->L.off[12], e->at(e->W.wfrag[3])));       // deconv1 input gradient
+        // wfrag: 0 conv4 forward, 1 conv4 input gradient, 2 deconv1 forward, 3 deconv1 input gradient -- one launch
+        CK(mi_ares_pack_weights4(st, e->params + e->L.off[6], e->params + e->L.off[12], e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3])));
         e->ares_ok = 1;
     }
     return MI_OK;

@@ -143,6 +143,9 @@ int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* frames, int fr
  * nothing was launched: use the general ops above / below). */
 long long mi_ares_weight_bytes(void);
 int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out);
+/* the four copies the VAE engine keeps, in one launch: wf0 conv4 forward (form 0 of conv4's kernel), wf1 conv4 input gradient (form 1 of it), wf2 deconv1 forward (form 1 of
+ * deconv1's kernel), wf3 deconv1 input gradient (form 0 of it) */
+int mi_ares_pack_weights4(void* stream, const float* conv4_w, const float* deconv1_w, void* wf0, void* wf1, void* wf2, void* wf3);
 int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
