@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     // ---- this wave's weight stream: 32 output channels, 128 fragments of 1 KiB, AR_D in flight ----
     const int nt = nh * 4 + wave;                         // 32-channel tile of the 256 outputs
     const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)nt * AC_KS) * 64 + lane;
+    // Every block walks the SAME weight stream: started together, the 32 CUs of an XCD would ask one L2 channel for the same 1 KiB at the same moment, step after
+    // step (first version: 617 cycles per k-step for 96 cycles of MFMA).  Each block therefore starts its reduction at its own k-step and wraps around (fp32
+    // accumulation in a fixed, per-block order): the CUs of an XCD are spread over the whole stream.
+    const int rot = ((b >> 4) * 8) & (AC_KS - 1);
     u16x8 bq[AR_D];
 #pragma unroll
-    for (int d = 0; d < AR_D; ++d) bq[d] = wl[d * 64];
+    for (int d = 0; d < AR_D; ++d) bq[d] = wl[((d + rot) & (AC_KS - 1)) * 64];
 
     // ---- per-lane A addressing: row r = 32 i + lrow of the block = (frame f, output pixel (oy, ox)) ----
     uint32_t pixbase[3];
@@ -101,24 +105,24 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     };
     u16x8 an[3];
     {
-        const uint32_t o = a_off(0);
+        const uint32_t o = a_off(rot);
 #pragma unroll
         for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
     }
     for (int k8 = 0; k8 < AC_KS; k8 += AR_D) {
 #pragma unroll
         for (int d = 0; d < AR_D; ++d) {
-            const int ks = k8 + d;
+            const int st = k8 + d;                        // step of this block; k-step (st + rot) mod 128
             u16x8 a[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) a[i] = an[i];
-            if (ks + 1 < AC_KS) {                         // next step's A fragments are requested before this step's MFMAs
-                const uint32_t o = a_off(ks + 1);
+            if (st + 1 < AC_KS) {                         // next step's A fragments are requested before this step's MFMAs
+                const uint32_t o = a_off((st + 1 + rot) & (AC_KS - 1));
 #pragma unroll
                 for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
             }
             const u16x8 bw = bq[d];
-            if (ks + AR_D < AC_KS) bq[d] = wl[(ks + AR_D) * 64];
+            if (st + AR_D < AC_KS) bq[d] = wl[((st + AR_D + rot) & (AC_KS - 1)) * 64];
 #pragma unroll
             for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);      // D[row = channel][col = pixel]
         }
@@ -162,9 +166,10 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
     }
 
     const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)(cls * 4 + wave) * AG_KS) * 64 + lane;
+    const int rot = ((fg >> 1) * 2) & (AG_KS - 1);        // (see ares_conv_kernel: the blocks of an XCD start their reductions spread over the weight stream)
     u16x8 bq[AR_D];
 #pragma unroll
-    for (int d = 0; d < AR_D; ++d) bq[d] = wl[d * 64];
+    for (int d = 0; d < AR_D; ++d) bq[d] = wl[((d + rot) & (AG_KS - 1)) * 64];
 
     // row r = 32 i + lrow of the block = (frame f, class pixel (j, ii)); tap (th, tw) reads input pixel (j - th, ii - tw) or the zero pixel
     int rf[9], rj[9], ri[9];
@@ -200,32 +205,32 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
 
     __syncthreads();
 
-    for (int tap = 0; tap < 4; ++tap) {
-        set_tap(tap);
-        u16x8 an[9];
-        {
-            const uint32_t o = a_off(tap * 16);
+    u16x8 an[9];
+    set_tap(rot >> 4);
+    {
+        const uint32_t o = a_off(rot);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
-        }
+        for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
+    }
 #pragma unroll 1
-        for (int k8 = 0; k8 < 16; k8 += AR_D) {
+    for (int k8 = 0; k8 < AG_KS; k8 += AR_D) {
 #pragma unroll
-            for (int d = 0; d < AR_D; ++d) {
-                const int ks = tap * 16 + k8 + d;
-                u16x8 a[9];
+        for (int d = 0; d < AR_D; ++d) {
+            const int st = k8 + d;                        // step of this block; k-step (st + rot) mod 64
+            u16x8 a[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) a[i] = an[i];
-                if (k8 + d + 1 < 16) {
-                    const uint32_t o = a_off(ks + 1);
+            for (int i = 0; i < 9; ++i) a[i] = an[i];
+            if (st + 1 < AG_KS) {
+                const int ksn = (st + 1 + rot) & (AG_KS - 1);
+                if ((ksn & 15) == 0) set_tap(ksn >> 4);   // (wave-uniform; the current step's fragments are already in registers)
+                const uint32_t o = a_off(ksn);
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
-                }
-                const u16x8 bw = bq[d];
-                if (ks + AR_D < AG_KS) bq[d] = wl[(ks + AR_D) * 64];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);
+                for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
             }
+            const u16x8 bw = bq[d];
+            if (st + AR_D < AG_KS) bq[d] = wl[((st + AR_D + rot) & (AG_KS - 1)) * 64];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);
         }
     }
     store_tile<bf16_t, A_DECONV, 9, 1>(p, acc, fg * (AG_F * AG_RPF), wave * 32, 0, 0, lrow, g, p.M, cls, ph, pw, 0);
