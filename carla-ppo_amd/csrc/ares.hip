@@ -72,7 +72,8 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
         p.M = B * AG_RPF; p.N = AG_N; p.OH = AG_OH; p.OW = AG_OW;
         for (int c = 0; c < 4; ++c) { p.dc_ohw[c] = make_fastdiv(AG_RPF); p.dc_ow[c] = make_fastdiv(9); }
         const int groups = (B + AG_F - 1) / AG_F;
-        MI_LAUNCH(ares_gather_kernel, dim3(groups * 4), dim3(256), 0, st, p);
+        const int nb = (groups + 7) / 8 * 32;                // block b: parity class (b >> 3) & 3, frame group (b & 7) + 8 (b >> 5)
+        MI_LAUNCH(ares_gather_kernel, dim3(nb), dim3(256), 0, st, p);
         const int rc = mi_check_launch("ares_gather_kernel");
         if (rc != MI_OK) return rc;
     }

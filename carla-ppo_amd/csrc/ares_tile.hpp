@@ -68,15 +68,18 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     }
 
     // ---- this wave's weight stream: 32 output channels, 128 fragments of 1 KiB, AR_D in flight ----
+    // (scalar base + 16 lane: the loads take the saddr form, no per-load 64-bit vector address arithmetic -- at one wave per SIMD every instruction of the
+    //  k-step loop is kernel time: the first version spent 23 VALU + 19 SALU instructions per step on addresses and register copies for 3 MFMAs, 27 us)
     const int nt = nh * 4 + wave;                         // 32-channel tile of the 256 outputs
-    const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)nt * AC_KS) * 64 + lane;
+    const char* const wbase = (const char*)p.wf + (size_t)nt * AC_KS * 1024;
+    const uint32_t lo16 = (uint32_t)lane * 16u;
+    auto wload = [&](int idx) -> u16x8 { return *(const u16x8*)(wbase + (size_t)idx * 1024 + lo16); };      // idx: wave-uniform
     // Every block walks the SAME weight stream: started together, the 32 CUs of an XCD would ask one L2 channel for the same 1 KiB at the same moment, step after
-    // step (first version: 617 cycles per k-step for 96 cycles of MFMA).  Each block therefore starts its reduction at its own k-step and wraps around (fp32
-    // accumulation in a fixed, per-block order): the CUs of an XCD are spread over the whole stream.
-    const int rot = ((b >> 4) * 8) & (AC_KS - 1);
+    // step.  Each block therefore starts its reduction at its own tap and wraps around (fp32 accumulation in a fixed, per-block order).
+    const int tap0 = (b >> 4) & 15;                       // 16 starting taps x 2 column halves = the 32 blocks of an XCD
     u16x8 bq[AR_D];
 #pragma unroll
-    for (int d = 0; d < AR_D; ++d) bq[d] = wl[((d + rot) & (AC_KS - 1)) * 64];
+    for (int d = 0; d < AR_D; ++d) bq[d] = wload(tap0 * 8 + d);
 
     // ---- per-lane A addressing: row r = 32 i + lrow of the block = (frame f, output pixel (oy, ox)) ----
     uint32_t pixbase[3];
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
         const int oy = rem >> 3, ox = rem & 7;
         pixbase[i] = (uint32_t)((f * AC_PIX + 2 * oy * AC_IW + 2 * ox) * 256);
     }
-    const int s0 = lrow & 15;                             // (8 f + 8 oy + ox) & 15 = r & 15: the row's share of the chunk rotation
+    const int s0g = (lrow & 15) + g;                      // (8 f + 8 oy + ox) & 15 = r & 15: the row's share of the chunk rotation (+ the lane group's chunk)
 
     f32x16 acc[3][1];
 #pragma unroll
@@ -97,35 +100,43 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
 
     __syncthreads();                                      // (s_waitcnt vmcnt(0) + barrier: the frames are in LDS -- and so are the first weight fragments)
 
-    auto a_off = [&](int ks) -> uint32_t {                // byte offset (same for the three tiles) of step ks' chunk relative to pixbase
-        const int tap = ks >> 3, ky = tap >> 2, kx = tap & 3;
-        const int j = (ks & 7) * 2 + g;
-        const int phys = (j + s0 + 8 * (ky >> 1) + (kx >> 1)) & 15;
-        return (uint32_t)((ky * AC_IW + kx) * 256 + phys * 16);
-    };
-    u16x8 an[3];
-    {
-        const uint32_t o = a_off(rot);
+    // tap (ky, kx): LDS byte offset of its pixel relative to the row's base pixel, and the byte position of chunk 0 of lane group g inside the (rotated) pixel;
+    // channel step c of the tap reads chunk position (q0 + 32 c) & 255
+    auto tap_of = [&](int tap, uint32_t (&tb)[3], uint32_t& q0) {
+        const int ky = tap >> 2, kx = tap & 3;            // (wave-uniform: scalar unit)
+        const uint32_t toff = (uint32_t)((ky * AC_IW + kx) * 256);
+        q0 = (uint32_t)((s0g + 8 * (ky >> 1) + (kx >> 1)) & 15) << 4;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
-    }
-    for (int k8 = 0; k8 < AC_KS; k8 += AR_D) {
+        for (int i = 0; i < 3; ++i) tb[i] = pixbase[i] + toff;
+    };
+    uint32_t tb[3], q0;
+    tap_of(tap0, tb, q0);
+    u16x8 A[2][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tb[i] + q0);
+#pragma unroll 1
+    for (int t8 = 0; t8 < 16; ++t8) {
+        uint32_t tbn[3], q0n;
+        tap_of((tap0 + t8 + 1) & 15, tbn, q0n);           // the next tap's addressing: its first fragments are requested during this tap's last step
+        const int wnext = ((tap0 + t8 + 1) & 15) * 8;     // weight fragments of the next tap
 #pragma unroll
         for (int d = 0; d < AR_D; ++d) {
-            const int st = k8 + d;                        // step of this block; k-step (st + rot) mod 128
-            u16x8 a[3];
+            if (d + 1 < AR_D) {
+                const uint32_t r = (q0 + 32u * (d + 1)) & 255u;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) a[i] = an[i];
-            if (st + 1 < AC_KS) {                         // next step's A fragments are requested before this step's MFMAs
-                const uint32_t o = a_off((st + 1 + rot) & (AC_KS - 1));
+                for (int i = 0; i < 3; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
+            } else if (t8 + 1 < 16) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) an[i] = *(const u16x8*)(lds + pixbase[i] + o);
+                for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
             }
             const u16x8 bw = bq[d];
-            if (st + AR_D < AC_KS) bq[d] = wl[((st + AR_D + rot) & (AC_KS - 1)) * 64];
+            if (t8 + 1 < 16) bq[d] = wload(wnext + d);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);      // D[row = channel][col = pixel]
+            for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
         }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tb[i] = tbn[i];
+        q0 = q0n;
     }
     store_tile<bf16_t, A_CONV, 3, 1>(p, acc, fg * (AC_F * 24), nt * 32, 0, 0, lrow, g, p.M, 0, 0, 0, 0);
 }
@@ -143,7 +154,8 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, g = lane >> 5;
     const int b = (int)blockIdx.x;
-    const int cls = b & 3, fg = b >> 2;
+    // the 32 blocks of an XCD (b % 8) cover the four parity classes x eight starting points of the reduction: no two of them walk the same weight stream in step
+    const int cls = (b >> 3) & 3, fg = (b & 7) + 8 * (b >> 5);
     const int ph = cls >> 1, pw = cls & 1;
     const int f0 = fg * AG_F;
     if (f0 >= p.B) return;
@@ -165,11 +177,13 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
         if (tid < 32) *(f32x4*)(lds + AG_ZERO + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const u16x8* __restrict__ wl = (const u16x8*)p.wf + ((long long)(cls * 4 + wave) * AG_KS) * 64 + lane;
-    const int rot = ((fg >> 1) * 2) & (AG_KS - 1);        // (see ares_conv_kernel: the blocks of an XCD start their reductions spread over the weight stream)
+    const char* const wbase = (const char*)p.wf + (size_t)(cls * 4 + wave) * AG_KS * 1024;
+    const uint32_t lo16 = (uint32_t)lane * 16u;
+    auto wload = [&](int idx) -> u16x8 { return *(const u16x8*)(wbase + (size_t)idx * 1024 + lo16); };      // idx: wave-uniform
+    const int o0 = (b >> 5) & 7;                          // starting point of this block's reduction, in units of 8 k-steps (see ares_conv_kernel)
     u16x8 bq[AR_D];
 #pragma unroll
-    for (int d = 0; d < AR_D; ++d) bq[d] = wl[((d + rot) & (AG_KS - 1)) * 64];
+    for (int d = 0; d < AR_D; ++d) bq[d] = wload(o0 * 8 + d);
 
     // row r = 32 i + lrow of the block = (frame f, class pixel (j, ii)); tap (th, tw) reads input pixel (j - th, ii - tw) or the zero pixel
     int rf[9], rj[9], ri[9];
@@ -180,8 +194,8 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
         const int rem = r - rf[i] * AG_RPF;
         rj[i] = rem / 9; ri[i] = rem - rj[i] * 9;
     }
-    const int s0 = lrow & 15;                             // (4 f + 9 j + ii) & 15 = r & 15
-    uint32_t abase[9];
+    const int s0g = (lrow & 15) + g;                      // (4 f + 9 j + ii) & 15 = r & 15 (+ the lane group's chunk)
+    uint32_t abase[9], q0;
     auto set_tap = [&](int tap) {
         const int th = tap >> 1, tw = tap & 1;
 #pragma unroll
@@ -190,11 +204,7 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
             const bool ok = y >= 0 && y < AG_IH && x >= 0 && x < AG_IW;
             abase[i] = ok ? (uint32_t)((rf[i] * AG_PIX + y * AG_IW + x) * 512) : (uint32_t)AG_ZERO;
         }
-    };
-    auto a_off = [&](int ks) -> uint32_t {                // offset inside the pixel (same for all nine tiles; the zero pixel is zero at every offset)
-        const int tap = ks >> 4, th = tap >> 1, tw = tap & 1;
-        const int j = (ks & 15) * 2 + g;
-        return (uint32_t)((j & 16) * 16 + ((j + s0 - 9 * th - tw) & 15) * 16);
+        q0 = (uint32_t)((s0g - 9 * th - tw) & 15) << 4;  // byte position of chunk 0 of lane group g inside a rotated 256-byte half (the zero pixel is zero everywhere)
     };
 
     f32x16 acc[9][1];
@@ -205,32 +215,34 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
 
     __syncthreads();
 
-    u16x8 an[9];
-    set_tap(rot >> 4);
+    // 8 octets of 8 k-steps: octet o = (tap o >> 1, channel half o & 1); channel step c of the octet reads chunk position half * 256 + ((q0 + 32 c) & 255)
+    u16x8 A[2][9];
+    set_tap(o0 >> 1);
     {
-        const uint32_t o = a_off(rot);
+        const uint32_t r = (uint32_t)(o0 & 1) * 256u + q0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
+        for (int i = 0; i < 9; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
     }
 #pragma unroll 1
-    for (int k8 = 0; k8 < AG_KS; k8 += AR_D) {
+    for (int t8 = 0; t8 < 8; ++t8) {
+        const int o = (o0 + t8) & 7, on = (o0 + t8 + 1) & 7;
+        const uint32_t hoff = (uint32_t)(o & 1) * 256u;
 #pragma unroll
         for (int d = 0; d < AR_D; ++d) {
-            const int st = k8 + d;                        // step of this block; k-step (st + rot) mod 64
-            u16x8 a[9];
+            if (d + 1 < AR_D) {
+                const uint32_t r = hoff + ((q0 + 32u * (d + 1)) & 255u);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) a[i] = an[i];
-            if (st + 1 < AG_KS) {
-                const int ksn = (st + 1 + rot) & (AG_KS - 1);
-                if ((ksn & 15) == 0) set_tap(ksn >> 4);   // (wave-uniform; the current step's fragments are already in registers)
-                const uint32_t o = a_off(ksn);
+                for (int i = 0; i < 9; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + abase[i] + r);
+            } else if (t8 + 1 < 8) {
+                if ((on & 1) == 0) set_tap(on >> 1);      // (wave-uniform; this step's fragments are already in registers)
+                const uint32_t r = (uint32_t)(on & 1) * 256u + q0;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) an[i] = *(const u16x8*)(lds + abase[i] + o);
+                for (int i = 0; i < 9; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
             }
             const u16x8 bw = bq[d];
-            if (st + AR_D < AG_KS) bq[d] = wl[((st + AR_D + rot) & (AG_KS - 1)) * 64];
+            if (t8 + 1 < 8) bq[d] = wload(on * 8 + d);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, a[i], acc[i][0]);
+            for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
         }
     }
     store_tile<bf16_t, A_DECONV, 9, 1>(p, acc, fg * (AG_F * AG_RPF), wave * 32, 0, 0, lrow, g, p.M, cls, ph, pw, 0);
