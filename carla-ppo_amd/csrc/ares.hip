@@ -55,8 +55,8 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
     *launched = 0;
     if (!ares_on() || dtype != MI_BF16 || form < 0 || form > 1 || !x || !wf || !out || B < 1) return MI_OK;
     if ((((uintptr_t)x) | ((uintptr_t)wf) | ((uintptr_t)out) | ((uintptr_t)mask) | ((uintptr_t)bias)) & 15) return MI_OK;
-    const long long xb = (long long)B * 36864;             // 8 x 18 x 128 = 3 x 8 x 256 bf16 per frame... (both forms: 18,432 elements)
-    if (xb >= (long long)G2_OOB || (long long)B * 144 * 128 >= (1ll << 31)) return MI_OK;
+    const long long xb = (long long)B * (form == 0 ? 8 * 18 * 128 : 3 * 8 * 256) * 2;      // the descriptor's range check supplies the zeros of a ragged last frame group
+    if (xb >= (long long)G2_OOB) return MI_OK;
     AresParams p = {};
     p.x = x; p.x_bytes = (uint32_t)xb; p.wf = wf; p.B = B;
     p.out = out; p.bias = bias; p.mask = mask; p.relu = relu; p.out_f32 = 0;

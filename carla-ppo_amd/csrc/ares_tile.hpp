@@ -54,16 +54,18 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     {
         const int pq = lane >> 4, pc = lane & 15;         // pixel of the quad, PHYSICAL chunk this lane fills
+        // block-local pixel q = 4 t + pq is pixel f0 * 144 + q of the tensor (frames are contiguous; pixels past the last frame fall outside the descriptor:
+        // zeros); its (frame, y, x) -- needed for the chunk rotation only -- advance by 16 pixels per iteration without a division
+        int f = 0, y = 0, x = 4 * wave + pq;              // q < 16 < IW on the first iteration
+        uint32_t vq = (uint32_t)((f0 * AC_PIX + 4 * wave + pq) * 256);
 #pragma unroll 4
         for (int t = wave; t < AC_F * AC_PIX / 4; t += 4) {
-            const int q = 4 * t + pq;                     // block-local pixel
-            const int f = q / AC_PIX, rem = q - f * AC_PIX;
-            const int y = rem / AC_IW, x = rem - y * AC_IW;
             const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
             const int jc = (pc - s) & 15;                 // logical chunk that lives at physical position pc
-            const int frame = f0 + f;
-            const uint32_t vo = frame < p.B ? (uint32_t)((frame * AC_PIX + rem) * 256 + jc * 16) : G2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
+            vq += 16u * 256u;
+            x += 16;
+            if (x >= AC_IW) { x -= AC_IW; y += 1; if (y >= AC_IH) { y = 0; f += 1; } }
         }
     }
 
@@ -77,9 +79,9 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     // Every block walks the SAME weight stream: started together, the 32 CUs of an XCD would ask one L2 channel for the same 1 KiB at the same moment, step after
     // step.  Each block therefore starts its reduction at its own tap and wraps around (fp32 accumulation in a fixed, per-block order).
     const int tap0 = (b >> 4) & 15;                       // 16 starting taps x 2 column halves = the 32 blocks of an XCD
-    u16x8 bq[AR_D];
+    u16x8 bq[2 * AR_D];                                   // two taps' worth of fragments in flight (16 KiB per wave: the L2 round trip under load is ~1.5k cycles, a tap is 768)
 #pragma unroll
-    for (int d = 0; d < AR_D; ++d) bq[d] = wload(tap0 * 8 + d);
+    for (int d = 0; d < 2 * AR_D; ++d) bq[d] = wload(((tap0 + (d >> 3)) & 15) * 8 + (d & 7));
 
     // ---- per-lane A addressing: row r = 32 i + lrow of the block = (frame f, output pixel (oy, ox)) ----
     uint32_t pixbase[3];
@@ -115,28 +117,32 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tb[i] + q0);
 #pragma unroll 1
-    for (int t8 = 0; t8 < 16; ++t8) {
-        uint32_t tbn[3], q0n;
-        tap_of((tap0 + t8 + 1) & 15, tbn, q0n);           // the next tap's addressing: its first fragments are requested during this tap's last step
-        const int wnext = ((tap0 + t8 + 1) & 15) * 8;     // weight fragments of the next tap
+    for (int t2 = 0; t2 < 8; ++t2) {
 #pragma unroll
-        for (int d = 0; d < AR_D; ++d) {
-            if (d + 1 < AR_D) {
-                const uint32_t r = (q0 + 32u * (d + 1)) & 255u;
+        for (int h = 0; h < 2; ++h) {                     // tap number tl of this block's order; its fragments sit in ring half h
+            const int tl = 2 * t2 + h;
+            uint32_t tbn[3], q0n;
+            tap_of((tap0 + tl + 1) & 15, tbn, q0n);       // the next tap's addressing: its first fragments are requested during this tap's last step
+            const int wnext = ((tap0 + tl + 2) & 15) * 8; // this ring half is refilled with the fragments of the tap after next
 #pragma unroll
-                for (int i = 0; i < 3; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
-            } else if (t8 + 1 < 16) {
+            for (int d = 0; d < AR_D; ++d) {
+                if (d + 1 < AR_D) {
+                    const uint32_t r = (q0 + 32u * (d + 1)) & 255u;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
+                    for (int i = 0; i < 3; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
+                } else if (tl + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
+                }
+                const u16x8 bw = bq[8 * h + d];
+                if (tl + 2 < 16) bq[8 * h + d] = wload(wnext + d);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
             }
-            const u16x8 bw = bq[d];
-            if (t8 + 1 < 16) bq[d] = wload(wnext + d);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
+            for (int i = 0; i < 3; ++i) tb[i] = tbn[i];
+            q0 = q0n;
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tb[i] = tbn[i];
-        q0 = q0n;
     }
     store_tile<bf16_t, A_CONV, 3, 1>(p, acc, fg * (AC_F * 24), nt * 32, 0, 0, lrow, g, p.M, 0, 0, 0, 0);
 }
@@ -163,16 +169,18 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     {
         const int pq = lane >> 5, pc = lane & 31;         // pixel of the pair, PHYSICAL chunk (two 256-byte halves of 16 chunks, each rotated by itself)
+        // block-local pixel q = 2 t + pq = tensor pixel f0 * 24 + q; 8 pixels (one input row) further per iteration: x stays, y and the frame advance
+        const int x = (2 * wave + pq) & 7;
+        int f = 0, y = 0;
+        uint32_t vq = (uint32_t)((f0 * AG_PIX + 2 * wave + pq) * 512);
 #pragma unroll 4
         for (int t = wave; t < AG_F * AG_PIX / 2; t += 4) {
-            const int q = 2 * t + pq;
-            const int f = q / AG_PIX, rem = q - f * AG_PIX;
-            const int y = rem >> 3, x = rem & 7;
             const int s = (4 * f + 9 * y + x) & 15;
             const int jc = (pc & 16) | ((pc - s) & 15);
-            const int frame = f0 + f;
-            const uint32_t vo = frame < p.B ? (uint32_t)((frame * AG_PIX + rem) * 512 + jc * 16) : G2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
+            vq += 8u * 512u;
+            y += 1;
+            if (y >= AG_IH) { y = 0; f += 1; }
         }
         if (tid < 32) *(f32x4*)(lds + AG_ZERO + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
