@@ -468,7 +468,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     if (tail_try) {
         static int kev = -1;
         if (kev < 0) { const char* ev = getenv("MI355_KEVENT"); kev = ev ? atoi(ev) : 1; }
-        const bool carry = kev && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
+        const bool carry = kev && kev != 3 && e->side_ok == 1 && e->defer_fin && e->tm.mode != 1;      // (MI355_KEVENT=3: in the backward pass only)      // (mi_vae_train_step: nothing else is issued between this kernel and the backward pass)
         if (carry) mi_tl_stop_event = e->ev_ready;
         TOP(e, stream, OP_DECONV_FWD + 3, mi_deconv2d_tail_fused(stream, d.dtype, e->at(e->W.dec[3]), B, g.dh[3], g.dw[3], g.dc[3], e->wptr(18), e->wtptr(18), e->bptr(19), DEC_K[3], DEC_K[3], g.dc[4],
                                            tgt, frames_u8, idx, (long long)P, d.loss_kind, inv_batch, e->at(e->W.gdec[3]), e->gptr(18),
@@ -690,7 +690,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         }
     }
     if (upper || lower) {
-        bool enc_fused = false;
+        bool enc_fused = false, dense_done = false;
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             if (i == NCONV - 1 ? !upper : !lower) continue;
             const void* gy = e->at(W.gact[i + 1]);
@@ -721,6 +721,17 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             if (own) mi_tapwgrad_defer_pause(0);
             CK(rcw);
             if (i == 1 && late_dense && !use_third && tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }      // from here to the end of the pass every small slab sum on st is one job of the fused launch
+            // MI355_DENSE_EARLY=1 (round 4 A/B): the latent layers' filter gradients in FRONT of the encoder-head kernel instead of behind it: behind it they only
+            // start when conv2's filter gradient on the other stream releases its compute units (64 KB of LDS next to 147 KB: no co-residence) and end the pass late
+            static int dense_early = -1;
+            if (dense_early < 0) { const char* ev = getenv("MI355_DENSE_EARLY"); dense_early = (ev && ev[0] == '1') ? 1 : 0; }
+            if (i == 1 && dense_early && late_dense && !use_third && tail_defer && !dense_done) {
+                TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), bias_fused ? e->gptr(11) : nullptr));
+                if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+                TOP(e, st, OP_HEADS_WGRAD, dense_wgrad(st, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), bias_fused ? e->gptr(9) : nullptr));
+                if (!bias_fused) TOP(e, st, OP_HEADS_BIAS, bias_grad(st, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+                dense_done = true;
+            }
             if (i == 1 && d.dtype == MI_BF16 && e->bits1_ok && e->W.enc_slab_bytes > 0 && g.c[0] == 3 && g.c[1] == 32 && g.c[2] == 64) {
                 // conv2's input gradient feeds nothing but conv1's filter gradient: both in one launch, the 99 MB tensor between them never exists (enchead_tile.hpp)
                 int nblk = 0;
@@ -745,15 +756,19 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
             if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }
-            if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
-            TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
+            if (!dense_done) {
+                if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
+                TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
+            }
             if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
             if (defer) { mi_tapwgrad_flush(sw); }            // (the deferred slab reductions first: they end the other stream's real work; join() then finds the list empty)
             // the heads' gradients: behind a fused encoder head the caller's stream is the one that ends early (conv1's filter gradient is no longer a launch of its own)
             void* sh = (enc_fused && heads_main) ? st : sw;
-            if (tail_defer && sh != st) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }      // (what follows is issued on the other stream: nothing of it may land in st's list)
-            if (!bias_fused) TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
-            TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9)));
+            if (tail_defer && sh != st && !dense_done) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }      // (what follows is issued on the other stream: nothing of it may land in st's list)
+            if (!dense_done) {
+                if (!bias_fused) TOP(e, sh, OP_HEADS_BIAS, bias_grad(sh, e->at(W.dheads), B, 2 * d.z_dim, e->gptr(9)));
+                TOP(e, sh, OP_HEADS_WGRAD, dense_wgrad(sh, e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9)));
+            }
             if (tail_defer) { CK(mi_small_reduce_flush(st)); mi_small_reduce_defer(0); tail_defer = false; }
         }
         if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }
