@@ -14,6 +14,12 @@ static bool ares_on() {                                     // MI355_ARES=0: the
     return on != 0;
 }
 
+static int ares_cfg() {                                    // MI355_ARES_CFG: bit 0 conv form with 4 frames per block, bit 1 gather form with 8 (the first, one-block-per-CU shapes)
+    static int c = -1;
+    if (c < 0) { const char* e = getenv("MI355_ARES_CFG"); c = e ? atoi(e) : 0; }
+    return c;
+}
+
 extern "C" {
 
 // bytes of one fragment-ordered weight copy (either form: 16 x 128 x 256 bf16)
@@ -63,17 +69,21 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
     hipStream_t st = (hipStream_t)stream;
     if (form == 0) {
         p.M = B * 24; p.N = AC_N; p.OH = AC_OH; p.OW = AC_OW;
-        const int groups = (B + AC_F - 1) / AC_F;
+        const int F = ares_cfg() & 1 ? 4 : 2;               // frames per block (MI355_ARES_CFG bit 0: the one-block-per-CU form)
+        const int groups = (B + F - 1) / F;
         const int nb = (groups + 7) / 8 * 16;                // block b: frame group (b & 7) + 8 (b >> 4), column half (b >> 3) & 1
-        MI_LAUNCH(ares_conv_kernel, dim3(nb), dim3(256), 0, st, p);
+        if (F == 4) MI_LAUNCH((ares_conv_kernel<4, 1>), dim3(nb), dim3(256), 0, st, p);
+        else MI_LAUNCH((ares_conv_kernel<2, 2>), dim3(nb), dim3(256), 0, st, p);
         const int rc = mi_check_launch("ares_conv_kernel");
         if (rc != MI_OK) return rc;
     } else {
         p.M = B * AG_RPF; p.N = AG_N; p.OH = AG_OH; p.OW = AG_OW;
         for (int c = 0; c < 4; ++c) { p.dc_ohw[c] = make_fastdiv(AG_RPF); p.dc_ow[c] = make_fastdiv(9); }
-        const int groups = (B + AG_F - 1) / AG_F;
+        const int F = ares_cfg() & 2 ? 8 : 4;               // (bit 1: the one-block-per-CU form of the gather kernel)
+        const int groups = (B + F - 1) / F;
         const int nb = (groups + 7) / 8 * 32;                // block b: parity class (b >> 3) & 3, frame group (b & 7) + 8 (b >> 5)
-        MI_LAUNCH(ares_gather_kernel, dim3(nb), dim3(256), 0, st, p);
+        if (F == 8) MI_LAUNCH((ares_gather_kernel<8, 1>), dim3(nb), dim3(256), 0, st, p);
+        else MI_LAUNCH((ares_gather_kernel<4, 2>), dim3(nb), dim3(256), 0, st, p);
         const int rc = mi_check_launch("ares_gather_kernel");
         if (rc != MI_OK) return rc;
     }

@@ -34,23 +34,26 @@ struct AresParams {
 };
 
 // ---- conv form: [B,8,18,128] -> [B,3,8,256], k = 4, s = 2 ----
-constexpr int AC_F = 4, AC_IH = 8, AC_IW = 18, AC_C = 128, AC_OH = 3, AC_OW = 8, AC_N = 256;
+constexpr int AC_IH = 8, AC_IW = 18, AC_C = 128, AC_OH = 3, AC_OW = 8, AC_N = 256;
 constexpr int AC_PIX = AC_IH * AC_IW;                     // 144 pixels per frame, 256 B each
 constexpr int AC_KS = 16 * AC_C / 16;                     // 128 k16-steps (16 taps x 8)
-constexpr int AC_LDS = AC_F * AC_PIX * 256;               // 147,456 B
 constexpr int AR_D = 8;                                   // weight fragments in flight per wave
 
-__global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[AC_LDS];
+// F frames per block (4: 96 rows = three full 32-row tiles, 147 KB of LDS, one block per CU; 2: 48 rows = 1.5 tiles computed as two, 74 KB, TWO blocks per CU --
+// one block's staging runs under the other's MFMAs and a second wave per SIMD covers the weight stream's latency: round 4 A/B, MI355_ARES_CFG)
+template <int F, int WPE>
+__global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p) {
+    constexpr int ROWS = F * 24, TM = (ROWS + 31) / 32;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[F * AC_PIX * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, g = lane >> 5;
     // blocks b and b + 8 (same XCD: b % 8) are the two column halves of one frame group: its frames come out of that XCD's L2 the second time
     const int b = (int)blockIdx.x;
     const int nh = (b >> 3) & 1, fg = (b & 7) + 8 * (b >> 4);
-    const int f0 = fg * AC_F;
+    const int f0 = fg * F;
     if (f0 >= p.B) return;
 
-    // ---- stage the group's frames: 144 LDS-DMA instructions of 1 KiB (4 pixels x 16 chunks), source-side chunk rotation ----
+    // ---- stage the group's frames: F x 36 LDS-DMA instructions of 1 KiB (4 pixels x 16 chunks), source-side chunk rotation ----
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     {
         const int pq = lane >> 4, pc = lane & 15;         // pixel of the quad, PHYSICAL chunk this lane fills
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
         int f = 0, y = 0, x = 4 * wave + pq;              // q < 16 < IW on the first iteration
         uint32_t vq = (uint32_t)((f0 * AC_PIX + 4 * wave + pq) * 256);
 #pragma unroll 4
-        for (int t = wave; t < AC_F * AC_PIX / 4; t += 4) {
+        for (int t = wave; t < F * AC_PIX / 4; t += 4) {
             const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
             const int jc = (pc - s) & 15;                 // logical chunk that lives at physical position pc
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -84,19 +87,21 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
     for (int d = 0; d < 2 * AR_D; ++d) bq[d] = wload(((tap0 + (d >> 3)) & 15) * 8 + (d & 7));
 
     // ---- per-lane A addressing: row r = 32 i + lrow of the block = (frame f, output pixel (oy, ox)) ----
-    uint32_t pixbase[3];
+    uint32_t pixbase[TM];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < TM; ++i) {
         const int r = i * 32 + lrow;
-        const int f = r / 24, rem = r - f * 24;
+        int f = r / 24;
+        const int rem = r - f * 24;
+        if (f >= F) f = F - 1;                            // (rows past the block's last frame: any resident pixel; store_tile's row limit drops them)
         const int oy = rem >> 3, ox = rem & 7;
         pixbase[i] = (uint32_t)((f * AC_PIX + 2 * oy * AC_IW + 2 * ox) * 256);
     }
     const int s0g = (lrow & 15) + g;                      // (8 f + 8 oy + ox) & 15 = r & 15: the row's share of the chunk rotation (+ the lane group's chunk)
 
-    f32x16 acc[3][1];
+    f32x16 acc[TM][1];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
@@ -104,24 +109,24 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
 
     // tap (ky, kx): LDS byte offset of its pixel relative to the row's base pixel, and the byte position of chunk 0 of lane group g inside the (rotated) pixel;
     // channel step c of the tap reads chunk position (q0 + 32 c) & 255
-    auto tap_of = [&](int tap, uint32_t (&tb)[3], uint32_t& q0) {
+    auto tap_of = [&](int tap, uint32_t (&tb)[TM], uint32_t& q0) {
         const int ky = tap >> 2, kx = tap & 3;            // (wave-uniform: scalar unit)
         const uint32_t toff = (uint32_t)((ky * AC_IW + kx) * 256);
         q0 = (uint32_t)((s0g + 8 * (ky >> 1) + (kx >> 1)) & 15) << 4;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) tb[i] = pixbase[i] + toff;
+        for (int i = 0; i < TM; ++i) tb[i] = pixbase[i] + toff;
     };
-    uint32_t tb[3], q0;
+    uint32_t tb[TM], q0;
     tap_of(tap0, tb, q0);
-    u16x8 A[2][3];
+    u16x8 A[2][TM];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tb[i] + q0);
+    for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + tb[i] + q0);
 #pragma unroll 1
     for (int t2 = 0; t2 < 8; ++t2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                     // tap number tl of this block's order; its fragments sit in ring half h
             const int tl = 2 * t2 + h;
-            uint32_t tbn[3], q0n;
+            uint32_t tbn[TM], q0n;
             tap_of((tap0 + tl + 1) & 15, tbn, q0n);       // the next tap's addressing: its first fragments are requested during this tap's last step
             const int wnext = ((tap0 + tl + 2) & 15) * 8; // this ring half is refilled with the fragments of the tap after next
 #pragma unroll
@@ -129,41 +134,45 @@ __global__ __launch_bounds__(256, 1) void ares_conv_kernel(const AresParams p) {
                 if (d + 1 < AR_D) {
                     const uint32_t r = (q0 + 32u * (d + 1)) & 255u;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
+                    for (int i = 0; i < TM; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
                 } else if (tl + 1 < 16) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
+                    for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
                 }
                 const u16x8 bw = bq[8 * h + d];
                 if (tl + 2 < 16) bq[8 * h + d] = wload(wnext + d);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
+                for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) tb[i] = tbn[i];
+            for (int i = 0; i < TM; ++i) tb[i] = tbn[i];
             q0 = q0n;
         }
     }
-    store_tile<bf16_t, A_CONV, 3, 1>(p, acc, fg * (AC_F * 24), nt * 32, 0, 0, lrow, g, p.M, 0, 0, 0, 0);
+    // (rows of the block beyond ROWS belong to the next frame group: the row limit of the call stops at this block's last row)
+    const int mlim = min(p.M, (fg + 1) * ROWS);
+    store_tile<bf16_t, A_CONV, TM, 1>(p, acc, fg * ROWS, nt * 32, 0, 0, lrow, g, mlim, 0, 0, 0, 0);
 }
 
 // ---- gather form: [B,3,8,256] -> [B,8,18,128], k = 4, s = 2 (stride-2 transposed conv; one GEMM per output parity class) ----
-constexpr int AG_F = 8, AG_IH = 3, AG_IW = 8, AG_C = 256, AG_OH = 8, AG_OW = 18, AG_N = 128;
+constexpr int AG_IH = 3, AG_IW = 8, AG_C = 256, AG_OH = 8, AG_OW = 18, AG_N = 128;
 constexpr int AG_PIX = AG_IH * AG_IW;                     // 24 pixels per frame, 512 B each
 constexpr int AG_KS = 4 * AG_C / 16;                      // 64 k16-steps (2 x 2 taps x 16)
-constexpr int AG_ZERO = AG_F * AG_PIX * 512;              // byte offset of the all-zero pixel (taps that fall outside the input)
-constexpr int AG_LDS = AG_ZERO + 512;
 constexpr int AG_RPF = 36;                                // output pixels of one parity class per frame (4 x 9)
 
-__global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[AG_LDS];
+// F frames per block (8: 288 rows per class = nine 32-row tiles, 98 KB, one block per CU; 4: 144 rows = 4.5 tiles computed as five, 49 KB, two blocks per CU)
+template <int F, int WPE>
+__global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams p) {
+    constexpr int ROWS = F * AG_RPF, TM = (ROWS + 31) / 32;
+    constexpr int AG_ZERO = F * AG_PIX * 512;             // byte offset of the all-zero pixel (taps that fall outside the input)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[AG_ZERO + 512];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, g = lane >> 5;
     const int b = (int)blockIdx.x;
     // the 32 blocks of an XCD (b % 8) cover the four parity classes x eight starting points of the reduction: no two of them walk the same weight stream in step
     const int cls = (b >> 3) & 3, fg = (b & 7) + 8 * (b >> 5);
     const int ph = cls >> 1, pw = cls & 1;
-    const int f0 = fg * AG_F;
+    const int f0 = fg * F;
     if (f0 >= p.B) return;
 
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
         int f = 0, y = 0;
         uint32_t vq = (uint32_t)((f0 * AG_PIX + 2 * wave + pq) * 512);
 #pragma unroll 4
-        for (int t = wave; t < AG_F * AG_PIX / 2; t += 4) {
+        for (int t = wave; t < F * AG_PIX / 2; t += 4) {
             const int s = (4 * f + 9 * y + x) & 15;
             const int jc = (pc & 16) | ((pc - s) & 15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -194,20 +203,21 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
     for (int d = 0; d < AR_D; ++d) bq[d] = wload(o0 * 8 + d);
 
     // row r = 32 i + lrow of the block = (frame f, class pixel (j, ii)); tap (th, tw) reads input pixel (j - th, ii - tw) or the zero pixel
-    int rf[9], rj[9], ri[9];
+    int rf[TM], rj[TM], ri[TM];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < TM; ++i) {
         const int r = i * 32 + lrow;
         rf[i] = r / AG_RPF;
         const int rem = r - rf[i] * AG_RPF;
+        if (rf[i] >= F) rf[i] = F - 1;                    // (rows past the block's last frame: any resident pixel; never stored)
         rj[i] = rem / 9; ri[i] = rem - rj[i] * 9;
     }
     const int s0g = (lrow & 15) + g;                      // (4 f + 9 j + ii) & 15 = r & 15 (+ the lane group's chunk)
-    uint32_t abase[9], q0;
+    uint32_t abase[TM], q0;
     auto set_tap = [&](int tap) {
         const int th = tap >> 1, tw = tap & 1;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < TM; ++i) {
             const int y = rj[i] - th, x = ri[i] - tw;
             const bool ok = y >= 0 && y < AG_IH && x >= 0 && x < AG_IW;
             abase[i] = ok ? (uint32_t)((rf[i] * AG_PIX + y * AG_IW + x) * 512) : (uint32_t)AG_ZERO;
@@ -215,21 +225,21 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
         q0 = (uint32_t)((s0g - 9 * th - tw) & 15) << 4;  // byte position of chunk 0 of lane group g inside a rotated 256-byte half (the zero pixel is zero everywhere)
     };
 
-    f32x16 acc[9][1];
+    f32x16 acc[TM][1];
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
     __syncthreads();
 
     // 8 octets of 8 k-steps: octet o = (tap o >> 1, channel half o & 1); channel step c of the octet reads chunk position half * 256 + ((q0 + 32 c) & 255)
-    u16x8 A[2][9];
+    u16x8 A[2][TM];
     set_tap(o0 >> 1);
     {
         const uint32_t r = (uint32_t)(o0 & 1) * 256u + q0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
+        for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
     }
 #pragma unroll 1
     for (int t8 = 0; t8 < 8; ++t8) {
@@ -240,20 +250,21 @@ __global__ __launch_bounds__(256, 1) void ares_gather_kernel(const AresParams p)
             if (d + 1 < AR_D) {
                 const uint32_t r = hoff + ((q0 + 32u * (d + 1)) & 255u);
 #pragma unroll
-                for (int i = 0; i < 9; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + abase[i] + r);
+                for (int i = 0; i < TM; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + abase[i] + r);
             } else if (t8 + 1 < 8) {
                 if ((on & 1) == 0) set_tap(on >> 1);      // (wave-uniform; this step's fragments are already in registers)
                 const uint32_t r = (uint32_t)(on & 1) * 256u + q0;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
+                for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
             }
             const u16x8 bw = bq[d];
             if (t8 + 1 < 8) bq[d] = wload(on * 8 + d);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
+            for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
         }
     }
-    store_tile<bf16_t, A_DECONV, 9, 1>(p, acc, fg * (AG_F * AG_RPF), wave * 32, 0, 0, lrow, g, p.M, cls, ph, pw, 0);
+    const int mlim = min(p.M, (fg + 1) * ROWS);
+    store_tile<bf16_t, A_DECONV, TM, 1>(p, acc, fg * ROWS, wave * 32, 0, 0, lrow, g, mlim, cls, ph, pw, 0);
 }
 
 // ---- weights -> fragment order (bf16), from the fp32 master tensor ----
