@@ -66,6 +66,7 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
     AresParams p = {};
     p.x = x; p.x_bytes = (uint32_t)xb; p.wf = wf; p.B = B;
     p.out = out; p.bias = bias; p.mask = mask; p.relu = relu; p.out_f32 = 0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MI355_ARES_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     hipStream_t st = (hipStream_t)stream;
     if (form == 0) {
         p.M = B * 24; p.N = AC_N; p.OH = AC_OH; p.OW = AC_OW;

@@ -31,7 +31,22 @@ struct AresParams {
     void* out; const float* bias; const void* mask; int relu, out_f32;
     int N, OH, OW;
     FastDiv dc_ohw[4], dc_ow[4];
+    int dbg;                                              // MI355_ARES_DBG (timing experiments, wrong results): 1 no k-loop, 2 no staging, 3 neither
 };
+
+// LDS fragment reads issued and waited for BY HAND (the idiom of rwconv.hip): hipcc sinks every ds_read next to the MFMA that consumes it -- the first build of these
+// kernels ran "ds_read; s_waitcnt lgkmcnt(0); v_mfma" three times per k-step, a full LDS latency in front of every MFMA (208 cycles per step for 96 of MFMA).
+// asm volatile keeps the issue order; the wait names the fragments it releases as in/out operands, so their MFMAs cannot move above it.  LDS returns in order:
+// lgkmcnt(N) = all but the N most recent reads have landed.
+__device__ __forceinline__ void ar_lds_read(u16x8& a, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(a) : "v"(addr)); }
+template <int N> __device__ __forceinline__ void ar_lds_wait(u16x8 (&a)[2]) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ar_lds_wait(u16x8 (&a)[3]) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N)); }
+template <int N> __device__ __forceinline__ void ar_lds_wait(u16x8 (&a)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ar_lds_wait(u16x8 (&a)[9]) {
+    asm volatile("s_waitcnt lgkmcnt(%9)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]) : "n"(N));
+}
 
 // ---- conv form: [B,8,18,128] -> [B,3,8,256], k = 4, s = 2 ----
 constexpr int AC_IH = 8, AC_IW = 18, AC_C = 128, AC_OH = 3, AC_OW = 8, AC_N = 256;
@@ -62,7 +77,7 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
         int f = 0, y = 0, x = 4 * wave + pq;              // q < 16 < IW on the first iteration
         uint32_t vq = (uint32_t)((f0 * AC_PIX + 4 * wave + pq) * 256);
 #pragma unroll 4
-        for (int t = wave; t < F * AC_PIX / 4; t += 4) {
+        for (int t = wave; t < ((p.dbg & 2) ? 0 : F * AC_PIX / 4); t += 4) {
             const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
             const int jc = (pc - s) & 15;                 // logical chunk that lives at physical position pc
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -118,11 +133,12 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
     };
     uint32_t tb[TM], q0;
     tap_of(tap0, tb, q0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     u16x8 A[2][TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + tb[i] + q0);
+    for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tb[i] + q0);
 #pragma unroll 1
-    for (int t2 = 0; t2 < 8; ++t2) {
+    for (int t2 = 0; t2 < ((p.dbg & 1) ? 0 : 8); ++t2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                     // tap number tl of this block's order; its fragments sit in ring half h
             const int tl = 2 * t2 + h;
@@ -132,15 +148,16 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
 #pragma unroll
             for (int d = 0; d < AR_D; ++d) {
                 if (d + 1 < AR_D) {
-                    const uint32_t r = (q0 + 32u * (d + 1)) & 255u;
+                    const uint32_t r = lds0 + ((q0 + 32u * (d + 1)) & 255u);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + tb[i] + r);
-                } else if (tl + 1 < 16) {
+                    for (int i = 0; i < TM; ++i) ar_lds_read(A[(d + 1) & 1][i], tb[i] + r);
+                } else {                                  // (unconditional: behind the last tap this re-reads the first one's fragments -- a branch per step costs more)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + tbn[i] + q0n);
+                    for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tbn[i] + q0n);
                 }
+                ar_lds_wait<TM>(A[d & 1]);                // this step's fragments have landed (the TM reads just issued may still be in flight)
                 const u16x8 bw = bq[8 * h + d];
-                if (tl + 2 < 16) bq[8 * h + d] = wload(wnext + d);
+                bq[8 * h + d] = wload(wnext + d);         // (unconditional as well: the last two taps re-request fragments nobody consumes)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);      // D[row = channel][col = pixel]
             }
@@ -149,6 +166,7 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
             q0 = q0n;
         }
     }
+    ar_lds_wait<0>(A[0]);                                 // (the over-read of the last step: its destination registers are free only once it has landed)
     // (rows of the block beyond ROWS belong to the next frame group: the row limit of the call stops at this block's last row)
     const int mlim = min(p.M, (fg + 1) * ROWS);
     store_tile<bf16_t, A_CONV, TM, 1>(p, acc, fg * ROWS, nt * 32, 0, 0, lrow, g, mlim, 0, 0, 0, 0);
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams 
         int f = 0, y = 0;
         uint32_t vq = (uint32_t)((f0 * AG_PIX + 2 * wave + pq) * 512);
 #pragma unroll 4
-        for (int t = wave; t < F * AG_PIX / 2; t += 4) {
+        for (int t = wave; t < ((p.dbg & 2) ? 0 : F * AG_PIX / 2); t += 4) {
             const int s = (4 * f + 9 * y + x) & 15;
             const int jc = (pc & 16) | ((pc - s) & 15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -234,35 +252,38 @@ __global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams 
     __syncthreads();
 
     // 8 octets of 8 k-steps: octet o = (tap o >> 1, channel half o & 1); channel step c of the octet reads chunk position half * 256 + ((q0 + 32 c) & 255)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     u16x8 A[2][TM];
     set_tap(o0 >> 1);
     {
-        const uint32_t r = (uint32_t)(o0 & 1) * 256u + q0;
+        const uint32_t r = lds0 + (uint32_t)(o0 & 1) * 256u + q0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
+        for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], abase[i] + r);
     }
 #pragma unroll 1
-    for (int t8 = 0; t8 < 8; ++t8) {
+    for (int t8 = 0; t8 < ((p.dbg & 1) ? 0 : 8); ++t8) {
         const int o = (o0 + t8) & 7, on = (o0 + t8 + 1) & 7;
         const uint32_t hoff = (uint32_t)(o & 1) * 256u;
 #pragma unroll
         for (int d = 0; d < AR_D; ++d) {
             if (d + 1 < AR_D) {
-                const uint32_t r = hoff + ((q0 + 32u * (d + 1)) & 255u);
+                const uint32_t r = lds0 + hoff + ((q0 + 32u * (d + 1)) & 255u);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) A[(d + 1) & 1][i] = *(const u16x8*)(lds + abase[i] + r);
-            } else if (t8 + 1 < 8) {
-                if ((on & 1) == 0) set_tap(on >> 1);      // (wave-uniform; this step's fragments are already in registers)
-                const uint32_t r = (uint32_t)(on & 1) * 256u + q0;
+                for (int i = 0; i < TM; ++i) ar_lds_read(A[(d + 1) & 1][i], abase[i] + r);
+            } else {                                      // (unconditional, see ares_conv_kernel)
+                if ((on & 1) == 0) set_tap(on >> 1);      // (wave-uniform; this step's fragments were requested with the old addresses)
+                const uint32_t r = lds0 + (uint32_t)(on & 1) * 256u + q0;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) A[0][i] = *(const u16x8*)(lds + abase[i] + r);
+                for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], abase[i] + r);
             }
+            ar_lds_wait<TM>(A[d & 1]);
             const u16x8 bw = bq[d];
-            if (t8 + 1 < 8) bq[d] = wload(on * 8 + d);
+            bq[d] = wload(on * 8 + d);
 #pragma unroll
             for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
         }
     }
+    ar_lds_wait<0>(A[0]);
     const int mlim = min(p.M, (fg + 1) * ROWS);
     store_tile<bf16_t, A_DECONV, TM, 1>(p, acc, fg * ROWS, wave * 32, 0, 0, lrow, g, mlim, cls, ph, pw, 0);
 }
