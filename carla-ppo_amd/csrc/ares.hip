@@ -73,7 +73,8 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
         const int F = ares_cfg() & 1 ? 4 : 2;               // frames per block (MI355_ARES_CFG bit 0: the one-block-per-CU form)
         const int groups = (B + F - 1) / F;
         const int nb = (groups + 7) / 8 * 16;                // block b: frame group (b & 7) + 8 (b >> 4), column half (b >> 3) & 1
-        if (F == 4) MI_LAUNCH((ares_conv_kernel<4, 1>), dim3(nb), dim3(256), 0, st, p);
+        if (F == 4 && (ares_cfg() & 4)) MI_LAUNCH(ares_conv8_kernel, dim3(nb), dim3(512), 0, st, p);      // (bit 2: the reduction split over two waves per SIMD)
+        else if (F == 4) MI_LAUNCH((ares_conv_kernel<4, 1>), dim3(nb), dim3(256), 0, st, p);
         else MI_LAUNCH((ares_conv_kernel<2, 2>), dim3(nb), dim3(256), 0, st, p);
         const int rc = mi_check_launch("ares_conv_kernel");
         if (rc != MI_OK) return rc;
