@@ -14,7 +14,7 @@ static bool ares_on() {                                     // MI355_ARES=0: the
     return on != 0;
 }
 
-static int ares_cfg() {                                    // MI355_ARES_CFG: bit 0 conv form with 4 frames per block, bit 1 gather form with 8 (the first, one-block-per-CU shapes)
+static int ares_cfg() {                                    // MI355_ARES_CFG (A/B runs): bit 0 conv form with 2 frames per block (two blocks per CU), bit 1 gather form with 8 (one block per CU)
     static int c = -1;
     if (c < 0) { const char* e = getenv("MI355_ARES_CFG"); c = e ? atoi(e) : 0; }
     return c;
@@ -70,11 +70,10 @@ int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const 
     hipStream_t st = (hipStream_t)stream;
     if (form == 0) {
         p.M = B * 24; p.N = AC_N; p.OH = AC_OH; p.OW = AC_OW;
-        const int F = ares_cfg() & 1 ? 4 : 2;               // frames per block (MI355_ARES_CFG bit 0: the one-block-per-CU form)
+        const int F = ares_cfg() & 1 ? 2 : 4;               // frames per block (MI355_ARES_CFG bit 0: the two-blocks-per-CU form, measured slower)
         const int groups = (B + F - 1) / F;
         const int nb = (groups + 7) / 8 * 16;                // block b: frame group (b & 7) + 8 (b >> 4), column half (b >> 3) & 1
-        if (F == 4 && (ares_cfg() & 4)) MI_LAUNCH(ares_conv8_kernel, dim3(nb), dim3(512), 0, st, p);      // (bit 2: the reduction split over two waves per SIMD)
-        else if (F == 4) MI_LAUNCH((ares_conv_kernel<4, 1>), dim3(nb), dim3(256), 0, st, p);
+        if (F == 4) MI_LAUNCH((ares_conv_kernel<4, 1>), dim3(nb), dim3(256), 0, st, p);
         else MI_LAUNCH((ares_conv_kernel<2, 2>), dim3(nb), dim3(256), 0, st, p);
         const int rc = mi_check_launch("ares_conv_kernel");
         if (rc != MI_OK) return rc;

@@ -16,7 +16,13 @@
 //     chunk positions for every tap (conflict-free; a per-tap constant shifts all lanes alike);
 //   * grid = exactly one block per CU at batch 512: conv form 128 frame groups (4 frames = 96 rows) x 2 column halves; gather form 64 frame groups
 //     (8 frames = 288 rows per parity class) x 4 classes.
-// MFMA work per block: conv form 3 x 128 = 384, gather form 9 x 64 = 576 v_mfma_f32_32x32x16_bf16 per wave = 5.1 / 7.7 us at full issue rate.
+// MFMA work per block: conv form 3 x 128 = 384 v_mfma_f32_32x32x16_bf16 per wave, gather form 5 x 64 = 320 per wave x two waves per SIMD.  At the rate the chip
+// sustains with all 1,024 SIMDs on that instruction (tools/probes/mfma_probe.hip: 16.6 ns per MFMA per SIMD = 32 cycles at the ~1.93 GHz the power limit leaves
+// under full matrix load -- 2.0 PFLOP/s, not the 2.5 of the 2.4 GHz boost clock) that is 6.4 / 10.6 us; the k loops measure ~10.5 / ~16 us (60-65 %), the kernels
+// 19 / 26 us in the step (staging 1-5 us warm / cold, epilogue, launch) against 29.5 / 41.4 us for the im2col tile kernels they replace.
+// Measured and dropped (round 4): two frames per block / two blocks per CU for the conv form (1.5 row tiles computed as two: 24.1 vs 20.4 us); the conv form's
+// reduction split over two waves per SIMD (20.0 vs 20.6 us: the loop is not issue-bound at one wave per SIMD -- the "missing" cycles were the clock);
+// eight frames per block for the gather form (29.4 vs 27.1 us).
 #pragma once
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
@@ -168,130 +174,6 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
     }
     ar_lds_wait<0>(A[0]);                                 // (the over-read of the last step: its destination registers are free only once it has landed)
     // (rows of the block beyond ROWS belong to the next frame group: the row limit of the call stops at this block's last row)
-    const int mlim = min(p.M, (fg + 1) * ROWS);
-    store_tile<bf16_t, A_CONV, TM, 1>(p, acc, fg * ROWS, nt * 32, 0, 0, lrow, g, mlim, 0, 0, 0, 0);
-}
-
-// The same layer with the REDUCTION SPLIT over two waves per SIMD (512 threads: waves w and w + 4 share a SIMD and the 32 output channels w & 3; wave half
-// kh = w >> 2 takes eight of the sixteen taps).  At one wave per SIMD the k-step loop is bound by instruction ISSUE, not by the matrix pipe: with every memory
-// operation removed it still took 163 cycles per step for 96 cycles of MFMA (3 MFMAs + ~17 address / wait / scalar instructions at ~4 cycles each: the
-// experiments of MI355_ARES_DBG).  A second wave per SIMD issues its fillers under the first one's MFMAs.  The two partial accumulators meet in LDS (the
-// staged frames are dead by then) and the kh = 0 waves run the epilogue.
-__global__ __launch_bounds__(512, 2) void ares_conv8_kernel(const AresParams p) {
-    constexpr int F = 4, ROWS = F * 24, TM = 3;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[F * AC_PIX * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 31, g = lane >> 5;
-    const int wn = wave & 3, kh = wave >> 2;
-    const int b = (int)blockIdx.x;
-    const int nh = (b >> 3) & 1, fg = (b & 7) + 8 * (b >> 4);
-    const int f0 = fg * F;
-    if (f0 >= p.B) return;
-
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    {
-        const int pq = lane >> 4, pc = lane & 15;
-        // eight waves: block-local pixel q = 4 t + pq advances by 32 pixels (one row of 18 and 14 more) per iteration
-        const int q0 = 4 * wave + pq;                     // < 32
-        int f = 0, y = q0 >= AC_IW ? 1 : 0, x = q0 >= AC_IW ? q0 - AC_IW : q0;
-        uint32_t vq = (uint32_t)((f0 * AC_PIX + q0) * 256);
-#pragma unroll 2
-        for (int t = wave; t < ((p.dbg & 2) ? 0 : F * AC_PIX / 4); t += 8) {
-            const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
-            const int jc = (pc - s) & 15;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
-            vq += 32u * 256u;
-            x += 14; y += 1;
-            if (x >= AC_IW) { x -= AC_IW; y += 1; }
-            if (y >= AC_IH) { y -= AC_IH; f += 1; }
-        }
-    }
-
-    const int nt = nh * 4 + wn;
-    const char* const wbase = (const char*)p.wf + (size_t)nt * AC_KS * 1024;
-    const uint32_t lo16 = (uint32_t)lane * 16u;
-    auto wload = [&](int idx) -> u16x8 { return *(const u16x8*)(wbase + (size_t)idx * 1024 + lo16); };
-    const int tap0 = (((b >> 4) & 15) + 8 * kh) & 15;     // this wave's first tap: the block's starting point (see ares_conv_kernel) + its half of the sixteen
-    u16x8 bq[2 * AR_D];
-#pragma unroll
-    for (int d = 0; d < 2 * AR_D; ++d) bq[d] = wload(((tap0 + (d >> 3)) & 15) * 8 + (d & 7));
-
-    uint32_t pixbase[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = i * 32 + lrow;
-        const int f = r / 24, rem = r - f * 24;
-        const int oy = rem >> 3, ox = rem & 7;
-        pixbase[i] = (uint32_t)((f * AC_PIX + 2 * oy * AC_IW + 2 * ox) * 256);
-    }
-    const int s0g = (lrow & 15) + g;
-
-    f32x16 acc[TM][1];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-
-    __syncthreads();
-
-    auto tap_of = [&](int tap, uint32_t (&tb)[TM], uint32_t& q0) {
-        const int ky = tap >> 2, kx = tap & 3;
-        const uint32_t toff = (uint32_t)((ky * AC_IW + kx) * 256);
-        q0 = (uint32_t)((s0g + 8 * (ky >> 1) + (kx >> 1)) & 15) << 4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) tb[i] = pixbase[i] + toff;
-    };
-    uint32_t tb[TM], q0;
-    tap_of(tap0, tb, q0);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    u16x8 A[2][TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tb[i] + q0);
-#pragma unroll 1
-    for (int t2 = 0; t2 < ((p.dbg & 1) ? 0 : 4); ++t2) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tl = 2 * t2 + h;                    // 0 .. 7: this wave's taps
-            uint32_t tbn[TM], q0n;
-            tap_of((tap0 + tl + 1) & 15, tbn, q0n);
-            const int wnext = ((tap0 + tl + 2) & 15) * 8;
-#pragma unroll
-            for (int d = 0; d < AR_D; ++d) {
-                if (d + 1 < AR_D) {
-                    const uint32_t r = lds0 + ((q0 + 32u * (d + 1)) & 255u);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) ar_lds_read(A[(d + 1) & 1][i], tb[i] + r);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tbn[i] + q0n);
-                }
-                ar_lds_wait<TM>(A[d & 1]);
-                const u16x8 bw = bq[8 * h + d];
-                bq[8 * h + d] = wload(wnext + d);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) tb[i] = tbn[i];
-            q0 = q0n;
-        }
-    }
-    ar_lds_wait<0>(A[0]);
-    // the two halves of the reduction meet: [wn][tile][register][lane] floats in the (dead) frame buffer, 48 KB
-    __syncthreads();
-    float* const red = (float*)lds;
-    if (kh == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wn * TM + i) * 16 + r) * 64 + lane] = acc[i][0][r];
-    }
-    __syncthreads();
-    if (kh == 1) return;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] += red[((wn * TM + i) * 16 + r) * 64 + lane];
     const int mlim = min(p.M, (fg + 1) * ROWS);
     store_tile<bf16_t, A_CONV, TM, 1>(p, acc, fg * ROWS, nt * 32, 0, 0, lrow, g, mlim, 0, 0, 0, 0);
 }
