@@ -294,13 +294,126 @@ __global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams 
     store_tile<bf16_t, A_DECONV, TM, 1>(p, acc, fg * ROWS, wave * 32, 0, 0, lrow, g, mlim, cls, ph, pw, 0);
 }
 
+// ---- gather form, mid layer: [B,8,18,128] -> [B,18,38,64], k = 4, s = 2 (deconv2 forward / conv3's input gradient) ----
+// One FRAME per block (36,864 B of LDS; two blocks per CU by registers -- one block's staging and epilogues run under the other's MFMAs; three would spill), all four parity classes in
+// turn (171 = 9 x 19 output pixels per class and frame).  The four waves are 2 output tiles (N = 64) x 2 row halves of 96 rows (three 32-row tiles; rows
+// 171 .. 191 of the second half are computed on whatever pixel their address hits and never stored).  Per class 4 taps x 8 channel steps; the weight
+// stream of a wave is [class][tile][32 fragments]; the class order starts at block-dependent class (no two neighbours walk the same stream in step).
+constexpr int G2_IH = 8, G2_IW = 18, G2_OH = 18, G2_OW = 38, G2_N = 64;
+constexpr int G2_PIX = G2_IH * G2_IW;                     // 144 pixels of 256 B
+constexpr int G2_RPF = 9 * 19;                            // 171 output pixels of one parity class per frame
+constexpr int G2_ZERO = G2_PIX * 256;
+
+__global__ __launch_bounds__(256, 2) void ares_gather2_kernel(const AresParams p) {
+    constexpr int TM = 3;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G2_ZERO + 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, g = lane >> 5;
+    const int frame = (int)blockIdx.x;
+    if (frame >= p.B) return;
+    const int nt = wave & 1, rh = wave >> 1;
+
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    {
+        const int pq = lane >> 4, pc = lane & 15;
+        int y = 0, x = 4 * wave + pq;                     // pixel q = 4 t + pq, 16 pixels further per iteration; rotation s(y, x) = (19 y + x) & 15
+        uint32_t vq = (uint32_t)((frame * G2_PIX + 4 * wave + pq) * 256);
+#pragma unroll 3
+        for (int t = wave; t < ((p.dbg & 2) ? 0 : G2_PIX / 4); t += 4) {
+            const int s = (3 * y + x) & 15;
+            const int jc = (pc - s) & 15;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
+            vq += 16u * 256u;
+            x += 16;
+            if (x >= G2_IW) { x -= G2_IW; y += 1; }
+        }
+        if (tid < 16) *(f32x4*)(lds + G2_ZERO + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const uint32_t lo16 = (uint32_t)lane * 16u;
+    const char* const wf = (const char*)p.wf + (size_t)nt * 32 * 1024;
+    auto wload = [&](int cls_, int idx) -> u16x8 { return *(const u16x8*)(wf + ((size_t)cls_ * 64 + (size_t)idx) * 1024 + lo16); };      // fragment idx (0 .. 31) of (class, tile nt)
+    const int cls0 = frame & 3;
+    u16x8 bq[AR_D];
+#pragma unroll
+    for (int d = 0; d < AR_D; ++d) bq[d] = wload(cls0, d);
+
+    int rj[TM], ri[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = rh * 96 + i * 32 + lrow;            // class-local output pixel of the frame (>= 171: dropped by the store's row limit)
+        rj[i] = r / 19; ri[i] = r - rj[i] * 19;
+    }
+    const int s0g = (lrow & 15) + g;                      // (19 j + ii) & 15 = r & 15 (96 and 32 are multiples of 16) + the lane group's chunk
+    auto tap_of = [&](int tap, uint32_t (&tb)[TM], uint32_t& q0) {
+        const int th = tap >> 1, tw = tap & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int y = rj[i] - th, x = ri[i] - tw;
+            const bool ok = y >= 0 && y < G2_IH && x >= 0 && x < G2_IW;
+            tb[i] = ok ? (uint32_t)((y * G2_IW + x) * 256) : (uint32_t)G2_ZERO;
+        }
+        q0 = (uint32_t)((s0g - 3 * th - tw) & 15) << 4;
+    };
+
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    __syncthreads();
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    uint32_t tb[TM], q0;
+    tap_of(0, tb, q0);
+    u16x8 A[2][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tb[i] + q0);
+    const int mlim = min(p.M, (frame + 1) * G2_RPF);
+#pragma unroll 1
+    for (int G = 0; G < ((p.dbg & 1) ? 0 : 16); ++G) {    // group = (class in this block's order, tap): 8 channel steps
+        const int cls = (cls0 + (G >> 2)) & 3, tap = G & 3;
+        const int Gn = (G + 1) & 15, clsn = (cls0 + (Gn >> 2)) & 3;
+        uint32_t tbn[TM], q0n;
+        tap_of(Gn & 3, tbn, q0n);
+#pragma unroll
+        for (int d = 0; d < AR_D; ++d) {
+            if (d + 1 < AR_D) {
+                const uint32_t r = lds0 + ((q0 + 32u * (d + 1)) & 255u);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ar_lds_read(A[(d + 1) & 1][i], tb[i] + r);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tbn[i] + q0n);
+            }
+            ar_lds_wait<TM>(A[d & 1]);
+            const u16x8 bw = bq[d];
+            bq[d] = wload(clsn, (Gn & 3) * 8 + d);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) Frag<bf16_t>::mma(bw, A[d & 1][i], acc[i][0]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tb[i] = tbn[i];
+        q0 = q0n;
+        if (tap == 3) {                                   // the class is complete: store its three tiles, start the next class from zero
+            store_tile<bf16_t, A_DECONV, TM, 1>(p, acc, frame * G2_RPF + rh * 96, nt * 32, 0, 0, lrow, g, mlim, cls, cls >> 1, cls & 1, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        }
+    }
+    ar_lds_wait<0>(A[0]);
+}
+
 // ---- weights -> fragment order (bf16), from the fp32 master tensor ----
 // form 0 (conv form): src is [K = 16 x 128][N = 256] (HWIO conv kernel, or a [kh,kw,out,in] transposed-conv kernel read as HWIO for its input gradient):
 //     dst[((nt * 128 + ks) * 64 + l) * 8 + e] = src[(ks * 16 + (l >> 5) * 8 + e) * 256 + nt * 32 + (l & 31)]
 // form 1 (gather form): src is [kh][kw][n = 128][c = 256] ([kh,kw,out,in] transposed-conv kernel, or an HWIO conv kernel read that way for its input gradient):
 //     dst[(((cls * 4 + nt) * 64 + ks) * 64 + l) * 8 + e] = src[((kh * 4 + kw) * 128 + nt * 32 + (l & 31)) * 256 + (ks & 15) * 16 + (l >> 5) * 8 + e],
 //     tap = ks >> 4 = (th, tw), (kh, kw) = (ph + 2 th, pw + 2 tw), cls = (ph, pw)
-struct AresPackJobs { const float* src[4]; bf16_t* dst[4]; int form[4]; int n; };      // up to four copies in one launch: job = blockIdx.x >> 8
+struct AresPackJobs { const float* src[8]; bf16_t* dst[8]; int form[8]; int n; };      // up to eight copies in one launch: job = blockIdx.x >> 8
 __global__ __launch_bounds__(256) void ares_pack_kernel(const AresPackJobs jobs) {
     const int job = (int)blockIdx.x >> 8;
     if (job >= jobs.n) return;
@@ -315,6 +428,14 @@ __global__ __launch_bounds__(256) void ares_pack_kernel(const AresPackJobs jobs)
         const int k = ks * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 256 + n];
+    } else if (form == 2) {                               // gather form, mid layer: [kh][kw][n = 64][c = 128] -> [class][tile (2)][32 fragments]; 256 fragments = 256 KB
+        if (frag >= 256) return;
+        const int ks = frag & 31, nt = (frag >> 5) & 1, cls = frag >> 6;
+        const int tap = ks >> 3, th = tap >> 1, tw = tap & 1;
+        const int kh = (cls >> 1) + 2 * th, kw = (cls & 1) + 2 * tw;
+        const float* s = src + ((long long)((kh * 4 + kw) * 64 + nt * 32 + (l & 31))) * 128 + (ks & 7) * 16 + (l >> 5) * 8;
+        const f32x4 a = *(const f32x4*)s, c = *(const f32x4*)(s + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
     } else {
         const int ks = frag & 63, nt = (frag >> 6) & 3, cls = frag >> 8;
         const int tap = ks >> 4, th = tap >> 1, tw = tap & 1;

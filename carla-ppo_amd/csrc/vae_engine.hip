@@ -76,8 +76,8 @@ struct Workspace {
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64)
-    long long wfrag[4];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
-                              // gradient, deconv1 forward, deconv1 input gradient (1 MB each; rewritten behind every optimiser step with the K-contiguous copies)
+    long long wfrag[6];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
+                              // gradient, deconv1 forward, deconv1 input gradient (1 MB each), conv3 input gradient, deconv2 forward (256 KB each); rewritten behind every optimiser step with the K-contiguous copies
     long long total;
     // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
     // finds the region a kernel wrote past (the bounds-checking debug mode of the new build)
@@ -135,6 +135,7 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int ares_mid;                       // ... and the mid-layer copies (conv3's input gradient, deconv2 forward)
     int ares_ok;                        // the fragment-ordered weight copies exist (bf16 engine, the model's geometry): the four small-grid layers run on the activation-resident kernels
     int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
     hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
@@ -214,7 +215,7 @@ void make_workspace(VaeEngine& e) {
         W.roll = add(W.roll_bytes);
     }
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256);
-    for (int i = 0; i < 4; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());
+    for (int i = 0; i < 6; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());
     W.total = o;
 }
 
@@ -302,6 +303,11 @@ int run_decoder(VaeEngine* e, void* st, int B, int last = 4, int want_bits = 0) 
             TOP(e, st, OP_DECONV_FWD + i, mi_ares_conv(st, d.dtype, 1, e->at(e->W.dec[0]), B, e->at(e->W.wfrag[2]), e->bptr(13), 1, nullptr, e->at(e->W.dec[1]), &launched));
             if (launched) continue;
         }
+        if (i == 1 && e->ares_ok && e->ares_mid) {
+            int launched = 0;
+            TOP(e, st, OP_DECONV_FWD + i, mi_ares_conv(st, d.dtype, 2, e->at(e->W.dec[1]), B, e->at(e->W.wfrag[5]), e->bptr(15), 1, nullptr, e->at(e->W.dec[2]), &launched));
+            if (launched) continue;
+        }
         TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd_bits(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1]), bits ? e->at(e->W.bits_dec3) : nullptr, bits ? &e->bits3_ok : nullptr));
     }
@@ -318,13 +324,16 @@ int refresh_transposed(VaeEngine* e, void* st) {
     off[n] = e->L.off[10]; K[n] = d.z_dim; N[n] = g.flat; ++n;
     for (int i = 0; i < 4; ++i) { off[n] = e->L.off[12 + 2 * i]; K[n] = DEC_K[i] * DEC_K[i] * g.dc[i + 1]; N[n] = g.dc[i]; ++n; }
     CK(mi_transpose_weights(st, d.dtype, e->params, e->wt, off, K, N, n));
-    e->ares_ok = 0;
+    e->ares_ok = 0; e->ares_mid = 0;
     static int ares_on = -1;
     if (ares_on < 0) { const char* ev = getenv("MI355_ARES"); ares_on = (ev && ev[0] == '0') ? 0 : 1; }
     if (ares_on && d.dtype == MI_BF16 && g.ih[3] == 8 && g.iw[3] == 18 && g.c[3] == 128 && g.c[4] == 256 && g.dh[0] == 3 && g.dw[0] == 8 && g.dc[0] == 256 && g.dc[1] == 128 && DEC_K[0] == 4) {
         // conv4's kernel: HWIO [4][4][128][256]; deconv1's kernel: [kh][kw][out = 128][in = 256] -- the same [16][128][256] shape, read either way (ares.hip)
         // wfrag: 0 conv4 forward, 1 conv4 input gradient, 2 deconv1 forward, 3 deconv1 input gradient -- one launch
-        CK(mi_ares_pack_weights4(st, e->params + e->L.off[6], e->params + e->L.off[12], e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3])));
+        const bool mid = g.c[2] == 64 && g.c[3] == 128 && g.dc[1] == 128 && g.dc[2] == 64 && DEC_K[1] == 4;      // (4: conv3 input gradient, 5: deconv2 forward)
+        CK(mi_ares_pack_weights6(st, e->params + e->L.off[6], e->params + e->L.off[12], mid ? e->params + e->L.off[4] : nullptr, mid ? e->params + e->L.off[14] : nullptr,
+                                 e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3]), mid ? e->at(e->W.wfrag[4]) : nullptr, mid ? e->at(e->W.wfrag[5]) : nullptr));
+        e->ares_mid = mid ? 1 : 0;
         e->ares_ok = 1;
     }
     return MI_OK;
@@ -740,6 +749,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                 if (nblk > 0) { enc_fused = true; continue; }
             }
             if (i > 1) arm();
+            if (i == 2 && e->ares_ok && e->ares_mid) {       // conv3's input gradient: the mid-layer gather form, ReluGrad mask = conv2's output
+                int launched = 0;
+                TOP(e, st, OP_CONV_DGRAD + i, mi_ares_conv(st, d.dtype, 2, gy, B, e->at(W.wfrag[4]), nullptr, 0, e->at(W.act[2]), e->at(W.gact[2]), &launched));
+                if (launched) { armed_ok(); continue; }
+            }
             if (i == 3 && e->ares_ok) {                      // conv4's input gradient: gather form on the activation-resident kernel, ReluGrad mask = conv3's output
                 int launched = 0;
                 TOP(e, st, OP_CONV_DGRAD + i, mi_ares_conv(st, d.dtype, 1, gy, B, e->at(W.wfrag[1]), nullptr, 0, e->at(W.act[3]), e->at(W.gact[3]), &launched));

@@ -146,6 +146,10 @@ int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_o
 /* the four copies the VAE engine keeps, in one launch: wf0 conv4 forward (form 0 of conv4's kernel), wf1 conv4 input gradient (form 1 of it), wf2 deconv1 forward (form 1 of
  * deconv1's kernel), wf3 deconv1 input gradient (form 0 of it) */
 int mi_ares_pack_weights4(void* stream, const float* conv4_w, const float* deconv1_w, void* wf0, void* wf1, void* wf2, void* wf3);
+/* form 2 of mi_ares_conv / mi_ares_pack_weights: the MID-layer gather form, [B,8,18,128] -> [B,18,38,64] (deconv2 forward, vae/models.py:262, and conv3's input
+ * gradient): w is [4][4][64][128] read as [kh][kw][n][c] (deconv2's [kh,kw,out,in] kernel, or conv3's HWIO kernel); its fragment copy is 256 KB.
+ * mi_ares_pack_weights6 = mi_ares_pack_weights4 + those two copies (conv3_w -> wf4, deconv2_w -> wf5; either pair may be NULL) in one launch. */
+int mi_ares_pack_weights6(void* stream, const float* conv4_w, const float* deconv1_w, const float* conv3_w, const float* deconv2_w, void* wf0, void* wf1, void* wf2, void* wf3, void* wf4, void* wf5);
 int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);

@@ -259,6 +259,28 @@ def test_activation_resident_small_grid_layers(B):
     refg2 = (yg * (rounded(maskg, td) > 0)).numpy()
     rt, at = tols("bf16", float(np.abs(refg2).max()))
     assert_close(host(og2), refg2, rt, at, "gather form: input gradient of a conv (mask)")
+    # ---- gather form, mid layer: [B,8,18,128] -> [B,18,38,64] (deconv2 forward / conv3's input gradient) ----
+    if B <= 64:
+        xm = rng.randn(B, 8, 18, 128).astype(np.float32)
+        wm = (rng.randn(4, 4, 64, 128) / np.sqrt(4 * 128)).astype(np.float32)       # [kh,kw,out=64,in=128] (deconv2) == HWIO [kh,kw,ci=64,co=128] (conv3)
+        biasm = (0.1 * rng.randn(64)).astype(np.float32)
+        maskm = rng.randn(B, 18, 38, 64).astype(np.float32)
+        ym = _nhwc(F.conv_transpose2d(_nchw(rounded(xm, td)), rounded(wm, td).permute(3, 2, 0, 1), None, stride=2))
+        assert tuple(ym.shape) == (B, 18, 38, 64)
+        wfm = torch.empty(nb, device="cuda", dtype=torch.uint8)
+        L.mi_ares_pack_weights(stream(), 2, P(dev(wm)), wfm.data_ptr())
+        xmd = dev(xm, td)
+        om = alloc(td, B, 18, 38, 64, fill=7.0)
+        L.mi_ares_conv(stream(), code, 2, xmd.data_ptr(), B, wfm.data_ptr(), P(dev(biasm)), 1, None, om.data_ptr(), launched.ctypes.data)
+        assert launched[0] == 1
+        refm = F.relu(ym + torch.from_numpy(biasm).double()).numpy()
+        rt, at = tols("bf16", float(np.abs(refm).max()))
+        assert_close(host(om), refm, rt, at, "mid gather form: deconv2 forward (bias + relu)")
+        om2 = alloc(td, B, 18, 38, 64, fill=7.0)
+        L.mi_ares_conv(stream(), code, 2, xmd.data_ptr(), B, wfm.data_ptr(), None, 0, P(dev(maskm, td)), om2.data_ptr(), launched.ctypes.data)
+        refm2 = (ym * (rounded(maskm, td) > 0)).numpy()
+        rt, at = tols("bf16", float(np.abs(refm2).max()))
+        assert_close(host(om2), refm2, rt, at, "mid gather form: input gradient of conv3 (mask)")
     # not eligible: other storage types -> nothing launched, the caller takes the general kernels
     L.mi_ares_conv(stream(), DT["f32"][0], 0, xd.data_ptr(), B, wf.data_ptr(), None, 0, None, out.data_ptr(), launched.ctypes.data)
     assert launched[0] == 0

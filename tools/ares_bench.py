@@ -42,6 +42,18 @@ def timed(fn, n=30, cold=False):
     return ts[len(ts) // 2], ts[0]
 
 
+x2 = torch.randn(B, 8, 18, 128, device="cuda", generator=g).to(bf)
+w2 = (torch.randn(4, 4, 64, 128, device="cuda", generator=g) / 22.0)
+w2b = w2.to(bf).contiguous()
+bias2 = torch.zeros(64, device="cuda")
+wf2 = torch.empty(nb, device="cuda", dtype=torch.uint8)
+L.mi_ares_pack_weights(st, 2, w2.data_ptr(), wf2.data_ptr())
+o2 = torch.empty(B, 18, 38, 64, device="cuda", dtype=bf)
+os.environ.setdefault("MI355_ARES_MID", "1")
+for cold in (False, True):
+    e_ = timed(lambda: L.mi_ares_conv(st, 1, 2, x2.data_ptr(), B, wf2.data_ptr(), bias2.data_ptr(), 1, None, o2.data_ptr(), flag.ctypes.data), cold=cold)
+    f_ = timed(lambda: L.mi_deconv2d_nhwc_fwd(st, 1, x2.data_ptr(), B, 8, 18, 128, w2b.data_ptr(), bias2.data_ptr(), 4, 4, 64, 1, o2.data_ptr()), cold=cold)
+    print("B=%d %s: mid gather form  ares %.1f us (min %.1f)  general %.1f us (min %.1f)  (launched %d)" % ((B, "cold" if cold else "warm") + e_ + f_ + (int(flag[0]),)))
 for cold in (False, True):
     tag = "cold (512 MB written in between)" if cold else "warm"
     a = timed(lambda: L.mi_ares_conv(st, 1, 0, x0.data_ptr(), B, wf0.data_ptr(), bias0.data_ptr(), 1, None, o0.data_ptr(), flag.ctypes.data), cold=cold)
