@@ -84,6 +84,7 @@ class VaeDevice:
         self.grad_buckets = [(1, self.decoder_offset, self.n_flat), (3, c4, self.decoder_offset), (4, 0, c4)]
 
     def _create(self, max_batch):
+        recreated = self.handle is not None
         if self.handle is not None:
             self.L.mi_vae_destroy(self.handle)
             self.handle = None
@@ -100,6 +101,8 @@ class VaeDevice:
         if getattr(self, "_seed", None) is not None:        # a re-created engine (larger workspace) moves on to a fresh noise stream
             self._seed += 0x9E3779B97F4A7C15
             self.L.mi_vae_set_seed(self.handle, int(self._seed) & 0xFFFFFFFFFFFFFFFF)
+        if recreated:                                       # the derived weight copies that live INSIDE the workspace (the fragment-ordered kernels of the activation-resident
+            self.sync_shadow()                              # layers) went with the old one: without this the first step of the new engine runs the general kernels
 
     def ensure_batch(self, b):
         if b > self.max_batch:

@@ -1,0 +1,14 @@
+#!/bin/bash
+# one gpurun call: the driver's GPU suite five times in a row, then the round's bench + profile passes
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+tag=${1:-r04a}
+: > gpurun_out/suite_loop_$tag.log
+for i in 1 2 3 4 5; do
+  echo "=== run $i ===" >> gpurun_out/suite_loop_$tag.log
+  timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4 >> gpurun_out/suite_loop_$tag.log
+  echo "rc=${PIPESTATUS[0]}" >> gpurun_out/suite_loop_$tag.log
+done
+cat gpurun_out/suite_loop_$tag.log
+tools/profile_round.sh $tag
