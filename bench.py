@@ -345,7 +345,7 @@ def mlp_extra(tmp, B, pool_u8, idx, steps=30, warm=5):
     dt = time.perf_counter() - t0
     flops = 6.0 * B * (38400 * 512 + 512 * 256 + 256 * 128 + 64 * 256 + 256 * 512 + 512 * 38400)
     return {"frames_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "dense_tflops": flops * steps / dt / 1e12,
-            "note": "dense-layer kernels of the C ABI sequenced from the host (mi355/mlp_vae_device.py); 39.5 M parameters: the Adam pass alone moves 1.2 GB per step"}
+            "note": "native MlpVAE engine (csrc/mlp_engine.hip): one C call per step; 39.5 M parameters: the Adam pass alone moves 1.1 GB per step"}
 
 
 def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):

@@ -56,6 +56,8 @@ int g_gemm2_on = -1;
 static int gemm2_stages_env() { const char* e = getenv("MI355_GEMM2_STAGES"); return e ? atoi(e) : 2; }
 int g_gemm2_stages = gemm2_stages_env();                    // gemm2 128 x 64 tiles: LDS stages of the K pipeline (2 | 3 | 4); mi_set_tuning key 20
 static int gemm2_tile_env() { const char* e = getenv("MI355_GEMM2_TILE"); return e ? atoi(e) : 2; }
+static int gemm2_splitk_env() { const char* e = getenv("MI355_GEMM2_SPLITK"); return (e && e[0] == '0') ? 0 : 1; }
+int g_gemm2_splitk = gemm2_splitk_env();                                   // split-K dense layers (raw fp32 slabs) on the LDS-DMA tiles instead of the first-generation kernel (round 4: the 38400-long reductions of the MlpVAE)
 int g_gemm2_tile = gemm2_tile_env();                                       // wide-output gemm2 layers: 0 auto (64 x 64 tiles on small grids), 1 always 64 x 64, 2 never, 3 always 128 x 128 (64 x 64 wave tiles: 1 KB of LDS reads per MFMA instead of 1.5); mi_set_tuning key 17
 int g_tap_min = -2;
 bool gemm2_enabled() {
@@ -211,9 +213,10 @@ static int sr_kl(long long n, int nslab) {                // slab lanes per elem
     while (kl < 256 && kl * 2 <= nslab && (quads * kl + 255) / 256 < 96) kl *= 2;
     return kl;
 }
-static void sr_add(SmallReduceParams& f, const float* slabs, long long stride, int nslab, long long n, float* out) {
+static void sr_add(SmallReduceParams& f, const float* slabs, long long stride, int nslab, long long n, float* out, int overwrite = 0) {
     const int j = f.njobs++;
-    if (j == 0) f.first[0] = 0;
+    if (j == 0) { f.first[0] = 0; f.ovw = 0; }
+    if (overwrite) f.ovw |= 1u << j;
     f.slabs[j] = slabs; f.out[j] = out; f.stride[j] = stride; f.n[j] = n; f.nslab[j] = nslab;
     f.kl[j] = sr_kl(n, nslab);
     f.vec[j] = ((((uintptr_t)slabs) | ((uintptr_t)out)) & 15) == 0 && stride % 4 == 0;
@@ -291,7 +294,7 @@ static int tapwgrad_flush_reduces(void* stream) {
         return mi_check_launch("reduce_tiled_kernel");
     }
     static thread_local FusedReduceParams f;              // (4 KB: kept off the stack; the launch copies it into the kernel-argument buffer)
-    f.n = n; f.first[0] = 0; f.bias.njobs = 0; f.bias.first[0] = 0;
+    f.n = n; f.first[0] = 0; f.bias.njobs = 0; f.bias.first[0] = 0; f.bias.ovw = 0;
     for (int i = 0; i < n; ++i) {
         const PendingReduce& r = g_pending[i];
         f.q[i] = r.q; f.splits[i] = r.splits; f.ngroups[i] = r.ngroups; f.kind[i] = r.kind; f.ry[i] = (int)reduce_ry(r);
@@ -629,8 +632,9 @@ int try_narrow_conv(hipStream_t st, int dtype, const void* src, int src_f32, con
 }
 
 // conv-form (A_CONV x B_NK).  Returns 1 if launched, 0 if not eligible, <0 on error.
-int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
-    if (p.a_frame_idx || p.ksplit_len > 0) return 0;
+int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p, int gz = 1) {
+    if (p.a_frame_idx) return 0;
+    if (p.ksplit_len > 0 && (!g_gemm2_splitk || p.stride != 1 || p.KH != 1 || p.KW != 1 || (p.ksplit_len * esz_of(dtype)) % 128 != 0)) return 0;   // split-K: dense layers, whole 128-byte stages per split
     if (p.stride == 2 && !p.out_f32) {
         const int r5 = mi_try_rwconv_conv(st, dtype, p.a, p.b, p.nbatch, p.IH, p.IW, p.C, p.OH, p.OW, p.N, p.KH, p.KW, p.ldb, p.out, p.bias, p.mask, p.relu);
         if (r5 != 0) return r5;
@@ -648,10 +652,11 @@ int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p) {
     q.M = p.M; q.N = p.N; q.K = p.K; q.nbatch = p.nbatch;
     q.run = p.KW * p.C; q.div_run = make_fastdiv(q.run); q.div_ohw = p.div_ohw; q.div_ow = p.div_ow;
     q.ldb = p.ldb;
+    q.ksplit_len = p.ksplit_len > 0 ? p.ksplit_len : 0;
     copy_epilogue(q, p);
-    int rc = dtype == MI_F32 ? launch_gemm2_tiles<float, A_CONV, B_NK, false>(st, q, q.M, 1)
-           : dtype == MI_BF16X3 ? launch_gemm2_tiles<split_t, A_CONV, B_NK, false>(st, q, q.M, 1)
-                             : launch_gemm2_tiles<bf16_t, A_CONV, B_NK, false>(st, q, q.M, 1);
+    int rc = dtype == MI_F32 ? launch_gemm2_tiles<float, A_CONV, B_NK, false>(st, q, q.M, gz)
+           : dtype == MI_BF16X3 ? launch_gemm2_tiles<split_t, A_CONV, B_NK, false>(st, q, q.M, gz)
+                             : launch_gemm2_tiles<bf16_t, A_CONV, B_NK, false>(st, q, q.M, gz);
     return rc == MI_OK ? 1 : rc;
 }
 
@@ -683,7 +688,7 @@ template <int BMODE>
 int conv_form_gemm(hipStream_t st, int dtype, int in_f32, GemmParams& p, int gz) {
     const int C = p.C;
     if (BMODE == B_NK && !(in_f32 && dtype != MI_F32)) {
-        const int r2 = try_conv_form_gemm2(st, dtype, p);
+        const int r2 = try_conv_form_gemm2(st, dtype, p, gz);
         if (r2 != 0) return r2 > 0 ? MI_OK : r2;
     }
     const bool a16 = (((uintptr_t)p.a) & 15) == 0;
@@ -782,7 +787,7 @@ static int wgrad_splits(int dtype, int M, int Kc, int N, int target_blocks, int*
 
 // scratch (optional): the pixel splits store per-split slabs there and one ordered pass adds them to out -- two runs are bitwise equal; without
 // scratch (or with too little of it) the splits meet in fp32 atomics on out (run-to-run differences in the last bit)
-int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0) {
+int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0, int overwrite = 0) {
     const int Kce = p.Kc + (p.ones_row ? 1 : 0);          // rows of the result incl. the bias row
     const bool wide = Kce > 64;                           // 128 kc rows per block: halves the re-reads of the small tensor
     const int gx = wide ? (Kce + 127) / 128 : 1, gy = (p.N + 63) / 64;
@@ -792,6 +797,9 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     p.debug_skip_out = g_wgrad_skip;
     p.slabs = nullptr; p.slab_stride = ((long long)Kce * p.N + 3) / 4 * 4;
     if (splits > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)splits * p.slab_stride * 4) p.slabs = (float*)scratch;
+    // overwrite: out = result (no zeroed buffer, no atomics): plain stores from the single split, or the ordered slab sum storing instead of adding
+    if (overwrite && splits > 1 && !p.slabs) return mi_fail(MI_ERR_ARG, "wgrad: the overwriting form needs scratch for its row splits (mi_gemm_wgrad_scratch_bytes)");
+    p.overwrite = overwrite && splits == 1 ? 1 : 0;
     dim3 g(gx, gy, splits);
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
@@ -824,8 +832,8 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
 #undef WG_LAUNCH
     int rc = mi_check_launch("wgrad_kernel");
     if (rc == MI_OK && p.slabs) {
-        rc = mi_reduce_slabs(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out);
-        if (rc == MI_OK && p.ones_row) rc = mi_reduce_slabs(st, p.slabs + (long long)p.Kc * p.N, p.slab_stride, splits, (long long)p.N, p.dbias);
+        rc = mi_reduce_slabs(st, p.slabs, p.slab_stride, splits, (long long)p.Kc * p.N, p.out, overwrite);
+        if (rc == MI_OK && p.ones_row) rc = mi_reduce_slabs(st, p.slabs + (long long)p.Kc * p.N, p.slab_stride, splits, (long long)p.N, p.dbias, overwrite);
     }
     return rc;
 }
@@ -860,12 +868,12 @@ static int sr_launch(hipStream_t st) {
     f.njobs = 0;
     return mi_check_launch("reduce_small_fused_kernel");
 }
-int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out) {
+int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out, int overwrite) {
     if (nslab < 1 || n < 1) return MI_OK;
     SmallReduceParams& f = t_sr;
     if (!t_sr_defer) f.njobs = 0;
     if (f.njobs == SR_MAX) { const int rc = sr_launch(st); if (rc != MI_OK) return rc; }      // (a full list is issued as it is: still one fixed order per job)
-    sr_add(f, slabs, stride, nslab, n, out);
+    sr_add(f, slabs, stride, nslab, n, out, overwrite);
     return t_sr_defer ? MI_OK : sr_launch(st);
 }
 extern "C" int mi_small_reduce_defer(int on) {              // returns the previous mode; switching drops what an aborted pass may have left in the list
@@ -1240,6 +1248,22 @@ int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int
 // same; dbias != NULL: dbias[n] += sum_m dy[m, n] as well -- the layer's BiasAddGrad as one more row of the same product (a column of ones appended to `a` inside
 // the kernel's loader): no separate column-sum launch
 int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes) {
+    return mi_gemm_wgrad_bias_set(stream, dtype, a, dy, M, K, N, dw, dbias, scratch, scratch_bytes, 0);
+}
+
+// same; overwrite != 0: dw (and dbias) = the gradient instead of += : plain stores (one row split) or the storing form of the ordered slab sum -- the gradient buffer
+// need not be zeroed between steps and no element is touched by an atomic (the MlpVAE engine: 39.5 M weights, the zeroing alone was 158 MB per step)
+int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes, int overwrite) {
+    // large result, short reduction, storing form: whole 128 x 128 tiles of dW per block over all rows (dwg_tile.hpp)
+    static int dwg_on = -1;
+    if (dwg_on < 0) { const char* e = getenv("MI355_DWG"); dwg_on = (e && e[0] == '0') ? 0 : 1; }
+    if (overwrite && dwg_on && dtype == MI_BF16 && M >= 1 && K % 128 == 0 && N % 128 == 0 && (long long)(K / 128) * (N / 128) >= 256 &&
+        ((((uintptr_t)a) | ((uintptr_t)dy) | ((uintptr_t)dw)) & 15) == 0 && fits_desc((long long)M * K * 2) && fits_desc((long long)M * N * 2)) {
+        DwgParams q = {a, (uint32_t)((long long)M * K * 2), dy, (uint32_t)((long long)M * N * 2), dw, dbias, M, K, N, K / 128, N / 128};
+        const int per = (q.KT * q.NT + 7) / 8;
+        MI_LAUNCH(dwg_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
+        return mi_check_launch("dwg_kernel");
+    }
     WgradParams p = {};
     p.ones_row = dbias ? 1 : 0; p.dbias = dbias;
     p.big = a; p.frame_idx = nullptr;
@@ -1247,7 +1271,7 @@ int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy
     const int vb = dtype == MI_BF16 ? 8 : 4;
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
-    return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks, scratch, scratch_bytes);
+    return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks, scratch, scratch_bytes, overwrite);
 }
 
 }  // extern "C"

@@ -298,6 +298,12 @@ __global__ __launch_bounds__(FIN_NT) void finalize_losses_kernel(const float* __
 // alpha = lr*sqrt(1-b2^t)/(1-b1^t) comes from the host (fp32).  Optionally refreshes the bf16 shadow weights the
 // MFMA kernels read and clears the gradient for the next step's atomics (saves a memset + a cast pass).
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_tf_update(float& pp, float& mm, float& vv, const float gg, const float alpha, const float omb1, const float omb2, const float epsilon) {
+    mm += (gg - mm) * omb1;
+    vv += (gg * gg - vv) * omb2;
+    pp -= (mm * alpha) / (sqrtf(vv) + epsilon);
+}
+
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                       float* __restrict__ g, long long n, float alpha_arg, const float* __restrict__ alpha_dev, float omb1,
                                                       float omb2, float epsilon, void* __restrict__ shadow_any, int shadow_split, int clear_grad) {
@@ -310,9 +316,9 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
         f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i], gv = ((f32x4*)g)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            mv[e] += (gv[e] - mv[e]) * omb1;
-            vv[e] += (gv[e] * gv[e] - vv[e]) * omb2;
-            pv[e] -= (mv[e] * alpha) / (sqrtf(vv[e]) + epsilon);
+            float pp = pv[e], mm = mv[e], v1 = vv[e];
+            adam_tf_update(pp, mm, v1, gv[e], alpha, omb1, omb2, epsilon);
+            pv[e] = pp; mv[e] = mm; vv[e] = v1;
         }
         ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
         if (clear_grad) { f32x4 zz = {0.f, 0.f, 0.f, 0.f}; ((f32x4*)g)[i] = zz; }
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, flo
     // tail (n not a multiple of 4)
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gg = g[i], mm = m[i], vv = v[i], pp = p[i];
-        mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2; pp -= (mm * alpha) / (sqrtf(vv) + epsilon);
+        adam_tf_update(pp, mm, vv, gg, alpha, omb1, omb2, epsilon);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (clear_grad) g[i] = 0.f;
         if (shadow) shadow[i] = f32_to_bf16(pp);
@@ -350,6 +356,124 @@ __global__ __launch_bounds__(256) void cast_split_f32_kernel(const split_t* __re
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = f32_to_bf16(src[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TF ApplyAdam that also writes BOTH weight layouts the MFMA kernels read (round 4, the MlpVAE engine: 39.5 M weights -- the separate transpose pass behind Adam
+// re-read 158 MB and wrote 79 MB per step at 2.8 TB/s): every [K, N] kernel of the flat buffer is walked in 64 x 64 tiles -- p / m / v / g as 16-byte vectors along
+// N (256 contiguous bytes per tile row), the storage-type copy in the same layout (`shadow`, bf16 engines), and, through an LDS transpose, the K-contiguous copy
+// wt[n][k] as 16-byte vectors along K.  Everything outside the listed kernels (biases) is covered by `flat` ranges handled by the blocks behind the tile blocks.
+// The arithmetic is adam_tf_update, the same inline function as adam_tf_kernel: bit-identical parameters.
+// ---------------------------------------------------------------------------------------------------
+constexpr int AL_MAX = 16;
+struct AdamLayoutJobs {
+    long long off[AL_MAX]; int K[AL_MAX], N[AL_MAX], tile0[AL_MAX + 1]; int count;          // the 2-D kernels: tiles tile0[t] .. tile0[t + 1]
+    long long foff[AL_MAX], fn[AL_MAX]; int fblk0[AL_MAX + 1]; int fcount;                 // flat ranges: 1,024 elements per block
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, float* __restrict__ g, const AdamLayoutJobs jb,
+                                                              float alpha_arg, const float* __restrict__ alpha_dev, float omb1, float omb2, float epsilon,
+                                                              TT* __restrict__ shadow, TT* __restrict__ wt, int clear_grad) {
+    constexpr int PITCH = sizeof(TT) == 2 ? 66 : 65;     // bf16: 33 dwords per row; fp32: 65 -- the transposed reads of a wave hit distinct banks
+    __shared__ TT tile[64 * PITCH];
+    const float alpha = alpha_dev ? alpha_dev[0] : alpha_arg;
+    const int tid = threadIdx.x, b = (int)blockIdx.x;
+    const int ntile = jb.tile0[jb.count];
+    if (b >= ntile) {                                     // (block-uniform) flat ranges: biases
+        const int fb = b - ntile;
+        int t = 0;
+#pragma unroll
+        for (int i = 1; i < AL_MAX; ++i) t += (i < jb.fcount && fb >= jb.fblk0[i]) ? 1 : 0;
+        const long long base = jb.foff[t], n = jb.fn[t];
+        for (int j = 0; j < 4; ++j) {
+            const long long i = (long long)(fb - jb.fblk0[t]) * 1024 + j * 256 + tid;
+            if (i < n) {
+                float gg = g[base + i], mm = m[base + i], vv = v[base + i], pp = p[base + i];
+                adam_tf_update(pp, mm, vv, gg, alpha, omb1, omb2, epsilon);
+                p[base + i] = pp; m[base + i] = mm; v[base + i] = vv;
+                if (clear_grad) g[base + i] = 0.f;
+                if (shadow) shadow[base + i] = Elem<TT>::from_f32(pp);
+            }
+        }
+        return;
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 1; i < AL_MAX; ++i) t += (i < jb.count && b >= jb.tile0[i]) ? 1 : 0;
+    const int K = jb.K[t], N = jb.N[t];
+    const long long off = jb.off[t];
+    const int tiles_n = (N + 63) >> 6;
+    const int local = b - jb.tile0[t];
+    const int k0 = (local / tiles_n) << 6, n0 = (local % tiles_n) << 6;
+    const int c4 = (tid & 15) << 2, r0 = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i, k = k0 + r, n = n0 + c4;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (k < K && n < N) {                             // (N % 4 == 0: a vector is inside or outside as a whole)
+            const long long e = off + (long long)k * N + n;
+            pv = *(const f32x4*)(p + e);
+            f32x4 mv = *(const f32x4*)(m + e), vv = *(const f32x4*)(v + e);
+            const f32x4 gv = *(const f32x4*)(g + e);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float pp = pv[q], mm = mv[q], v1 = vv[q];
+                adam_tf_update(pp, mm, v1, gv[q], alpha, omb1, omb2, epsilon);
+                pv[q] = pp; mv[q] = mm; vv[q] = v1;
+            }
+            *(f32x4*)(p + e) = pv; *(f32x4*)(m + e) = mv; *(f32x4*)(v + e) = vv;
+            if (clear_grad) { const f32x4 zz = {0.f, 0.f, 0.f, 0.f}; *(f32x4*)(g + e) = zz; }
+            if (shadow) {
+                if constexpr (sizeof(TT) == 2) {
+                    u16x4 sv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] = f32_to_bf16(pv[q]);
+                    *(u16x4*)(shadow + e) = sv;
+                } else *(f32x4*)(shadow + e) = pv;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[r * PITCH + c4 + q] = Elem<TT>::from_f32(pv[q]);
+    }
+    __syncthreads();
+    if (!wt) return;
+    // wt[off + n * K + k]: thread (n = tid >> 2, quarter = tid & 3) writes 16 consecutive k of its row
+    const int nn = tid >> 2, kq = (tid & 3) << 4;
+    const int n = n0 + nn;
+    if (n >= N) return;
+    TT* const dst = wt + off + (long long)n * K + k0 + kq;
+    constexpr int VE = 16 / (int)sizeof(TT);             // elements per 16-byte store
+    const bool vec_ok = ((K % VE) | (int)(off % VE)) == 0 && k0 + kq + 16 <= K;
+    if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 16 / VE; ++j) {
+            PackN<TT, VE> o;
+#pragma unroll
+            for (int q = 0; q < VE; ++q) o.v[q] = tile[(kq + j * VE + q) * PITCH + nn];
+            *(PackN<TT, VE>*)(dst + j * VE) = o;
+        }
+    } else {
+        for (int q = 0; q < 16; ++q) if (k0 + kq + q < K) dst[q] = tile[(kq + q) * PITCH + nn];
+    }
+}
+
+// rows idx[b] (or b) of a float32 table -> a dense [B, row_len] tensor of the engine's storage type: the MlpVAE engine's frame staging in ONE launch
+// (index_select + contiguous + cast were three passes over the 79 MB minibatch)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long row_len, T* __restrict__ out) {
+    const int b = (int)blockIdx.y;
+    const float* s = src + (idx ? (long long)idx[b] : (long long)b) * row_len;
+    T* d = out + (long long)b * row_len;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= row_len && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+        const f32x4 a = *(const f32x4*)(s + i), c = *(const f32x4*)(s + i + 4);
+        const float fa[4] = {a[0], a[1], a[2], a[3]}, fc[4] = {c[0], c[1], c[2], c[3]};
+        *(PackN<T, 4>*)(d + i) = pack4<T>(fa);
+        *(PackN<T, 4>*)(d + i + 4) = pack4<T>(fc);
+    } else {
+        for (int q = 0; q < 8; ++q) if (i + q < row_len) d[i + q] = Elem<T>::from_f32(s[i + q]);
+    }
 }
 
 // raw camera bytes -> [0, 1] frames: float32(k) / float32(255), correctly rounded (the value the reference's host preprocessing
@@ -647,6 +771,58 @@ int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long l
     if (n == 0) return MI_OK;
     hipLaunchKernelGGL(u8_to_unit_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return mi_check_launch("u8_to_unit");
+}
+
+// TF ApplyAdam over the flat buffer [0, n) that also refreshes both weight copies of the `count` listed [K, N] kernels (offsets in floats, N % 4 == 0, offsets % 4 == 0):
+// shadow (storage-type copy, same layout; NULL for fp32 engines) and wt (K-contiguous copy wt[off + n * K + k]; may be NULL).  dtype MI_F32 / MI_BF16 = element type of
+// both copies.  Everything between / behind the listed kernels (the biases) gets the plain update (+ shadow).  The kernels must be listed in ascending offset order
+// and must not overlap.  Same arithmetic as mi_adam_tf_flat: bit-identical p / m / v.
+int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, int count,
+                       float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad) {
+    if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: dtype must be MI_F32 or MI_BF16");
+    if (count < 0 || count > AL_MAX) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: 0 <= count <= 16");
+    if ((((uintptr_t)param) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad)) & 15) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: buffers must be 16-byte aligned");
+    if ((shadow && (((uintptr_t)shadow) & 15)) || (wt && (((uintptr_t)wt) & 15))) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: weight copies must be 16-byte aligned");
+    AdamLayoutJobs jb = {};
+    long long pos = 0;
+    int tiles = 0, fblk = 0;
+    auto add_flat = [&](long long lo, long long hi) -> bool {
+        if (hi <= lo) return true;
+        if (jb.fcount == AL_MAX) return false;
+        jb.foff[jb.fcount] = lo; jb.fn[jb.fcount] = hi - lo; jb.fblk0[jb.fcount] = fblk;
+        fblk += (int)((hi - lo + 1023) / 1024); ++jb.fcount;
+        return true;
+    };
+    for (int i = 0; i < count; ++i) {
+        const long long sz = (long long)K[i] * N[i];
+        if (K[i] < 1 || N[i] < 4 || N[i] % 4 != 0 || offsets[i] % 4 != 0) return mi_fail(MI_ERR_SHAPE, "mi_adam_tf_layouts: kernels need N % 4 == 0 and an offset that is a multiple of 4");
+        if (offsets[i] < pos || offsets[i] + sz > n) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: kernels must be listed in ascending, non-overlapping order inside [0, n)");
+        if (!add_flat(pos, offsets[i])) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: too many ranges between the kernels");
+        jb.off[i] = offsets[i]; jb.K[i] = K[i]; jb.N[i] = N[i]; jb.tile0[i] = tiles;
+        tiles += ((K[i] + 63) / 64) * ((N[i] + 63) / 64);
+        pos = offsets[i] + sz;
+    }
+    if (!add_flat(pos, n)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: too many ranges between the kernels");
+    jb.count = count;
+    for (int i = count; i <= AL_MAX; ++i) jb.tile0[i] = tiles;
+    for (int i = jb.fcount; i <= AL_MAX; ++i) jb.fblk0[i] = fblk;
+    if (tiles + fblk == 0) return MI_OK;
+    if (dtype == MI_BF16) hipLaunchKernelGGL(adam_tf_layouts_kernel<bf16_t>, dim3(tiles + fblk), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, jb, alpha, alpha_dev,
+                                             1.0f - beta1, 1.0f - beta2, epsilon, (bf16_t*)shadow, (bf16_t*)wt, clear_grad);
+    else hipLaunchKernelGGL(adam_tf_layouts_kernel<float>, dim3(tiles + fblk), dim3(256), 0, (hipStream_t)stream, param, m, v, grad, jb, alpha, alpha_dev,
+                            1.0f - beta1, 1.0f - beta2, epsilon, (float*)shadow, (float*)wt, clear_grad);
+    return mi_check_launch("adam_tf_layouts");
+}
+
+// out[b, :] = storage_type(src[idx[b], :])  (idx NULL: rows 0 .. B-1); dtype MI_F32 (a gathered copy) or MI_BF16
+int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* idx, int B, long long row_len, void* out) {
+    if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast: dtype must be MI_F32 or MI_BF16");
+    if (!src || !out || B < 0 || row_len < 1) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast: bad arguments");
+    if (B == 0) return MI_OK;
+    const dim3 g((unsigned)((row_len + 2047) / 2048), (unsigned)B);
+    if (dtype == MI_BF16) hipLaunchKernelGGL(gather_rows_cast_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out);
+    else hipLaunchKernelGGL(gather_rows_cast_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out);
+    return mi_check_launch("gather_rows_cast");
 }
 
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count) {

@@ -32,6 +32,7 @@ struct Gemm2Params {
     FastDiv dc_ohw[4], dc_ow[4], dc_c, dc_tw[2];
     int ldb;
     void* out; const float* bias; const void* mask; int relu; int out_f32;
+    int ksplit_len;                  // A_CONV, > 0: split-K -- blockIdx.z owns k in [z * len, (z + 1) * len) (len a multiple of the 128-byte stage) and writes raw fp32 slab z
 };
 
 // BM x BN output tile (pixels x channels), 256 threads = 4 waves.  UTAP: every 128-byte stage lies inside one deconv tap
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
         K = p.Th[ph] * p.Tw[pw] * p.C;
         if (m0 >= M) return;
     }
-    const int nk = (K + BKE - 1) / BKE;
+    int kbeg = 0;
+    if constexpr (AMODE == A_CONV) {
+        if (p.ksplit_len > 0) { kbeg = (int)blockIdx.z * p.ksplit_len; K = min(K, kbeg + p.ksplit_len); }      // (K = one past this split's last k)
+    }
+    const int nk = (K - kbeg + BKE - 1) / BKE;
 
     // ---------------- DMA lane roles ----------------
     // wave w fills 8-row groups of one parity (w & 1), so the swizzle term (row >> 1) & 7 is the same for all of a thread's rows
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
     }
 
     auto issue = [&](int ks, int buf) {
-        const int k0 = ks * BKE;                           // wave-uniform
+        const int k0 = kbeg + ks * BKE;                    // wave-uniform
         const int k = k0 + cch * VE;
         const bool kok = k < K;
         uint32_t koffA, koffB, bit = 0;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
         }
     }
 
-    store_tile<T, AMODE, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lgrp, M, cls, ph, pw, 0);
+    store_tile<T, AMODE, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lgrp, M, cls, ph, pw, (AMODE == A_CONV && p.ksplit_len > 0) ? (int)blockIdx.z : 0);
 }
 
 }  // namespace mi

@@ -21,6 +21,7 @@
 #include "gemm2_tile.hpp"
 #include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"
+#include "dwg_tile.hpp"
 #include "tapwgrad_tile.hpp"
 #include "narrow_tile.hpp"
 #include "dectail_tile.hpp"

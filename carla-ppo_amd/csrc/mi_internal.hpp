@@ -36,7 +36,7 @@ int mi_rwconv_mode(int set);                     // mi_set_tuning key 13: 0 off,
 void mi_get_trace(long long** buf, int* cap);     // the debug stamp buffer of mi_debug_set_trace
 
 // out[0 .. n) += sum over nslab slabs of slabs[k * stride + i] (reduce_small_fused_kernel, tapwgrad_tile.hpp; fixed summation order, no atomics) -- conv_ops.hip
-int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out);
+int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out, int overwrite = 0);   // overwrite: out = sum
 // deferred mode of mi_reduce_slabs (per host thread): jobs are recorded and mi_small_reduce_flush(stream) issues all of them as ONE launch -- conv_ops.hip
 extern "C" int mi_small_reduce_defer(int on);
 extern "C" int mi_small_reduce_flush(void* stream);

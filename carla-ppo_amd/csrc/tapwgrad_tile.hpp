@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void reduce_tiled_kernel(const TapWgradParams 
 // One job of an ordered slab sum: out[i] += sum_k slabs[k * stride + i], i < n.  The block is 256 / KL groups of four elements x KL slab lanes (KL: a power of
 // two chosen from the job's shape only); the lanes' partial sums meet in LDS (one barrier) and are added in lane order.
 __device__ __forceinline__ void sr_job_body(const float* __restrict__ slabs, float* __restrict__ out, long long stride, long long n, int nslab, int KL, int vec_ok,
-                                            int local_block, f32x4* sm) {
+                                            int local_block, f32x4* sm, int overwrite = 0) {
     const int QPB = 256 / KL;
     const int q = (int)threadIdx.x & (QPB - 1), kl = (int)threadIdx.x / QPB;
     const long long i4 = ((long long)local_block * QPB + q) * 4;
@@ -757,7 +757,10 @@ __device__ __forceinline__ void sr_job_body(const float* __restrict__ slabs, flo
         } else if (kl == 0) for (int k = 1; k < KL; ++k) s += sm[k * QPB + q];
     }
     if (kl == 0 && i4 < n) {
-        if (vec_ok && i4 + 4 <= n) { f32x4 o = *(f32x4*)(out + i4); o += s; *(f32x4*)(out + i4) = o; }
+        if (overwrite) {                                  // out = sum (the caller's buffer need not be zeroed)
+            if (vec_ok && i4 + 4 <= n) *(f32x4*)(out + i4) = s;
+            else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] = s[e];
+        } else if (vec_ok && i4 + 4 <= n) { f32x4 o = *(f32x4*)(out + i4); o += s; *(f32x4*)(out + i4) = o; }
         else for (int e = 0; e < 4; ++e) if (i4 + e < n) out[i4 + e] += s[e];
     }
 }
@@ -766,12 +769,13 @@ struct SmallReduceParams {
     const float* slabs[SR_MAX]; float* out[SR_MAX]; long long stride[SR_MAX], n[SR_MAX];
     int nslab[SR_MAX], kl[SR_MAX], vec[SR_MAX], first[SR_MAX + 1];
     int njobs;
+    unsigned ovw;                                        // bit j: job j stores its sums (out = ...) instead of adding them to out
 };
 __device__ __forceinline__ void sr_dispatch(const SmallReduceParams& f, int b, f32x4* sm) {
     int j = 0;
 #pragma unroll
     for (int i = 1; i < SR_MAX; ++i) j += (i < f.njobs && b >= f.first[i]) ? 1 : 0;
-    sr_job_body(f.slabs[j], f.out[j], f.stride[j], f.n[j], f.nslab[j], f.kl[j], f.vec[j], b - f.first[j], sm);
+    sr_job_body(f.slabs[j], f.out[j], f.stride[j], f.n[j], f.nslab[j], f.kl[j], f.vec[j], b - f.first[j], sm, (int)((f.ovw >> j) & 1u));
 }
 
 // All deferred reductions of one backward pass in ONE launch (six layers: ~190 MB of slabs, 35-40 us at HBM speed against 130 us as six

@@ -26,6 +26,7 @@ struct WgradParams {
     int m_per_split;                 // multiple of BP
     int debug_skip_out;              // debug (mi_set_tuning key 2): drop the atomic accumulation to time the main loop alone
     float* slabs; long long slab_stride;   // optional: split z stores its partial sums at slabs[z * slab_stride + kc * N + n] (plain stores, every in-range element exactly once)
+    int overwrite;                   // one split, no slabs: out = result with plain stores instead of out += by atomics (the caller's buffer need not be zeroed)
     int ones_row; float* dbias;      // ones_row != 0: the big tensor carries a virtual column kc == Kc of ones, so row Kc of the result is the column sum of S -- the layer's
                                      // BiasAddGrad rides on the filter gradient (dense layers: one launch less per layer; slab row Kc, or atomics on dbias without slabs)
 };
@@ -216,9 +217,11 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             const int n = n0 + wn * 32 + lrow;
             if (kc < p.Kc && n < p.N) {
                 if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                else if (p.overwrite) p.out[(long long)kc * p.N + n] = acc[i][r];
                 else atomicAdd(&p.out[(long long)kc * p.N + n], acc[i][r]);
             } else if (p.ones_row && kc == p.Kc && n < p.N) {
                 if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                else if (p.overwrite) p.dbias[n] = acc[i][r];
                 else atomicAdd(&p.dbias[n], acc[i][r]);
             }
         }

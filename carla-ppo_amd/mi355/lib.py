@@ -24,7 +24,7 @@ _CTYPES = {
     "long long*": ctypes.c_void_p, "const long long*": ctypes.c_void_p, "void": None,
     "unsigned long long": ctypes.c_ulonglong, "unsigned long long*": ctypes.c_void_p,
     "void**": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
-    "const MiVaeDesc*": ctypes.c_void_p, "const MiPpoDesc*": ctypes.c_void_p,
+    "const MiVaeDesc*": ctypes.c_void_p, "const MiPpoDesc*": ctypes.c_void_p, "const MiMlpVaeDesc*": ctypes.c_void_p,
 }
 
 
@@ -32,6 +32,15 @@ class MiVaeDesc(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int), ("max_batch", ctypes.c_int), ("ih", ctypes.c_int), ("iw", ctypes.c_int),
                 ("cin", ctypes.c_int), ("ct", ctypes.c_int), ("z_dim", ctypes.c_int), ("loss_kind", ctypes.c_int),
                 ("beta", ctypes.c_float), ("kl_tolerance", ctypes.c_float)]
+
+
+MI_MLP_MAX_HIDDEN = 4
+
+
+class MiMlpVaeDesc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int), ("max_batch", ctypes.c_int), ("source_size", ctypes.c_int), ("target_size", ctypes.c_int), ("z_dim", ctypes.c_int),
+                ("n_enc", ctypes.c_int), ("n_dec", ctypes.c_int), ("enc", ctypes.c_int * MI_MLP_MAX_HIDDEN), ("dec", ctypes.c_int * MI_MLP_MAX_HIDDEN),
+                ("loss_kind", ctypes.c_int), ("with_optimizer", ctypes.c_int), ("beta", ctypes.c_float), ("kl_tolerance", ctypes.c_float)]
 
 
 class MiPpoDesc(ctypes.Structure):
@@ -79,7 +88,7 @@ class _Lib:
             fn = getattr(self.cdll, name)          # AttributeError if the header declares a symbol the .so lacks
             fn.restype = _CTYPES[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
-            if ret == "int" and not name.endswith(("_version", "_chunks", "_blocks", "_floats", "_bytes", "_count", "_size", "_tuning", "_ok")):
+            if ret == "int" and not name.endswith(("_version", "_chunks", "_blocks", "_floats", "_bytes", "_count", "_size", "_tuning", "_ok", "_offset")):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)
@@ -87,6 +96,7 @@ class _Lib:
     def check_struct_sizes(self):
         assert self.mi_vae_desc_size() == ctypes.sizeof(MiVaeDesc), "MiVaeDesc layout mismatch between header and binding"
         assert self.mi_ppo_desc_size() == ctypes.sizeof(MiPpoDesc), "MiPpoDesc layout mismatch between header and binding"
+        assert self.mi_mlpvae_desc_size() == ctypes.sizeof(MiMlpVaeDesc), "MiMlpVaeDesc layout mismatch between header and binding"
 
     def _checked(self, name, fn):
         def call(*a):

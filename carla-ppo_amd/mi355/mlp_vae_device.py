@@ -1,11 +1,10 @@
-"""Device side of the MlpVAE (reference vae/models.py:271-299 on top of the base VAE graph :85-142): the same interface as
-VaeDevice, composed from the op-level entry points of the C ABI (dense forward / input gradient `mi_gemm_bias_act`, filter gradient
-`mi_gemm_wgrad`, bias gradient `mi_colsum`, `mi_vae_reparam_kl_fwd/bwd`, `mi_bce_logits_fwd_bwd`, `mi_vae_finalize_losses`,
-`mi_adam_tf_flat`).  The ConvVAE has a native engine (csrc/vae_engine.hip) because its 45 launches per step need stream
-orchestration; the MLP is seven dense layers in a row, so the sequencing lives here and every FLOP stays in libmi355_carla.so.
+"""Device side of the MlpVAE (reference vae/models.py:271-299 on top of the base VAE graph :85-142): the same interface as VaeDevice over the native MlpVAE engine
+(csrc/mlp_engine.hip, round 4): one C call per SGD step (`mi_mlpvae_train_step`), the frame rows gathered and converted in one launch, bias gradients as a ones row of
+the filter gradients, gradients stored (no zeroing, no atomics), Adam writing both weight layouts.  Rounds 1-3 sequenced the op-level entry points from here.
 
 No CPU fallback: constructing the device without a GPU or without the built library raises.
 """
+import ctypes
 from collections import OrderedDict
 
 import numpy as np
@@ -43,24 +42,27 @@ class MlpVaeDevice:
         for n in (self.S, self.P, self.z_dim) + self.enc_sizes + self.dec_sizes:
             if n % vec != 0:
                 raise ValueError("MlpVAE: every layer width must be a multiple of %d (16-byte vectors), got %d" % (vec, n))
-        self.handle = None                                  # (no native engine object; kept for interface symmetry)
-        # dense layers in forward order: (kernel name, K, N); the two heads share one [K, 2Z] GEMM like the ConvVAE engine
-        self.enc = [("vae/encoder/dense" + ("_%d" % i if i else ""), k, n) for i, (k, n) in enumerate(zip((self.S,) + self.enc_sizes[:-1], self.enc_sizes))]
-        dec_out = self.dec_sizes + (self.P,)
-        self.dec = [("vae/decoder/dense" + ("_%d" % i if i else ""), k, n) for i, (k, n) in enumerate(zip((self.z_dim,) + dec_out[:-1], dec_out))]
-        self.layout = OrderedDict()
-        off = 0
-        for name, k, n in self.enc:
-            self.layout[name + "/kernel"], off = (off, k * n), off + k * n
-            self.layout[name + "/bias"], off = (off, n), off + n
-        kh = self.enc_sizes[-1]
-        self.layout["@heads/kernel"], off = (off, kh * 2 * self.z_dim), off + kh * 2 * self.z_dim
-        self.layout["@heads/bias"], off = (off, 2 * self.z_dim), off + 2 * self.z_dim
-        self.decoder_offset = off                            # grads[decoder_offset:] are complete first in backward
-        for name, k, n in self.dec:
-            self.layout[name + "/kernel"], off = (off, k * n), off + k * n
-            self.layout[name + "/bias"], off = (off, n), off + n
-        self.n_flat = off
+        if not (1 <= len(self.enc_sizes) <= milib.MI_MLP_MAX_HIDDEN and 1 <= len(self.dec_sizes) <= milib.MI_MLP_MAX_HIDDEN):
+            raise ValueError("MlpVAE: 1 .. %d hidden layers per side" % milib.MI_MLP_MAX_HIDDEN)
+        self.handle = None
+        # tensor names in the engine's order (mi_mlpvae_param_layout): the two heads are one [K, 2Z] kernel like in the ConvVAE engine
+        names = []
+        for i in range(len(self.enc_sizes)):
+            names += ["vae/encoder/dense" + ("_%d" % i if i else "") + s for s in ("/kernel", "/bias")]
+        names += ["@heads/kernel", "@heads/bias"]
+        for i in range(len(self.dec_sizes) + 1):
+            names += ["vae/decoder/dense" + ("_%d" % i if i else "") + s for s in ("/kernel", "/bias")]
+        d = self._desc(1)
+        n = self.L.mi_mlpvae_param_floats(ctypes.byref(d))
+        if n <= 0:
+            raise milib.MiError("mi_mlpvae_param_floats: " + self.L.cdll.mi_last_error().decode())
+        self.n_flat = int(n)
+        cnt = self.L.mi_mlpvae_tensor_count(ctypes.byref(d))
+        assert cnt == len(names), (cnt, names)
+        off, size = np.zeros(cnt, np.int64), np.zeros(cnt, np.int64)
+        self.L.mi_mlpvae_param_layout(ctypes.byref(d), off.ctypes.data, size.ctypes.data, cnt)
+        self.layout = OrderedDict((name, (int(o), int(s))) for name, o, s in zip(names, off, size))
+        self.decoder_offset = self.layout["vae/decoder/dense/kernel"][0]                      # grads[decoder_offset:] are complete first in backward
         self.grad_buckets = [(1, self.decoder_offset, self.n_flat), (2, 0, self.decoder_offset)]   # (backward part, lo, hi), see VaeDevice
         z = lambda dt=torch.float32: torch.zeros(self.n_flat, device=self.device, dtype=dt)   # noqa: E731
         self.params = z()
@@ -68,70 +70,78 @@ class MlpVaeDevice:
         self.adam_m = z() if with_optimizer else None
         self.adam_v = z() if with_optimizer else None
         self.shadow = z(torch.bfloat16) if self.bf16 else None
-        # K-contiguous copies [N][K] of every dense kernel for the forward GEMMs (the MFMA kernels stream the B operand along K): refreshed after
-        # every optimiser step by mi_transpose_weights; the input gradients read the [K, N] originals, which ARE K-contiguous for x * W^T
+        # K-contiguous copies [N][K] of every dense kernel for the forward GEMMs (the MFMA kernels stream the B operand along K), rewritten by the optimiser step itself
+        # (mi_adam_tf_layouts); the input gradients read the [K, N] originals, which ARE K-contiguous for x * W^T
         self.weights_t = z(self.T)
-        kern = [(self.layout[name + "/kernel"][0], k, n) for name, k, n in self.enc] + [(self.layout["@heads/kernel"][0], self.enc_sizes[-1], 2 * self.z_dim)] \
-            + [(self.layout[name + "/kernel"][0], k, n) for name, k, n in self.dec]
-        self._tr_off = np.array([o for o, _, _ in kern], np.int64)
-        self._tr_k = np.array([k for _, k, _ in kern], np.int32)
-        self._tr_n = np.array([n for _, _, n in kern], np.int32)
-        self.slab = None                                    # split-K partial sums of the long-K layers (allocated on first use)
         self.metrics = torch.zeros(3, device=self.device)
-        self.losses = torch.zeros(2, device=self.device)
-        self.nchunks = int(self.L.mi_recon_loss_chunks(self.P))
         self.max_batch = 0
-        self.last_B = 0
-        self.ensure_batch(max_batch)
+        self._create(max_batch)
 
-    # ---- buffers ----
+    def _desc(self, max_batch):
+        d = milib.MiMlpVaeDesc()
+        d.dtype, d.max_batch, d.source_size, d.target_size, d.z_dim = self.dtype, int(max_batch), self.S, self.P, self.z_dim
+        d.n_enc, d.n_dec = len(self.enc_sizes), len(self.dec_sizes)
+        for i, h in enumerate(self.enc_sizes):
+            d.enc[i] = h
+        for i, h in enumerate(self.dec_sizes):
+            d.dec[i] = h
+        d.loss_kind, d.with_optimizer, d.beta, d.kl_tolerance = self.loss_kind, 1 if self.with_optimizer else 0, self.beta, self.kl_tolerance
+        return d
+
+    def _create(self, max_batch):
+        if self.handle is not None:
+            self.L.mi_mlpvae_destroy(self.handle)
+            self.handle = None
+        d = self._desc(max_batch)
+        nbytes = self.L.mi_mlpvae_workspace_bytes(ctypes.byref(d))
+        if nbytes <= 0:
+            raise milib.MiError("mi_mlpvae_workspace_bytes: " + self.L.cdll.mi_last_error().decode())
+        self.workspace = torch.empty(int(nbytes), device=self.device, dtype=torch.uint8)
+        p = milib.ptr
+        self.handle = self.L.mi_mlpvae_create(ctypes.byref(d), p(self.params), p(self.grads), p(self.adam_m), p(self.adam_v), p(self.shadow), p(self.weights_t),
+                                              p(self.workspace), int(nbytes))
+        if not self.handle:
+            raise milib.MiError("mi_mlpvae_create: " + self.L.cdll.mi_last_error().decode())
+        self.max_batch = int(max_batch)
+        self.losses = self._view(0, 2)
+
     def ensure_batch(self, b):
-        if b <= self.max_batch:
-            return
-        B, dev, T = int(b), self.device, self.T
-        e = lambda *s, dt=T: torch.empty(*s, device=dev, dtype=dt)                            # noqa: E731
-        self.x = e(B, self.S)
-        self.h = [e(B, n) for _, _, n in self.enc]                                            # ReLU outputs of the encoder layers
-        self.heads = e(B, 2 * self.z_dim, dt=torch.float32)
-        self.mean, self.logvar, self.kl_row = (e(B, self.z_dim, dt=torch.float32), e(B, self.z_dim, dt=torch.float32), e(B, dt=torch.float32))
-        self.z = e(B, self.z_dim)
-        self.zf32 = e(B, self.z_dim, dt=torch.float32)
-        self.d = [e(B, n) for _, _, n in self.dec]                                            # decoder activations; d[-1] = logits
-        self.partial = e(B * self.nchunks, dt=torch.float32)
-        if self.with_optimizer:
-            self.g_d = [e(B, n) for _, _, n in self.dec]                                      # gradients of the decoder activations
-            self.dz = e(B, self.z_dim, dt=torch.float32)
-            self.dheads = e(B, 2 * self.z_dim)
-            self.g_h = [e(B, n) for _, _, n in self.enc]
-        self.max_batch = B
+        if b > self.max_batch:
+            torch.cuda.synchronize(self.device)
+            self._create(b)                                 # (the weight copies live outside the workspace: nothing to rebuild)
+
+    def _view(self, which, n, dtype=torch.float32):
+        """Zero-copy torch view of an engine buffer inside the workspace."""
+        addr = self.L.mi_mlpvae_buffer(self.handle, which)
+        off = addr - self.workspace.data_ptr()
+        esz = torch.empty(0, dtype=dtype).element_size()
+        return self.workspace[off:off + n * esz].view(dtype)
+
+    @property
+    def mean(self):
+        return self._view(1, self.max_batch * self.z_dim).view(self.max_batch, self.z_dim)
+
+    @property
+    def logvar(self):
+        return self._view(2, self.max_batch * self.z_dim).view(self.max_batch, self.z_dim)
 
     def close(self):
-        pass
+        if self.handle is not None:
+            self.L.mi_mlpvae_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _w(self, name):
-        """Device pointer of a kernel in the dtype the GEMMs read (bf16 shadow copy or the fp32 master)."""
-        o, _ = self.layout[name]
-        return (self.shadow if self.bf16 else self.params)[o:].data_ptr()
-
-    def _p(self, buf, name):
-        o, _ = self.layout[name]
-        return buf[o:].data_ptr()
-
     def sync_shadow(self):
-        if self.bf16:
-            self.L.mi_cast_f32_to_bf16(self.stream(), self.params.data_ptr(), self.shadow.data_ptr(), self.n_flat)
-        self._refresh_transposed()
-
-    def _refresh_transposed(self):
-        self.L.mi_transpose_weights(self.stream(), self.dtype, self.params.data_ptr(), self.weights_t.data_ptr(), self._tr_off.ctypes.data, self._tr_k.ctypes.data,
-                                    self._tr_n.ctypes.data, len(self._tr_off))
-
-    def _wt(self, name):
-        o, _ = self.layout[name]
-        return self.weights_t[o:].data_ptr()
+        """Refresh the derived weight copies (bf16 shadow, K-contiguous kernels) after self.params was written from outside."""
+        self.L.mi_mlpvae_sync_shadow(self.handle, self.stream())
 
     # ---- TF-named variables <-> flat layout ----
     def _to_flat(self, named):
@@ -183,134 +193,45 @@ class MlpVaeDevice:
     def export_grads(self):
         return self._from_flat(self.grads.cpu().numpy())
 
-    # ---- building blocks ----
-    SPLIT_K = 4096                                          # reductions at least this long are split over the chip (38400 -> 30 slabs) and finished by mi_splitk_finish
-
-    def _dense(self, a, M, K, wname, N, bias, relu, out, out_f32=0, w_layout=0, mask=None):
-        """out = mask(act(a W + bias)).  w_layout 0: forward, through the K-contiguous copy; 1: input gradient (x * W^T on the [K, N] original)."""
-        M, K, N = int(M), int(K), int(N)
-        w = self._wt(wname) if w_layout == 0 else self._w(wname)
-        mk = mask.data_ptr() if mask is not None else None
-        if K >= self.SPLIT_K and K % 128 == 0:
-            ns = max(1, min(32, K // 1280))
-            while K % (ns * 128) != 0 and ns > 1:
-                ns -= 1
-            if ns > 1:
-                need = ns * M * N
-                if self.slab is None or self.slab.numel() < need:
-                    self.slab = torch.empty(need, device=self.device, dtype=torch.float32)
-                self.L.mi_gemm_bias_act(self.stream(), self.dtype, a.data_ptr(), M, K, w, 1, N, None, 0, None, self.slab.data_ptr(), 1, ns)
-                self.L.mi_splitk_finish(self.stream(), self.dtype, self.slab.data_ptr(), ns, M, N, bias, int(relu), mk, out.data_ptr(), int(out_f32))
-                return
-        self.L.mi_gemm_bias_act(self.stream(), self.dtype, a.data_ptr(), M, K, w, 1, N, bias, int(relu), mk, out.data_ptr(), int(out_f32), 1)
-
-    def _stage_input(self, src, idx, B):
-        rows = src if idx is None else src.index_select(0, idx.to(torch.int64))               # plumbing: row gather of the frame table
-        rows = rows[:B].contiguous()
-        if self.bf16:
-            self.L.mi_cast_f32_to_bf16(self.stream(), rows.data_ptr(), self.x.data_ptr(), B * self.S)
-            return self.x
-        return rows
-
-    def _encode(self, x, B):
-        a = x
-        for (name, k, n), h in zip(self.enc, self.h):
-            self._dense(a, B, k, name + "/kernel", n, self._p(self.params, name + "/bias"), 1, h)
-            a = h
-        self._dense(a, B, self.enc_sizes[-1], "@heads/kernel", 2 * self.z_dim, None, 0, self.heads, out_f32=1)
-        return a
-
-    def _reparam(self, B, eps, sample):
-        ob = self.layout["@heads/bias"][0]
-        self.L.mi_vae_reparam_kl_fwd(self.stream(), self.dtype, self.heads.data_ptr(), 1, self.params[ob:].data_ptr(), self.params[ob + self.z_dim:].data_ptr(),
-                                     milib.ptr(eps), int(sample), B, self.z_dim, self.mean.data_ptr(), self.logvar.data_ptr(), self.z.data_ptr(), self.kl_row.data_ptr())
-
-    def _decode(self, z, B):
-        a = z
-        for i, ((name, k, n), d) in enumerate(zip(self.dec, self.d)):
-            self._dense(a, B, k, name + "/kernel", n, self._p(self.params, name + "/bias"), 1 if i + 1 < len(self.dec) else 0, d)
-            a = d
-        return a
-
     # ---- steps (all asynchronous on the current torch stream) ----
+    @staticmethod
+    def _f32(t, what):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("MlpVAE: %s must be a float32 device tensor, got %s" % (what, t.dtype))
+        return t
+
     def forward(self, src, tgt, idx, B, inv_batch, eps, sample, want_grad, accumulate_metrics=True):
         self.ensure_batch(B)
-        B = int(B)
-        x = self._stage_input(src, idx, B)
-        self._last_x = x
-        self._encode(x, B)
-        self._reparam(B, eps, sample)
-        logits = self._decode(self.z, B)
-        kl_floor = self.kl_tolerance * self.z_dim if self.kl_tolerance > 0 else 0.0
-        self.L.mi_bce_logits_fwd_bwd(self.stream(), self.dtype, logits.data_ptr(), tgt.data_ptr(), milib.ptr(idx), self.P, B, self.P, self.loss_kind,
-                                     float(inv_batch), self.g_d[-1].data_ptr() if (want_grad and self.with_optimizer) else None, self.partial.data_ptr())
-        self.L.mi_vae_finalize_losses(self.stream(), self.partial.data_ptr(), self.nchunks, self.kl_row.data_ptr(), float(kl_floor), B, float(inv_batch),
-                                      self.losses.data_ptr(), self.metrics.data_ptr() if accumulate_metrics else None, float(B * inv_batch))
-        self.last_B = B
+        p = milib.ptr
+        self.L.mi_mlpvae_forward(self.handle, self.stream(), p(self._f32(src, "the source table")), p(self._f32(tgt, "the target table")), p(idx), int(B), float(inv_batch),
+                                 p(eps), int(sample), int(want_grad), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def backward(self, src, idx, eps, inv_batch, part=0):
         """part 0 = everything, 1 = decoder half (+ dz), 2 = encoder half: the data-parallel host all-reduces grads[decoder_offset:] in between."""
-        B, st, L, dt = self.last_B, self.stream(), self.L, self.dtype
-        if B < 1:
-            raise milib.MiError("MlpVaeDevice.backward: no forward pass recorded")
-        if part in (0, 1):
-            for i in range(len(self.dec) - 1, -1, -1):
-                name, k, n = self.dec[i]
-                gy = self.g_d[i]
-                a = self.d[i - 1] if i > 0 else self.z
-                L.mi_colsum(st, dt, gy.data_ptr(), B, n, self._p(self.grads, name + "/bias"))
-                L.mi_gemm_wgrad(st, dt, a.data_ptr(), gy.data_ptr(), B, k, n, self._p(self.grads, name + "/kernel"))
-                if i > 0:       # dx = gy W^T, ReLU-grad mask = the layer input (a ReLU output): W[k, n] read as [N_out = k][K_in = n]
-                    self._dense(gy, B, n, name + "/kernel", k, None, 0, self.g_d[i - 1], w_layout=1, mask=self.d[i - 1])
-                else:
-                    self._dense(gy, B, n, name + "/kernel", k, None, 0, self.dz, out_f32=1, w_layout=1)
-        if part in (0, 2):
-            kl_floor = self.kl_tolerance * self.z_dim if self.kl_tolerance > 0 else 0.0
-            L.mi_vae_reparam_kl_bwd(st, dt, self.dz.data_ptr(), 1, self.mean.data_ptr(), self.logvar.data_ptr(), milib.ptr(eps), self.kl_row.data_ptr(),
-                                    self.beta, float(kl_floor), float(inv_batch), B, self.z_dim, self.dheads.data_ptr())
-            kh = self.enc_sizes[-1]
-            L.mi_colsum(st, dt, self.dheads.data_ptr(), B, 2 * self.z_dim, self._p(self.grads, "@heads/bias"))
-            L.mi_gemm_wgrad(st, dt, self.h[-1].data_ptr(), self.dheads.data_ptr(), B, kh, 2 * self.z_dim, self._p(self.grads, "@heads/kernel"))
-            self._dense(self.dheads, B, 2 * self.z_dim, "@heads/kernel", kh, None, 0, self.g_h[-1], w_layout=1, mask=self.h[-1])
-            for i in range(len(self.enc) - 1, -1, -1):
-                name, k, n = self.enc[i]
-                gy = self.g_h[i]
-                a = self.h[i - 1] if i > 0 else self._last_x
-                L.mi_colsum(st, dt, gy.data_ptr(), B, n, self._p(self.grads, name + "/bias"))
-                L.mi_gemm_wgrad(st, dt, a.data_ptr(), gy.data_ptr(), B, k, n, self._p(self.grads, name + "/kernel"))
-                if i > 0:
-                    self._dense(gy, B, n, name + "/kernel", k, None, 0, self.g_h[i - 1], w_layout=1, mask=self.h[i - 1])
+        self.L.mi_mlpvae_backward(self.handle, self.stream(), milib.ptr(eps), float(inv_batch), int(part))
 
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
-        self.L.mi_adam_tf_flat(self.stream(), self.params.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.grads.data_ptr(), self.n_flat,
-                               float(alpha), float(beta1), float(beta2), float(epsilon), self.shadow.data_ptr() if self.bf16 else None, 1)
-        self._refresh_transposed()
+        self.L.mi_mlpvae_apply_adam(self.handle, self.stream(), float(alpha), float(beta1), float(beta2), float(epsilon))
+
+    def train_step(self, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, accumulate_metrics=True):
+        """One whole SGD step in one C call (single-rank path)."""
+        self.ensure_batch(B)
+        p = milib.ptr
+        self.L.mi_mlpvae_train_step(self.handle, self.stream(), p(self._f32(src, "the source table")), p(self._f32(tgt, "the target table")), p(idx), int(B), float(inv_batch),
+                                    p(eps), float(alpha), float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)
-        self._encode(self._stage_input(src, idx, int(B)), int(B))
-        self._reparam(int(B), None, 0)
-        out.copy_(self.mean[:int(B)])
+        self.L.mi_mlpvae_encode(self.handle, self.stream(), milib.ptr(self._f32(src, "the source table")), milib.ptr(idx), int(B), milib.ptr(out))
 
     def decode(self, z, B, out):
         self.ensure_batch(B)
-        B = int(B)
         zz = z.to(torch.float32).contiguous()
-        if self.bf16:
-            self.L.mi_cast_f32_to_bf16(self.stream(), zz.data_ptr(), self.z.data_ptr(), B * self.z_dim)
-            zin = self.z
-        else:
-            zin = zz
-        logits = self._decode(zin, B)
-        self.L.mi_sigmoid(self.stream(), self.dtype, logits.data_ptr(), out.data_ptr(), B * self.P)
+        self.L.mi_mlpvae_decode(self.handle, self.stream(), milib.ptr(zz), int(B), milib.ptr(out))
 
     def reconstruct(self, src, idx, B, eps, sample, out):
         self.ensure_batch(B)
-        B = int(B)
-        self._encode(self._stage_input(src, idx, B), B)
-        self._reparam(B, eps, sample)
-        logits = self._decode(self.z, B)
-        self.L.mi_sigmoid(self.stream(), self.dtype, logits.data_ptr(), out.data_ptr(), B * self.P)
+        self.L.mi_mlpvae_reconstruct(self.handle, self.stream(), milib.ptr(self._f32(src, "the source table")), milib.ptr(idx), int(B), milib.ptr(eps), int(sample), milib.ptr(out))
 
     def range_ok(self, t):
         flag = torch.zeros(1, device=self.device, dtype=torch.int32)

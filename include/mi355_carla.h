@@ -51,6 +51,23 @@ typedef struct MiVaeDesc {
     float kl_tolerance;
 } MiVaeDesc;
 
+/* MlpVAE (vae/models.py:271-299): dense encoder / decoder around the same latent block; up to MI_MLP_MAX_HIDDEN hidden layers per side */
+#define MI_MLP_MAX_HIDDEN 4
+typedef struct MiMlpVaeDesc {
+    int dtype;          /* MI_F32 | MI_BF16 */
+    int max_batch;
+    int source_size;    /* prod(source_shape), e.g. 80*160*3 = 38400 */
+    int target_size;    /* prod(target_shape) */
+    int z_dim;
+    int n_enc, n_dec;   /* hidden layers: encoder_sizes (512, 256) -> 2, decoder_sizes (256, 512) -> 2; the output layer to target_size is implied */
+    int enc[MI_MLP_MAX_HIDDEN];
+    int dec[MI_MLP_MAX_HIDDEN];
+    int loss_kind;      /* 0 bce_loss, 1 bce_loss_v2, 2 mse_loss */
+    int with_optimizer; /* 0: inference-only engine (no gradient buffers in the workspace) */
+    float beta;
+    float kl_tolerance;
+} MiMlpVaeDesc;
+
 typedef struct MiPpoDesc {
     int max_batch;
     int input_dim;      /* z_dim + measurements = 67 (train.py:85) */
@@ -170,6 +187,9 @@ long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N);
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes);
 /* same + the layer's BiasAddGrad in the same launch: dbias[n] += sum_m dy[m,n] (a column of ones appended to `a` inside the kernel's loader; dbias may be NULL) */
 int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes);
+/* same; overwrite != 0: dw (and dbias) = the gradient instead of += (plain stores / the storing form of the ordered sum): the gradient buffer need not be zeroed and no
+ * element is touched by an atomic.  Row splits then NEED the scratch (MI_ERR_ARG otherwise). */
+int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes, int overwrite);
 
 /* ---- VAE elementwise / reduction kernels ---- */
 /* Normal(mean, exp(.5 lv)).sample + kl_divergence — vae/models.py:7-9,101-105 (eps injected; TF RNG is unseeded) */
@@ -195,6 +215,12 @@ int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad,
 int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 /* same; the shadow weight copy the MFMA kernels read is of storage type shadow_dtype: MI_BF16 (2 bytes per weight) or MI_BF16X3 (split, 4 bytes) */
 int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, int shadow_dtype, int clear_grad);
+/* TF ApplyAdam over the flat buffer [0, n) that ALSO refreshes both weight copies of the `count` (<= 16) listed [K, N] kernels (offsets in floats, ascending, N % 4 == 0,
+ * offsets % 4 == 0) in the same launch: shadow = storage-type copy in the master layout (NULL for fp32 engines), wt = K-contiguous copy wt[off + n * K + k] (what
+ * mi_transpose_weights writes; may be NULL).  dtype MI_F32 | MI_BF16 = element type of both copies.  Bit-identical p / m / v to mi_adam_tf_flat. */
+int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
+/* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch gathered and converted in one launch; dtype MI_F32 | MI_BF16 */
+int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* idx, int B, long long row_len, void* out);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
 /* fp32 <-> split storage (dtype MI_BF16X3): word = bf16(x) << 16 | bf16(x - bf16(x)); back: hi + lo */
 int mi_cast_f32_to_split(void* stream, const float* src, void* dst, long long n);
@@ -261,6 +287,28 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
 int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
 int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
+
+/* ---- MlpVAE engine (round 4; vae/models.py:271-299 on the base graph :85-142): the same surface as the ConvVAE engine for the dense variant.  Frame tables are float32
+ * [n_frames, source_size] / [n_frames, target_size] on the device; the noise eps [B, z_dim] comes from the caller (mi_normal_philox); gradients are STORED into the
+ * gradient buffer by every backward pass (not accumulated).  Tensor order of mi_mlpvae_param_layout: encoder layers {kernel [K, N], bias}, heads {kernel [K, 2 z] =
+ * [mean | logstd_sqare], bias}, decoder layers incl. the output layer {kernel, bias}; no padding between tensors. ---- */
+int mi_mlpvae_desc_size(void);
+long long mi_mlpvae_param_floats(const MiMlpVaeDesc* d);
+int mi_mlpvae_tensor_count(const MiMlpVaeDesc* d);
+int mi_mlpvae_param_layout(const MiMlpVaeDesc* d, long long* offsets, long long* sizes, int n);
+long long mi_mlpvae_workspace_bytes(const MiMlpVaeDesc* d);
+void* mi_mlpvae_create(const MiMlpVaeDesc* d, float* params, float* grads, float* adam_m, float* adam_v, void* shadow, void* weights_t, void* workspace, long long workspace_bytes);
+void mi_mlpvae_destroy(void* h);
+int mi_mlpvae_sync_shadow(void* h, void* stream);
+void* mi_mlpvae_buffer(void* h, int which);
+long long mi_mlpvae_decoder_offset(void* h);
+int mi_mlpvae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
+int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch, int part);
+int mi_mlpvae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
+int mi_mlpvae_train_step(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
+int mi_mlpvae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out);
+int mi_mlpvae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
+int mi_mlpvae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
 /* one environment step of the rollout loop in one call — vae_common.py:45-61 (encode_state) + ppo.py:231-251 (predict): raw uint8 frame [IH,IW,3] and
  * measurements -> out [num_actions + 1 + z_dim] = action | value | z; noise [num_actions] for sampling or NULL with greedy.  Exact fp32.

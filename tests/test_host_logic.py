@@ -20,7 +20,7 @@ def test_shared_library_exports_every_declared_symbol():
     L = milib.get()                                   # raises if the .so is missing or lacks a declared symbol
     for name in protos:
         assert hasattr(L.cdll, name), name
-    assert L.mi_abi_version() == 4
+    assert L.mi_abi_version() == 5
     assert L.mi_vae_desc_size() == ctypes.sizeof(milib.MiVaeDesc) and L.mi_ppo_desc_size() == ctypes.sizeof(milib.MiPpoDesc)
     # every public entry point cites the reference op it replaces
     text = open(milib.HEADER).read()

@@ -353,6 +353,99 @@ def test_dense_wgrad(dt, shape):
     assert_close(host(dw), ref.numpy(), 1e-5, 3e-5 * float(ref.abs().max()), "dense wgrad")
     L.mi_gemm_wgrad(stream(), code, P(dev(a, td)), P(dev(dy, td)), M, K, N, dw.data_ptr())      # accumulates
     assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
+    # storing form (the MlpVAE engine): garbage in the buffers, the same bits out as the first call into zeros -- plain stores (one row split) or the storing ordered sum
+    dw, db = torch.full((K, N), 7.5, device="cuda"), torch.full((N,), -3.25, device="cuda")
+    L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, 1)
+    assert np.array_equal(host(dw), runs[0][0]) and np.array_equal(host(db), runs[0][1])
+    if nb > 0:                                          # row splits without scratch cannot store: refused, not silently accumulated
+        with pytest.raises(milib.MiError):
+            L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)
+
+
+@pytest.mark.parametrize("shape", [(512, 4096, 1024), (77, 512, 8192), (33, 4096, 1024)])
+def test_dense_wgrad_whole_tiles_over_all_rows(shape):
+    """Round 4 (dwg_tile.hpp, the MlpVAE's two large layers): storing dense filter gradient with >= 256 tiles of 128 x 128 -- LDS-DMA stages of 32 rows, both operands
+    read through the hardware transpose from swizzled rows, bias gradient by a ones operand -- against float64; both tile orders (k-major / n-major), a ragged last
+    stage (rows past M are zero-filled by the descriptor), garbage in the output buffers beforehand, and two runs bitwise equal."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    M, K, N = shape
+    rng = np.random.RandomState(M + K)
+    a, dy = rng.randn(M, K).astype(np.float32), rng.randn(M, N).astype(np.float32)
+    ref = (rounded(a, td).T @ rounded(dy, td)).numpy()
+    refb = rounded(dy, td).sum(0).numpy()
+    ad, dyd = dev(a, td), dev(dy, td)
+    outs = []
+    for fill in (3.0, -7.0):
+        dw, db = torch.full((K, N), fill, device="cuda"), torch.full((N,), fill, device="cuda")
+        L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)      # (no scratch: only the tile kernel can do this)
+        outs.append((host(dw), host(db)))
+    assert_close(outs[0][0], ref, 1e-5, 3e-5 * float(np.abs(ref).max()), "dense wgrad (whole tiles)")
+    assert_close(outs[0][1], refb, 1e-5, 3e-5 * float(np.abs(refb).max()), "bias row (ones operand)")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    dw = torch.full((K, N), 5.0, device="cuda")
+    L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), None, None, 0, 1)                   # without the bias row
+    assert np.array_equal(host(dw), outs[0][0])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_adam_writing_both_weight_layouts_equals_adam_then_transposes(dt):
+    """Round 4 (MlpVAE engine): mi_adam_tf_layouts = mi_adam_tf_flat + mi_transpose_weights in one launch -- p / m / v, the storage-type copy and the K-contiguous
+    kernel copies BITWISE equal to the two-pass form; kernels with partial 64 x 64 tiles, a K that is not a multiple of the 16-byte vector, biases between them and a tail."""
+    L = milib.get()
+    code, td = DT[dt]
+    rng = np.random.RandomState(3)
+    kern = [(100, 72), (64, 128), (8, 260), (130, 64)]                         # (K, N): N % 4 == 0
+    offs, o = [], 0
+    for K, N in kern:
+        offs.append(o); o += K * N + N                                      # kernel, then its bias
+    n = o + 12                                                               # + a tail outside every kernel
+    p0 = rng.randn(n).astype(np.float32); g0 = (rng.randn(n) * 0.1).astype(np.float32)
+    m0 = (rng.randn(n) * 0.01).astype(np.float32); v0 = (rng.rand(n) * 1e-3).astype(np.float32)
+    off_a, K_a, N_a = np.array(offs, np.int64), np.array([k for k, _ in kern], np.int32), np.array([nn for _, nn in kern], np.int32)
+    alpha = 1e-3
+    def run(fused, clear):
+        p, m, v, g = dev(p0), dev(m0), dev(v0), dev(g0)
+        sh = torch.zeros(n, device="cuda", dtype=td) if dt == "bf16" else None
+        wt = torch.zeros(n, device="cuda", dtype=td)
+        if fused:
+            L.mi_adam_tf_layouts(stream(), code, p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), n, off_a.ctypes.data, K_a.ctypes.data, N_a.ctypes.data, len(kern),
+                                 alpha, None, 0.9, 0.999, 1e-8, sh.data_ptr() if sh is not None else None, wt.data_ptr(), clear)
+        else:
+            L.mi_adam_tf_flat(stream(), p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), n, alpha, 0.9, 0.999, 1e-8, sh.data_ptr() if sh is not None else None, clear)
+            L.mi_transpose_weights(stream(), code, p.data_ptr(), wt.data_ptr(), off_a.ctypes.data, K_a.ctypes.data, N_a.ctypes.data, len(kern))
+        torch.cuda.synchronize()
+        out = [host(p), host(m), host(v), host(g), wt.view(torch.int16 if dt == "bf16" else torch.int32).cpu().numpy()]
+        if sh is not None:
+            out.append(sh.view(torch.int16).cpu().numpy())
+        return out
+    for clear in (0, 1):
+        a_, b_ = run(True, clear), run(False, clear)
+        for i, (x, y) in enumerate(zip(a_, b_)):
+            if i == 4:                                                       # the transposed copy: only the kernels' ranges are defined
+                for o_, (K, N) in zip(offs, kern):
+                    assert np.array_equal(x[o_:o_ + K * N], y[o_:o_ + K * N]), ("wt", K, N)
+            else:
+                assert np.array_equal(x, y), i
+    assert not np.array_equal(a_[0], p0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gather_rows_cast(dt):
+    """mi_gather_rows_cast: rows idx[b] of a float32 table in the engine's storage type (the MlpVAE engine's frame staging), incl. a row length with a scalar tail."""
+    L = milib.get()
+    code, td = DT[dt]
+    rng = np.random.RandomState(1)
+    for row_len in (38400, 2052, 7):
+        tab = rng.rand(9, row_len).astype(np.float32)
+        idx = np.array([4, 0, 8, 8, 2], np.int32)
+        tab_d, idx_d = dev(tab), torch.from_numpy(idx).cuda()
+        out = torch.zeros(len(idx), row_len, device="cuda", dtype=td)
+        L.mi_gather_rows_cast(stream(), code, tab_d.data_ptr(), idx_d.data_ptr(), len(idx), row_len, out.data_ptr())
+        assert np.array_equal(host(out), rounded(tab[idx], td).numpy())
+        out2 = torch.zeros(3, row_len, device="cuda", dtype=td)
+        L.mi_gather_rows_cast(stream(), code, tab_d.data_ptr(), None, 3, row_len, out2.data_ptr())
+        assert np.array_equal(host(out2), rounded(tab[:3], td).numpy())
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -9,7 +9,7 @@ import numpy as np
 from mi355 import lib as milib
 
 L = milib.get()
-assert L.mi_abi_version() == 4
+assert L.mi_abi_version() == 5
 print("library:", milib.LIB_PATH)
 
 # ---- VAE descriptor arithmetic for every dtype / loss / geometry the models use, with and without the guard mode ----
@@ -44,6 +44,41 @@ for guards in ("0", "1"):
 del os.environ["MI355_DEBUG_GUARDS"]
 bad = vae_desc(1); bad.ih = 7
 assert L.mi_vae_workspace_bytes(ctypes.byref(bad)) < 0 and b"geometry" in L.cdll.mi_last_error()
+
+# ---- MlpVAE descriptor arithmetic (round 4 engine): layout without padding in the reference's variable order, workspace, error paths ----
+def mlp_desc(dtype, enc=(512, 256), dec=(256, 512), S=38400, P=38400, z=64, max_batch=64, opt=1):
+    d = milib.MiMlpVaeDesc()
+    d.dtype, d.max_batch, d.source_size, d.target_size, d.z_dim, d.n_enc, d.n_dec = dtype, max_batch, S, P, z, len(enc), len(dec)
+    for i, h in enumerate(enc):
+        d.enc[i] = h
+    for i, h in enumerate(dec):
+        d.dec[i] = h
+    d.loss_kind, d.with_optimizer, d.beta, d.kl_tolerance = 0, opt, 1.0, 0.0
+    return d
+
+for dtype in (0, 1):
+    for enc, dec, P_ in (((512, 256), (256, 512), 38400), ((64,), (32, 48, 64), 12800), ((8, 16, 24, 32), (8,), 38400)):
+        if dtype == 1 and any(h % 8 for h in enc + dec):
+            continue
+        for opt in (0, 1):
+            d = mlp_desc(dtype, enc, dec, P=P_, opt=opt)
+            n = L.mi_mlpvae_param_floats(ctypes.byref(d))
+            nt = L.mi_mlpvae_tensor_count(ctypes.byref(d))
+            assert nt == 2 * (len(enc) + 1 + len(dec) + 1)
+            offs = (ctypes.c_longlong * nt)(); sizes = (ctypes.c_longlong * nt)()
+            L.mi_mlpvae_param_layout(ctypes.byref(d), ctypes.addressof(offs), ctypes.addressof(sizes), nt)
+            assert offs[0] == 0 and sum(sizes) == n and all(offs[i + 1] == offs[i] + sizes[i] for i in range(nt - 1))
+            widths = (38400,) + enc
+            assert [sizes[2 * i] for i in range(len(enc))] == [widths[i] * widths[i + 1] for i in range(len(enc))] and sizes[2 * len(enc)] == enc[-1] * 128
+            ws = L.mi_mlpvae_workspace_bytes(ctypes.byref(d))
+            assert ws > 0 and ws % 256 == 0
+            assert not L.mi_mlpvae_create(ctypes.byref(d), None, None, None, None, None, None, None, 0) and L.cdll.mi_last_error()
+            assert not L.mi_mlpvae_create(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 256, 16)            # workspace too small
+            assert not L.mi_mlpvae_create(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 257, ws)            # workspace misaligned
+for bad in (mlp_desc(2), mlp_desc(1, enc=(500, 256)), mlp_desc(0, enc=()), mlp_desc(0, z=0), mlp_desc(0, S=38402)):
+    assert L.mi_mlpvae_workspace_bytes(ctypes.byref(bad)) < 0 and b"unsupported" in L.cdll.mi_last_error()
+assert L.cdll.mi_mlpvae_forward(None, None, None, None, None, 4, 0.25, None, 0, 0, None, 0.0) != 0 and b"null handle" in L.cdll.mi_last_error()
+assert L.mi_mlpvae_decoder_offset(None) == -1 and L.mi_mlpvae_buffer(None, 0) is None
 
 # ---- PPO descriptor arithmetic ----
 pd = milib.MiPpoDesc()

@@ -8,12 +8,12 @@ for p in (os.path.join(ROOT, "carla-ppo_amd"), ROOT):
 import numpy as np, torch
 from vae.models import MlpVAE
 
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=30); ap.add_argument("--batch", type=int, default=512)
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=30); ap.add_argument("--batch", type=int, default=512); ap.add_argument("--precision", default="bf16,fp32")
 args = ap.parse_args()
 B = args.batch
 rng = np.random.RandomState(0)
 frames = rng.randint(0, 256, (1024, 80, 160, 3)).astype(np.float32) / 255.0
-for precision in ("bf16", "fp32"):
+for precision in args.precision.split(","):
     m = MlpVAE(np.array([80, 160, 3]), z_dim=64, model_dir=tempfile.mkdtemp(), precision=precision, seed=0)
     m.init_session(init_logging=False)
     dev = m._need_dev()
