@@ -1261,7 +1261,10 @@ int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* d
         ((((uintptr_t)a) | ((uintptr_t)dy) | ((uintptr_t)dw)) & 15) == 0 && fits_desc((long long)M * K * 2) && fits_desc((long long)M * N * 2)) {
         DwgParams q = {a, (uint32_t)((long long)M * K * 2), dy, (uint32_t)((long long)M * N * 2), dw, dbias, M, K, N, K / 128, N / 128};
         const int per = (q.KT * q.NT + 7) / 8;
-        MI_LAUNCH(dwg_kernel, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
+        static int nst = -1;
+        if (nst < 0) { const char* e = getenv("MI355_DWG_NST"); nst = (e && atoi(e) == 4) ? 4 : 3; }
+        if (nst == 3) MI_LAUNCH(dwg_kernel<3>, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
+        else MI_LAUNCH(dwg_kernel<4>, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
         return mi_check_launch("dwg_kernel");
     }
     WgradParams p = {};

@@ -24,11 +24,12 @@ struct DwgParams {
     int KT, NT;                      // tiles of 128 along k and n
 };
 
-constexpr int DWG_NST = 4;
 constexpr int DWG_ROWS = 32;                               // rows (m) per stage
 constexpr int DWG_STAGE = 2 * DWG_ROWS * 256;              // bytes: the A rows, then the dy rows
 
-__global__ __launch_bounds__(256, 2) void dwg_kernel(const DwgParams p) {
+// DWG_NST stages of 16 KB: 4 -> two blocks per CU, 3 -> three (132 VGPRs fit three waves per SIMD)
+template <int DWG_NST>
+__global__ __launch_bounds__(256, DWG_NST == 3 ? 3 : 2) void dwg_kernel(const DwgParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[DWG_NST * DWG_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;               // the wave's 64 x 64 quarter of the tile

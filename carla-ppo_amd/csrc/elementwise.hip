@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 constexpr int AL_MAX = 16;
 struct AdamLayoutJobs {
     long long off[AL_MAX]; int K[AL_MAX], N[AL_MAX], tile0[AL_MAX + 1]; int count;          // the 2-D kernels: tiles tile0[t] .. tile0[t + 1]
+    unsigned no_shadow, no_wt;                                                              // bit t: kernel t has no storage-type copy / no K-contiguous copy (nobody reads it)
     long long foff[AL_MAX], fn[AL_MAX]; int fblk0[AL_MAX + 1]; int fcount;                 // flat ranges: 1,024 elements per block
 };
 
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
             }
             *(f32x4*)(p + e) = pv; *(f32x4*)(m + e) = mv; *(f32x4*)(v + e) = vv;
             if (clear_grad) { const f32x4 zz = {0.f, 0.f, 0.f, 0.f}; *(f32x4*)(g + e) = zz; }
-            if (shadow) {
+            if (shadow && !((jb.no_shadow >> t) & 1u)) {
                 if constexpr (sizeof(TT) == 2) {
                     u16x4 sv;
 #pragma unroll
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
         for (int q = 0; q < 4; ++q) tile[r * PITCH + c4 + q] = Elem<TT>::from_f32(pv[q]);
     }
     __syncthreads();
-    if (!wt) return;
+    if (!wt || ((jb.no_wt >> t) & 1u)) return;
     // wt[off + n * K + k]: thread (n = tid >> 2, quarter = tid & 3) writes 16 consecutive k of its row
     const int nn = tid >> 2, kq = (tid & 3) << 4;
     const int n = n0 + nn;
@@ -776,8 +777,9 @@ int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long l
 // TF ApplyAdam over the flat buffer [0, n) that also refreshes both weight copies of the `count` listed [K, N] kernels (offsets in floats, N % 4 == 0, offsets % 4 == 0):
 // shadow (storage-type copy, same layout; NULL for fp32 engines) and wt (K-contiguous copy wt[off + n * K + k]; may be NULL).  dtype MI_F32 / MI_BF16 = element type of
 // both copies.  Everything between / behind the listed kernels (the biases) gets the plain update (+ shadow).  The kernels must be listed in ascending offset order
-// and must not overlap.  Same arithmetic as mi_adam_tf_flat: bit-identical p / m / v.
-int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, int count,
+// and must not overlap.  skip (may be NULL): per kernel, bit 0 = leave its shadow copy alone, bit 1 = leave its K-contiguous copy alone (copies nobody reads:
+// the first layer of an encoder has no input gradient).  Same arithmetic as mi_adam_tf_flat: bit-identical p / m / v.
+int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count,
                        float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad) {
     if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: dtype must be MI_F32 or MI_BF16");
     if (count < 0 || count > AL_MAX) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: 0 <= count <= 16");
@@ -799,6 +801,8 @@ int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v
         if (offsets[i] < pos || offsets[i] + sz > n) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: kernels must be listed in ascending, non-overlapping order inside [0, n)");
         if (!add_flat(pos, offsets[i])) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: too many ranges between the kernels");
         jb.off[i] = offsets[i]; jb.K[i] = K[i]; jb.N[i] = N[i]; jb.tile0[i] = tiles;
+        if (skip && (skip[i] & 1)) jb.no_shadow |= 1u << i;
+        if (skip && (skip[i] & 2)) jb.no_wt |= 1u << i;
         tiles += ((K[i] + 63) / 64) * ((N[i] + 63) / 64);
         pos = offsets[i] + sz;
     }

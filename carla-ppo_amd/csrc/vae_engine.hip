@@ -253,7 +253,12 @@ int check_batch(const VaeEngine* e, int B) {
 
 unsigned ready_event_flags() {                         // MI355_KEVENT=2: the hand-over event with timing enabled (A/B: what hipExtLaunchKernelGGL's stop event wants)
     const char* ev = getenv("MI355_KEVENT");
-    return (ev && atoi(ev) == 2) ? hipEventDefault : hipEventDisableTiming;
+    unsigned f = (ev && atoi(ev) == 2) ? hipEventDefault : hipEventDisableTiming;
+    // the hand-over events are consumed on this device only: MI355_EVENT_SCOPE=1 device-scope release, =2 no system-scope fence (A/B; default 0 = the runtime's default)
+    const char* sc = getenv("MI355_EVENT_SCOPE");
+    if (sc && atoi(sc) == 1) f |= hipEventReleaseToDevice;
+    if (sc && atoi(sc) == 2) f |= hipEventDisableSystemFence;
+    return f;
 }
 
 bool relu_bits_enabled() {                             // MI355_RELU_BITS=0: the input gradients read the activation tensors as ReluGrad masks (A/B runs)
@@ -545,7 +550,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     if (two_streams < 0) { const char* ev = getenv("MI355_BWD_STREAMS"); two_streams = (ev && ev[0] == '0') ? 0 : 1; }
     if (two_streams && !e->side_ok) {
         if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
-            hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
+            hipEventCreateWithFlags(&e->ev_done, ready_event_flags()) == hipSuccess) e->side_ok = 1;
         else e->side_ok = -1;
     }
     static int third_on = -1;                             // MI355_THIRD=1: the latent layers' filter / bias gradients, the tail's slab sum and the loss finalisation on a third stream
@@ -817,7 +822,7 @@ static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alph
     if (layouts_on && e->d.dtype != MI_BF16X3) {
         long long off[10]; int K[10], N[10];
         const int n = kernel_table(e, off, K, N);
-        TOP(e, stream, OP_ADAM, mi_adam_tf_layouts(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, n, alpha, alpha_dev, beta1, beta2, epsilon,
+        TOP(e, stream, OP_ADAM, mi_adam_tf_layouts(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, nullptr, n, alpha, alpha_dev, beta1, beta2, epsilon,
                                                    e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 1));
         return refresh_transposed(e, stream, true);
     }

@@ -404,12 +404,13 @@ def test_adam_writing_both_weight_layouts_equals_adam_then_transposes(dt):
     m0 = (rng.randn(n) * 0.01).astype(np.float32); v0 = (rng.rand(n) * 1e-3).astype(np.float32)
     off_a, K_a, N_a = np.array(offs, np.int64), np.array([k for k, _ in kern], np.int32), np.array([nn for _, nn in kern], np.int32)
     alpha = 1e-3
-    def run(fused, clear):
+    skip = np.array([0, 1, 2, 3], np.int32)                                   # kernel 1: no shadow copy, 2: no K-contiguous copy, 3: neither
+    def run(fused, clear, use_skip=False):
         p, m, v, g = dev(p0), dev(m0), dev(v0), dev(g0)
         sh = torch.zeros(n, device="cuda", dtype=td) if dt == "bf16" else None
         wt = torch.zeros(n, device="cuda", dtype=td)
         if fused:
-            L.mi_adam_tf_layouts(stream(), code, p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), n, off_a.ctypes.data, K_a.ctypes.data, N_a.ctypes.data, len(kern),
+            L.mi_adam_tf_layouts(stream(), code, p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), n, off_a.ctypes.data, K_a.ctypes.data, N_a.ctypes.data, skip.ctypes.data if use_skip else None, len(kern),
                                  alpha, None, 0.9, 0.999, 1e-8, sh.data_ptr() if sh is not None else None, wt.data_ptr(), clear)
         else:
             L.mi_adam_tf_flat(stream(), p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), n, alpha, 0.9, 0.999, 1e-8, sh.data_ptr() if sh is not None else None, clear)
@@ -428,6 +429,14 @@ def test_adam_writing_both_weight_layouts_equals_adam_then_transposes(dt):
             else:
                 assert np.array_equal(x, y), i
     assert not np.array_equal(a_[0], p0)
+    # skipped copies stay untouched (zeros), everything else is as before
+    a_, b_ = run(True, 0, use_skip=True), run(False, 0)
+    assert all(np.array_equal(a_[i], b_[i]) for i in range(4))
+    for i_, (o_, (K, N)) in enumerate(zip(offs, kern)):
+        sl = slice(o_, o_ + K * N)
+        assert np.array_equal(a_[4][sl], b_[4][sl]) if not (skip[i_] & 2) else not a_[4][sl].any()
+        if dt == "bf16":
+            assert np.array_equal(a_[5][sl], b_[5][sl]) if not (skip[i_] & 1) else not a_[5][sl].any()
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
