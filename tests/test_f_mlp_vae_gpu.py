@@ -108,3 +108,46 @@ def test_mlp_vae_bf16_trains_and_checkpoints(tmp_path):
     m2.init_session(init_logging=False)
     assert m2.load_latest_checkpoint() is True and m2.get_step_idx() == 3
     assert m.train_step(src, src, eps=eps) == pytest.approx(m2.train_step(src, src, eps=eps), rel=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_mlp_vae_backward_in_two_parts_and_whole_step_call(tmp_path, precision):
+    """The engine's data-parallel surface and its one-call step (round 4, csrc/mlp_engine.hip): backward(part 1) + backward(part 2) -- between which the host all-reduces
+    grads[decoder_offset:] -- leaves bitwise the gradients of backward(part 0), garbage in the gradient buffer beforehand included (backward STORES); mi_mlpvae_train_step
+    equals forward + backward + apply_adam bitwise (parameters, both Adam slots), at a batch that is not a multiple of the 32-row stages and through an index vector."""
+    import torch
+    src_shape, enc, dec, B = (80, 160, 3), (512, 256), (256, 512), 37
+    rng = np.random.RandomState(2)
+    table = (rng.randint(0, 256, (50,) + src_shape).astype(np.float32) / 255.0)
+    eps = rng.standard_normal((B, 64)).astype(np.float32)
+    idx = rng.permutation(50)[:B].astype(np.int32)
+    params = _mlp_params(9, src_shape, src_shape, enc, dec)
+
+    def model(tag):
+        m = MlpVAE(np.array(src_shape), z_dim=64, model_dir=str(tmp_path / tag), precision=precision, learning_rate=1e-4)
+        m.set_weights(params)
+        m.init_session(init_logging=False)
+        return m
+    m = model("a")
+    s_dev, e_dev, i_dev = m._frames(table, 38400, "src"), m._eps(B, eps), torch.from_numpy(idx).cuda()
+    d = m.dev
+    d.forward(s_dev, s_dev, i_dev, B, 1.0 / B, e_dev, 1, 1)
+    d.grads.fill_(123.0)
+    d.backward(s_dev, i_dev, e_dev, 1.0 / B, 0)
+    whole = d.grads.clone()
+    d.grads.fill_(-7.0)
+    d.backward(s_dev, i_dev, e_dev, 1.0 / B, 1)
+    assert torch.equal(d.grads[d.decoder_offset:], whole[d.decoder_offset:]) and bool((d.grads[:d.decoder_offset] == -7.0).all())
+    d.backward(s_dev, i_dev, e_dev, 1.0 / B, 2)
+    assert torch.equal(d.grads, whole)
+    assert [(p_, lo, hi) for p_, lo, hi in d.grad_buckets] == [(1, d.decoder_offset, d.n_flat), (2, 0, d.decoder_offset)]
+    # three steps: op by op against the one-call form
+    m2 = model("b")
+    for _ in range(3):
+        d.forward(s_dev, s_dev, i_dev, B, 1.0 / B, e_dev, 1, 1)
+        d.backward(s_dev, i_dev, e_dev, 1.0 / B, 0)
+        m._adam_step()
+        m2._train_minibatch(s_dev, s_dev, i_dev, B, 1.0 / B, e_dev)
+    for a_, b_ in ((d.params, m2.dev.params), (d.adam_m, m2.dev.adam_m), (d.adam_v, m2.dev.adam_v), (d.weights_t, m2.dev.weights_t)):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(d.params, torch.from_numpy(d._to_flat(params)).cuda())
