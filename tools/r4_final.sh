@@ -7,8 +7,9 @@ tag=${1:-r04a}
 : > gpurun_out/suite_loop_$tag.log
 for i in 1 2 3 4 5; do
   echo "=== run $i ===" >> gpurun_out/suite_loop_$tag.log
-  timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4 >> gpurun_out/suite_loop_$tag.log
-  echo "rc=${PIPESTATUS[0]}" >> gpurun_out/suite_loop_$tag.log
+  timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/suite_run_${tag}_$i.log 2>&1
+  echo "rc=$?" >> gpurun_out/suite_loop_$tag.log
+  grep -E "passed|failed|error" gpurun_out/suite_run_${tag}_$i.log | tail -3 >> gpurun_out/suite_loop_$tag.log
 done
 cat gpurun_out/suite_loop_$tag.log
 tools/profile_round.sh $tag
