@@ -28,6 +28,47 @@ def test_shared_library_exports_every_declared_symbol():
         assert must in text
 
 
+def test_mlpvae_engine_layout_is_the_reference_variable_list():
+    """Round 4 (csrc/mlp_engine.hip): the flat parameter buffer of the MlpVAE engine holds the reference's trainable variables (vae/models.py:287-297, TF creation order,
+    `mi355.init.mlp_vae_variables`) back to back -- the two heads as one [K, 2 z] kernel -- for the reference's sizes and for odd ones; 39.5 M parameters at the defaults."""
+    from mi355 import lib as milib
+    from mi355.init import mlp_vae_variables
+    L = milib.get()
+    assert L.mi_mlpvae_desc_size() == ctypes.sizeof(milib.MiMlpVaeDesc)
+    for enc, dec, tgt in (((512, 256), (256, 512), (80, 160, 3)), ((64,), (32, 48, 64), (80, 160, 1)), ((8, 16, 24, 32), (8,), (80, 160, 3))):
+        d = milib.MiMlpVaeDesc()
+        d.dtype, d.max_batch, d.source_size, d.target_size, d.z_dim, d.n_enc, d.n_dec = 0, 16, 38400, int(np.prod(tgt)), 64, len(enc), len(dec)
+        for i, h in enumerate(enc):
+            d.enc[i] = h
+        for i, h in enumerate(dec):
+            d.dec[i] = h
+        d.loss_kind, d.with_optimizer, d.beta, d.kl_tolerance = 0, 1, 1.0, 0.0
+        nt = L.mi_mlpvae_tensor_count(ctypes.byref(d))
+        off, size = np.zeros(nt, np.int64), np.zeros(nt, np.int64)
+        L.mi_mlpvae_param_layout(ctypes.byref(d), off.ctypes.data, size.ctypes.data, nt)
+        v = mlp_vae_variables(64, (80, 160, 3), tgt, enc, dec)
+        want = []
+        for name, shape in v.items():
+            if name.startswith(("vae/mean/", "vae/logstd_sqare/")):
+                if name == "vae/mean/kernel":
+                    want.append(2 * int(np.prod(shape)))
+                elif name == "vae/mean/bias":
+                    want.append(2 * int(shape[0]))
+                continue
+            want.append(int(np.prod(shape)))
+        assert list(size) == want and off[0] == 0 and (off[1:] == np.cumsum(size)[:-1]).all()
+        assert L.mi_mlpvae_param_floats(ctypes.byref(d)) == sum(int(np.prod(s_)) for s_ in v.values())
+    assert sum(int(np.prod(s_)) for s_ in mlp_vae_variables(64, (80, 160, 3), (80, 160, 3)).values()) == L.mi_mlpvae_param_floats(ctypes.byref(_mlp_default_desc(milib)))
+
+
+def _mlp_default_desc(milib):
+    d = milib.MiMlpVaeDesc()
+    d.dtype, d.max_batch, d.source_size, d.target_size, d.z_dim, d.n_enc, d.n_dec = 1, 512, 38400, 38400, 64, 2, 2
+    d.enc[0], d.enc[1], d.dec[0], d.dec[1] = 512, 256, 256, 512
+    d.loss_kind, d.with_optimizer, d.beta, d.kl_tolerance = 0, 1, 1.0, 0.0
+    return d
+
+
 def test_param_layout_queries_match_reference_parameter_counts():
     from mi355 import lib as milib
     L = milib.get()
