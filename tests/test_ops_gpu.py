@@ -353,13 +353,6 @@ def test_dense_wgrad(dt, shape):
     assert_close(host(dw), ref.numpy(), 1e-5, 3e-5 * float(ref.abs().max()), "dense wgrad")
     L.mi_gemm_wgrad(stream(), code, P(dev(a, td)), P(dev(dy, td)), M, K, N, dw.data_ptr())      # accumulates
     assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
-    # storing form (the MlpVAE engine): garbage in the buffers, the same bits out as the first call into zeros -- plain stores (one row split) or the storing ordered sum
-    dw, db = torch.full((K, N), 7.5, device="cuda"), torch.full((N,), -3.25, device="cuda")
-    L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, 1)
-    assert np.array_equal(host(dw), runs[0][0]) and np.array_equal(host(db), runs[0][1])
-    if nb > 0:                                          # row splits without scratch cannot store: refused, not silently accumulated
-        with pytest.raises(milib.MiError):
-            L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)
 
 
 @pytest.mark.parametrize("shape", [(512, 4096, 1024), (77, 512, 8192), (33, 4096, 1024)])
@@ -494,6 +487,13 @@ def test_ordered_dense_wgrad_with_bias_row_and_colsum(dt, shape):
     dw = torch.from_numpy(runs[0][0]).cuda()
     L.mi_gemm_wgrad_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), ws.data_ptr(), nb)
     assert_close(host(dw), 2 * ref.numpy(), 1e-5, 6e-5 * float(ref.abs().max()), "dense wgrad accumulate")
+    # storing form (the MlpVAE engine): garbage in the buffers, the same bits out as the first call into zeros -- plain stores (one row split) or the storing ordered sum
+    dw, db = torch.full((K, N), 7.5, device="cuda"), torch.full((N,), -3.25, device="cuda")
+    L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, 1)
+    assert np.array_equal(host(dw), runs[0][0]) and np.array_equal(host(db), runs[0][1])
+    if nb > 0:                                          # row splits without scratch cannot store: refused, not silently accumulated
+        with pytest.raises(milib.MiError):
+            L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)
 
 
 @pytest.mark.parametrize("dt", DTS)
