@@ -12,4 +12,4 @@ for i in 1 2 3 4 5; do
   grep -E "passed|failed|error" gpurun_out/suite_run_${tag}_$i.log | tail -3 >> gpurun_out/suite_loop_$tag.log
 done
 cat gpurun_out/suite_loop_$tag.log
-tools/profile_round.sh $tag
+[ "$2" = "noprofile" ] || tools/profile_round.sh $tag
