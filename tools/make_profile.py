@@ -64,7 +64,8 @@ NAMES_R03 = [("dectail_kernel<true>", None, "deconv4.fwd (decoder tail: deconv4 
 # step ran before the fragment-ordered weight copies existed: not listed)
 R04_GONE = ("conv4.fwd / deconv1.dgrad", "deconv1.fwd / conv4.dgrad", "deconv2.fwd", "conv3.dgrad", "deconv2.fwd / conv3.dgrad")
 NAMES_R04 = [("ares_conv_kernel<4, 1>", None, "conv4.fwd / deconv1.dgrad"), ("ares_gather_kernel<4, 2>", None, "deconv1.fwd / conv4.dgrad"),
-             ("ares_gather2_kernel", None, "deconv2.fwd / conv3.dgrad"), ("reduce_small_fused_kernel", "1365x1x1", "end-of-pass slab sums (one launch)")] \
+             ("ares_gather2_kernel", None, "deconv2.fwd / conv3.dgrad"), ("reduce_small_fused_kernel", "1365x1x1", "end-of-pass slab sums (one launch)"),
+             ("adam_tf_layouts_kernel<bf16>", None, "adam (writes both weight layouts)")] \
     + [n for n in NAMES_R03 if n[2] not in R04_GONE]
 NAMES = NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic = [], {}

@@ -13,7 +13,7 @@ def short(name):
     return name.replace("unsigned short", "bf16")[:64]
 
 
-def main(path, marker="adam_tf_kernel"):
+def main(path, marker="adam_tf_"):            # adam_tf_kernel (rounds 1-3) / adam_tf_layouts_kernel (round 4)
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
