@@ -215,12 +215,13 @@ int mi_adam_tf_flat(void* stream, float* param, float* m, float* v, float* grad,
 int mi_adam_tf_flat_dev(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* bf16_shadow, int clear_grad);
 /* same; the shadow weight copy the MFMA kernels read is of storage type shadow_dtype: MI_BF16 (2 bytes per weight) or MI_BF16X3 (split, 4 bytes) */
 int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float* grad, long long n, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, int shadow_dtype, int clear_grad);
-/* TF ApplyAdam over the flat buffer [0, n) that ALSO refreshes both weight copies of the `count` (<= 16) listed [K, N] kernels (offsets in floats, ascending, N % 4 == 0,
+/* TF ApplyAdam (tf.train.AdamOptimizer.minimize, vae/models.py:140-142) over the flat buffer [0, n) that ALSO refreshes both weight copies of the `count` (<= 16) listed [K, N] kernels (offsets in floats, ascending, N % 4 == 0,
  * offsets % 4 == 0) in the same launch: shadow = storage-type copy in the master layout (NULL for fp32 engines), wt = K-contiguous copy wt[off + n * K + k] (what
  * mi_transpose_weights writes; may be NULL).  dtype MI_F32 | MI_BF16 = element type of both copies.  skip (may be NULL): per kernel, bit 0 = do not write its shadow
  * copy, bit 1 = do not write its K-contiguous copy (copies that nobody reads).  Bit-identical p / m / v to mi_adam_tf_flat. */
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
-/* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch gathered and converted in one launch; dtype MI_F32 | MI_BF16 */
+/* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch (the feed_dict slice of vae/models.py:211-216) gathered and
+ * converted in one launch; dtype MI_F32 | MI_BF16 */
 int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* idx, int B, long long row_len, void* out);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
 /* fp32 <-> split storage (dtype MI_BF16X3): word = bf16(x) << 16 | bf16(x - bf16(x)); back: hi + lo */
