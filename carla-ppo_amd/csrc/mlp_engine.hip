@@ -35,6 +35,7 @@ struct MlpEngine {
     int nchunks, esz;
     int last_B;
     const void* last_x;
+    hipStream_t side; hipEvent_t ev_fork, ev_chain, ev_done; int side_ok;      // second stream of a full backward pass (created on first use)
     char* at(long long o) const { return ws + o; }
     const void* w(const Dense& l) const { return d.dtype == MI_BF16 ? (const void*)((const unsigned short*)shadow + l.wo) : (const void*)(params + l.wo); }
     const void* w_t(const Dense& l) const { return d.dtype == MI_BF16 ? (const void*)((const unsigned short*)wt + l.wo) : (const void*)((const float*)wt + l.wo); }
@@ -222,7 +223,12 @@ void* mi_mlpvae_create(const MiMlpVaeDesc* d, float* params, float* grads, float
     return e;
 }
 
-void mi_mlpvae_destroy(void* h) { delete (MlpEngine*)h; }
+void mi_mlpvae_destroy(void* h) {
+    MlpEngine* e = (MlpEngine*)h;
+    if (!e) return;
+    if (e->side_ok == 1) { hipStreamSynchronize(e->side); hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_chain); hipEventDestroy(e->ev_done); hipStreamDestroy(e->side); }
+    delete e;
+}
 
 // refresh the derived weight copies after the master weights were written from outside (load / broadcast)
 int mi_mlpvae_sync_shadow(void* h, void* stream) {
@@ -285,20 +291,42 @@ int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch,
     // the ordered slab sums of the layers whose filter gradient is split over rows (the small ones) are recorded and issued as ONE launch at the end of the part
     // (eight 4.5 us launches per step otherwise); every layer owns a piece of the scratch until then
     struct SrGuard { int prev; SrGuard() : prev(mi_small_reduce_defer(1)) {} ~SrGuard() { mi_small_reduce_defer(prev); } } sr_guard;
+    // A full pass (part 0) runs on two streams: the input-gradient chain is a row of dependent kernels, eight of them a few microseconds of work on an empty GPU, and no
+    // filter gradient is on it.  The output layer's filter gradient (needs only the loss gradient) runs UNDER the chain on the second stream; behind the chain the small
+    // layers' filter gradients run there next to the first layer's on the caller's stream.  Two events on the caller's stream, one join.  MI355_MLP_STREAMS=0: one stream.
+    static int streams_on = -1;
+    if (streams_on < 0) { const char* ev = getenv("MI355_MLP_STREAMS"); streams_on = (ev && ev[0] == '0') ? 0 : 1; }
+    if (part == 0 && streams_on && e->side_ok == 0) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&e->ev_chain, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) == hipSuccess) e->side_ok = 1;
+        else e->side_ok = -1;
+    }
+    const bool fork = part == 0 && streams_on && e->side_ok == 1;
+    hipStream_t sm = (hipStream_t)stream;
     long long scr_used = 0;
-    auto wgrad = [&](const Dense& l, const void* a, const void* gy) {
+    auto wgrad_on = [&](void* s_, const Dense& l, const void* a, const void* gy) {
         const long long need = al256(mi_gemm_wgrad_scratch_bytes(dt, 1 << 20, l.K, l.N));
         if (scr_used + need > e->scratch_bytes) return mi_fail(MI_ERR_STATE, "mi_mlpvae_backward: scratch exhausted");
         void* scr = e->at(e->o_scratch + scr_used);
         scr_used += need;
-        return mi_gemm_wgrad_bias_set(stream, dt, a, gy, B, l.K, l.N, e->grads + l.wo, e->grads + l.bo, scr, need, 1);
+        return mi_gemm_wgrad_bias_set(s_, dt, a, gy, B, l.K, l.N, e->grads + l.wo, e->grads + l.bo, scr, need, 1);
     };
+    struct Later { const Dense* l; const void* a; const void* gy; } later[2 * ML_MAX + 2];
+    int nlater = 0;
+    // where a layer's filter gradient goes: one stream -> right here; two streams -> the output layer's at once on the second stream, the others behind the chain
+    auto wgrad = [&](const Dense& l, const void* a, const void* gy, bool output_layer) -> int {
+        if (!fork) return wgrad_on(stream, l, a, gy);
+        if (output_layer) return wgrad_on((void*)e->side, l, a, gy);
+        later[nlater].l = &l; later[nlater].a = a; later[nlater].gy = gy; ++nlater;
+        return MI_OK;
+    };
+    if (fork) { hipEventRecord(e->ev_fork, sm); hipStreamWaitEvent(e->side, e->ev_fork, 0); }      // (the loss gradient and every activation are complete on the caller's stream here)
     if (part == 0 || part == 1) {
         for (int i = e->nd - 1; i >= 0; --i) {
             const Dense& l = e->dec[i];
             const void* gy = e->at(e->o_gd[i]);
             const void* a = i > 0 ? e->at(e->o_d[i - 1]) : e->at(e->o_z);
-            CK(wgrad(l, a, gy));
+            CK(wgrad(l, a, gy, i == e->nd - 1));
             // dx = gy W^T, ReluGrad mask = the layer's input (a ReLU output): W[k, n] read as [N_out = k][K_in = n]
             if (i > 0) CK(dense(e, stream, gy, B, l.N, e->w(l), l.K, nullptr, 0, e->at(e->o_d[i - 1]), e->at(e->o_gd[i - 1]), 0));
             else CK(dense(e, stream, gy, B, l.N, e->w(l), l.K, nullptr, 0, nullptr, e->at(e->o_dz), 1));
@@ -308,15 +336,26 @@ int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch,
         const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * Z : 0.f;
         CK(mi_vae_reparam_kl_bwd(stream, dt, (const float*)e->at(e->o_dz), 1, (const float*)e->at(e->o_mean), (const float*)e->at(e->o_logvar), eps, (const float*)e->at(e->o_klrow),
                                  d.beta, kl_floor, inv_batch, B, Z, e->at(e->o_dheads)));
-        CK(wgrad(e->heads, e->at(e->o_h[e->ne - 1]), e->at(e->o_dheads)));
+        CK(wgrad(e->heads, e->at(e->o_h[e->ne - 1]), e->at(e->o_dheads), false));
         CK(dense(e, stream, e->at(e->o_dheads), B, e->heads.N, e->w(e->heads), e->heads.K, nullptr, 0, e->at(e->o_h[e->ne - 1]), e->at(e->o_gh[e->ne - 1]), 0));
         for (int i = e->ne - 1; i >= 0; --i) {
             const Dense& l = e->enc[i];
             const void* gy = e->at(e->o_gh[i]);
             const void* a = i > 0 ? (const void*)e->at(e->o_h[i - 1]) : e->last_x;
-            CK(wgrad(l, a, gy));
+            CK(wgrad(l, a, gy, false));
             if (i > 0) CK(dense(e, stream, gy, B, l.N, e->w(l), l.K, nullptr, 0, e->at(e->o_h[i - 1]), e->at(e->o_gh[i - 1]), 0));
         }
+    }
+    if (fork) {
+        // behind the chain: every gradient of an activation exists.  All but the LAST recorded layer (the first encoder layer: the big one) on the second stream, their
+        // slab sums as one launch there; the first encoder layer's on the caller's stream next to them (its own slab sum, if it has one, by the flush below)
+        hipEventRecord(e->ev_chain, sm); hipStreamWaitEvent(e->side, e->ev_chain, 0);
+        for (int j = 0; j + 1 < nlater; ++j) CK(wgrad_on((void*)e->side, *later[j].l, later[j].a, later[j].gy));
+        CK(mi_small_reduce_flush((void*)e->side));
+        if (nlater > 0) CK(wgrad_on(stream, *later[nlater - 1].l, later[nlater - 1].a, later[nlater - 1].gy));
+        const int rc = mi_small_reduce_flush(stream);
+        hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent(sm, e->ev_done, 0);
+        return rc;
     }
     return mi_small_reduce_flush(stream);
 }
