@@ -881,7 +881,7 @@ def test_split_storage_products_carry_sixteen_bits():
 
 
 @pytest.mark.parametrize("kind,u8", [(0, True), (0, False), (1, True), (2, False)])
-@pytest.mark.parametrize("B,IH,IW", [(3, 39, 79), (2, 7, 15), (1, 10, 33)])
+@pytest.mark.parametrize("B,IH,IW", [(3, 39, 79), (2, 7, 15), (1, 10, 33), (512, 39, 79)])
 def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     """mi_deconv2d_tail_fused (deconv4 forward + loss + its input gradient + its filter gradient in one launch, dectail_tile.hpp) against the three
     separately validated ops it replaces (mi_deconv2d_nhwc_fwd_bce_u8, mi_deconv2d_nhwc_dgrad with the activation as ReluGrad mask,
@@ -889,6 +889,8 @@ def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     the input gradient bit for bit (same summation order), loss and bias-gradient sums to fp32 summation order, the filter gradient to 1e-5 of its
     max; the gradient buffer is ACCUMULATED into."""
     import ctypes
+    if B == 512 and (kind, u8) != (0, True):
+        pytest.skip("the benchmarked batch (768-block grid, XCD-contiguous tile ranges, several tiles per block) runs once, in the production configuration")
     L = milib.get()
     code, td = DT["bf16"]
     Ci, Co, k = 32, 3, 4
@@ -906,7 +908,7 @@ def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     wt = torch.zeros(k * k * Co * Ci, device="cuda", dtype=td)
     offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
     L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
-    cap = 16384
+    cap = 16384 if B < 64 else 1 << 20
     # --- the three ops ---
     lp, bp = torch.zeros(cap, device="cuda"), torch.zeros(cap, 4, device="cuda")
     dl = alloc(td, B, OH, OW, Co, fill=0.0)
@@ -940,17 +942,19 @@ def test_decoder_tail_fused_equals_the_three_ops(kind, u8, B, IH, IW):
     assert_close(got_b, bias_ref, 1e-5, 1e-5 * float(np.abs(bias_ref).max()) + 1e-7, "bias gradient sums")
     assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), float((dx.float() - dx_ref.float()).abs().max())
     s = float(dw_ref.abs().max())
-    assert_close(host(dw) - 0.25, host(dw_ref), 1e-5, 2e-5 * s, "filter gradient")
+    assert_close(host(dw) - 0.25, host(dw_ref), 1e-5, (2e-5 if B < 64 else 2e-4) * s, "filter gradient")      # (1.6 M positions per element at batch 512: fp32 summation order)
 
 
 @pytest.mark.parametrize("u8", [True, False])
-@pytest.mark.parametrize("B,FH,FW", [(3, 80, 160), (2, 38, 70), (1, 20, 132)])
+@pytest.mark.parametrize("B,FH,FW", [(3, 80, 160), (2, 38, 70), (1, 20, 132), (512, 80, 160)])
 def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     """mi_conv2d_head_bwd_fused (conv2's input gradient + conv1's filter and bias gradient in one launch, enchead_tile.hpp; the gradient of conv1's output never
     exists) against the two separately validated ops it replaces -- mi_conv2d_nhwc_dgrad_bits, then mi_conv2d_nhwc_wgrad_ws on its output -- on the model's geometry
     and two ragged ones (8 x 16 tiles overhanging the image, odd slot counts), camera bytes and fp32 frames, gathered through a frame index, ACCUMULATING into the
     gradient buffers; and against the float64 statement of the same two contractions (bf16 operands, the intermediate rounded to bf16 like the stored tensor)."""
     import ctypes
+    if B == 512 and not u8:
+        pytest.skip("the benchmarked batch runs once, on camera bytes (the production configuration)")
     L = milib.get()
     code, td = DT["bf16"]
     IH, IW = (FH - 4) // 2 + 1, (FW - 4) // 2 + 1
@@ -997,6 +1001,8 @@ def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     # intermediate value now and then) and across blocks
     assert_close(host(dw) - 0.5, host(dw_ref), 1e-3, 2e-4 * sw, "conv1 filter gradient, fused vs two ops")
     assert_close(host(db) + 0.25, host(db_ref), 1e-3, 2e-4 * sb, "conv1 bias gradient, fused vs two ops")
+    if B == 512:
+        return                                              # (the float64 statement below is a CPU conv over the whole batch: the small geometries carry it)
     # --- float64 statement ---
     t64 = lambda a: torch.from_numpy(np.asarray(a, np.float64))      # noqa: E731
     dyb, w2b = host(dyd).astype(np.float64), host(w2d).astype(np.float64)
