@@ -26,6 +26,7 @@ struct PpoEngine {
     char* ws;
     // workspace offsets (bytes)
     long long s_pad, h1, h2, g1, g2, u, vraw, h1o, h2o, uo, du, dv, dh2, dh1, dg2, dg1, partial, losses, mean, low, high, ws_total;
+    long long f_gslab;                            // per-chunk gradient slabs of the large-minibatch step (max_batch > 256): [ceil(max_batch / 256)][total]
     long long f_h1, f_h2, f_dh1, f_dh2, f_part;   // fused step (ppo_fused.hip): [3][M][H1], [3][M][H2], [2][M][H1], [2][M][H2], loss-block partials
     int last_M;
     hipStream_t side; hipEvent_t ev_fork, ev_join; int side_ok;     // second stream of the forked minibatch step (0 = not tried, 1 = ok, -1 = unavailable)
@@ -57,6 +58,7 @@ void layout(PpoEngine& e) {
     e.losses = wa(256); e.mean = wa(M * d.num_actions * 4); e.low = wa(256); e.high = wa(256);
     e.f_h1 = wa(3 * M * d.h1 * 4); e.f_h2 = wa(3 * M * d.h2 * 4); e.f_dh1 = wa(2 * M * d.h1 * 4); e.f_dh2 = wa(2 * M * d.h2 * 4);
     e.f_part = wa((long long)mi_ppo_fused_partial_floats((int)M) * 4);
+    e.f_gslab = wa(M > 256 ? ((M + 255) / 256) * e.total * 4 : 0);
     e.ws_total = w;
 }
 
@@ -108,6 +110,7 @@ void fill_fused(const PpoEngine* e, PpoFusedParams& q, const float* states, int 
     q.h1 = (float*)e->at(e->f_h1); q.h2 = (float*)e->at(e->f_h2); q.dh1 = (float*)e->at(e->f_dh1); q.dh2 = (float*)e->at(e->f_dh2);
     q.du = (float*)e->at(e->du); q.dv = (float*)e->at(e->dv); q.partial = (float*)e->at(e->f_part); q.losses = (float*)e->at(e->losses);
     q.mean_out = (float*)e->at(e->mean);
+    q.gslab = d.max_batch > 256 ? (float*)e->at(e->f_gslab) : nullptr; q.gslab_stride = e->total;      // (total is a multiple of 8 floats: pad8 per tensor)
     q.n_nets = 3;
     q.clip_eps = d.clip_eps; q.value_scale = d.value_scale; q.entropy_scale = d.entropy_scale;
 }

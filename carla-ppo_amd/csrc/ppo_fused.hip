@@ -68,9 +68,9 @@ __device__ __forceinline__ void pf_adam(float* p, float* m, float* v, float g, c
     *m = mm; *v = vv;
     *p -= (mm * q.alpha) / (sqrtf(vv) + q.epsilon);
 }
-template <bool FUSE> __device__ __forceinline__ void pf_emit(const PpoFusedParams& q, long long idx, float g) {
+template <bool FUSE> __device__ __forceinline__ void pf_emit(const PpoFusedParams& q, long long idx, float g, float* gb) {      // gb: q.grads, or this row chunk's slab
     if constexpr (FUSE) pf_adam(q.theta + idx, q.adam_m + idx, q.adam_v + idx, g, q);
-    else q.grads[idx] = g;
+    else gb[idx] = g;
 }
 
 __device__ __forceinline__ const float* pf_theta(const PpoFusedParams& q, int net) { return net == 2 ? q.theta_old : q.theta; }
@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
     const int per_net = KT2 * NT2 + KT1 * NT1 + KTH;
     int t = blockIdx.x * 4 + wave;
     const bool split = !FUSE && q.m_chunk > 0;            // large minibatches: blockIdx.y = row chunk
+    float* const gb = split ? q.gslab + (long long)blockIdx.y * q.gslab_stride : q.grads;      // where this wave's gradients go: the chunk's slab (every element of a slab
+                                                                                               // is written by exactly one wave; an ordered pass adds the slabs) or the buffer
     if (t == 2 * per_net && blockIdx.y != 0) return;
     if (t == 2 * per_net) {                               // spare wave: loss scalars + logstd (fixed block order: deterministic)
         // lane k sums column k of the per-block partials (one load chain per lane instead of PF_NPART chains on lane 0: this wave's latency was
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         for (int a = 0; a < PF_MAX_ACT; ++a) if (a < q.A) { L[5 + a] = sum[3 + PF_MAX_ACT + a] * q.inv_m; L[5 + q.A + a] = sd[a]; }
         // the entropy term is state independent: under data parallelism grad_scale = local_M / global_M shares it across the ranks
 #pragma unroll
-        for (int a = 0; a < PF_MAX_ACT; ++a) if (a < q.A) pf_emit<FUSE>(q, q.off[6] + a, sum[3 + a] - q.entropy_scale * q.grad_scale);
+        for (int a = 0; a < PF_MAX_ACT; ++a) if (a < q.A) pf_emit<FUSE>(q, q.off[6] + a, sum[3 + a] - q.entropy_scale * q.grad_scale, gb);
         return;
     }
     if (t > 2 * per_net) return;
@@ -521,12 +523,11 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(const PpoFusedParams q) 
         for (int r = 0; r < 16; ++r) {
             const int kr = kt * 32 + pf_row(r, lgrp);
             const long long idx = oW + (long long)kr * ldw + n;
-            if (split) { if (kr < Kx) atomicAdd(q.grads + idx, acc[r]); }      // (the buffer was zeroed by the host side of the launch)
-            else if (kr < Kx) q.grads[idx] = acc[r];
-            else if (kr < kvalid) q.grads[idx] = 0.f;
+            if (kr < Kx) gb[idx] = acc[r];
+            else if (kr < kvalid) gb[idx] = 0.f;
         }
     }
-    if (kt == 0 && lgrp == 0) { if (split) atomicAdd(q.grads + ob + n, accb[0]); else pf_emit<FUSE>(q, ob + n, accb[0]); }
+    if (kt == 0 && lgrp == 0) pf_emit<FUSE>(q, ob + n, accb[0], gb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -645,10 +646,16 @@ int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
     q.m_chunk = 0;
     if (fuse_adam) {
         hipLaunchKernelGGL(ppo_wgrad_kernel<true>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
-    } else if (q.M > 256) {                               // row chunks of 256, gradients meet in atomics on the zeroed buffer
+    } else if (q.M > 256) {                               // row chunks of 256: every chunk stores its own gradient slab, one ordered pass adds them (no atomics: round 4)
+        const int chunks = (q.M + 255) / 256;
+        if (!q.gslab) return mi_fail(MI_ERR_STATE, "ppo fused step: the engine's workspace has no gradient slabs for minibatches above 256 rows");
         q.m_chunk = 256;
-        if (hipMemsetAsync(q.grads, 0, (size_t)q.n_params * 4, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "ppo fused step: memset failed");
-        hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4, (q.M + 255) / 256), dim3(256), 0, st, q);
+        // (the alignment gaps between the tensors are written by nobody: zeroed, so that the sum leaves zeros there like the memset of the gradient buffer did)
+        if (hipMemsetAsync(q.gslab, 0, (size_t)chunks * q.gslab_stride * 4, st) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "ppo fused step: memset failed");
+        hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4, chunks), dim3(256), 0, st, q);
+        const int rc2 = mi_check_launch("ppo_fused_step");
+        if (rc2 != MI_OK) return rc2;
+        return mi_reduce_slabs(st, q.gslab, q.gslab_stride, chunks, q.n_params, q.grads, 1);
     } else hipLaunchKernelGGL(ppo_wgrad_kernel<false>, dim3((tiles + 3) / 4), dim3(256), 0, st, q);
     return mi_check_launch("ppo_fused_step");
 }

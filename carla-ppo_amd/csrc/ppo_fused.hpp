@@ -24,7 +24,9 @@ struct PpoFusedParams {
     float alpha, omb1, omb2, epsilon;                     // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); omb = 1 - beta
     int n_loss_blocks;
     int m_chunk;                                          // weight-gradient launch: 0 = one wave sums the whole minibatch of its tile (M <= 256); > 0: rows per
-                                                          // blockIdx.y (multiple of 32), partial sums meet in fp32 atomics on the zeroed gradient buffer (no fused Adam)
+                                                          // blockIdx.y (multiple of 32): chunk c STORES its partial gradient into gslab + c * gslab_stride and one ordered
+                                                          // pass adds the chunks (round 4: no atomics, two runs bitwise equal; no fused Adam)
+    float* gslab; long long gslab_stride;                 // per-chunk gradient slabs of the large-minibatch form (engine workspace; nullptr when max_batch <= 256)
 };
 
 }  // namespace mi
