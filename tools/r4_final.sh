@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 tag=${1:-r04a}
 : > gpurun_out/suite_loop_$tag.log
-for i in 1 2 3 4 5; do
+for i in $(seq 1 ${RUNS:-5}); do
   echo "=== run $i ===" >> gpurun_out/suite_loop_$tag.log
   timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/suite_run_${tag}_$i.log 2>&1
   echo "rc=$?" >> gpurun_out/suite_loop_$tag.log
