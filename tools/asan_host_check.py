@@ -80,6 +80,23 @@ for bad in (mlp_desc(2), mlp_desc(1, enc=(500, 256)), mlp_desc(0, enc=()), mlp_d
 assert L.cdll.mi_mlpvae_forward(None, None, None, None, None, 4, 0.25, None, 0, 0, None, 0.0) != 0 and b"null handle" in L.cdll.mi_last_error()
 assert L.mi_mlpvae_decoder_offset(None) == -1 and L.mi_mlpvae_buffer(None, 0) is None
 
+# ---- argument checks of the round-4 optimiser / staging launchers (every one of these returns before anything is launched) ----
+off1 = (ctypes.c_longlong * 2)(0, 4096); K1 = (ctypes.c_int * 2)(64, 64); N1 = (ctypes.c_int * 2)(64, 64)
+adam = L.cdll.mi_adam_tf_layouts
+base = dict(stream=None, dtype=1, p=4096, m=8192, v=12288, g=16384, n=10000)
+def adam_rc(dtype=1, p=4096, n=10000, offs=off1, K=K1, N=N1, count=2, shadow=32768, wt=65536):
+    return adam(None, dtype, p, 8192, 12288, 16384, n, ctypes.addressof(offs), ctypes.addressof(K), ctypes.addressof(N), None, count, 1e-3, None, 0.9, 0.999, 1e-8, shadow, wt, 0)
+assert adam_rc(dtype=2) != 0 and b"MI_F32 or MI_BF16" in L.cdll.mi_last_error()
+assert adam_rc(count=17) != 0
+assert adam_rc(p=4100) != 0 and b"16-byte aligned" in L.cdll.mi_last_error()
+assert adam_rc(wt=65540) != 0
+assert adam_rc(N=(ctypes.c_int * 2)(64, 62)) != 0 and b"N % 4" in L.cdll.mi_last_error()
+assert adam_rc(offs=(ctypes.c_longlong * 2)(0, 2048)) != 0 and b"non-overlapping" in L.cdll.mi_last_error()      # second kernel starts inside the first
+assert adam_rc(n=8000) != 0                                                                                      # second kernel ends behind the buffer
+assert L.cdll.mi_gather_rows_cast(None, 2, 4096, None, 4, 128, 8192) != 0
+assert L.cdll.mi_gather_rows_cast(None, 1, None, None, 4, 128, 8192) != 0 and L.cdll.mi_gather_rows_cast(None, 1, 4096, None, 4, 0, 8192) != 0
+assert L.cdll.mi_gather_rows_cast(None, 1, 4096, None, 0, 128, 8192) == 0                                         # empty batch: nothing to do
+
 # ---- PPO descriptor arithmetic ----
 pd = milib.MiPpoDesc()
 print("MiPpoDesc fields:", [f[0] for f in milib.MiPpoDesc._fields_])
