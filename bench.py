@@ -11,6 +11,9 @@ drawn inside the reparameterisation kernel).  Nothing runs on the timed path but
 `value` = frames/s of the whole job = N*512*K / max-over-ranks(time of exactly K steps).
 
 Extra objects on the same JSON line:
+  box           in-run calibration of THIS GPU (mi_device_probe, csrc/probe.hip): sustained bf16 MFMA TFLOP/s and the shader clock under it, HBM streaming read /
+                copy TB/s, sysfs clocks / power where readable -- measured after --condition-ms of untimed steps (the DVFS ramp) and before the counted
+                warm-up; `roofline.frac_of_box` prices the dominant kernel against these instead of the datasheet.
   roofline      the dominant kernel of the step (picked from a per-op HIP-event profile during warm-up), timed with HIP
                 events on the launch stream over the K timed steps; achieved = algorithmic FLOPs (or bytes) / avg duration;
                 `bound` = whichever of the two floors (algorithmic bytes / 8 TB/s, algorithmic FLOPs / MFMA peak) is higher.
@@ -407,6 +410,62 @@ def _library_stamp():
     return {"abi": int(L.mi_abi_version()), "built": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path))) if path and os.path.exists(path) else None}
 
 
+def _sysfs_gpu(local):
+    """Best-effort readings of the amdgpu sysfs files of this rank's GPU (absent in some containers: every field may be missing): current shader / memory clock,
+    power cap and average power.  Never fatal."""
+    out = {}
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if not cards:
+            return out
+        base = os.path.dirname(cards[min(local, len(cards) - 1)])
+
+        def starred(fn):
+            for line in open(os.path.join(base, fn)).read().splitlines():
+                if line.strip().endswith("*"):
+                    return float(line.split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            return None
+        for key, fn in (("sysfs_sclk_mhz", "pp_dpm_sclk"), ("sysfs_mclk_mhz", "pp_dpm_mclk")):
+            try:
+                v = starred(fn)
+                if v is not None:
+                    out[key] = v
+            except Exception:
+                pass
+        for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+            for key, fn, scale in (("power_cap_w", "power1_cap", 1e-6), ("power_avg_w", "power1_average", 1e-6), ("power_now_w", "power1_input", 1e-6)):
+                try:
+                    out[key] = float(open(os.path.join(hw, fn)).read().strip()) * scale
+                except Exception:
+                    pass
+    except Exception:
+        pass
+    return out
+
+
+def box_probe(dev, local=0, millis=5):
+    """In-run box calibration: the library's own MFMA / HBM probes (csrc/probe.hip, mi_device_probe) on this GPU, right now -- what the
+    datasheet peaks of PEAK are worth on the box that produced this line.  ~60 ms of GPU time, outside the timed region."""
+    L = dev.L
+    want = int(L.mi_device_probe_scratch_bytes())
+    free = torch.cuda.mem_get_info()[0]
+    nbytes = max(min(want, int(free * 0.5)), 64 << 20)
+    scratch = torch.empty(nbytes, device=dev.device, dtype=torch.uint8)
+    out8 = np.zeros(8, np.float32)
+    torch.cuda.synchronize()
+    L.mi_device_probe(dev.stream(), scratch.data_ptr(), nbytes, millis, out8.ctypes.data)
+    del scratch
+    box = {"mfma_bf16_tflops": round(float(out8[0]), 1), "sclk_mhz": round(float(out8[1]), 0),
+           "mfma_bf16_tflops_first_launch": round(float(out8[2]), 1), "sclk_mhz_first_launch": round(float(out8[3]), 0),
+           "hbm_read_tbps": round(float(out8[4]), 3), "hbm_copy_tbps": round(float(out8[5]), 3), "compute_units": int(out8[6]),
+           "hbm_probe_bytes": int(out8[7]),
+           "how": "mi_device_probe: 3 x %d ms of v_mfma_f32_32x32x16_bf16 (4 accumulators, 2 waves / SIMD, 1 block / CU; rate = mean of launches 2-3; sclk = s_memtime / "
+                  "s_memrealtime of one wave), 16-byte streaming read and half-to-half copy of the probe buffer (best of 3)" % millis}
+    box.update(_sysfs_gpu(local))
+    return box
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,6 +482,9 @@ def main():
     ap.add_argument("--no-mlp", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
     ap.add_argument("--replay-rows", type=int, default=1024)
+    ap.add_argument("--condition-ms", type=float, default=300.0, help="untimed steps in FRONT of the counted warm-up until this much wall time has passed: the box reaches its "
+                                                                    "sustained clocks / power state before anything is measured (0 = off)")
+    ap.add_argument("--no-box", action="store_true", help="skip the in-run box calibration (mi_device_probe)")
     args = ap.parse_args()
 
     from mi355 import dist as midist
@@ -465,6 +527,23 @@ def main():
     def step(i):
         model._train_minibatch(pool, pool, idx[i % n_idx], B, inv_b, None)     # eps=None: drawn inside the reparameterisation kernel
 
+    # ---- clock conditioning (untimed, in front of the counted warm-up): the driver's command is 5 + 20 steps = 25 ms of GPU work from an idle
+    # box, i.e. measured on the DVFS ramp; >= --condition-ms of the very same steps first, then the box calibration, then the counted warm-up ----
+    conditioned = 0
+    if args.condition_ms > 0:
+        t_c = time.perf_counter()
+        while (time.perf_counter() - t_c) * 1e3 < args.condition_ms:
+            for _ in range(20):
+                step(conditioned); conditioned += 1
+            torch.cuda.synchronize()
+    box = None
+    if not args.no_box:
+        try:
+            box = box_probe(dev, local)
+        except Exception as e:
+            box = {"error": repr(e)}
+        for _ in range(20 if args.condition_ms > 0 else 0):      # (the probes ran at their own power point: back to the step's before the warm-up)
+            step(conditioned); conditioned += 1
     # ---- warm-up (untimed); two of the warm-up steps run with every op bracketed by HIP events to find the dominant kernel ----
     for i in range(max(args.warmup - 2, 0)):
         step(i)
@@ -511,6 +590,12 @@ def main():
         if dominant == "deconv4.fwd" and tail_fused:
             roofline["kernel"] = "deconv4.fwd = decoder tail (dectail_kernel: deconv4 forward + reconstruction loss + input gradient + filter gradient)"
         roofline["launches_timed"] = int(cnt_d[di])
+        if box and "error" not in box:
+            # the same achieved rate against what THIS box sustains (mi_device_probe, minutes^-1 ago): separates "the kernel" from "the box" when two runs disagree
+            box_peak = box["hbm_read_tbps"] * 1e3 if roofline["bound"] == "hbm" else box["mfma_bf16_tflops"] * (PEAK[{"bf16": "mfma_bf16", "bf16x3": "mfma_bf16x3"}.get(args.precision, "mfma_f32")] / PEAK["mfma_bf16"])
+            if box_peak > 0:
+                roofline["frac_of_box"] = roofline["achieved"] / box_peak
+                roofline["box_peak"] = box_peak
         roofline["timing"] = how
         # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction),
         # measured offline on this same workload and committed under profiles/ (PMC counters cannot be read from inside the bench)
@@ -566,9 +651,12 @@ def main():
                        "storage": "bf16 activations/weights, fp32 accumulate, fp32 master weights+Adam" if args.precision == "bf16" else "fp32",
                        "library": _library_stamp()},
             "roofline": roofline,
+            "box": box,
+            "conditioning": {"untimed_steps_before_warmup": conditioned, "target_ms": args.condition_ms},
             "step_model_flops_utilisation": {"algorithmic_tflops_per_step": step_flops / 1e12,
                                              "achieved_tflops": step_flops * args.steps / elapsed / 1e12,
                                              "frac_of_mfma_peak": step_flops * args.steps / elapsed / PEAK[{"bf16": "mfma_bf16", "bf16x3": "mfma_bf16x3"}.get(args.precision, "mfma_f32")]},
+            "per_op_ms_note": "every op bracketed by HIP events, one at a time (two warm-up steps): isolated launch times, not in-step times",
             "per_op_ms": {k: round(v, 4) for k, v in sorted(per_op.items(), key=lambda kv: -kv[1])},
             "final_losses": {"reconstruction": float(losses[0]), "kl": float(losses[1])},
             "data_parallel": dp,
@@ -605,6 +693,8 @@ def main():
                 out["replay"] = replay_extra(tmp, args.replay_rows)
             except Exception as e:
                 out["replay"] = {"error": repr(e)}
+        if box and "error" not in box and box.get("mfma_bf16_tflops", 0) > 0 and args.precision == "bf16":
+            out["step_model_flops_utilisation"]["frac_of_box_mfma_rate"] = out["step_model_flops_utilisation"]["achieved_tflops"] / box["mfma_bf16_tflops"]
         print(json.dumps(out), flush=True)
     midist.barrier()
     if world > 1:

@@ -85,6 +85,13 @@ int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int ar
 /* CRC-32C of a HOST buffer (running value in, 0 to start): the checksum of the reference's TensorFlow bundle checkpoints
  * (tf.train.Saver files written / read by vae/models.py:154,172-186 and ppo.py:184,202-216); used by mi355/tf_bundle.py.  Returns the crc. */
 unsigned int mi_crc32c(unsigned int crc, const void* data, long long n);
+/* Box calibration (round 5; SURVEY 8d "confirm on the box"; no reference counterpart): what THIS GPU sustains right now on the two resources the rooflines are priced
+ * against -- bench.py prints it as "box" next to every datasheet fraction.  scratch: device buffer, >= 64 MiB, ideally mi_device_probe_scratch_bytes() (6 x the
+ * Infinity Cache); millis: length of each of the three MFMA launches (1..50).  SYNCHRONOUS (HIP events).  out8: 0 sustained v_mfma_f32_32x32x16_bf16 rate in TFLOP/s
+ * (mean of launches 2 and 3), 1 shader clock during them in MHz (s_memtime / s_memrealtime), 2 / 3 the same for the FIRST launch (clocks as the caller left them),
+ * 4 HBM streaming read TB/s, 5 HBM copy TB/s (read + written bytes), 6 compute units, 7 bytes the HBM probes walked. */
+long long mi_device_probe_scratch_bytes(void);
+int mi_device_probe(void* stream, void* scratch, long long scratch_bytes, int millis, float* out8);
 /* Kernel-selection knobs (process-global, not part of the reference surface; defaults come from the environment variables of
  * the same meaning).  key 0: gemm2 LDS-DMA tiles on/off (MI355_GEMM2); key 1: minimum block count for the raw-staged
  * tapconv kernel, -1 = never (MI355_TAPCONV / MI355_TAPCONV_MINBLOCKS); key 2: debug, drop the wgrad_kernel atomics;

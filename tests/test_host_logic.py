@@ -20,7 +20,7 @@ def test_shared_library_exports_every_declared_symbol():
     L = milib.get()                                   # raises if the .so is missing or lacks a declared symbol
     for name in protos:
         assert hasattr(L.cdll, name), name
-    assert L.mi_abi_version() == 5
+    assert L.mi_abi_version() == 6
     assert L.mi_vae_desc_size() == ctypes.sizeof(milib.MiVaeDesc) and L.mi_ppo_desc_size() == ctypes.sizeof(milib.MiPpoDesc)
     # every public entry point cites the reference op it replaces
     text = open(milib.HEADER).read()
@@ -516,3 +516,14 @@ def test_gpu_free_entry_points_of_the_c_abi():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "asan host check: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_probe_argument_validation_without_a_gpu():
+    """mi_device_probe (round 5, box calibration): refuses missing / short / misaligned buffers before it touches the device."""
+    from mi355 import lib as milib
+    L = milib.get()
+    assert L.mi_device_probe_scratch_bytes() >= (512 << 20)
+    out8 = np.zeros(8, np.float32)
+    for scratch, nbytes, out in ((None, 1 << 30, out8.ctypes.data), (4096, 1 << 20, out8.ctypes.data), (4096 + 8, 1 << 30, out8.ctypes.data), (4096, 1 << 30, None)):
+        with pytest.raises(milib.MiError):
+            L.mi_device_probe(None, scratch, nbytes, 5, out)
