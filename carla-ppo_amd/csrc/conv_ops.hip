@@ -860,8 +860,12 @@ inline bool needs_merge(int C, int dtype, int in_f32) {
 // flush stream (the engine gives each its own piece of scratch and flushes on the stream that produced them).
 static thread_local SmallReduceParams t_sr;
 static thread_local int t_sr_defer = 0;
-static int sr_launch(hipStream_t st) {
-    SmallReduceParams& f = t_sr;
+// The recorded list belongs to ONE stream (round 5): the stream of its first job, or the one the engine named with mi_small_reduce_bind.  A job that
+// arrives from another stream while the pass defers (a layer the engine issues on its filter-gradient stream, e.g. conv1's narrow filter gradient with
+// MI355_WGRAD_MAIN_MASK bit 0 clear) is launched at once on ITS stream instead of being flushed later on a stream that never waited for its slabs.
+static thread_local hipStream_t t_sr_stream = nullptr;
+static thread_local bool t_sr_bound = false;
+static int sr_launch_params(hipStream_t st, SmallReduceParams& f) {
     if (f.njobs == 0) return MI_OK;
     for (int i = f.njobs; i < SR_MAX; ++i) f.first[i + 1] = f.first[f.njobs];
     MI_LAUNCH(reduce_small_fused_kernel, dim3((unsigned)f.first[f.njobs]), dim3(256), 0, st, f);
@@ -871,18 +875,36 @@ static int sr_launch(hipStream_t st) {
 int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int nslab, long long n, float* out, int overwrite) {
     if (nslab < 1 || n < 1) return MI_OK;
     SmallReduceParams& f = t_sr;
-    if (!t_sr_defer) f.njobs = 0;
-    if (f.njobs == SR_MAX) { const int rc = sr_launch(st); if (rc != MI_OK) return rc; }      // (a full list is issued as it is: still one fixed order per job)
+    if (!t_sr_defer || ((f.njobs > 0 || t_sr_bound) && st != t_sr_stream)) {      // not deferring, or not the list's stream: one launch of its own, right here
+        SmallReduceParams one = {};
+        sr_add(one, slabs, stride, nslab, n, out, overwrite);
+        return sr_launch_params(st, one);
+    }
+    if (f.njobs == SR_MAX) { const int rc = sr_launch_params(t_sr_stream, f); if (rc != MI_OK) return rc; }      // (a full list is issued as it is, on its own stream: still one fixed order per job)
+    if (f.njobs == 0 && !t_sr_bound) t_sr_stream = st;
     sr_add(f, slabs, stride, nslab, n, out, overwrite);
-    return t_sr_defer ? MI_OK : sr_launch(st);
+    return MI_OK;
 }
 extern "C" int mi_small_reduce_defer(int on) {              // returns the previous mode; switching drops what an aborted pass may have left in the list
     const int prev = t_sr_defer;
     t_sr_defer = on ? 1 : 0;
-    t_sr.njobs = 0;
+    t_sr.njobs = 0; t_sr.first[0] = 0;
+    t_sr_bound = false; t_sr_stream = nullptr;
     return prev;
 }
-extern "C" int mi_small_reduce_flush(void* stream) { return sr_launch((hipStream_t)stream); }
+extern "C" int mi_small_reduce_bind(void* stream) {         // the deferring pass names the stream its list will be flushed on (jobs from any other stream launch at once)
+    if (t_sr.njobs > 0 && (hipStream_t)stream != t_sr_stream) return mi_fail(MI_ERR_STATE, "mi_small_reduce_bind: jobs of another stream are pending");
+    t_sr_stream = (hipStream_t)stream; t_sr_bound = true;
+    return MI_OK;
+}
+extern "C" int mi_small_reduce_flush(void* stream) {
+    if (t_sr.njobs == 0) return MI_OK;
+    if ((hipStream_t)stream != t_sr_stream) {               // a programming error in the calling engine: nothing is lost (the list runs where its slabs are complete), but say so
+        const int rc = sr_launch_params(t_sr_stream, t_sr);
+        return rc != MI_OK ? rc : mi_fail(MI_ERR_STATE, "mi_small_reduce_flush: the recorded jobs belong to another stream (issued there)");
+    }
+    return sr_launch_params(t_sr_stream, t_sr);
+}
 extern "C" int mi_small_reduce_deferring(void) { return t_sr_defer; }
 
 bool mi_narrow_enabled() { return narrow_enabled(); }

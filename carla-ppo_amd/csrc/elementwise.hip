@@ -462,11 +462,11 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
 // rows idx[b] (or b) of a float32 table -> a dense [B, row_len] tensor of the engine's storage type: the MlpVAE engine's frame staging in ONE launch
 // (index_select + contiguous + cast were three passes over the 79 MB minibatch)
 template <typename T>
-__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long row_len, T* __restrict__ out) {
-    const int b = (int)blockIdx.y;
+__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long row_len, T* __restrict__ out, unsigned chunks) {
+    const int b = (int)(blockIdx.x / chunks);            // (row, chunk) folded into grid.x: any batch size (grid.y stops at 65535)
     const float* s = src + (idx ? (long long)idx[b] : (long long)b) * row_len;
     T* d = out + (long long)b * row_len;
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    const long long i = ((long long)(blockIdx.x % chunks) * 256 + threadIdx.x) * 8;
     if (i + 8 <= row_len && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
         const f32x4 a = *(const f32x4*)(s + i), c = *(const f32x4*)(s + i + 4);
         const float fa[4] = {a[0], a[1], a[2], a[3]}, fc[4] = {c[0], c[1], c[2], c[3]};
@@ -823,9 +823,11 @@ int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* id
     if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast: dtype must be MI_F32 or MI_BF16");
     if (!src || !out || B < 0 || row_len < 1) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast: bad arguments");
     if (B == 0) return MI_OK;
-    const dim3 g((unsigned)((row_len + 2047) / 2048), (unsigned)B);
-    if (dtype == MI_BF16) hipLaunchKernelGGL(gather_rows_cast_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out);
-    else hipLaunchKernelGGL(gather_rows_cast_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out);
+    const long long chunks = (row_len + 2047) / 2048;
+    if (chunks * B > 0x7fffffffll) return mi_fail(MI_ERR_SHAPE, "mi_gather_rows_cast: B x row_len beyond one launch");
+    const dim3 g((unsigned)(chunks * B));
+    if (dtype == MI_BF16) hipLaunchKernelGGL(gather_rows_cast_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out, (unsigned)chunks);
+    else hipLaunchKernelGGL(gather_rows_cast_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out, (unsigned)chunks);
     return mi_check_launch("gather_rows_cast");
 }
 

@@ -40,5 +40,6 @@ int mi_reduce_slabs(hipStream_t st, const float* slabs, long long stride, int ns
 // deferred mode of mi_reduce_slabs (per host thread): jobs are recorded and mi_small_reduce_flush(stream) issues all of them as ONE launch -- conv_ops.hip
 extern "C" int mi_small_reduce_defer(int on);
 extern "C" int mi_small_reduce_flush(void* stream);
+extern "C" int mi_small_reduce_bind(void* stream);      // the list of the deferring pass belongs to `stream`; mi_reduce_slabs calls from other streams launch immediately (round 5)
 extern "C" int mi_small_reduce_deferring(void);
 bool mi_narrow_enabled();                        // the narrow-layer kernels are switched on (mi_set_tuning key 4 / MI355_NARROW) -- conv_ops.hip

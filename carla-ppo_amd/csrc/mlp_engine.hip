@@ -320,7 +320,17 @@ int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch,
         later[nlater].l = &l; later[nlater].a = a; later[nlater].gy = gy; ++nlater;
         return MI_OK;
     };
-    if (fork) { hipEventRecord(e->ev_fork, sm); hipStreamWaitEvent(e->side, e->ev_fork, 0); }      // (the loss gradient and every activation are complete on the caller's stream here)
+    // every return path below joins the second stream back (an error return between fork and join must not leave work of this pass pending on the caller's buffers
+    // with nothing ordered behind it: ADVICE r04)
+    struct JoinGuard {
+        MlpEngine* e; hipStream_t sm; bool armed;
+        int join() { armed = false; return (hipEventRecord(e->ev_done, e->side) == hipSuccess && hipStreamWaitEvent(sm, e->ev_done, 0) == hipSuccess) ? MI_OK : mi_fail(MI_ERR_LAUNCH, "mi_mlpvae_backward: stream join failed"); }
+        ~JoinGuard() { if (armed) (void)join(); }
+    } join_guard{e, sm, false};
+    if (fork) {      // (the loss gradient and every activation are complete on the caller's stream here)
+        if (hipEventRecord(e->ev_fork, sm) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_fork, 0) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_mlpvae_backward: stream fork failed");
+        join_guard.armed = true;
+    }
     if (part == 0 || part == 1) {
         for (int i = e->nd - 1; i >= 0; --i) {
             const Dense& l = e->dec[i];
@@ -349,13 +359,13 @@ int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch,
     if (fork) {
         // behind the chain: every gradient of an activation exists.  All but the LAST recorded layer (the first encoder layer: the big one) on the second stream, their
         // slab sums as one launch there; the first encoder layer's on the caller's stream next to them (its own slab sum, if it has one, by the flush below)
-        hipEventRecord(e->ev_chain, sm); hipStreamWaitEvent(e->side, e->ev_chain, 0);
+        if (hipEventRecord(e->ev_chain, sm) != hipSuccess || hipStreamWaitEvent(e->side, e->ev_chain, 0) != hipSuccess) return mi_fail(MI_ERR_LAUNCH, "mi_mlpvae_backward: stream hand-over failed");
         for (int j = 0; j + 1 < nlater; ++j) CK(wgrad_on((void*)e->side, *later[j].l, later[j].a, later[j].gy));
         CK(mi_small_reduce_flush((void*)e->side));
         if (nlater > 0) CK(wgrad_on(stream, *later[nlater - 1].l, later[nlater - 1].a, later[nlater - 1].gy));
         const int rc = mi_small_reduce_flush(stream);
-        hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent(sm, e->ev_done, 0);
-        return rc;
+        const int rcj = join_guard.join();
+        return rc != MI_OK ? rc : rcj;
     }
     return mi_small_reduce_flush(stream);
 }
@@ -374,6 +384,9 @@ int mi_mlpvae_apply_adam(void* h, void* stream, float alpha, float beta1, float 
     kernel_table(e, off, K, N, &n);
     int skip[16] = {0};
     skip[0] = 1;                                          // the first encoder layer has no input gradient: nobody reads its [K, N] storage-type copy (39 MB of writes)
+    // INVARIANT: from the first optimiser step on, shadow[enc[0].wo ...] is STALE (it holds the weights of the last mi_mlpvae_sync_shadow); the engine
+    // reads layer 0 only through its K-contiguous copy wt (forward).  Anything that wants the storage-type weights of layer 0 in [K, N] order must call
+    // mi_mlpvae_sync_shadow first.
     return mi_adam_tf_layouts(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->total, off, K, N, skip, n, alpha, nullptr, beta1, beta2, epsilon,
                               e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 0);
 }

@@ -467,6 +467,7 @@ int mi_vae_forward(void* h, void* stream, const void* src, const void* tgt, int 
     VaeEngine* e = (VaeEngine*)h;
     CK(check_batch(e, B));
     const MiVaeDesc& d = e->d; const Geom& g = e->g;
+    struct StopEventGuard { ~StopEventGuard() { mi_tl_stop_event = nullptr; } } stop_guard;      // an error return between arming and the launch must not leave the event armed for this thread's next, unrelated launch
     CK(run_encoder(e, stream, src, frames_u8, idx, B, eps, sample, want_grad));
     e->last_u8 = frames_u8 ? 1 : 0;
     const int P = g.dh[4] * g.dw[4] * g.dc[4];
@@ -561,6 +562,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         else e->third_ok = -1;
     }
     const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
+    struct StopEventGuard { ~StopEventGuard() { mi_tl_stop_event = nullptr; } } stop_guard;      // (see mi_vae_forward)
     void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
     // Hand-over of a gradient tensor from the caller's stream to the filter-gradient stream.  Round 3 form: hipEventRecord behind the producing kernel -- a marker
     // packet of its own that costs the PRODUCING queue a 6-8 us bubble each time (six per step on the critical queue, profiles/r03_d).  Round 4 (MI355_KEVENT=0: the record form; measured 0.913 -> 0.896 ms per step, two interleaved pairs on one box):
@@ -745,7 +747,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             }();
             if (own) mi_tapwgrad_defer_pause(0);
             CK(rcw);
-            if (i == 1 && late_dense && !use_third && tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }      // from here to the end of the pass every small slab sum on st is one job of the fused launch
+            if (i == 1 && late_dense && !use_third && tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); mi_small_reduce_bind(st); tail_defer = true; }      // from here to the end of the pass every small slab sum on st is one job of the fused launch
             // MI355_DENSE_EARLY=1 (round 4 A/B): the latent layers' filter gradients in FRONT of the encoder-head kernel instead of behind it: behind it they only
             // start when conv2's filter gradient on the other stream releases its compute units (64 KB of LDS next to 147 KB: no co-residence) and end the pass late
             static int dense_early = -1;
@@ -785,7 +787,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (late_dense && dbg_skip_tail) { if (defer) mi_tapwgrad_flush(sw); e->tail_nblk = 0; e->fin.pending = 0; }
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
-            if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); tail_defer = true; }
+            if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); mi_small_reduce_bind(st); tail_defer = true; }
             if (!dense_done) {
                 if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
                 TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));

@@ -205,10 +205,15 @@ class MlpVaeDevice:
         p = milib.ptr
         self.L.mi_mlpvae_forward(self.handle, self.stream(), p(self._f32(src, "the source table")), p(self._f32(tgt, "the target table")), p(idx), int(B), float(inv_batch),
                                  p(eps), int(sample), int(want_grad), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
+        # the fp32 engine with idx == None reads the first layer's filter-gradient operand straight from `src` in backward(): keep the table alive until then
+        # (a temporary freed between forward() and backward(part=2) of the data-parallel path would be read after free -- ADVICE r04)
+        self._last_src = src if want_grad else None
 
     def backward(self, src, idx, eps, inv_batch, part=0):
         """part 0 = everything, 1 = decoder half (+ dz), 2 = encoder half: the data-parallel host all-reduces grads[decoder_offset:] in between."""
         self.L.mi_mlpvae_backward(self.handle, self.stream(), milib.ptr(eps), float(inv_batch), int(part))
+        if part in (0, 2):
+            self._last_src = None
 
     def apply_adam(self, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.L.mi_mlpvae_apply_adam(self.handle, self.stream(), float(alpha), float(beta1), float(beta2), float(epsilon))

@@ -228,7 +228,8 @@ int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float
  * copy, bit 1 = do not write its K-contiguous copy (copies that nobody reads).  Bit-identical p / m / v to mi_adam_tf_flat. */
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
 /* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch (the feed_dict slice of vae/models.py:211-216) gathered and
- * converted in one launch; dtype MI_F32 | MI_BF16 */
+ * converted in one launch; dtype MI_F32 | MI_BF16.  The table's row count is not an argument: idx[b] must lie inside the table (the host mirror builds every index vector from
+ * arange(N) permutations, vae/models.py:207-212) */
 int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* idx, int B, long long row_len, void* out);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
 /* fp32 <-> split storage (dtype MI_BF16X3): word = bf16(x) << 16 | bf16(x - bf16(x)); back: hi + lo */
