@@ -9,6 +9,8 @@
 // Rendezvous (who is rank 0, how the 128-byte id reaches the others) is the caller's business: mi_comm_unique_id on rank 0, any
 // out-of-band channel (the Python side uses the torch.distributed store it already has), mi_comm_init everywhere.
 #include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_runtime.h>
@@ -61,7 +63,16 @@ struct MiComm {
     hipEvent_t ready, done;
     int pending;                                          // buckets queued on `side` since the last mi_comm_wait
     int algo;                                             // gradient-bucket schedule: 0 ncclAllReduce, 1 reduce-scatter + all-gather (mi_comm_set_algo: the SAME value on every rank)
+    // RECORDING communicator (mi_comm_init_recording, round 5): no RCCL, no stream, no device -- every collective this communicator would issue is appended to the
+    // caller's host log as {op, floats (bytes for a broadcast), async?, buffer address} and the data is left alone (the sum over ONE rank).  Test infrastructure of the
+    // data-parallel step (tests assert that mi_vae_train_step_dp issues the schedule the host path issues, on every rank of 2 / 4 / 8, without a second GPU).
+    long long* rec; int rec_cap, rec_n;
 };
+enum { REC_ALLREDUCE = 1, REC_REDUCE_SCATTER = 2, REC_ALLGATHER = 3, REC_BROADCAST = 4, REC_WAIT = 5 };
+void rec_add(MiComm* c, int op, long long count, int async, const void* buf) {
+    if (c->rec_n < c->rec_cap) { long long* e = c->rec + 4ll * c->rec_n; e[0] = op; e[1] = count; e[2] = async; e[3] = (long long)(uintptr_t)buf; }
+    c->rec_n += 1;                                        // (counts past the capacity too: the caller sees that its log was too short)
+}
 
 // Gradient-bucket schedule: 0 = ncclAllReduce (RCCL picks ring / tree / one-shot itself), 1 = reduce-scatter + all-gather: on the
 // fully connected xGMI mesh of one node every rank owns 1/W of the bucket, receives the other ranks' pieces of ITS slice over the seven direct
@@ -87,8 +98,15 @@ int rccl_fail(const char* what, ncclResult_t r) {
 }
 
 // in-place sum of buf[0..n) over the ranks on stream `st`
-int allreduce_on(MiComm* c, float* buf, long long n, hipStream_t st) {
+int allreduce_on(MiComm* c, float* buf, long long n, hipStream_t st, int async = 0) {
     const Plan p = plan_of(c->algo, c->world, c->rank, n);
+    if (c->rec) {
+        if (p.rsag) {
+            rec_add(c, REC_REDUCE_SCATTER, p.chunk, async, buf); rec_add(c, REC_ALLGATHER, p.chunk, async, buf + p.mine);
+            if (p.tail_n > 0) rec_add(c, REC_ALLREDUCE, p.tail_n, async, buf + p.tail_off);
+        } else rec_add(c, REC_ALLREDUCE, n, async, buf);
+        return MI_OK;
+    }
     if (p.rsag && g_rccl.ReduceScatter && g_rccl.AllGather) {
         // slice r of the first chunk * W elements belongs to rank r (both calls in RCCL's in-place form); the n % W tail rides along as a tiny all-reduce
         float* mine = buf + p.mine;
@@ -115,6 +133,9 @@ int mi_comm_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
 // binds RCCL (dlopen + every entry point) WITHOUT creating anything: every rank calls this before the collective mi_comm_init, so that a
 // rank whose library is missing can tell the others instead of leaving them inside ncclCommInitRank (mi355/dist.py, step 1)
 int mi_comm_probe(void) { return load_rccl(); }
+// 1: the bound RCCL has ncclReduceScatter and ncclAllGather (the reduce-scatter + all-gather schedule can be set); 0: not, or nothing bound yet.  The host agrees on the
+// MINIMUM of this over the ranks before any rank calls mi_comm_set_algo(1) (one rank failing set_algo alone would leave the others in a collective)
+int mi_comm_has_rsag(void) { return (g_rccl.lib && g_rccl.ReduceScatter && g_rccl.AllGather) ? 1 : 0; }
 
 // rank 0: a fresh rendezvous id (mi_comm_id_bytes() = 128 bytes) to hand to every other rank
 int mi_comm_unique_id(unsigned char* id_out) {
@@ -149,12 +170,25 @@ int mi_comm_init(void** comm_out, int rank, int world, const unsigned char* id) 
     return MI_OK;
 }
 
+// A communicator that RECORDS instead of communicating (see MiComm::rec): rank / world are only what the schedule is computed for.  log: HOST memory, 4 long long per
+// entry {op (1 all-reduce, 2 reduce-scatter, 3 all-gather, 4 broadcast, 5 wait), floats (bytes for op 4), 1 if issued by the _async form, buffer address};
+// mi_comm_recorded = entries issued so far (may exceed the capacity: the log was too short).  Needs neither RCCL nor a GPU.
+int mi_comm_init_recording(void** comm_out, int rank, int world, long long* log, int log_capacity) {
+    if (!comm_out || !log || log_capacity < 1 || world < 1 || rank < 0 || rank >= world) return mi_fail(MI_ERR_ARG, "mi_comm_init_recording: bad arguments");
+    MiComm* c = (MiComm*)calloc(1, sizeof(MiComm));
+    if (!c) return mi_fail(MI_ERR_STATE, "mi_comm_init_recording: out of host memory");
+    c->rank = rank; c->world = world; c->rec = log; c->rec_cap = log_capacity; c->rec_n = 0;
+    *comm_out = c;
+    return MI_OK;
+}
+int mi_comm_recorded(void* comm) { MiComm* c = (MiComm*)comm; return (c && c->rec) ? c->rec_n : -1; }
+
 // the gradient-bucket schedule of this communicator: 0 = ncclAllReduce, 1 = reduce-scatter + all-gather (needs both entry points in the bound library).  Every rank
-// must set the SAME value (the caller agrees on it first: mi355/dist.py); returns the previous one
+// must set the SAME value (the caller agrees on it first: mi355/dist.py, which also agrees on whether EVERY rank's library has both entry points); returns MI_OK
 int mi_comm_set_algo(void* comm, int algo) {
     MiComm* c = (MiComm*)comm;
     if (!c || algo < 0 || algo > 1) return mi_fail(MI_ERR_ARG, "mi_comm_set_algo: bad arguments");
-    if (algo == 1 && !(g_rccl.ReduceScatter && g_rccl.AllGather)) return mi_fail(MI_ERR_STATE, "mi_comm_set_algo: the bound RCCL lacks ncclReduceScatter / ncclAllGather");
+    if (algo == 1 && !c->rec && !(g_rccl.ReduceScatter && g_rccl.AllGather)) return mi_fail(MI_ERR_STATE, "mi_comm_set_algo: the bound RCCL lacks ncclReduceScatter / ncclAllGather");
     c->algo = algo;
     return MI_OK;
 }
@@ -171,6 +205,7 @@ int mi_comm_allreduce_plan(int algo, int world, int rank, long long n, long long
 int mi_comm_destroy(void* comm) {
     MiComm* c = (MiComm*)comm;
     if (!c) return MI_OK;
+    if (c->rec) { free(c); return MI_OK; }
     (void)hipStreamSynchronize(c->side);
     ncclResult_t r = g_rccl.CommDestroy(c->comm);
     (void)hipEventDestroy(c->ready); (void)hipEventDestroy(c->done); (void)hipStreamDestroy(c->side);
@@ -192,6 +227,7 @@ int mi_allreduce_sum_f32_async(void* comm, void* stream, float* buf, long long n
     MiComm* c = (MiComm*)comm;
     if (!c || !buf || n < 0) return mi_fail(MI_ERR_ARG, "mi_allreduce_sum_f32_async: bad arguments");
     if (n == 0) return MI_OK;
+    if (c->rec) { c->pending += 1; return allreduce_on(c, buf, n, nullptr, 1); }
     if (hipEventRecord(c->ready, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(c->side, c->ready, 0) != hipSuccess)
         return mi_fail(MI_ERR_LAUNCH, "mi_allreduce_sum_f32_async: event chaining failed");
     const int rc = allreduce_on(c, buf, n, c->side);
@@ -205,6 +241,7 @@ int mi_comm_wait(void* comm, void* stream) {
     MiComm* c = (MiComm*)comm;
     if (!c) return mi_fail(MI_ERR_ARG, "mi_comm_wait: null communicator");
     if (!c->pending) return MI_OK;
+    if (c->rec) { rec_add(c, REC_WAIT, c->pending, 0, nullptr); c->pending = 0; return MI_OK; }
     if (hipEventRecord(c->done, c->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, c->done, 0) != hipSuccess)
         return mi_fail(MI_ERR_LAUNCH, "mi_comm_wait: event chaining failed");
     c->pending = 0;
@@ -216,6 +253,7 @@ int mi_broadcast(void* comm, void* stream, void* buf, long long bytes, int root)
     MiComm* c = (MiComm*)comm;
     if (!c || !buf || bytes < 0 || root < 0 || root >= c->world) return mi_fail(MI_ERR_ARG, "mi_broadcast: bad arguments");
     if (bytes == 0) return MI_OK;
+    if (c->rec) { rec_add(c, REC_BROADCAST, bytes, 0, buf); return MI_OK; }
     ncclResult_t r = g_rccl.Broadcast(buf, buf, (size_t)bytes, ncclChar, root, c->comm, (hipStream_t)stream);
     return r == ncclSuccess ? MI_OK : rccl_fail("ncclBroadcast", r);
 }

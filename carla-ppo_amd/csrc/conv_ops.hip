@@ -653,6 +653,11 @@ int try_conv_form_gemm2(hipStream_t st, int dtype, const GemmParams& p, int gz =
     q.run = p.KW * p.C; q.div_run = make_fastdiv(q.run); q.div_ohw = p.div_ohw; q.div_ow = p.div_ow;
     q.ldb = p.ldb;
     q.ksplit_len = p.ksplit_len > 0 ? p.ksplit_len : 0;
+    {   // dense layers (1 x 1 "convolutions" of one position per row): XCD-contiguous numbering of the whole grid (MI355_GEMM2_REMAP3=0: x only, as for the convolutions)
+        static int remap3_on = -1;
+        if (remap3_on < 0) { const char* e = getenv("MI355_GEMM2_REMAP3"); remap3_on = (e && e[0] == '0') ? 0 : 1; }
+        q.remap3 = (remap3_on && p.stride == 1 && p.KH == 1 && p.KW == 1) ? 1 : 0;
+    }
     copy_epilogue(q, p);
     int rc = dtype == MI_F32 ? launch_gemm2_tiles<float, A_CONV, B_NK, false>(st, q, q.M, gz)
            : dtype == MI_BF16X3 ? launch_gemm2_tiles<split_t, A_CONV, B_NK, false>(st, q, q.M, gz)

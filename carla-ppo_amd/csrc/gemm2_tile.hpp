@@ -32,6 +32,8 @@ struct Gemm2Params {
     FastDiv dc_ohw[4], dc_ow[4], dc_c, dc_tw[2];
     int ldb;
     void* out; const float* bias; const void* mask; int relu; int out_f32;
+    int remap3;                      // A_CONV, dense layers (round 5): the WHOLE (x, y, z) grid is renumbered so that every XCD owns a contiguous range of tiles with x (the row tiles
+                                     // that share one weight tile) fastest -- the 2.9-3.9 x L2 -> LDS re-reads of profiles/r04_c section 5 (consecutive block ids = consecutive XCDs)
     int ksplit_len;                  // A_CONV, > 0: split-K -- blockIdx.z owns k in [z * len, (z + 1) * len) (len a multiple of the 128-byte stage) and writes raw fp32 slab z
 };
 
@@ -65,20 +67,28 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lgrp = lane >> 5;
 
-    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
-    const int n0 = blockIdx.y * BN;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    if (AMODE == A_CONV && p.remap3) {
+        const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+        const int lin = xcd_remap(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        bx = lin % gx; by = (lin / gx) % gy; bz = lin / (gx * gy);
+    } else {
+        bx = xcd_remap(bx, (int)gridDim.x);
+    }
+    const int m0 = bx * BM;
+    const int n0 = by * BN;
 
     int M = p.M, K = p.K;
     int cls = 0, ph = 0, pw = 0;
     if constexpr (AMODE == A_DECONV) {
-        cls = blockIdx.z; ph = cls >> 1; pw = cls & 1;
+        cls = bz; ph = cls >> 1; pw = cls & 1;
         M = p.nbatch * p.OHc[ph] * p.OWc[pw];
         K = p.Th[ph] * p.Tw[pw] * p.C;
         if (m0 >= M) return;
     }
     int kbeg = 0;
     if constexpr (AMODE == A_CONV) {
-        if (p.ksplit_len > 0) { kbeg = (int)blockIdx.z * p.ksplit_len; K = min(K, kbeg + p.ksplit_len); }      // (K = one past this split's last k)
+        if (p.ksplit_len > 0) { kbeg = bz * p.ksplit_len; K = min(K, kbeg + p.ksplit_len); }      // (K = one past this split's last k)
     }
     const int nk = (K - kbeg + BKE - 1) / BKE;
 
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(GEMM_NT) void gemm2_kernel(const Gemm2Params p) {
         }
     }
 
-    store_tile<T, AMODE, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lgrp, M, cls, ph, pw, (AMODE == A_CONV && p.ksplit_len > 0) ? (int)blockIdx.z : 0);
+    store_tile<T, AMODE, TM, TN>(p, acc, m0, n0, wm, wn, lrow, lgrp, M, cls, ph, pw, (AMODE == A_CONV && p.ksplit_len > 0) ? bz : 0);
 }
 
 }  // namespace mi

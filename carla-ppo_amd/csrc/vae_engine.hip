@@ -868,6 +868,39 @@ int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, i
     return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
 }
 
+// Gradient buckets of the data-parallel step in the order the backward pass completes them: 3 x {engine part, first float, one past the last float} of the flat
+// gradient buffer -- decoder (part 1: dense1 .. deconv4, 43 % of the parameters) | heads + conv4 (part 3, 51 %) | conv3 .. conv1 (part 4, 6 %).  Pure function of the
+// descriptor (no GPU); the host mirror (mi355/vae_device.py grad_buckets) and mi_vae_train_step_dp both follow it.
+int mi_vae_dp_buckets(const MiVaeDesc* d, long long* out9) {
+    VaeEngine e;
+    if (!d || !out9 || !init_engine(e, d)) return mi_fail(MI_ERR_SHAPE, "mi_vae_dp_buckets: unsupported geometry or missing output");
+    const long long dec = e.L.off[10], c4 = e.L.off[6];
+    const long long b[9] = {1, dec, e.L.total, 3, c4, dec, 4, 0, c4};
+    for (int i = 0; i < 9; ++i) out9[i] = b[i];
+    return MI_OK;
+}
+
+// One whole DATA-PARALLEL SGD step in ONE call (round 5; SURVEY 8e, north_star "RCCL all-reduce of gradients over xGMI"): forward + ELBO of this
+// rank's rows (inv_batch = 1 / B_global), the backward pass in the three parts of mi_vae_dp_buckets with each finished bucket's all-reduce queued on the communicator's
+// own stream (mi_allreduce_sum_f32_async: it runs under the next part), mi_comm_wait, TF-Adam -- the sequence vae/models.py's host loop used to issue as three
+// backward calls + three Python-side collectives per step.  comm: a communicator of mi_comm_init (or a recording one).  Nothing synchronises the host.
+int mi_vae_train_step_dp(void* h, void* comm, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps,
+                         float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight) {
+    VaeEngine* e = (VaeEngine*)h;
+    CK(check_batch(e, B));
+    if (!comm) return mi_fail(MI_ERR_ARG, "mi_vae_train_step_dp: null communicator (single rank: mi_vae_train_step)");
+    if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_vae_train_step_dp: engine created without a gradient buffer");
+    long long bk[9];
+    CK(mi_vae_dp_buckets(&e->d, bk));
+    CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+    for (int i = 0; i < 3; ++i) {
+        CK(mi_vae_backward(h, stream, src, idx, eps, inv_batch, (int)bk[3 * i]));
+        CK(mi_allreduce_sum_f32_async(comm, stream, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]));
+    }
+    CK(mi_comm_wait(comm, stream));
+    return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
+}
+
 // One environment step of the rollout loop in ONE call (callers vae_common.py:45-61, train.py:142, run_eval.py:54):
 //   frame_u8 [IH,IW,3] raw camera bytes (device) -> /255 -> conv x 4 -> mean z -> state = [z, measurements] -> PPO.predict
 //   out (device, num_actions + 1 + z_dim floats) = [action | value | z]; noise [num_actions] (device) for sampling, NULL with greedy.

@@ -115,11 +115,14 @@ def mi_comm():
         c = _MiComm(handle, L)
         # the bucket schedule is a property of the communicator and must be the same everywhere: every rank states what its environment asks for, the
         # minimum wins (one rank without MI355_COMM_ALGO=rsag keeps all of them on ncclAllReduce), and only then is it set
-        want_algo = torch.tensor([1 if os.environ.get("MI355_COMM_ALGO") == "rsag" else 0], dtype=torch.int32, device=dev)
+        # ... and what its bound library can do (a rank whose RCCL lacks ReduceScatter / AllGather would fail set_algo ALONE and skip the probe collectives
+        # below while the others enter them): the agreed value is MIN over ranks of (environment asks for rsag AND the library has both entry points)
+        want_rsag = os.environ.get("MI355_COMM_ALGO") == "rsag" and bool(L.mi_comm_has_rsag())
+        want_algo = torch.tensor([1 if want_rsag else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(want_algo, op=dist.ReduceOp.MIN)
         algo = int(want_algo.item())
         if algo:
-            L.mi_comm_set_algo(handle, algo)
+            L.mi_comm_set_algo(handle, algo)                # (cannot fail on one rank only any more)
         # known sums through BOTH entry points, sized so that the selected schedule is the one exercised (rank slices of >= 1024 floats at any world size)
         n_probe = 4096 * W
         probe = torch.full((n_probe,), float(r + 1), dtype=torch.float32, device=dev)
@@ -146,6 +149,24 @@ def mi_comm():
 
 
 _atexit_registered = [False]
+_recording = [None]
+
+
+def recording_comm():
+    """A communicator of the C ABI that records instead of communicating (mi_comm_init_recording): bench.py times the data-parallel step WITHOUT its collectives
+    through the very same C call (mi_vae_train_step_dp) by handing it this one.  The log is a small ring nobody reads."""
+    if _recording[0] is None:
+        import ctypes
+        import numpy as np
+        from mi355 import lib as milib
+        L = milib.get()
+        log = np.zeros((64, 4), np.int64)
+        h = ctypes.c_void_p()
+        L.mi_comm_init_recording(ctypes.addressof(h), rank(), world_size(), log.ctypes.data, 64)
+        c = _MiComm(h, L)
+        c._log = log                                    # keeps the host buffer alive as long as the handle
+        _recording[0] = c
+    return _recording[0]
 
 
 def shutdown():

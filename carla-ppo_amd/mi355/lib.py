@@ -88,7 +88,7 @@ class _Lib:
             fn = getattr(self.cdll, name)          # AttributeError if the header declares a symbol the .so lacks
             fn.restype = _CTYPES[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
-            if ret == "int" and not name.endswith(("_version", "_chunks", "_blocks", "_floats", "_bytes", "_count", "_size", "_tuning", "_ok", "_offset")):
+            if ret == "int" and not name.endswith(("_version", "_chunks", "_blocks", "_floats", "_bytes", "_count", "_size", "_tuning", "_ok", "_offset", "_rsag", "_recorded")):
                 setattr(self, name, self._checked(name, fn))
             else:
                 setattr(self, name, fn)

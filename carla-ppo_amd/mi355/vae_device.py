@@ -80,8 +80,11 @@ class VaeDevice:
         # data-parallel gradient buckets in the order backward completes them: (engine part, first float, one past the last float).
         # decoder (43 % of the parameters) | heads + conv4 (51 %) | conv3..conv1 (6 %): only the last, small bucket is reduced with
         # nothing left to overlap it.
+        bk = np.zeros(9, np.int64)
+        self.L.mi_vae_dp_buckets(ctypes.byref(d), bk.ctypes.data)          # the library's own table: mi_vae_train_step_dp walks the same one
+        self.grad_buckets = [tuple(int(x) for x in bk[3 * i:3 * i + 3]) for i in range(3)]
         c4 = self.layout["vae/encoder/conv4/kernel"][0]
-        self.grad_buckets = [(1, self.decoder_offset, self.n_flat), (3, c4, self.decoder_offset), (4, 0, c4)]
+        assert self.grad_buckets == [(1, self.decoder_offset, self.n_flat), (3, c4, self.decoder_offset), (4, 0, c4)]
 
     def _create(self, max_batch):
         recreated = self.handle is not None
@@ -233,6 +236,14 @@ class VaeDevice:
         p = milib.ptr
         self.L.mi_vae_train_step(self.handle, self.stream(), p(src), p(tgt), self._u8(src, tgt), p(idx), int(B), float(inv_batch), p(eps), float(alpha),
                                  float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
+
+    def train_step_dp(self, comm_handle, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, accumulate_metrics=True):
+        """One whole DATA-PARALLEL SGD step in one C call: forward, backward in bucket order with each bucket's all-reduce queued on the library communicator's
+        stream under the next part, join, Adam (mi_vae_train_step_dp).  comm_handle: the C-ABI communicator (mi355/dist.py)."""
+        self.ensure_batch(B)
+        p = milib.ptr
+        self.L.mi_vae_train_step_dp(self.handle, comm_handle, self.stream(), p(src), p(tgt), self._u8(src, tgt), p(idx), int(B), float(inv_batch), p(eps), float(alpha),
+                                    float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)

@@ -299,6 +299,19 @@ class VAE():
             self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
             self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
             return
+        if midist.world_size() > 1 and hasattr(dev, "train_step_dp") and os.environ.get("MI355_DP_HOST_LOOP") != "1":
+            comm = midist.mi_comm()
+            if comm is not None and os.environ.get("MI355_DP_SKIP_ALLREDUCE") == "1":
+                comm = midist.recording_comm()         # bench.py only: the same C call with the collectives recorded instead of issued (exposed all-reduce time)
+            if comm is not None:
+                # data parallel with the library's own communicator live: the whole step -- the three backward parts, their bucket all-reduces on the communicator's
+                # stream, the join, Adam -- is ONE C call, as the single-rank step is (round 5; MI355_DP_HOST_LOOP=1: the host-sequenced loop below, A/B runs)
+                dev.train_step_dp(comm.handle, src, tgt, idx, n_local, inv_batch, eps, adam_alpha(self.learning_rate_value, self.beta1_power, self.beta2_power),
+                                  ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+                self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
+                self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
+                return
+        # fallback transport (torch.distributed carries the buckets: gloo in the tests, or a rank without a usable RCCL) and the MlpVAE: host-sequenced
         dev.forward(src, tgt, idx, n_local, inv_batch, eps, 1, 1)
         if midist.world_size() > 1:
             pending = []

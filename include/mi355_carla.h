@@ -293,6 +293,11 @@ int mi_vae_apply_adam(void* h, void* stream, float alpha, float beta1, float bet
 int mi_vae_set_seed(void* h, unsigned long long seed);
 /* one whole SGD step = the reference's sess.run([train_step, ...]) (vae/models.py:213-216) in ONE call (eager launches on the caller's stream + the engine's filter-gradient stream; nothing synchronises the host) */
 int mi_vae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
+/* the data-parallel form of the same step in ONE call (no reference counterpart: the reference is single-process): this rank's rows with inv_batch = 1 / B_global,
+ * backward in the three parts of mi_vae_dp_buckets, each finished bucket's all-reduce on the communicator's own stream under the next part, mi_comm_wait, TF-Adam.
+ * mi_vae_dp_buckets (pure, no GPU): out9 = 3 x {part, first float, one past the last float of the flat gradient buffer} in completion order. */
+int mi_vae_dp_buckets(const MiVaeDesc* d, long long* out9);
+int mi_vae_train_step_dp(void* h, void* comm, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
 /* VAE.encode / generate_from_latent (= north_star "decode") / reconstruct — vae/models.py:188-202 */
 int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
@@ -341,6 +346,13 @@ int mi_rollout_step(void* vae_h, void* ppo_h, void* stream, const unsigned char*
  *   mi_comm_allreduce_plan      what one all-reduce of n floats issues on a given rank under a schedule (pure function, no GPU: checked on the CPU for every rank):
  *                               out5 = {rsag?, floats per rank slice, this rank's slice offset, tail offset, tail floats} */
 int mi_comm_probe(void);
+/* 1: the bound RCCL offers the reduce-scatter + all-gather schedule (both entry points); the host takes the minimum over the ranks before anybody calls mi_comm_set_algo(1) */
+int mi_comm_has_rsag(void);
+/* A communicator that RECORDS what it would issue instead of communicating (no RCCL, no GPU; test infrastructure of the data-parallel step): log = HOST memory, 4 long long per
+ * entry {op: 1 all-reduce 2 reduce-scatter 3 all-gather 4 broadcast 5 wait, floats (bytes for 4; buckets joined for 5), issued by the _async form?, buffer address}; the data is
+ * left alone (the sum over one rank).  mi_comm_recorded: entries issued so far, -1 for a real communicator.  mi_comm_set_algo / mi_comm_destroy work on it as usual. */
+int mi_comm_init_recording(void** comm_out, int rank, int world, long long* log, int log_capacity);
+int mi_comm_recorded(void* comm);
 int mi_comm_set_algo(void* comm, int algo);
 int mi_comm_allreduce_plan(int algo, int world, int rank, long long n, long long* out5);
 int mi_comm_id_bytes(void);

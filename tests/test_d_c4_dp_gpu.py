@@ -112,3 +112,51 @@ def test_bench_data_parallel_path_with_two_ranks_on_one_gpu(tmp_path):
     dp = d["data_parallel"]
     assert len(dp["ms_per_step_by_rank"]) == 2 and dp["gradient_bytes_per_step"] > 0 and "transport" in dp
     assert d["roofline"] is not None and d["cpu_baseline"] is None
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_dp_step_as_one_c_call_equals_the_host_loop(tmp_path, precision):
+    """Round 5: mi_vae_train_step_dp -- forward, the three backward parts with each finished bucket queued on the communicator, the join, Adam -- as
+    ONE C call, driven here with a RECORDING communicator (what one GPU allows: it logs what it would issue and leaves the data alone = the sum over one rank).
+    Two SGD steps: the parameters are bitwise those of the host-sequenced loop (forward, backward(part) x 3, Adam: the path vae/models.py used to run per step), and the
+    log is the bucket schedule of mi_vae_dp_buckets -- three async all-reduces over [lo, hi) of the gradient buffer, one join -- per step."""
+    import ctypes
+    from mi355 import lib as milib
+    from vae.models import adam_alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON
+    L = milib.get()
+    B = 48
+    frames = synth_frames(B, seed=77)
+    eps = np.random.RandomState(5).standard_normal((2, B, 64)).astype(np.float32)
+    params = trained_like_params(4)
+    res = []
+    for mode in ("c_call", "host_loop"):
+        m = make(tmp_path / (precision + mode), precision, params=params, seed=0)
+        dev = m.dev
+        src = m._frames(frames, 38400, "src")
+        log = np.zeros((16, 4), np.int64)
+        h = ctypes.c_void_p()
+        L.mi_comm_init_recording(ctypes.addressof(h), 0, 2, log.ctypes.data, 16)
+        b1p, b2p = np.float32(ADAM_BETA1), np.float32(ADAM_BETA2)
+        for s in range(2):
+            e = m._eps(B, eps[s])
+            alpha = adam_alpha(1e-4, b1p, b2p)
+            if mode == "c_call":
+                dev.train_step_dp(h, src, src, None, B, 0.5 / B, e, alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+            else:
+                dev.forward(src, src, None, B, 0.5 / B, e, 1, 1)
+                for part, lo, hi in dev.grad_buckets:
+                    dev.backward(src, None, e, 0.5 / B, part=part)
+                dev.apply_adam(alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+            b1p, b2p = np.float32(b1p * np.float32(ADAM_BETA1)), np.float32(b2p * np.float32(ADAM_BETA2))
+        torch.cuda.synchronize()
+        n = L.mi_comm_recorded(h)
+        L.mi_comm_destroy(h)
+        res.append((dev.export_params(), dev.losses.cpu().numpy().copy(), log[:max(n, 0)].copy(), dev.grads.data_ptr(), list(dev.grad_buckets)))
+        m.dev.close()
+    (p_c, l_c, log_c, gptr, buckets), (p_h, l_h, log_h, _, _) = res
+    assert len(log_h) == 0 and len(log_c) == 8
+    want = [(1, hi - lo, 1, gptr + 4 * lo) for (_, lo, hi) in buckets] + [(5, 3, 0, 0)]
+    assert [tuple(int(x) for x in e) for e in log_c] == want + want
+    assert np.array_equal(l_c, l_h)
+    for k in p_h:
+        assert np.array_equal(p_c[k], p_h[k]), k

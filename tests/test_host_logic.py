@@ -482,6 +482,52 @@ def test_dp_collective_schedule_is_identical_on_every_rank(tmp_path, monkeypatch
                     assert rsag == 1 and chunk == n // world and [int(pl[2]) for pl in plans] == [r * chunk for r in range(world)]
                     assert tail_off == chunk * world and tail_n == n - chunk * world and 0 <= tail_n < world
     assert all(len(s) == len(per_rank[0]) for s in per_rank)
+    # Round 5: the data-parallel step is ONE C call (mi_vae_train_step_dp) that walks the library's own bucket table (mi_vae_dp_buckets) and queues every bucket through
+    # mi_allreduce_sum_f32_async on the communicator.  Replayed here on a RECORDING communicator (mi_comm_init_recording: no RCCL, no GPU) per rank and schedule: the
+    # (op, floats, async) sequence the library issues is the one the host loop above issues, identical on every rank, and ends in one join of the three buckets.
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    d = milib.MiVaeDesc(1, 512, 80, 160, 3, 3, 64, 0, 1.0, 0.0)
+    bk = np.zeros(9, np.int64)
+    L.mi_vae_dp_buckets(ctypes.byref(d), bk.ctypes.data)
+    buckets = [tuple(int(x) for x in bk[3 * i:3 * i + 3]) for i in range(3)]
+    assert buckets == _ScheduleDev().grad_buckets
+    host_step = [c for c in per_rank[0] if c[0] == "all_reduce_sum" and c[2]][:3]
+    assert [hi - lo for (_, lo, hi) in buckets] == [c[1] for c in host_step]
+    base = 1 << 20                                        # a made-up gradient-buffer address: a recording communicator never dereferences it
+    for algo in (0, 1):
+        logs = []
+        for r in range(world):
+            log = np.zeros((32, 4), np.int64)
+            h = ctypes.c_void_p()
+            L.mi_comm_init_recording(ctypes.addressof(h), r, world, log.ctypes.data, 32)
+            L.mi_comm_set_algo(h, algo)
+            for (_, lo, hi) in buckets:
+                L.mi_allreduce_sum_f32_async(h, None, base + 4 * lo, hi - lo)
+            L.mi_comm_wait(h, None)
+            n = L.mi_comm_recorded(h)
+            assert 0 < n <= 32
+            L.mi_comm_destroy(h)
+            logs.append(log[:n].copy())
+        ops = [[(int(e[0]), int(e[1]), int(e[2])) for e in lg] for lg in logs]
+        assert all(o == ops[0] for o in ops[1:]), (world, algo)                 # every rank: the same ops with the same element counts
+        assert ops[0][-1] == (5, 3, 0)                                           # one join of the three buckets in front of the optimiser step
+        if algo == 0:
+            assert ops[0][:-1] == [(1, c[1], 1) for c in host_step]              # = the host loop's three async bucket all-reduces
+        else:
+            i = 0
+            for (_, lo, hi) in buckets:
+                n_b, chunk = hi - lo, (hi - lo) // world
+                assert chunk >= 1024
+                assert ops[0][i] == (2, chunk, 1) and ops[0][i + 1] == (3, chunk, 1)
+                for r in range(world):                                           # rank r gathers ITS slice: offset r * chunk of the bucket
+                    assert int(logs[r][i][3]) == base + 4 * lo and int(logs[r][i + 1][3]) == base + 4 * (lo + r * chunk)
+                i += 2
+                if n_b - chunk * world:
+                    assert ops[0][i] == (1, n_b - chunk * world, 1)
+                    i += 1
+            assert i == len(ops[0]) - 1
 
 
 def test_ppo_logging_path_issues_no_collective(tmp_path, monkeypatch):
