@@ -689,6 +689,23 @@ int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int ns
     return mi_check_launch("reparam_kl_bwd");
 }
 
+// SURVEY 8b's name for the pair: forward half when heads != NULL, backward half when dz_slabs != NULL (both: forward, then backward on what it wrote)
+int mi_vae_reparam_kl_fwd_bwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z,
+                              float* mean, float* logvar, void* z, float* kl_row, const float* dz_slabs, int dz_nsplit, float beta, float kl_floor, float inv_batch, void* dheads) {
+    if (!heads && !dz_slabs) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd_bwd: neither half requested (heads and dz_slabs are both NULL)");
+    if (!mean || !logvar || !kl_row || B < 1 || Z < 1) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd_bwd: missing mean / logvar / kl_row buffers or empty shape");
+    if (heads) {
+        if (!z || (sample && !eps)) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd_bwd: the forward half needs z (and eps when sampling)");
+        const int rc = mi_vae_reparam_kl_fwd(stream, dtype, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, z, kl_row);
+        if (rc != MI_OK) return rc;
+    }
+    if (dz_slabs) {
+        if (!dheads || !eps) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd_bwd: the backward half needs dheads and the noise of the forward pass");
+        return mi_vae_reparam_kl_bwd(stream, dtype, dz_slabs, dz_nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, dheads);
+    }
+    return MI_OK;
+}
+
 int mi_recon_loss_chunks(int P) { return (P + BCE_CHUNK - 1) / BCE_CHUNK; }
 
 // logits [B,P] (T) vs labels (fp32 frames, optionally gathered through frame_idx) -> partial[B][chunks], dlogits [B,P] (T, may be null)

@@ -197,15 +197,18 @@ void make_workspace(VaeEngine& e) {
     // 256 position splits x the largest per-split slab (deconv3: 25 taps x 64 x 32 floats), rounded up
     // one region per raw-staged filter gradient of a backward pass (split storage: + the unfolded dW').  Round 4: the fp32 engine has them too -- every
     // filter / bias gradient of every engine reduces its position splits through slabs in a fixed order (two runs of a step are bitwise equal)
-    W.scratch_bytes = SCRATCH_REGIONS * (64ll << 20);
-    W.scratch = add(W.scratch_bytes);
-    W.scratch_main_bytes = 64ll << 20; W.scratch_main = add(W.scratch_main_bytes);
-    W.scratch_third_bytes = 16ll << 20; W.scratch_third = add(W.scratch_third_bytes);
-    W.scratch_side_bytes = 16ll << 20; W.scratch_side = add(W.scratch_side_bytes);
-    W.scratch_tail_bytes = 32ll << 20; W.scratch_tail = add(W.scratch_tail_bytes);
-    W.tail_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 6144 : 0;                 // up to 8 resident blocks per CU x 6 KB
+    // An inference-only engine (MiVaeDesc::inference_only: VAE(training=False) -- rollout, evaluation, encode) never runs a backward pass: no slab scratch at all
+    // (every B = 1 rollout engine paid ~0.5 GB of HBM for it).  The slab sizes do not depend on the batch: 256 position splits x the largest per-split slab.
+    const bool train = d.inference_only == 0;
+    W.scratch_bytes = train ? SCRATCH_REGIONS * (64ll << 20) : 0;
+    W.scratch = add(train ? W.scratch_bytes : 256);
+    W.scratch_main_bytes = train ? 64ll << 20 : 0; W.scratch_main = add(train ? W.scratch_main_bytes : 256);
+    W.scratch_third_bytes = train ? 16ll << 20 : 0; W.scratch_third = add(train ? W.scratch_third_bytes : 256);
+    W.scratch_side_bytes = train ? 16ll << 20 : 0; W.scratch_side = add(train ? W.scratch_side_bytes : 256);
+    W.scratch_tail_bytes = train ? 32ll << 20 : 0; W.scratch_tail = add(train ? W.scratch_tail_bytes : 256);
+    W.tail_slab_bytes = (train && d.dtype == MI_BF16) ? 2048ll * 6144 : 0;      // up to 8 resident blocks per CU x 6 KB
     W.tail_slabs = add(W.tail_slab_bytes > 0 ? W.tail_slab_bytes : 256);
-    W.enc_slab_bytes = d.dtype == MI_BF16 ? 2048ll * 8320 : 0;                  // up to 8 resident blocks per CU x (64 x 32 + 32) floats
+    W.enc_slab_bytes = (train && d.dtype == MI_BF16) ? 2048ll * 8320 : 0;       // up to 8 resident blocks per CU x (64 x 32 + 32) floats
     W.enc_slabs = add(W.enc_slab_bytes > 0 ? W.enc_slab_bytes : 256);
     W.bits_act1 = add(B * g.ih[1] * g.iw[1] * (g.c[1] / 16) * 4); W.bits_dec3 = add(B * g.dh[3] * g.dw[3] * (g.dc[3] / 16) * 4);
     {
@@ -388,6 +391,7 @@ void* mi_vae_create(const MiVaeDesc* d, float* params, float* grads, float* adam
     if (!d || !init_engine(*e, d)) { free(e); mi_fail(MI_ERR_SHAPE, "mi_vae_create: unsupported geometry"); return nullptr; }
     if (d->dtype != MI_F32 && d->dtype != MI_BF16 && d->dtype != MI_BF16X3) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: dtype must be 0 (f32), 1 (bf16) or 2 (split storage, bf16x3)"); return nullptr; }
     if (d->dtype != MI_F32 && !bf16_shadow) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: bf16 / split mode needs the shadow weight buffer (2 / 4 bytes per parameter)"); return nullptr; }
+    if (d->inference_only && grads) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: an inference_only engine takes no gradient buffer (its workspace has no gradient scratch)"); return nullptr; }
     if (!params || !weights_t || !workspace || workspace_bytes < e->W.total) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: missing buffers or workspace too small"); return nullptr; }
     if ((((uintptr_t)params) | ((uintptr_t)workspace) | ((uintptr_t)bf16_shadow) | ((uintptr_t)grads)) & 255) { free(e); mi_fail(MI_ERR_ARG, "mi_vae_create: buffers must be 256-byte aligned"); return nullptr; }
     e->params = params; e->grads = grads; e->m = adam_m; e->v = adam_v; e->shadow = bf16_shadow; e->wt = weights_t; e->ws = (char*)workspace;

@@ -31,7 +31,7 @@ _CTYPES = {
 class MiVaeDesc(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int), ("max_batch", ctypes.c_int), ("ih", ctypes.c_int), ("iw", ctypes.c_int),
                 ("cin", ctypes.c_int), ("ct", ctypes.c_int), ("z_dim", ctypes.c_int), ("loss_kind", ctypes.c_int),
-                ("beta", ctypes.c_float), ("kl_tolerance", ctypes.c_float)]
+                ("beta", ctypes.c_float), ("kl_tolerance", ctypes.c_float), ("inference_only", ctypes.c_int)]
 
 
 MI_MLP_MAX_HIDDEN = 4

@@ -54,7 +54,7 @@ class VaeDevice:
     # ---- buffers ----
     def _desc(self, max_batch):
         return milib.MiVaeDesc(self.dtype, int(max_batch), self.source_shape[0], self.source_shape[1], self.source_shape[2],
-                               self.target_shape[2], self.z_dim, self.loss_kind, self.beta, self.kl_tolerance)
+                               self.target_shape[2], self.z_dim, self.loss_kind, self.beta, self.kl_tolerance, 0 if self.with_optimizer else 1)
 
     def _alloc_params(self):
         d = self._desc(1)

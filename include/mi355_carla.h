@@ -49,6 +49,8 @@ typedef struct MiVaeDesc {
     int loss_kind;      /* 0 bce_loss, 1 bce_loss_v2, 2 mse_loss (vae/models.py:11-22) */
     float beta;
     float kl_tolerance;
+    int inference_only; /* != 0: no backward pass will ever run on this engine (VAE(training=False): rollout / evaluation / encode): the workspace carries no
+                         * filter-gradient scratch (~0.5 GB less); mi_vae_create then wants grads == NULL.  0 (the zero-initialised default): a training engine */
 } MiVaeDesc;
 
 /* MlpVAE (vae/models.py:271-299): dense encoder / decoder around the same latent block; up to MI_MLP_MAX_HIDDEN hidden layers per side */
@@ -126,7 +128,8 @@ int mi_deconv2d_nhwc_fwd_bits(void* stream, int dtype, const void* x, int B, int
 int mi_deconv2d_nhwc_dgrad_bits(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, const void* mask_bits, void* dx);
 /* Conv2DBackpropInput (+ fused ReluGrad of the layer below through `mask`) — backward of vae/models.py:250-253 */
 int mi_conv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int KH, int KW, int Cin, int IH, int IW, const void* mask, void* dx);
-/* Conv2DBackpropFilter: dw += im2col(x)^T dy (position splits meet in fp32 atomics; the _ws form with scratch is the deterministic one) */
+/* Conv2DBackpropFilter: dw += im2col(x)^T dy.  NON-DETERMINISTIC summation order: the position splits meet in fp32 atomics (two runs may differ in the last bits);
+ * the _ws form below (caller scratch) is the deterministic one and the only one the engines use */
 int mi_conv2d_nhwc_wgrad(void* stream, int dtype, const void* x, const int* frame_idx, int x_is_f32, int B, int IH, int IW, int Cin, const void* dy, int KH, int KW, int Cout, float* dw);
 /* same, with caller scratch for the split reduction (every kernel generation and storage type: per-split partial sums added in a fixed order, no atomics,
  * bitwise reproducible; 64 MiB covers every layer of the model at any batch size; may be NULL) and, when dbias != NULL,
@@ -177,7 +180,8 @@ int mi_ares_pack_weights6(void* stream, const float* conv4_w, const float* decon
 int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
-/* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x */
+/* backward of conv2d_transpose wrt its kernel: dw[kh,kw,co,ci] += im2col(dy)^T x.  The form WITHOUT scratch is NON-DETERMINISTIC (fp32 atomics across the position
+ * splits); the _ws form is the deterministic one (per-split partial sums added in a fixed order) */
 int mi_deconv2d_nhwc_wgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw);
 int mi_deconv2d_nhwc_wgrad_ws(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* x, int KH, int KW, int Cin, float* dw, void* scratch, long long scratch_bytes, float* dbias);
 /* tf.layers.dense (MatMul + BiasAdd + Relu) and its input gradient — vae/models.py:97-98,259; utils.py:25-28; ppo.py:43-55.
@@ -186,7 +190,7 @@ int mi_gemm_bias_act(void* stream, int dtype, const void* a, int M, int K, const
 /* the finishing pass of a split-K dense layer: out[m,n] = mask(act(sum_s slabs[s][m][n] + bias[n])) -- the bias / ReLU / ReluGrad epilogue mi_gemm_bias_act
  * cannot apply to raw slabs (MlpVAE, vae/models.py:271-299: the 38400-long reductions of its first layer and of its last layer's input gradient) */
 int mi_splitk_finish(void* stream, int dtype, const float* slabs, int nsplit, int M, int N, const float* bias, int relu, const void* mask, void* out, int out_f32);
-/* dense kernel gradient dw[K,N] += a^T dy (MatMul's weight gradient behind tf.gradients -- vae/models.py:142, ppo.py:143-144); the row splits meet in fp32 atomics */
+/* dense kernel gradient dw[K,N] += a^T dy (MatMul's weight gradient behind tf.gradients -- vae/models.py:142, ppo.py:143-144).  NON-DETERMINISTIC summation order: the row splits meet in fp32 atomics; use the _ws forms below */
 int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw);
 /* same with caller scratch (>= mi_gemm_wgrad_scratch_bytes; may be NULL = the form above): every row split stores its partial sums and one pass adds them to dw
  * in a fixed order -- two runs are bitwise equal (round 4; the parity engines use only this form) */
@@ -206,6 +210,9 @@ int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nspli
 int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row, unsigned long long* rng_state, float* eps_out);
 /* out[i] = N(0,1) element (offset + i) of Philox stream `seed` (exploration noise of ppo.py:58-60, tests) */
 int mi_normal_philox(void* stream, unsigned long long seed, unsigned long long offset, float* out, long long n);
+/* the two halves behind ONE entry point, as SURVEY 8b names it: heads != NULL runs the forward (as mi_vae_reparam_kl_fwd), dz_slabs != NULL runs the backward (as
+ * mi_vae_reparam_kl_bwd, on the mean / logvar / kl_row the forward half of this or an earlier call left in the same buffers); both: forward, then backward */
+int mi_vae_reparam_kl_fwd_bwd(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv, const float* eps, int sample, int B, int Z, float* mean, float* logvar, void* z, float* kl_row, const float* dz_slabs, int dz_nsplit, float beta, float kl_floor, float inv_batch, void* dheads);
 int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar, const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads);
 /* bce_loss / bce_loss_v2 / mse_loss + reduce_sum(axis=1) + gradient — vae/models.py:11-22,123-128 */
 int mi_recon_loss_chunks(int P);
@@ -239,7 +246,7 @@ int mi_cast_split_to_f32(void* stream, const void* src, float* dst, long long n)
 int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long long n);
 /* K-contiguous copies of the [K,N] kernels for the MFMA B operand: dst[off + n*K + k] = (T) src[off + k*N + n], count <= 16 tensors */
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count);
-/* BiasAddGrad: out[n] += sum_m x[m,n] (row blocks meet in fp32 atomics) */
+/* BiasAddGrad: out[n] += sum_m x[m,n].  NON-DETERMINISTIC summation order (row blocks meet in fp32 atomics); mi_colsum_ws is the deterministic form */
 int mi_colsum(void* stream, int dtype, const void* x, long long M, int N, float* out);
 /* same with caller scratch (>= mi_colsum_scratch_bytes; NULL = the form above): per-block column sums added up in a fixed order -- bitwise reproducible */
 long long mi_colsum_scratch_bytes(int dtype, long long M, int N);

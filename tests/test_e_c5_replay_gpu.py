@@ -25,7 +25,7 @@ def rel_err(a, b):
 
 
 # (4, 16, 24, 2): small, partial last minibatch.  (64, 128, 2048, 1): BASELINE configs[4]'s own shape -- horizon 128, global minibatch 2048 (the
-# large-minibatch form of the fused step: row chunks of 256 + atomics + flat Adam) -- at 1/16 of its 1024 trajectories, which is what the CPU
+# large-minibatch form of the fused step: row chunks of 256, each chunk's gradients in its own slab, one ordered slab sum, flat Adam -- no atomics) -- at 1/16 of its 1024 trajectories, which is what the CPU
 # oracle encodes in seconds (8,256 frames); train.py:171-207 end to end.
 @pytest.mark.parametrize("R,T,batch,epochs", [(4, 16, 24, 2), (64, 128, 2048, 1)])
 def test_synthetic_replay_matches_oracle_pipeline(tmp_path, R, T, batch, epochs):

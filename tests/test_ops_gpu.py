@@ -529,6 +529,19 @@ def test_reparam_kl_fwd_bwd(dt):
     ref = torch.cat([mu.grad, lv.grad], 1).numpy()
     rt, at = tols(dt, float(np.abs(ref).max()))
     assert_close(host(dh), ref, rt, at, "dheads")
+    # SURVEY 8b's single entry point: both halves in one call == the two calls above, bit for bit; each half alone as well
+    mean2 = torch.empty(B, Z, device="cuda"); logvar2 = torch.empty(B, Z, device="cuda"); z2 = alloc(td, B, Z); klr2 = torch.empty(B, device="cuda"); dh2 = alloc(td, B, 2 * Z)
+    L.mi_vae_reparam_kl_fwd_bwd(stream(), code, P(dev(heads)), ns, P(dev(bm)), P(dev(bl)), epsd.data_ptr(), 1, B, Z, mean2.data_ptr(), logvar2.data_ptr(), z2.data_ptr(),
+                                klr2.data_ptr(), P(dev(dzs)), 2, beta, tol, 1.0 / B, dh2.data_ptr())
+    for a, b_, what in ((mean2, mean, "mean"), (logvar2, logvar, "logvar"), (klr2, klr, "kl"), (z2, zd, "z"), (dh2, dh, "dheads")):
+        assert np.array_equal(host(a), host(b_)), what
+    dh3 = alloc(td, B, 2 * Z)
+    L.mi_vae_reparam_kl_fwd_bwd(stream(), code, None, 0, None, None, epsd.data_ptr(), 1, B, Z, mean2.data_ptr(), logvar2.data_ptr(), None, klr2.data_ptr(),
+                                P(dev(dzs)), 2, beta, tol, 1.0 / B, dh3.data_ptr())                    # backward half alone, on what the forward half left
+    assert np.array_equal(host(dh3), host(dh))
+    with pytest.raises(milib.MiError):
+        L.mi_vae_reparam_kl_fwd_bwd(stream(), code, None, 0, None, None, epsd.data_ptr(), 1, B, Z, mean2.data_ptr(), logvar2.data_ptr(), None, klr2.data_ptr(),
+                                    None, 0, beta, tol, 1.0 / B, None)
     # inference mode: z == mean, no eps needed
     L.mi_vae_reparam_kl_fwd(stream(), code, P(dev(heads)), ns, P(dev(bm)), P(dev(bl)), None, 0, B, Z,
                             mean.data_ptr(), logvar.data_ptr(), zd.data_ptr(), klr.data_ptr())
