@@ -31,6 +31,8 @@ def _desc(v):
         return {"list": [_desc(x) for x in v]}
     if isinstance(v, (bool, int, float, str)) or v is None:
         return v
+    if isinstance(v, np.generic):                       # numpy scalars (a value estimate, a reward): the value and its dtype
+        return {"scalar": v.item(), "dtype": str(v.dtype)}
     return {"type": type(v).__name__}
 
 
