@@ -314,6 +314,8 @@ static int x3_tapwgrad_env() { const char* e = getenv("MI355_X3_TAPWGRAD"); retu
 int g_x3_tapwgrad = x3_tapwgrad_env();                   // split-storage filter gradients on the doubled-channel bf16 kernel: 0 off (default: the bf16x3 step is bound by its other stream, 2.742 ms either way), 1 conv2 / conv3, 2 every eligible layer; mi_set_tuning key 21
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
+static int dwgs_env() { const char* e = getenv("MI355_DWGS"); return (e && e[0] == '0') ? 0 : 1; }
+int g_dwgs_on = dwgs_env();                              // LDS-free one-wave-per-tile dense filter gradient (dwgs_tile.hpp, round 5) for bf16 layers of up to 2048 tiles of 64 x 64; mi_set_tuning key 22
 static int dense_wgrad_blocks_env() { const char* e = getenv("MI355_DENSE_WGRAD_BLOCKS"); return e ? atoi(e) : 256; }
 int g_dense_wgrad_blocks = dense_wgrad_blocks_env();       // dense filter gradients: target block count (row splits); mi_set_tuning key 11
 static int nw_depth_env() { const char* e = getenv("MI355_NW_DEPTH"); return e ? atoi(e) : 3; }
@@ -951,6 +953,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 19) { prev = g_nw_depth; g_nw_depth = value; }
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
+    else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }
@@ -1293,6 +1296,16 @@ int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* d
         if (nst == 3) MI_LAUNCH(dwg_kernel<3>, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
         else MI_LAUNCH(dwg_kernel<4>, dim3((unsigned)(per * 8)), dim3(256), 0, (hipStream_t)stream, q);
         return mi_check_launch("dwg_kernel");
+    }
+    // medium results, short reduction (the latent layers of the ConvVAE at any minibatch that is a multiple of 16, the small layers of the MlpVAE): one WAVE per 64 x 64
+    // tile over all rows, no LDS, no row split, no scratch, adds or stores in place (dwgs_tile.hpp; MI355_DWGS=0 / key 22: the first-generation kernel below)
+    if (g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)(K / 64) * (N / 64) <= 2048 &&
+        (long long)M * K < (1ll << 31) && (long long)M * N < (1ll << 31)) {
+        DwgsParams q = {(const bf16_t*)a, (const bf16_t*)dy, dw, dbias, M, K, N, K / 64, N / 64, overwrite ? 1 : 0};
+        const int per = (q.KT * q.NT + 7) / 8;
+        if (overwrite) MI_LAUNCH(dwgs_kernel<true>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
+        else MI_LAUNCH(dwgs_kernel<false>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
+        return mi_check_launch("dwgs_kernel");
     }
     WgradParams p = {};
     p.ones_row = dbias ? 1 : 0; p.dbias = dbias;

@@ -22,6 +22,7 @@
 #include "tapconv_tile.hpp"
 #include "wgrad_tile.hpp"
 #include "dwg_tile.hpp"
+#include "dwgs_tile.hpp"
 #include "tapwgrad_tile.hpp"
 #include "narrow_tile.hpp"
 #include "dectail_tile.hpp"

@@ -381,6 +381,48 @@ def test_dense_wgrad_whole_tiles_over_all_rows(shape):
     assert np.array_equal(host(dw), outs[0][0])
 
 
+@pytest.mark.parametrize("shape", [(512, 6144, 128), (512, 64, 6144), (16, 64, 64), (48, 128, 192), (80, 512, 256), (2048, 256, 128)])
+def test_dense_wgrad_one_wave_per_tile_without_lds(shape):
+    """Round 5 (dwgs_tile.hpp): the LDS-free dense filter gradient -- one wave per 64 x 64 tile of dW over ALL rows, fragments gathered as column-pair
+    dwords and split by v_perm_b32, four steps of loads in flight, the bias row as a ones operand -- against float64 and against the first-generation kernel (tuning key 22
+    off); the latent layers of the ConvVAE at batch 512, row counts that are not multiples of 64 (tail steps), a long reduction; storing form over garbage and adding form
+    onto a previous result; no scratch; two runs bitwise equal."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    M, K, N = shape
+    rng = np.random.RandomState(M + K + N)
+    a, dy = rng.randn(M, K).astype(np.float32), rng.randn(M, N).astype(np.float32)
+    ref = (rounded(a, td).T @ rounded(dy, td)).numpy()
+    refb = rounded(dy, td).sum(0).numpy()
+    ad, dyd = dev(a, td), dev(dy, td)
+    outs = []
+    for fill in (3.0, -7.0):
+        dw, db = torch.full((K, N), fill, device="cuda"), torch.full((N,), fill, device="cuda")
+        L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)      # storing form, no scratch
+        outs.append((host(dw), host(db)))
+    tol = 3e-5 * float(np.abs(ref).max()) * max(1.0, (M / 512.0) ** 0.5)
+    assert_close(outs[0][0], ref, 1e-5, tol, "dense wgrad (one wave per tile)")
+    assert_close(outs[0][1], refb, 1e-5, 3e-5 * float(np.abs(refb).max()) * max(1.0, (M / 512.0) ** 0.5), "bias row (ones operand)")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # adding form: onto the previous result, with and without the bias row
+    dw, db = torch.from_numpy(outs[0][0]).cuda(), torch.from_numpy(outs[0][1]).cuda()
+    L.mi_gemm_wgrad_bias_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0)
+    assert np.array_equal(host(dw), outs[0][0] + outs[0][0]) and np.array_equal(host(db), outs[0][1] + outs[0][1])
+    L.mi_gemm_wgrad_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), None, 0)
+    assert np.array_equal(host(dw), outs[0][0] + outs[0][0] + outs[0][0]) and np.array_equal(host(db), outs[0][1] + outs[0][1])
+    # the first-generation kernel on the same operands (same bf16 products, fp32 sums in another order)
+    prev = L.mi_set_tuning(22, 0)
+    try:
+        nb = int(L.mi_gemm_wgrad_scratch_bytes(code, M, K, N))
+        ws = torch.empty(max(nb, 256), device="cuda", dtype=torch.uint8)
+        dw1, db1 = torch.zeros(K, N, device="cuda"), torch.zeros(N, device="cuda")
+        L.mi_gemm_wgrad_bias_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw1.data_ptr(), db1.data_ptr(), ws.data_ptr(), nb)
+        assert_close(host(dw1), outs[0][0], 1e-5, tol, "one wave per tile vs first generation")
+        assert_close(host(db1), outs[0][1], 1e-5, tol, "bias row vs first generation")
+    finally:
+        L.mi_set_tuning(22, prev)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_adam_writing_both_weight_layouts_equals_adam_then_transposes(dt):
     """Round 4 (MlpVAE engine): mi_adam_tf_layouts = mi_adam_tf_flat + mi_transpose_weights in one launch -- p / m / v, the storage-type copy and the K-contiguous
@@ -491,7 +533,8 @@ def test_ordered_dense_wgrad_with_bias_row_and_colsum(dt, shape):
     dw, db = torch.full((K, N), 7.5, device="cuda"), torch.full((N,), -3.25, device="cuda")
     L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb, 1)
     assert np.array_equal(host(dw), runs[0][0]) and np.array_equal(host(db), runs[0][1])
-    if nb > 0:                                          # row splits without scratch cannot store: refused, not silently accumulated
+    lds_free = dt == "bf16" and M % 16 == 0 and K % 64 == 0 and N % 64 == 0        # round 5: one wave per 64 x 64 tile over all rows (dwgs_tile.hpp) -- no splits, no scratch
+    if nb > 0 and not lds_free:                         # row splits without scratch cannot store: refused, not silently accumulated
         with pytest.raises(milib.MiError):
             L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0, 1)
 
