@@ -250,6 +250,11 @@ static int launch_fold(hipStream_t st, const PendingFold& f) {
 static thread_local PendingReduce g_pending[16];
 static thread_local int g_npending = 0, g_defer_reduces = 0, g_defer_pause = 0;
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element (a power of two <= 64, from the shape only): about 512 blocks in flight, at most ~16 slabs per thread
+    if (r.q.slab_tr > 0) {                                // piece-major slabs: a block = the 32 units of ONE 256-value piece x 8 slab lanes -> every pass of its threads reads
+        unsigned ry = 8;                                  // 8 adjacent splits x 512 (bf16) / 1024 (fp32) bytes = one contiguous 4 / 8 KB run, the next pass the run behind it
+        while (ry > 1 && (int)ry > r.splits) ry >>= 1;    // (fewer than 8 splits: shorter lanes, more units per block)
+        return ry;
+    }
     unsigned ry = 1;
     while (((unsigned)(r.ngroups / 512 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
     return ry;
@@ -402,6 +407,11 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= slab_bytes + bias_bytes && slab_floats < (1ll << 29) && (!dbias || N <= 256)) {
         q.slabs = (float*)scratch;
         if (dbias) q.bias_part = (float*)((char*)scratch + slab_bytes);
+    }
+    {   // piece-major slabs (round 5; MI355_SLAB_TR=0: split-major as before): the ordered reduce then streams contiguous memory
+        static int slab_tr_on = -1;
+        if (slab_tr_on < 0) { const char* e = getenv("MI355_SLAB_TR"); slab_tr_on = (e && e[0] == '0') ? 0 : 1; }
+        q.slab_tr = (q.slabs && slab_tr_on) ? splits : 0;
     }
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
@@ -1265,10 +1275,30 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
 }
 
 // same with caller scratch (>= mi_gemm_wgrad_scratch_bytes): the row splits store per-split slabs that one ordered pass adds to dw -- deterministic
+// the LDS-free one-wave-per-tile kernel (dwgs_tile.hpp) takes this layer
+static bool dwgs_eligible(int dtype, int M, int K, int N) {
+    return g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)(K / 64) * (N / 64) <= 2048 &&
+           (long long)M * K < (1ll << 31) && (long long)M * N < (1ll << 31);
+}
+// ... with this many row splits (a function of the shape only): up to 8, at most ~1024 waves, at least 4 load rounds per wave
+static int dwgs_msplit(int M, int K, int N) {
+    const int steps = M / 16, T = (K / 64) * (N / 64);
+    int ms = 1;
+    while (ms * 2 <= 8 && T * ms * 2 <= 1024 && steps % (ms * 2) == 0 && steps / (ms * 2) >= 4) ms *= 2;
+    return ms;
+}
+static long long dwgs_slab_floats(int K, int N) { return ((long long)(K + 1) * N + 3) / 4 * 4; }
+
 long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N) {
     if (M < 1 || K < 1 || N < 1) return 0;
     const int splits = wgrad_splits(dtype, M, K + 1, N, g_dense_wgrad_blocks, nullptr);      // (+ 1: room for the bias row of mi_gemm_wgrad_bias_ws)
-    return splits > 1 ? (long long)splits * (((long long)(K + 1) * N + 3) / 4 * 4) * 4 : 0;  // (one row split: a single block per element adds straight into dw)
+    long long need = splits > 1 ? (long long)splits * (((long long)(K + 1) * N + 3) / 4 * 4) * 4 : 0;  // (one row split: a single block per element adds straight into dw)
+    if (dwgs_eligible(dtype, M, K, N)) {                   // round 5: the row-split slabs of the one-wave-per-tile kernel (either kernel may run: the larger need)
+        const int ms = dwgs_msplit(M, K, N);
+        const long long d = ms > 1 ? (long long)ms * dwgs_slab_floats(K, N) * 4 : 0;
+        if (d > need) need = d;
+    }
+    return need;
 }
 
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes) {
@@ -1299,13 +1329,20 @@ int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* d
     }
     // medium results, short reduction (the latent layers of the ConvVAE at any minibatch that is a multiple of 16, the small layers of the MlpVAE): one WAVE per 64 x 64
     // tile over all rows, no LDS, no row split, no scratch, adds or stores in place (dwgs_tile.hpp; MI355_DWGS=0 / key 22: the first-generation kernel below)
-    if (g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)(K / 64) * (N / 64) <= 2048 &&
-        (long long)M * K < (1ll << 31) && (long long)M * N < (1ll << 31)) {
-        DwgsParams q = {(const bf16_t*)a, (const bf16_t*)dy, dw, dbias, M, K, N, K / 64, N / 64, overwrite ? 1 : 0};
-        const int per = (q.KT * q.NT + 7) / 8;
+    if (dwgs_eligible(dtype, M, K, N)) {
+        DwgsParams q = {(const bf16_t*)a, (const bf16_t*)dy, dw, dbias, M, K, N, K / 64, N / 64, overwrite ? 1 : 0, 1, nullptr, 0};
+        int ms = dwgs_msplit(M, K, N);
+        const long long stride = dwgs_slab_floats(K, N);
+        if (ms > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)ms * stride * 4) { q.msplit = ms; q.slabs = (float*)scratch; q.slab_stride = stride; }
+        const int per = (q.KT * q.NT * q.msplit + 7) / 8;
         if (overwrite) MI_LAUNCH(dwgs_kernel<true>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
         else MI_LAUNCH(dwgs_kernel<false>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
-        return mi_check_launch("dwgs_kernel");
+        int rc = mi_check_launch("dwgs_kernel");
+        if (rc == MI_OK && q.msplit > 1) {                 // the row splits: one ordered sum per output (recorded into the pass's small-reduce launch when the engine defers)
+            rc = mi_reduce_slabs((hipStream_t)stream, q.slabs, stride, q.msplit, (long long)K * N, dw, overwrite);
+            if (rc == MI_OK && dbias) rc = mi_reduce_slabs((hipStream_t)stream, q.slabs + (long long)K * N, stride, q.msplit, (long long)N, dbias, overwrite);
+        }
+        return rc;
     }
     WgradParams p = {};
     p.ones_row = dbias ? 1 : 0; p.dbias = dbias;

@@ -22,6 +22,11 @@ struct DwgsParams {
     int M, K, N;
     int KT, NT;                      // tiles of 64 along k and n
     int overwrite;                   // != 0: out = ..., 0: out += ...
+    // Row splits (msplit > 1): wave (tile, z) sums the rows [z M / msplit, (z + 1) M / msplit) and STORES its tile into slabs + z * slab_stride (dW layout [K][N], the bias
+    // row behind it at K * N); the ordered slab sum (mi_reduce_slabs: fixed order, deferred into the pass's one small-reduce launch by the engine) adds them to dW.  Why:
+    // one wave per tile is a chain of M / 16 dependent load rounds, and next to the HBM-saturating kernels at the end of the backward pass a round takes microseconds --
+    // 96 waves x 32 rounds ran 64 us in the step (gpurun_out/timeline_r05c.md); 768 waves x 4-8 rounds put the whole operand in flight at once.
+    int msplit; float* slabs; long long slab_stride;
 };
 
 constexpr int DWGS_DEPTH = 4;
@@ -44,20 +49,22 @@ template <bool OVERWRITE>
 __global__ __launch_bounds__(64) void dwgs_kernel(const DwgsParams p) {
     const int lane = threadIdx.x, lrow = lane & 31, lgrp = lane >> 5;
     // tile of this wave: XCD x (block b runs on XCD b % 8) owns a contiguous range of tiles, the dimension with fewer tiles fastest (neighbours share operand columns in L2)
-    const int T = p.KT * p.NT;
-    const int per = (T + 7) >> 3;
-    const int t = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (t >= T) return;
+    const int T = p.KT * p.NT, W = T * p.msplit;
+    const int per = (W + 7) >> 3;
+    const int w = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (w >= W) return;
+    const int t = w / p.msplit, z = w - t * p.msplit;         // (the row splits of a tile are neighbours: they share the tile's operand columns in L2)
     int kt, nt;
     if (p.NT <= p.KT) { kt = t / p.NT; nt = t - kt * p.NT; } else { nt = t / p.KT; kt = t - nt * p.KT; }
     const int k0 = kt * 64, n0 = nt * 64;
     const bool with_bias = p.dbias != nullptr && kt == 0;      // (wave-uniform)
 
     // lane (lrow, lgrp): columns 2 lrow, 2 lrow + 1 of the tile, rows 16 s + 8 lgrp + e (e = 0 .. 7) of step s
-    const bf16_t* pa = p.a + (long long)(8 * lgrp) * p.K + k0 + 2 * lrow;
-    const bf16_t* pb = p.dy + (long long)(8 * lgrp) * p.N + n0 + 2 * lrow;
+    const int ns = (p.M >> 4) / p.msplit;                      // (M % (16 msplit) == 0: checked by the launcher)
+    const long long m0 = (long long)z * ns * 16 + 8 * lgrp;
+    const bf16_t* pa = p.a + m0 * p.K + k0 + 2 * lrow;
+    const bf16_t* pb = p.dy + m0 * p.N + n0 + 2 * lrow;
     const long long stepA = 16ll * p.K, stepB = 16ll * p.N;
-    const int ns = p.M >> 4;                                   // (M % 16 == 0: checked by the launcher)
 
     uint32_t ra[DWGS_DEPTH][8], rb[DWGS_DEPTH][8];
     auto issue = [&](int d, int s) {
@@ -108,6 +115,18 @@ __global__ __launch_bounds__(64) void dwgs_kernel(const DwgsParams p) {
 #pragma unroll
     for (int d = 0; d < DWGS_DEPTH - 1; ++d) if (s0 + d < ns) step(d, s0 + d);      // M % 64 != 0: the last one to three steps (already in flight in slots 0 ..)
 
+    if (p.msplit > 1) {                                        // this split's partial tile -> its slab (plain stores; the ordered sum follows)
+        float* const slab = p.slabs + (long long)z * p.slab_stride;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            float* o = slab + (long long)(k0 + fi + 8 * lgrp) * p.N + n0 + 2 * lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dwgs_store2<true>(o + (long long)(2 * ((r & 3) + 8 * (r >> 2))) * p.N, acc[fi][0][r], acc[fi][1][r]);
+        }
+        if (with_bias && lgrp == 0) dwgs_store2<true>(slab + (long long)p.K * p.N + n0 + 2 * lrow, accb[0][0], accb[1][0]);
+        return;
+    }
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {
         float* o = p.out + (long long)(k0 + fi + 8 * lgrp) * p.N + n0 + 2 * lrow;      // row k0 + 2 (4 lgrp + ...) + fi

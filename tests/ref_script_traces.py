@@ -115,7 +115,7 @@ def make_dataset(root, n=40):
 TRAIN_VAE_CASES = {
     "rgb_cnn_restart": ["--z_dim", "64", "--batch_size", "4", "-restart"],
     "seg_mlp_continue": ["--use_segmentation_as_target", "1", "--model_type", "mlp", "--loss_type", "bce_v2", "--z_dim", "16", "--beta", "4", "--kl_tolerance", "0.5",
-                         "--learning_rate", "0.001", "--lr_decay", "0.98", "--batch_size", "2"],
+                         "--learning_rate", "0.0002", "--lr_decay", "0.98", "--batch_size", "2"],
 }
 
 

@@ -405,11 +405,27 @@ def test_dense_wgrad_one_wave_per_tile_without_lds(shape):
     assert_close(outs[0][1], refb, 1e-5, 3e-5 * float(np.abs(refb).max()) * max(1.0, (M / 512.0) ** 0.5), "bias row (ones operand)")
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     # adding form: onto the previous result, with and without the bias row
-    dw, db = torch.from_numpy(outs[0][0]).cuda(), torch.from_numpy(outs[0][1]).cuda()
+    w32, b32 = outs[0][0].astype(np.float32), outs[0][1].astype(np.float32)
+    dw, db = torch.from_numpy(w32).cuda(), torch.from_numpy(b32).cuda()
     L.mi_gemm_wgrad_bias_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), None, 0)
-    assert np.array_equal(host(dw), outs[0][0] + outs[0][0]) and np.array_equal(host(db), outs[0][1] + outs[0][1])
+    assert np.array_equal(host(dw).astype(np.float32), w32 + w32) and np.array_equal(host(db).astype(np.float32), b32 + b32)
     L.mi_gemm_wgrad_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), None, 0)
-    assert np.array_equal(host(dw), outs[0][0] + outs[0][0] + outs[0][0]) and np.array_equal(host(db), outs[0][1] + outs[0][1])
+    assert np.array_equal(host(dw).astype(np.float32), (w32 + w32) + w32) and np.array_equal(host(db).astype(np.float32), b32 + b32)
+    # with caller scratch the rows are split over up to 8 waves per tile (whole operand in flight at once) whose slabs one ordered pass sums: same products, another
+    # fp32 summation order; storing and adding forms, twice (bitwise equal)
+    nbs = int(L.mi_gemm_wgrad_scratch_bytes(code, M, K, N))
+    wss = torch.empty(max(nbs, 256), device="cuda", dtype=torch.uint8)
+    split_runs = []
+    for fill in (11.0, -2.0):
+        dw, db = torch.full((K, N), fill, device="cuda"), torch.full((N,), fill, device="cuda")
+        L.mi_gemm_wgrad_bias_set(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), wss.data_ptr(), nbs, 1)
+        split_runs.append((host(dw), host(db)))
+    assert_close(split_runs[0][0], ref, 1e-5, tol, "dense wgrad (row splits + ordered sum)")
+    assert_close(split_runs[0][1], refb, 1e-5, 3e-5 * float(np.abs(refb).max()) * max(1.0, (M / 512.0) ** 0.5), "bias row (row splits)")
+    assert np.array_equal(split_runs[0][0], split_runs[1][0]) and np.array_equal(split_runs[0][1], split_runs[1][1])
+    dw, db = torch.from_numpy(w32).cuda(), torch.from_numpy(b32).cuda()
+    L.mi_gemm_wgrad_bias_ws(stream(), code, ad.data_ptr(), dyd.data_ptr(), M, K, N, dw.data_ptr(), db.data_ptr(), wss.data_ptr(), nbs)
+    assert_close(host(dw), 2 * ref, 1e-5, 2 * tol, "adding form with row splits")
     # the first-generation kernel on the same operands (same bf16 products, fp32 sums in another order)
     prev = L.mi_set_tuning(22, 0)
     try:
