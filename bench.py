@@ -371,6 +371,9 @@ def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
     rewards, dones = rng.uniform(0, 1, (rows, T)), np.zeros((rows, T))
     stages = {}
     replay.replay_update(vae, ppo, frames[:8], meas[:8], actions[:8], rewards[:8], dones[:8], 0.99, 0.95, 1, batch)      # warm-up: engines sized
+    # ... and one untimed update of the FULL shape, so that both timed variants below run warm (the host-fed figure used to come from the cold first run and
+    # the resident one from the warm second -- not comparable as presented)
+    replay.replay_update(vae, ppo, frames, meas, actions, rewards, dones, 0.99, 0.95, 1, batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = replay.replay_update(vae, ppo, frames, meas, actions, rewards, dones, 0.99, 0.95, epochs, batch, stage_times=stages)

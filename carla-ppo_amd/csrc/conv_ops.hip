@@ -250,11 +250,6 @@ static int launch_fold(hipStream_t st, const PendingFold& f) {
 static thread_local PendingReduce g_pending[16];
 static thread_local int g_npending = 0, g_defer_reduces = 0, g_defer_pause = 0;
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element (a power of two <= 64, from the shape only): about 512 blocks in flight, at most ~16 slabs per thread
-    if (r.q.slab_tr > 0) {                                // piece-major slabs: a block = the 32 units of ONE 256-value piece x 8 slab lanes -> every pass of its threads reads
-        unsigned ry = 8;                                  // 8 adjacent splits x 512 (bf16) / 1024 (fp32) bytes = one contiguous 4 / 8 KB run, the next pass the run behind it
-        while (ry > 1 && (int)ry > r.splits) ry >>= 1;    // (fewer than 8 splits: shorter lanes, more units per block)
-        return ry;
-    }
     unsigned ry = 1;
     while (((unsigned)(r.ngroups / 512 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
     return ry;
@@ -315,8 +310,8 @@ static int tapwgrad_flush_reduces(void* stream) {
 // tapwgrad (tapwgrad_tile.hpp): bf16 weight gradients of the wide stride-2 layers on raw-staged slot tiles.
 // mi_set_tuning key 3 / MI355_TAPWGRAD=0 disables it.
 // ---------------------------------------------------------------------------------------------------------------
-static int x3_tapwgrad_env() { const char* e = getenv("MI355_X3_TAPWGRAD"); return e ? atoi(e) : 0; }
-int g_x3_tapwgrad = x3_tapwgrad_env();                   // split-storage filter gradients on the doubled-channel bf16 kernel: 0 off (default: the bf16x3 step is bound by its other stream, 2.742 ms either way), 1 conv2 / conv3, 2 every eligible layer; mi_set_tuning key 21
+static int x3_tapwgrad_env() { const char* e = getenv("MI355_X3_TAPWGRAD"); return e ? atoi(e) : 1; }
+int g_x3_tapwgrad = x3_tapwgrad_env();                   // split-storage filter gradients on the doubled-channel bf16 kernel: 0 off, 1 conv2 / conv3 (default since round 5: 2.637 -> 2.595 ms per bf16x3 step, two interleaved pairs on one box, gpurun_out/ab_x3_r05e.txt; round 4 measured no difference), 2 every eligible layer (2.870: the wide layers lose); mi_set_tuning key 21
 int g_tapwgrad_on = -1;
 int g_tapwgrad_split = 1;
 static int dwgs_env() { const char* e = getenv("MI355_DWGS"); return (e && e[0] == '0') ? 0 : 1; }
@@ -407,11 +402,6 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     if (scratch && splits > 1 && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= slab_bytes + bias_bytes && slab_floats < (1ll << 29) && (!dbias || N <= 256)) {
         q.slabs = (float*)scratch;
         if (dbias) q.bias_part = (float*)((char*)scratch + slab_bytes);
-    }
-    {   // piece-major slabs (round 5; MI355_SLAB_TR=0: split-major as before): the ordered reduce then streams contiguous memory
-        static int slab_tr_on = -1;
-        if (slab_tr_on < 0) { const char* e = getenv("MI355_SLAB_TR"); slab_tr_on = (e && e[0] == '0') ? 0 : 1; }
-        q.slab_tr = (q.slabs && slab_tr_on) ? splits : 0;
     }
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)

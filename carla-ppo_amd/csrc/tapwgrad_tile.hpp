@@ -47,22 +47,12 @@ struct TapWgradParams {
     float* slabs; long long slab_stride;   // optional: per-split partial sums [gridDim.x][slab_stride] (plain stores) reduced by reduce_slabs_kernel
     float* bias_part; int bias_nh;   // optional (with slabs): the bias-gradient partial sums of position split bx, half h go to bias_part[(bx * bias_nh + h) * NE + ne] (plain
                                      // stores, every element exactly once) and the ordered reduce adds them to dbias; NULL: fp32 atomics on dbias
-    int slab_tr;                     // > 0 (= the number of position splits; round 5): PIECE-MAJOR slabs -- the 256-value piece q of split bx lives at (q * slab_tr + bx) * 256, i.e. the
-                                     // splits of one piece are adjacent, and a block of the ordered reduce streams ONE contiguous region (splits x 512 bytes) instead of
-                                     // gathering 128-byte pieces at slab-stride distance (reduce_fused_kernel: 120 MB in 32 us = 3.7 TB/s before).  The writers' stores are
-                                     // whole pieces either way.  0: split-major [split][slab_stride]
     int slab_bf16;                   // the partial sums are stored ROUNDED TO BF16 (round 3; the bf16 engine's default, mi_set_tuning key 18): ~256 slabs per
                                      // element, each 2^-9 relative with independent signs, add ~1e-4 of the element's own scale to a gradient whose operands
                                      // were bf16 to begin with -- and halve the 211 MB written + 214 MB read per step that the slabs cost
     long long* trace; int trace_cap;   // debug stamps (mi_debug_set_trace)
     int dbg_cheap_addr;                // debug (mi_set_tuning key 2 == 2): trivial DMA addresses, wrong results, shows the cost of the address arithmetic
 };
-
-// value offset of piece (slot * 4 + g4) of position split bx inside the slab scratch, lane's four values (see TapWgradParams::slab_tr)
-__device__ __forceinline__ long long tw_slab_off(const TapWgradParams& p, int bx, long long slot, int g4, int lane) {
-    const long long piece = slot * 4 + g4;
-    return p.slab_tr > 0 ? (piece * p.slab_tr + bx) * 256 + lane * 4 : (long long)bx * p.slab_stride + piece * 256 + lane * 4;
-}
 
 // LDS-DMA issued through inline asm: hipcc drains every builtin LDS-DMA (s_waitcnt vmcnt(0)) in front of the next
 // ds_read_b64_tr_b16 it cannot prove disjoint, which would serialise prefetch and compute; asm loads are invisible to that
@@ -386,23 +376,25 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     // Without scratch: fp32 atomics straight into dW.
     auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
         if (p.slabs) {
-            const long long slot0 = (long long)(by * p.npairs + pi) * KT;
+            const long long eoff = (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
             if (p.slab_bf16) {
+                bf16_t* const dst = (bf16_t*)p.slabs + eoff;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const float v[4] = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
-                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)((bf16_t*)p.slabs + tw_slab_off(p, bx, slot0 + kt, g4, lane)));
+                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + (kt * 4 + g4) * 256));
                     }
                 return;
             }
+            float* const dst = p.slabs + eoff;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 v = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
-                    __builtin_nontemporal_store(v, (f32x4*)(p.slabs + tw_slab_off(p, bx, slot0 + kt, g4, lane)));      // written once, read once by the reduce: streaming
+                    __builtin_nontemporal_store(v, (f32x4*)(dst + (kt * 4 + g4) * 256));      // written once, read once by the reduce: streaming
                 }
             return;
         }
@@ -643,17 +635,19 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
                 const f32x16& t = acc[tb][kt];
-                const long long slot = ((long long)(by * p.npairs + pi) * KT) + kt;
+                const long long eoff = (long long)bx * p.slab_stride + (((long long)(by * p.npairs + pi) * KT) + kt) * 1024 + lane * 4;
                 if (p.slab_bf16) {
+                    bf16_t* const dst = (bf16_t*)p.slabs + eoff;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const float v[4] = {t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]};
-                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)((bf16_t*)p.slabs + tw_slab_off(p, bx, slot, g4, lane)));
+                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + g4 * 256));
                     }
                     continue;
                 }
+                float* const dst = p.slabs + eoff;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) __builtin_nontemporal_store(f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]}, (f32x4*)(p.slabs + tw_slab_off(p, bx, slot, g4, lane)));
+                for (int g4 = 0; g4 < 4; ++g4) __builtin_nontemporal_store(f32x4{t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]}, (f32x4*)(dst + g4 * 256));
             }
         }
     };
@@ -674,26 +668,22 @@ __device__ __forceinline__ void reduce_tiled_body(const TapWgradParams& p, int n
     const int uid = bx * upb + ul;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (uid < nunits) {
-        // value offset of this unit's 8 values in slab k: split-major uid * 8 + k * slab_stride; piece-major ((piece * nslab + k) * 256 + within), piece = uid * 8 / 256
-        const long long v0 = (long long)uid * 8;
-        const long long kstride = p.slab_tr > 0 ? 256 : p.slab_stride;
-        const long long ubase = p.slab_tr > 0 ? (v0 >> 8) * (long long)nslab * 256 + (v0 & 255) : v0;
         if (p.slab_bf16) {
-            const bf16_t* src = (const bf16_t*)p.slabs + ubase;
+            const bf16_t* src = (const bf16_t*)p.slabs + (long long)uid * 8;
 #pragma unroll 8
             for (int k = by; k < nslab; k += ry) {
-                const u32x4 w = __builtin_nontemporal_load((const u32x4*)(src + k * kstride));
+                const u32x4 w = __builtin_nontemporal_load((const u32x4*)(src + k * p.slab_stride));
                 s0[0] += __builtin_bit_cast(float, w[0] << 16); s0[1] += __builtin_bit_cast(float, w[0] & 0xffff0000u);
                 s0[2] += __builtin_bit_cast(float, w[1] << 16); s0[3] += __builtin_bit_cast(float, w[1] & 0xffff0000u);
                 s1[0] += __builtin_bit_cast(float, w[2] << 16); s1[1] += __builtin_bit_cast(float, w[2] & 0xffff0000u);
                 s1[2] += __builtin_bit_cast(float, w[3] << 16); s1[3] += __builtin_bit_cast(float, w[3] & 0xffff0000u);
             }
         } else {
-            const float* src = p.slabs + ubase;
+            const float* src = p.slabs + (long long)uid * 8;
 #pragma unroll 8
             for (int k = by; k < nslab; k += ry) {
-                s0 += __builtin_nontemporal_load((const f32x4*)(src + k * kstride));
-                s1 += __builtin_nontemporal_load((const f32x4*)(src + k * kstride + 4));
+                s0 += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride));
+                s1 += __builtin_nontemporal_load((const f32x4*)(src + k * p.slab_stride + 4));
             }
         }
     }
