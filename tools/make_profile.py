@@ -67,7 +67,9 @@ NAMES_R04 = [("ares_conv_kernel<4, 1>", None, "conv4.fwd / deconv1.dgrad"), ("ar
              ("ares_gather2_kernel", None, "deconv2.fwd / conv3.dgrad"), ("reduce_small_fused_kernel", "1365x1x1", "end-of-pass slab sums (one launch)"),
              ("adam_tf_layouts_kernel<bf16>", None, "adam (writes both weight layouts)")] \
     + [n for n in NAMES_R03 if n[2] not in R04_GONE]
-NAMES = NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
+# round 5: the latent layers' filter gradients on the LDS-free kernel (both launches have 768 waves: one row, averaged)
+NAMES_R05 = [("dwgs_kernel<false>", None, "dense1.wgrad + heads.wgrad (same kernel and grid: averaged)")] + NAMES_R04
+NAMES = NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic = [], {}
 for kern, grid, op in NAMES:
     keys = [k for k in sqr if k[0].strip("`") == kern and (grid is None or k[1] == grid)]
@@ -82,7 +84,7 @@ for kern, grid, op in NAMES:
     traffic[op] = {"kernel": kern, "grid": key[1], "us": us, "fetch_mb_corrected": fmb, "write_mb": wmb, "hbm_bytes_per_launch": (fmb + wmb) * 1e6, "mfma_util": util}
 doc = """# %s
 
-ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  Sources: `rocprofv3 --kernel-trace --stats` of
+ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  ONE `gpurun` call = one box, one library (stamp and the box's own calibration: `config.library` / `box` in the bench line below).  Sources: `rocprofv3 --kernel-trace --stats` of
 `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
 `rocprofv3 --pmc` passes (`tools/pmc_pass.sh`: SQ/GRBM counters, FETCH_SIZE alone, WRITE_SIZE alone -- one TCC-derived counter per pass, no trace
 domains combined with --pmc).  Assembled by `tools/make_profile.py`.
@@ -102,7 +104,7 @@ conv1 kernels of round 1 may be over-counted) + WRITE_SIZE, both reported in KB 
 |---|---|---:|---:|---:|---:|---:|
 %s
 
-## Kernel time table (25 steps incl. warm-up)
+## Kernel time table (every step of the profiled run: clock conditioning + warm-up + timed steps; the averages are IN-STEP times)
 
 %s
 
