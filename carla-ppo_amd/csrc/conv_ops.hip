@@ -1270,25 +1270,18 @@ static bool dwgs_eligible(int dtype, int M, int K, int N) {
     return g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)(K / 64) * (N / 64) <= 2048 &&
            (long long)M * K < (1ll << 31) && (long long)M * N < (1ll << 31);
 }
-// ... with this many row splits (a function of the shape only): up to 8, at most ~1024 waves, at least 4 load rounds per wave
-static int dwgs_msplit(int M, int K, int N) {
-    const int steps = M / 16, T = (K / 64) * (N / 64);
-    int ms = 1;
-    while (ms * 2 <= 8 && T * ms * 2 <= 1024 && steps % (ms * 2) == 0 && steps / (ms * 2) >= 4) ms *= 2;
-    return ms;
+// ... with this many waves per tile (row splits inside the block; a function of the row count only): at least two load rounds per wave
+static int dwgs_wsplit(int M) {
+    const int steps = M / 16;
+    if (steps % 4 == 0 && steps / 4 >= 2) return 4;
+    if (steps % 2 == 0 && steps / 2 >= 2) return 2;
+    return 1;
 }
-static long long dwgs_slab_floats(int K, int N) { return ((long long)(K + 1) * N + 3) / 4 * 4; }
 
 long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N) {
     if (M < 1 || K < 1 || N < 1) return 0;
     const int splits = wgrad_splits(dtype, M, K + 1, N, g_dense_wgrad_blocks, nullptr);      // (+ 1: room for the bias row of mi_gemm_wgrad_bias_ws)
-    long long need = splits > 1 ? (long long)splits * (((long long)(K + 1) * N + 3) / 4 * 4) * 4 : 0;  // (one row split: a single block per element adds straight into dw)
-    if (dwgs_eligible(dtype, M, K, N)) {                   // round 5: the row-split slabs of the one-wave-per-tile kernel (either kernel may run: the larger need)
-        const int ms = dwgs_msplit(M, K, N);
-        const long long d = ms > 1 ? (long long)ms * dwgs_slab_floats(K, N) * 4 : 0;
-        if (d > need) need = d;
-    }
-    return need;
+    return splits > 1 ? (long long)splits * (((long long)(K + 1) * N + 3) / 4 * 4) * 4 : 0;  // (one row split: a single block per element adds straight into dw)
 }
 
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes) {
@@ -1320,19 +1313,11 @@ int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* d
     // medium results, short reduction (the latent layers of the ConvVAE at any minibatch that is a multiple of 16, the small layers of the MlpVAE): one WAVE per 64 x 64
     // tile over all rows, no LDS, no row split, no scratch, adds or stores in place (dwgs_tile.hpp; MI355_DWGS=0 / key 22: the first-generation kernel below)
     if (dwgs_eligible(dtype, M, K, N)) {
-        DwgsParams q = {(const bf16_t*)a, (const bf16_t*)dy, dw, dbias, M, K, N, K / 64, N / 64, overwrite ? 1 : 0, 1, nullptr, 0};
-        int ms = dwgs_msplit(M, K, N);
-        const long long stride = dwgs_slab_floats(K, N);
-        if (ms > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 && scratch_bytes >= (long long)ms * stride * 4) { q.msplit = ms; q.slabs = (float*)scratch; q.slab_stride = stride; }
-        const int per = (q.KT * q.NT * q.msplit + 7) / 8;
-        if (overwrite) MI_LAUNCH(dwgs_kernel<true>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
-        else MI_LAUNCH(dwgs_kernel<false>, dim3((unsigned)(per * 8)), dim3(64), 0, (hipStream_t)stream, q);
-        int rc = mi_check_launch("dwgs_kernel");
-        if (rc == MI_OK && q.msplit > 1) {                 // the row splits: one ordered sum per output (recorded into the pass's small-reduce launch when the engine defers)
-            rc = mi_reduce_slabs((hipStream_t)stream, q.slabs, stride, q.msplit, (long long)K * N, dw, overwrite);
-            if (rc == MI_OK && dbias) rc = mi_reduce_slabs((hipStream_t)stream, q.slabs + (long long)K * N, stride, q.msplit, (long long)N, dbias, overwrite);
-        }
-        return rc;
+        DwgsParams q = {(const bf16_t*)a, (const bf16_t*)dy, dw, dbias, M, K, N, K / 64, N / 64, overwrite ? 1 : 0};
+        const int per = (q.KT * q.NT + 7) / 8, ws = dwgs_wsplit(M);
+        if (overwrite) MI_LAUNCH(dwgs_kernel<true>, dim3((unsigned)(per * 8)), dim3(64 * ws), 0, (hipStream_t)stream, q);
+        else MI_LAUNCH(dwgs_kernel<false>, dim3((unsigned)(per * 8)), dim3(64 * ws), 0, (hipStream_t)stream, q);
+        return mi_check_launch("dwgs_kernel");
     }
     WgradParams p = {};
     p.ones_row = dbias ? 1 : 0; p.dbias = dbias;

@@ -3,13 +3,14 @@
 //   dW[k][n] (+)= sum_m a[m][k] dy[m][n]      a [M, K], dy [M, N] bf16 row-major, M = the minibatch
 // What the first-generation kernel (wgrad_tile.hpp) made of these shapes: 64 KB of LDS per block, row splits whose slabs a second launch sums -- 12 us alone, and 31-44 us
 // each at the serial end of the backward pass, where its blocks find no CU next to the 147 KB-LDS filter-gradient blocks of the other queue (profiles/r04_a).
-// Here a block is ONE WAVE that owns a whole 64 x 64 tile of dW over ALL rows: no LDS, no barrier, no row split, no slab, no second launch.
+// Here a tile of 64 x 64 elements of dW is owned by ONE block of 1, 2 or 4 waves that split the rows between them: no operand staging in LDS, no slab, no second launch
+// (16 KB of LDS only for the waves' final in-order sum).
 // The reduction index m is the slow index of both operands, so the MFMA fragments (8 consecutive m per lane) are gathered: a lane loads the DWORD (columns 2 i, 2 i + 1)
 // of each of its 8 rows -- 32 lanes x 4 bytes = one full 128-byte line per row -- and two v_perm_b32 per row pair split the low / high halves into the fragment of the
 // EVEN column and the fragment of the ODD column.  A fragment pair (fi, fj) therefore produces the dW elements (k0 + 2 r + fi, n0 + 2 c + fj): the two column parities
 // of a lane are adjacent floats and leave as one 8-byte store (256 contiguous bytes per row of 32 lanes).  16 loads + 16 perms feed 4 MFMAs (+ 2 for the bias row);
 // DWGS_DEPTH steps of raw dwords are in flight (64 registers), the compiler's vmcnt counting "all but the newest 16 (DEPTH - 1)" for the step it packs.
-// The result is stored or added in place (each element is owned by exactly one wave: bitwise reproducible either way); BiasAddGrad = one more MFMA per step and column
+// The result is stored or added in place (each element is owned by exactly one block, its waves summed in a fixed order: bitwise reproducible either way); BiasAddGrad = one more MFMA per step and column
 // parity against an all-ones operand in the waves of the first k tile.
 #pragma once
 #include "common.hpp"
@@ -22,11 +23,11 @@ struct DwgsParams {
     int M, K, N;
     int KT, NT;                      // tiles of 64 along k and n
     int overwrite;                   // != 0: out = ..., 0: out += ...
-    // Row splits (msplit > 1): wave (tile, z) sums the rows [z M / msplit, (z + 1) M / msplit) and STORES its tile into slabs + z * slab_stride (dW layout [K][N], the bias
-    // row behind it at K * N); the ordered slab sum (mi_reduce_slabs: fixed order, deferred into the pass's one small-reduce launch by the engine) adds them to dW.  Why:
-    // one wave per tile is a chain of M / 16 dependent load rounds, and next to the HBM-saturating kernels at the end of the backward pass a round takes microseconds --
-    // 96 waves x 32 rounds ran 64 us in the step (gpurun_out/timeline_r05c.md); 768 waves x 4-8 rounds put the whole operand in flight at once.
-    int msplit; float* slabs; long long slab_stride;
+    // Row splits INSIDE the block: blockDim.x / 64 = 1, 2 or 4 waves share a tile, wave z sums the rows [z M / ws, (z + 1) M / ws); waves 0 .. ws - 2 add their tiles into a
+    // 16 KB LDS tile one after the other (fixed order: ((w0 + w1) + w2) + w3), the last wave adds that sum to its registers and stores.  Why split at all: one wave per tile
+    // is a chain of M / 16 dependent load rounds, and next to the HBM-saturating kernels at the end of the backward pass a round takes microseconds (96 waves x 32 rounds:
+    // 64 us in the step, gpurun_out/timeline_r05c.md).  Why not across blocks through slabs (the first row-split form of this round): 25 MB of slabs written and read again by
+    // the pass's small-reduce launch for 5 MB of gradients.
 };
 
 constexpr int DWGS_DEPTH = 4;
@@ -46,21 +47,22 @@ __device__ __forceinline__ void dwgs_store2(float* q, float x, float y) {
 }
 
 template <bool OVERWRITE>
-__global__ __launch_bounds__(64) void dwgs_kernel(const DwgsParams p) {
-    const int lane = threadIdx.x, lrow = lane & 31, lgrp = lane >> 5;
-    // tile of this wave: XCD x (block b runs on XCD b % 8) owns a contiguous range of tiles, the dimension with fewer tiles fastest (neighbours share operand columns in L2)
-    const int T = p.KT * p.NT, W = T * p.msplit;
-    const int per = (W + 7) >> 3;
-    const int w = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (w >= W) return;
-    const int t = w / p.msplit, z = w - t * p.msplit;         // (the row splits of a tile are neighbours: they share the tile's operand columns in L2)
+__global__ __launch_bounds__(256) void dwgs_kernel(const DwgsParams p) {
+    __shared__ float red[64 * 64 + 64];                        // the row splits' running sum: the tile [64][64], the bias row behind it
+    const int lane = threadIdx.x & 63, lrow = lane & 31, lgrp = lane >> 5;
+    const int z = (int)threadIdx.x >> 6, ws = (int)blockDim.x >> 6;      // this wave's row split / splits per tile
+    // tile of this block: XCD x (block b runs on XCD b % 8) owns a contiguous range of tiles, the dimension with fewer tiles fastest (neighbours share operand columns in L2)
+    const int T = p.KT * p.NT;
+    const int per = (T + 7) >> 3;
+    const int t = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (t >= T) return;                                        // (block-uniform)
     int kt, nt;
     if (p.NT <= p.KT) { kt = t / p.NT; nt = t - kt * p.NT; } else { nt = t / p.KT; kt = t - nt * p.KT; }
     const int k0 = kt * 64, n0 = nt * 64;
     const bool with_bias = p.dbias != nullptr && kt == 0;      // (wave-uniform)
 
     // lane (lrow, lgrp): columns 2 lrow, 2 lrow + 1 of the tile, rows 16 s + 8 lgrp + e (e = 0 .. 7) of step s
-    const int ns = (p.M >> 4) / p.msplit;                      // (M % (16 msplit) == 0: checked by the launcher)
+    const int ns = (p.M >> 4) / ws;                            // (M % (16 ws) == 0: checked by the launcher)
     const long long m0 = (long long)z * ns * 16 + 8 * lgrp;
     const bf16_t* pa = p.a + m0 * p.K + k0 + 2 * lrow;
     const bf16_t* pb = p.dy + m0 * p.N + n0 + 2 * lrow;
@@ -115,17 +117,38 @@ __global__ __launch_bounds__(64) void dwgs_kernel(const DwgsParams p) {
 #pragma unroll
     for (int d = 0; d < DWGS_DEPTH - 1; ++d) if (s0 + d < ns) step(d, s0 + d);      // M % 64 != 0: the last one to three steps (already in flight in slots 0 ..)
 
-    if (p.msplit > 1) {                                        // this split's partial tile -> its slab (plain stores; the ordered sum follows)
-        float* const slab = p.slabs + (long long)z * p.slab_stride;
+    if (ws > 1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        for (int zz = 0; zz + 1 < ws; ++zz) {                  // waves 0 .. ws - 2, one after the other: a fixed summation order
+            if (z == zz) {
 #pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            float* o = slab + (long long)(k0 + fi + 8 * lgrp) * p.N + n0 + 2 * lrow;
+                for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dwgs_store2<true>(o + (long long)(2 * ((r & 3) + 8 * (r >> 2))) * p.N, acc[fi][0][r], acc[fi][1][r]);
+                    for (int r = 0; r < 16; ++r) {
+                        f32x2* q = (f32x2*)&red[(fi + 8 * lgrp + 2 * ((r & 3) + 8 * (r >> 2))) * 64 + 2 * lrow];
+                        f32x2 v = {acc[fi][0][r], acc[fi][1][r]};
+                        if (zz > 0) { const f32x2 o = *q; v[0] = o[0] + v[0]; v[1] = o[1] + v[1]; }
+                        *q = v;
+                    }
+                if (lgrp == 0) {
+                    f32x2* q = (f32x2*)&red[64 * 64 + 2 * lrow];
+                    f32x2 v = {accb[0][0], accb[1][0]};
+                    if (zz > 0) { const f32x2 o = *q; v[0] = o[0] + v[0]; v[1] = o[1] + v[1]; }
+                    *q = v;
+                }
+            }
+            __syncthreads();
         }
-        if (with_bias && lgrp == 0) dwgs_store2<true>(slab + (long long)p.K * p.N + n0 + 2 * lrow, accb[0][0], accb[1][0]);
-        return;
+        if (z != ws - 1) return;                               // (no barrier behind this point)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x2 o = *(const f32x2*)&red[(fi + 8 * lgrp + 2 * ((r & 3) + 8 * (r >> 2))) * 64 + 2 * lrow];
+                acc[fi][0][r] = o[0] + acc[fi][0][r]; acc[fi][1][r] = o[1] + acc[fi][1][r];
+            }
+        const f32x2 ob = *(const f32x2*)&red[64 * 64 + 2 * lrow];      // (every lane reads it; lgrp 0 stores)
+        accb[0][0] = ob[0] + accb[0][0]; accb[1][0] = ob[1] + accb[1][0];
     }
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) {

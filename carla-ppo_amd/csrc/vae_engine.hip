@@ -673,6 +673,15 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             if (i > 0) armed_ok();
         }
         e->b4_fused = 0; e->tail_fused = 0;
+        {
+            // Round 5: the slab sums of the three DECODER filter gradients are issued here, behind deconv1's filter gradient, instead of with the encoder's at the very end:
+            // the filter-gradient stream idles ~20 us at this point (conv4's filter gradient waits for the latent chain dense1.dgrad -> reparam.bwd -> heads.dgrad on the
+            // caller's stream, six small launches that leave the chip nearly empty), and the reduce at the end of the pass -- which ends the longer of the two queues --
+            // shrinks from six layers to three.  MI355_MID_FLUSH=0: one reduce at the end (A/B runs).
+            static int mid_flush = -1;
+            if (mid_flush < 0) { const char* ev = getenv("MI355_MID_FLUSH"); mid_flush = (ev && ev[0] == '0') ? 0 : 1; }
+            if (defer && part == 0 && mid_flush) CK(mi_tapwgrad_flush(sw));
+        }
         if (e->tail_nblk > 0 && !late_dense) {               // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
             CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));      // (full two-stream backward: at the tail of the caller's stream, below)
             e->tail_nblk = 0;
