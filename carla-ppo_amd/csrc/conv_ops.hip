@@ -1267,7 +1267,11 @@ int mi_gemm_wgrad(void* stream, int dtype, const void* a, const void* dy, int M,
 // same with caller scratch (>= mi_gemm_wgrad_scratch_bytes): the row splits store per-split slabs that one ordered pass adds to dw -- deterministic
 // the LDS-free one-wave-per-tile kernel (dwgs_tile.hpp) takes this layer
 static bool dwgs_eligible(int dtype, int M, int K, int N) {
-    return g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)(K / 64) * (N / 64) <= 2048 &&
+    // up to 64 tiles (K N <= 256 K): the small layers of the MlpVAE (-1.7 ... -2.3 % on its step).  The latent layers of the ConvVAE (96 / 192 tiles) were measured on all
+    // three forms of this kernel -- one wave per tile, row splits through slabs, row splits inside the block -- at 0.8573 / 0.8168 / 0.8163 ms per step against 0.8449 / 0.8153 /
+    // 0.8032 on the first-generation kernel (same box within a pair): at the end of the backward pass their time is set by the 147 KB-LDS filter gradient that holds the
+    // CUs and by the slab reduce that saturates HBM, and the 64 KB-LDS row-split kernel rides that out better
+    return g_dwgs_on && dtype == MI_BF16 && M >= 16 && M % 16 == 0 && K % 64 == 0 && N % 64 == 0 && (long long)K * N <= 262144 &&
            (long long)M * K < (1ll << 31) && (long long)M * N < (1ll << 31);
 }
 // ... with this many waves per tile (row splits inside the block; a function of the row count only): at least two load rounds per wave

@@ -819,7 +819,13 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (use_third) { if (defer) mi_tapwgrad_flush(sw); hipStreamWaitEvent((hipStream_t)st, e->ev_third, 0); }
         if (e->fin.pending && (part == 0 || part == 2 || part == 4)) {      // the deferred loss scalars: on the caller's stream, in front of its wait for the other one
             e->fin.pending = 0;
-            TOP(e, st, OP_FINALIZE, mi_vae_finalize_losses_flat(st, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
+            // Round 5: behind the filter-gradient queue's last reduce instead (it ends ~20 us before the caller's queue does: the one-block kernel and its boundary leave
+            // the critical tail; everything it reads exists since the forward pass, what it writes -- the loss scalars, deconv4's bias gradient -- is read behind the join).
+            // MI355_FIN_SIDE=0: on the caller's stream as before.
+            static int fin_side = -1;
+            if (fin_side < 0) { const char* ev = getenv("MI355_FIN_SIDE"); fin_side = (ev && ev[0] == '0') ? 0 : 1; }
+            void* sf = (fork && fin_side && part == 0) ? sw : st;
+            TOP(e, sf, OP_FINALIZE, mi_vae_finalize_losses_flat(sf, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
                                            (float*)e->at(W.out2), e->fin.metrics3, e->fin.metric_weight, (const float*)e->at(W.bpart), e->fin.nblk, d.ct, e->fin.dbias));
         }
         join();
