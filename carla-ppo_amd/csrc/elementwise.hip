@@ -152,8 +152,9 @@ __global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit,
 constexpr int BCE_PER_THREAD = 24;
 constexpr int BCE_CHUNK = 256 * BCE_PER_THREAD;
 
-template <typename T>
-__global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
+// TL = float: labels in [0, 1]; TL = unsigned char (round 5): raw camera bytes, float32(k) / float32(255) formed exactly in registers (u8_to_unit_exact)
+template <typename T, typename TL>
+__global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ logits, const TL* __restrict__ labels,
                                                          const int* __restrict__ frame_idx, long long label_stride, int P,
                                                          int kind, float inv_b, T* __restrict__ dlogits,
                                                          float* __restrict__ partial, int nchunks, int Ct, float* __restrict__ dbias) {
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ l
     const int b = blockIdx.y, chunk = blockIdx.x;
     const long long fr = frame_idx ? (long long)frame_idx[b] : (long long)b;
     const T* x = logits + (long long)b * P;
-    const float* y = labels + fr * label_stride;
+    const TL* y = labels + fr * label_stride;
     T* dx = dlogits ? dlogits + (long long)b * P : nullptr;
     const int e0 = chunk * BCE_CHUNK + threadIdx.x * BCE_PER_THREAD;
-    const bool vec = (P % BCE_PER_THREAD) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dx)) & 15) == 0;   // whole groups, aligned rows
+    const bool vec = (P % BCE_PER_THREAD) == 0 && ((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0 && (((uintptr_t)y) & (sizeof(TL) == 1 ? 7 : 15)) == 0;   // whole groups, aligned rows
     float acc = 0.f;
     float gs[BCE_PER_THREAD];
 #pragma unroll
@@ -179,17 +180,27 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const T* __restrict__ l
 #pragma unroll
                 for (int k = 0; k < VE; ++k) xv[v * VE + k] = Elem<T>::to_f32(t.v[k]);
             }
+            if constexpr (sizeof(TL) == 1) {                // 24 label bytes = three 8-byte loads (e0 is a multiple of 24, the row 8-byte aligned)
 #pragma unroll
-            for (int v = 0; v < BCE_PER_THREAD / 4; ++v) {
-                const f32x4 t = *(const f32x4*)(y + e0 + v * 4);
+                for (int v = 0; v < BCE_PER_THREAD / 8; ++v) {
+                    const unsigned long long w = *(const unsigned long long*)(y + e0 + v * 8);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) yv[v * 4 + k] = t[k];
+                    for (int k = 0; k < 8; ++k) yv[v * 8 + k] = u8_to_unit_exact((float)((w >> (8 * k)) & 255ull));
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < BCE_PER_THREAD / 4; ++v) {
+                    const f32x4 t = *(const f32x4*)(y + e0 + v * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yv[v * 4 + k] = t[k];
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < BCE_PER_THREAD; ++j) {
                 const bool in = e0 + j < P;
-                xv[j] = in ? Elem<T>::to_f32(x[e0 + j]) : 0.f; yv[j] = in ? y[e0 + j] : 0.f;
+                xv[j] = in ? Elem<T>::to_f32(x[e0 + j]) : 0.f;
+                if constexpr (sizeof(TL) == 1) yv[j] = in ? u8_to_unit_exact((float)y[e0 + j]) : 0.f; else yv[j] = in ? y[e0 + j] : 0.f;
             }
         }
         T gq[BCE_PER_THREAD];
@@ -461,19 +472,34 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
 
 // rows idx[b] (or b) of a float32 table -> a dense [B, row_len] tensor of the engine's storage type: the MlpVAE engine's frame staging in ONE launch
 // (index_select + contiguous + cast were three passes over the 79 MB minibatch)
-template <typename T>
-__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const float* __restrict__ src, const int* __restrict__ idx, long long row_len, T* __restrict__ out, unsigned chunks) {
+// TS = float: a float32 table; TS = unsigned char (round 5): raw camera bytes k -> float32(k) / float32(255), correctly rounded (u8_to_unit_exact: the value the reference's
+// host preprocessing produces, vae/train_vae.py:15-18; rounded once more to the storage type for bf16)
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void gather_rows_cast_kernel(const TS* __restrict__ src, const int* __restrict__ idx, long long row_len, T* __restrict__ out, unsigned chunks) {
     const int b = (int)(blockIdx.x / chunks);            // (row, chunk) folded into grid.x: any batch size (grid.y stops at 65535)
-    const float* s = src + (idx ? (long long)idx[b] : (long long)b) * row_len;
+    const TS* s = src + (idx ? (long long)idx[b] : (long long)b) * row_len;
     T* d = out + (long long)b * row_len;
     const long long i = ((long long)(blockIdx.x % chunks) * 256 + threadIdx.x) * 8;
-    if (i + 8 <= row_len && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
-        const f32x4 a = *(const f32x4*)(s + i), c = *(const f32x4*)(s + i + 4);
-        const float fa[4] = {a[0], a[1], a[2], a[3]}, fc[4] = {c[0], c[1], c[2], c[3]};
-        *(PackN<T, 4>*)(d + i) = pack4<T>(fa);
-        *(PackN<T, 4>*)(d + i + 4) = pack4<T>(fc);
+    if constexpr (sizeof(TS) == 1) {
+        if (i + 8 <= row_len && (((uintptr_t)(s + i)) & 7) == 0 && (((uintptr_t)d) & 15) == 0) {
+            const unsigned long long w = *(const unsigned long long*)(s + i);
+            float fa[4], fc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fa[q] = u8_to_unit_exact((float)((w >> (8 * q)) & 255ull)); fc[q] = u8_to_unit_exact((float)((w >> (8 * q + 32)) & 255ull)); }
+            *(PackN<T, 4>*)(d + i) = pack4<T>(fa);
+            *(PackN<T, 4>*)(d + i + 4) = pack4<T>(fc);
+        } else {
+            for (int q = 0; q < 8; ++q) if (i + q < row_len) d[i + q] = Elem<T>::from_f32(u8_to_unit_exact((float)s[i + q]));
+        }
     } else {
-        for (int q = 0; q < 8; ++q) if (i + q < row_len) d[i + q] = Elem<T>::from_f32(s[i + q]);
+        if (i + 8 <= row_len && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+            const f32x4 a = *(const f32x4*)(s + i), c = *(const f32x4*)(s + i + 4);
+            const float fa[4] = {a[0], a[1], a[2], a[3]}, fc[4] = {c[0], c[1], c[2], c[3]};
+            *(PackN<T, 4>*)(d + i) = pack4<T>(fa);
+            *(PackN<T, 4>*)(d + i + 4) = pack4<T>(fc);
+        } else {
+            for (int q = 0; q < 8; ++q) if (i + q < row_len) d[i + q] = Elem<T>::from_f32(s[i + q]);
+        }
     }
 }
 
@@ -721,8 +747,19 @@ int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, cons
     dim3 g(nch, B), b(256);
     if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
     if (dbias && (channels < 1 || channels > 3 || !dlogits)) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd_bias: fused bias gradient needs 1..3 channels and dlogits");
-    BY_DTYPE(dtype, hipLaunchKernelGGL(recon_loss_kernel<TT>, g, b, 0, (hipStream_t)stream, (const TT*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (TT*)dlogits, partial, nch, channels, dbias));
+    BY_DTYPE(dtype, hipLaunchKernelGGL((recon_loss_kernel<TT, float>), g, b, 0, (hipStream_t)stream, (const TT*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (TT*)dlogits, partial, nch, channels, dbias));
     return mi_check_launch("recon_loss");
+}
+
+// the same with the labels as raw uint8 camera bytes (label_stride in bytes = values): float32(k) / float32(255) exactly, in registers
+int mi_bce_logits_fwd_bwd_u8(void* stream, int dtype, const void* logits, const unsigned char* labels, const int* frame_idx, long long label_stride,
+                             int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial) {
+    if (!logits || !labels || !partial || B < 1 || P < 1) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd_u8: bad arguments");
+    if (loss_kind < 0 || loss_kind > 2) return mi_fail(MI_ERR_ARG, "mi_bce_logits_fwd_bwd_u8: loss_kind must be 0 (bce), 1 (bce_v2) or 2 (mse)");
+    const int nch = mi_recon_loss_chunks(P);
+    dim3 g(nch, B), b(256);
+    BY_DTYPE(dtype, hipLaunchKernelGGL((recon_loss_kernel<TT, unsigned char>), g, b, 0, (hipStream_t)stream, (const TT*)logits, labels, frame_idx, label_stride, P, loss_kind, inv_batch, (TT*)dlogits, partial, nch, 1, (float*)nullptr));
+    return mi_check_launch("recon_loss_u8");
 }
 
 int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch,
@@ -843,9 +880,23 @@ int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* id
     const long long chunks = (row_len + 2047) / 2048;
     if (chunks * B > 0x7fffffffll) return mi_fail(MI_ERR_SHAPE, "mi_gather_rows_cast: B x row_len beyond one launch");
     const dim3 g((unsigned)(chunks * B));
-    if (dtype == MI_BF16) hipLaunchKernelGGL(gather_rows_cast_kernel<bf16_t>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out, (unsigned)chunks);
-    else hipLaunchKernelGGL(gather_rows_cast_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out, (unsigned)chunks);
+    if (dtype == MI_BF16) hipLaunchKernelGGL((gather_rows_cast_kernel<bf16_t, float>), g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out, (unsigned)chunks);
+    else hipLaunchKernelGGL((gather_rows_cast_kernel<float, float>), g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out, (unsigned)chunks);
     return mi_check_launch("gather_rows_cast");
+}
+
+// the same from a uint8 table of raw camera bytes: out[b, :] = storage_type(float32(src[idx[b], :]) / float32(255)) -- the reference's host preprocessing (vae/train_vae.py:15-18)
+// done where the minibatch is staged: a quarter of the table in HBM, a quarter of the gather's read traffic
+int mi_gather_rows_cast_u8(void* stream, int dtype, const unsigned char* src, const int* idx, int B, long long row_len, void* out) {
+    if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast_u8: dtype must be MI_F32 or MI_BF16");
+    if (!src || !out || B < 0 || row_len < 1) return mi_fail(MI_ERR_ARG, "mi_gather_rows_cast_u8: bad arguments");
+    if (B == 0) return MI_OK;
+    const long long chunks = (row_len + 2047) / 2048;
+    if (chunks * B > 0x7fffffffll) return mi_fail(MI_ERR_SHAPE, "mi_gather_rows_cast_u8: B x row_len beyond one launch");
+    const dim3 g((unsigned)(chunks * B));
+    if (dtype == MI_BF16) hipLaunchKernelGGL((gather_rows_cast_kernel<bf16_t, unsigned char>), g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (bf16_t*)out, (unsigned)chunks);
+    else hipLaunchKernelGGL((gather_rows_cast_kernel<float, unsigned char>), g, dim3(256), 0, (hipStream_t)stream, src, idx, row_len, (float*)out, (unsigned)chunks);
+    return mi_check_launch("gather_rows_cast_u8");
 }
 
 int mi_transpose_weights(void* stream, int dtype, const float* src, void* dst, const long long* offsets, const int* K, const int* N, int count) {

@@ -129,10 +129,12 @@ int dense(MlpEngine* e, void* st, const void* a, int M, int K, const void* w, in
 }
 
 // rows idx[0 .. B) (or the first B rows) of the float32 frame table in the engine's storage type
-int stage_input(MlpEngine* e, void* st, const float* src, const int* idx, int B, const void** x) {
+// (src_u8: the table holds raw uint8 camera bytes, normalised to float32(k) / float32(255) while the rows are staged -- round 5)
+int stage_input(MlpEngine* e, void* st, const void* src, int src_u8, const int* idx, int B, const void** x) {
     if (!src) return mi_fail(MI_ERR_ARG, "mlp vae engine: missing frame table");
-    if (e->d.dtype == MI_F32 && !idx) { *x = src; return MI_OK; }
-    CK(mi_gather_rows_cast(st, e->d.dtype, src, idx, B, e->d.source_size, e->at(e->o_x)));
+    if (e->d.dtype == MI_F32 && !idx && !src_u8) { *x = src; return MI_OK; }
+    if (src_u8) CK(mi_gather_rows_cast_u8(st, e->d.dtype, (const unsigned char*)src, idx, B, e->d.source_size, e->at(e->o_x)));
+    else CK(mi_gather_rows_cast(st, e->d.dtype, (const float*)src, idx, B, e->d.source_size, e->at(e->o_x)));
     *x = e->at(e->o_x);
     return MI_OK;
 }
@@ -257,21 +259,25 @@ void* mi_mlpvae_buffer(void* h, int which) {
 
 // forward + ELBO terms of one minibatch (vae/models.py:226-229 / the forward half of :213-216).  src / tgt: float32 frame tables [n_frames, S] / [n_frames, P] on the
 // device; idx: int32 [B] rows (NULL: the first B); inv_batch = 1 / B_global; eps [B, Z] (sample != 0); want_grad: also leave dlogits for mi_mlpvae_backward.
-int mi_mlpvae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad,
+int mi_mlpvae_forward(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad,
                       float* metrics3, float metric_weight) {
     MlpEngine* e = (MlpEngine*)h;
     CK(check_batch(e, B));
     if (!tgt) return mi_fail(MI_ERR_ARG, "mi_mlpvae_forward: missing target table");
     const MiMlpVaeDesc& d = e->d;
     const void* x = nullptr;
-    CK(stage_input(e, stream, src, idx, B, &x));
+    CK(stage_input(e, stream, src, frames_u8 & 1, idx, B, &x));
     CK(run_encoder(e, stream, x, B));
     CK(reparam(e, stream, B, eps, sample));
     CK(run_decoder(e, stream, e->at(e->o_z), B));
     const float kl_floor = d.kl_tolerance > 0.f ? d.kl_tolerance * d.z_dim : 0.f;
     const bool grad = want_grad && d.with_optimizer;
-    CK(mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->o_d[e->nd - 1]), tgt, idx, d.target_size, B, d.target_size, d.loss_kind, inv_batch,
-                             grad ? e->at(e->o_gd[e->nd - 1]) : nullptr, (float*)e->at(e->o_partial)));
+    if (frames_u8 & 2)
+        CK(mi_bce_logits_fwd_bwd_u8(stream, d.dtype, e->at(e->o_d[e->nd - 1]), (const unsigned char*)tgt, idx, d.target_size, B, d.target_size, d.loss_kind, inv_batch,
+                                    grad ? e->at(e->o_gd[e->nd - 1]) : nullptr, (float*)e->at(e->o_partial)));
+    else
+        CK(mi_bce_logits_fwd_bwd(stream, d.dtype, e->at(e->o_d[e->nd - 1]), (const float*)tgt, idx, d.target_size, B, d.target_size, d.loss_kind, inv_batch,
+                                 grad ? e->at(e->o_gd[e->nd - 1]) : nullptr, (float*)e->at(e->o_partial)));
     CK(mi_vae_finalize_losses(stream, (const float*)e->at(e->o_partial), e->nchunks, (const float*)e->at(e->o_klrow), kl_floor, B, inv_batch, (float*)e->at(e->o_out2),
                               metrics3, metric_weight));
     e->last_B = B; e->last_x = x;
@@ -392,20 +398,20 @@ int mi_mlpvae_apply_adam(void* h, void* stream, float alpha, float beta1, float 
 }
 
 // One whole SGD step (the reference's sess.run([train_step, ...]), vae/models.py:213-216) in ONE call; nothing synchronises the host
-int mi_mlpvae_train_step(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps,
+int mi_mlpvae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps,
                          float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight) {
-    CK(mi_mlpvae_forward(h, stream, src, tgt, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+    CK(mi_mlpvae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
     CK(mi_mlpvae_backward(h, stream, eps, inv_batch, 0));
     return mi_mlpvae_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
 }
 
 // VAE.encode (vae/models.py:199-202): frames -> mean [B, Z] fp32
-int mi_mlpvae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out) {
+int mi_mlpvae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out) {
     MlpEngine* e = (MlpEngine*)h;
     CK(check_batch(e, B));
     if (!mean_out) return mi_fail(MI_ERR_ARG, "mi_mlpvae_encode: missing output");
     const void* x = nullptr;
-    CK(stage_input(e, stream, src, idx, B, &x));
+    CK(stage_input(e, stream, src, frames_u8 & 1, idx, B, &x));
     CK(run_encoder(e, stream, x, B));
     CK(reparam(e, stream, B, nullptr, 0));
     if (hipMemcpyAsync(mean_out, e->at(e->o_mean), (size_t)B * e->d.z_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
@@ -425,12 +431,12 @@ int mi_mlpvae_decode(void* h, void* stream, const float* z, int B, float* recon_
 }
 
 // VAE.reconstruct (vae/models.py:196-197)
-int mi_mlpvae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out) {
+int mi_mlpvae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out) {
     MlpEngine* e = (MlpEngine*)h;
     CK(check_batch(e, B));
     if (!recon_out) return mi_fail(MI_ERR_ARG, "mi_mlpvae_reconstruct: missing output");
     const void* x = nullptr;
-    CK(stage_input(e, stream, src, idx, B, &x));
+    CK(stage_input(e, stream, src, frames_u8 & 1, idx, B, &x));
     CK(run_encoder(e, stream, x, B));
     CK(reparam(e, stream, B, eps, sample));
     CK(run_decoder(e, stream, e->at(e->o_z), B));

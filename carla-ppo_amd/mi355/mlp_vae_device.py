@@ -194,16 +194,23 @@ class MlpVaeDevice:
         return self._from_flat(self.grads.cpu().numpy())
 
     # ---- steps (all asynchronous on the current torch stream) ----
+    accepts_u8 = True                                   # round 5: frame tables may stay uint8 camera bytes in HBM (normalised where the minibatch is staged / in the loss kernel)
+
     @staticmethod
-    def _f32(t, what):
-        if t is not None and t.dtype != torch.float32:
-            raise TypeError("MlpVAE: %s must be a float32 device tensor, got %s" % (what, t.dtype))
+    def _tab(t, what):
+        if t is not None and t.dtype not in (torch.float32, torch.uint8):
+            raise TypeError("MlpVAE: %s must be a float32 or uint8 device tensor, got %s" % (what, t.dtype))
         return t
+
+    @staticmethod
+    def _u8(src, tgt=None):
+        """frames_u8 of the C ABI: bit 0 = the source table holds raw uint8 bytes, bit 1 = the target table does."""
+        return (1 if src is not None and src.dtype == torch.uint8 else 0) | (2 if tgt is not None and tgt.dtype == torch.uint8 else 0)
 
     def forward(self, src, tgt, idx, B, inv_batch, eps, sample, want_grad, accumulate_metrics=True):
         self.ensure_batch(B)
         p = milib.ptr
-        self.L.mi_mlpvae_forward(self.handle, self.stream(), p(self._f32(src, "the source table")), p(self._f32(tgt, "the target table")), p(idx), int(B), float(inv_batch),
+        self.L.mi_mlpvae_forward(self.handle, self.stream(), p(self._tab(src, "the source table")), p(self._tab(tgt, "the target table")), self._u8(src, tgt), p(idx), int(B), float(inv_batch),
                                  p(eps), int(sample), int(want_grad), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
         # the fp32 engine with idx == None reads the first layer's filter-gradient operand straight from `src` in backward(): keep the table alive until then
         # (a temporary freed between forward() and backward(part=2) of the data-parallel path would be read after free -- ADVICE r04)
@@ -222,12 +229,12 @@ class MlpVaeDevice:
         """One whole SGD step in one C call (single-rank path)."""
         self.ensure_batch(B)
         p = milib.ptr
-        self.L.mi_mlpvae_train_step(self.handle, self.stream(), p(self._f32(src, "the source table")), p(self._f32(tgt, "the target table")), p(idx), int(B), float(inv_batch),
+        self.L.mi_mlpvae_train_step(self.handle, self.stream(), p(self._tab(src, "the source table")), p(self._tab(tgt, "the target table")), self._u8(src, tgt), p(idx), int(B), float(inv_batch),
                                     p(eps), float(alpha), float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)
-        self.L.mi_mlpvae_encode(self.handle, self.stream(), milib.ptr(self._f32(src, "the source table")), milib.ptr(idx), int(B), milib.ptr(out))
+        self.L.mi_mlpvae_encode(self.handle, self.stream(), milib.ptr(self._tab(src, "the source table")), self._u8(src), milib.ptr(idx), int(B), milib.ptr(out))
 
     def decode(self, z, B, out):
         self.ensure_batch(B)
@@ -236,7 +243,7 @@ class MlpVaeDevice:
 
     def reconstruct(self, src, idx, B, eps, sample, out):
         self.ensure_batch(B)
-        self.L.mi_mlpvae_reconstruct(self.handle, self.stream(), milib.ptr(self._f32(src, "the source table")), milib.ptr(idx), int(B), milib.ptr(eps), int(sample), milib.ptr(out))
+        self.L.mi_mlpvae_reconstruct(self.handle, self.stream(), milib.ptr(self._tab(src, "the source table")), self._u8(src), milib.ptr(idx), int(B), milib.ptr(eps), int(sample), milib.ptr(out))
 
     def range_ok(self, t):
         flag = torch.zeros(1, device=self.device, dtype=torch.int32)

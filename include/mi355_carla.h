@@ -219,6 +219,8 @@ int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int ns
 int mi_recon_loss_chunks(int P);
 int mi_bce_logits_fwd_bwd(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial);
 /* same + the BiasAddGrad of the layer that produced the logits: dbias[c] += sum of the stored dlogits of channel c (channels = 1..3) */
+/* same with the labels as raw uint8 camera bytes (label_stride in values = bytes): float32(k) / float32(255) formed exactly in registers */
+int mi_bce_logits_fwd_bwd_u8(void* stream, int dtype, const void* logits, const unsigned char* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial);
 int mi_bce_logits_fwd_bwd_bias(void* stream, int dtype, const void* logits, const float* labels, const int* frame_idx, long long label_stride, int B, int P, int loss_kind, float inv_batch, void* dlogits, float* partial, int channels, float* dbias);
 /* reduce_mean over the batch, kl_tolerance clamp, tf.metrics.mean accumulators — vae/models.py:124-137,145-146 */
 int mi_vae_finalize_losses(void* stream, const float* partial, int nchunks, const float* kl_row, float kl_floor, int B, float inv_batch, float* out2, float* metrics3, float metric_weight);
@@ -239,6 +241,8 @@ int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v
  * converted in one launch; dtype MI_F32 | MI_BF16.  The table's row count is not an argument: idx[b] must lie inside the table (the host mirror builds every index vector from
  * arange(N) permutations, vae/models.py:207-212) */
 int mi_gather_rows_cast(void* stream, int dtype, const float* src, const int* idx, int B, long long row_len, void* out);
+/* the same from a uint8 table of raw camera bytes: out[b, :] = storage_type(float32(src[idx[b], :]) / float32(255)), correctly rounded (vae/train_vae.py:15-18 on the device) */
+int mi_gather_rows_cast_u8(void* stream, int dtype, const unsigned char* src, const int* idx, int B, long long row_len, void* out);
 int mi_cast_f32_to_bf16(void* stream, const float* src, void* dst, long long n);
 /* fp32 <-> split storage (dtype MI_BF16X3): word = bf16(x) << 16 | bf16(x - bf16(x)); back: hi + lo */
 int mi_cast_f32_to_split(void* stream, const float* src, void* dst, long long n);
@@ -311,7 +315,7 @@ int mi_vae_encode(void* h, void* stream, const void* src, int frames_u8, const i
 int mi_vae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
 int mi_vae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
-/* ---- MlpVAE engine (round 4; vae/models.py:271-299 on the base graph :85-142): the same surface as the ConvVAE engine for the dense variant.  Frame tables are float32
+/* ---- MlpVAE engine (round 4; vae/models.py:271-299 on the base graph :85-142): the same surface as the ConvVAE engine for the dense variant.  Frame tables are float32 (or, round 5, uint8 camera bytes: frames_u8)
  * [n_frames, source_size] / [n_frames, target_size] on the device; the noise eps [B, z_dim] comes from the caller (mi_normal_philox); gradients are STORED into the
  * gradient buffer by every backward pass (not accumulated).  Tensor order of mi_mlpvae_param_layout: encoder layers {kernel [K, N], bias}, heads {kernel [K, 2 z] =
  * [mean | logstd_sqare], bias}, decoder layers incl. the output layer {kernel, bias}; no padding between tensors. ---- */
@@ -325,13 +329,15 @@ void mi_mlpvae_destroy(void* h);
 int mi_mlpvae_sync_shadow(void* h, void* stream);
 void* mi_mlpvae_buffer(void* h, int which);
 long long mi_mlpvae_decoder_offset(void* h);
-int mi_mlpvae_forward(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
+/* round 5: src / tgt are `const void*` + frames_u8 (bit 0: src is a uint8 table of raw camera bytes, bit 1: tgt is; 0: float32 tables as before): the bytes are normalised to
+ * float32(k) / float32(255) -- the reference's host preprocessing, vae/train_vae.py:15-18 -- where the minibatch rows are staged / inside the loss kernel */
+int mi_mlpvae_forward(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, int sample, int want_grad, float* metrics3, float metric_weight);
 int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch, int part);
 int mi_mlpvae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
-int mi_mlpvae_train_step(void* h, void* stream, const float* src, const float* tgt, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
-int mi_mlpvae_encode(void* h, void* stream, const float* src, const int* idx, int B, float* mean_out);
+int mi_mlpvae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
+int mi_mlpvae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_mlpvae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
-int mi_mlpvae_reconstruct(void* h, void* stream, const float* src, const int* idx, int B, const float* eps, int sample, float* recon_out);
+int mi_mlpvae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
 
 /* one environment step of the rollout loop in one call — vae_common.py:45-61 (encode_state) + ppo.py:231-251 (predict): raw uint8 frame [IH,IW,3] and
  * measurements -> out [num_actions + 1 + z_dim] = action | value | z; noise [num_actions] for sampling or NULL with greedy.  Exact fp32.

@@ -151,3 +151,66 @@ def test_mlp_vae_backward_in_two_parts_and_whole_step_call(tmp_path, precision):
     for a_, b_ in ((d.params, m2.dev.params), (d.adam_m, m2.dev.adam_m), (d.adam_v, m2.dev.adam_v), (d.weights_t, m2.dev.weights_t)):
         assert torch.equal(a_, b_)
     assert not torch.equal(d.params, torch.from_numpy(d._to_flat(params)).cuda())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_mlp_vae_uint8_frame_tables_equal_the_float_tables(tmp_path, precision):
+    """Round 5: the MlpVAE engine reads uint8 camera-byte tables (frames_u8 of mi_mlpvae_*; mi_gather_rows_cast_u8 where the minibatch rows are staged,
+    mi_bce_logits_fwd_bwd_u8 for the labels): float32(k) / float32(255) exactly, so two SGD steps through gathered minibatches give BITWISE the losses, posterior means
+    and parameters of the same steps on the float32 table of k / 255 (the reference's host preprocessing, vae/train_vae.py:15-18), in both storage modes; the op-level
+    entry points against numpy as well (row length with a scalar tail, unaligned rows)."""
+    from mi355 import lib as milib
+    L = milib.get()
+    rng = np.random.RandomState(4)
+    N, B = 40, 16
+    u8 = rng.randint(0, 256, (N, 80, 160, 3), dtype=np.uint8)
+    f32 = u8.astype(np.float32) / np.float32(255.0)
+    eps = rng.standard_normal((2, B, 64)).astype(np.float32)
+    idx = torch.from_numpy(np.stack([rng.permutation(N)[:B] for _ in range(2)]).astype(np.int32)).cuda()
+    params = _mlp_params(5, (80, 160, 3), (80, 160, 3), (64, 32), (32, 64))
+    res = []
+    for table in (u8, f32):
+        m = MlpVAE(np.array([80, 160, 3]), encoder_sizes=(64, 32), decoder_sizes=(32, 64), z_dim=64, model_dir=str(tmp_path / ("m_%s_%s" % (precision, table.dtype))),
+                   precision=precision, learning_rate=1e-4, seed=0)
+        m.set_weights(params)
+        m.init_session(init_logging=False)
+        t = m._frames(table, 38400, "src", keep_u8_ok=True)
+        assert t.dtype == (torch.uint8 if table.dtype == np.uint8 else torch.float32)
+        losses = []
+        for s in range(2):
+            m._train_minibatch(t, t, idx[s], B, 1.0 / B, m._eps(B, eps[s]))
+            losses.append(m.dev.losses.cpu().numpy().copy())
+        mean = torch.empty(B, 64, device="cuda")
+        m.dev.encode(t, idx[0], B, mean)
+        res.append((np.array(losses), mean.cpu().numpy(), m.dev.export_params()))
+        m.dev.close()
+    (l8, m8, p8), (lf, mf, pf) = res
+    assert np.array_equal(l8, lf) and np.array_equal(m8, mf)
+    for k in pf:
+        assert np.array_equal(p8[k], pf[k]), k
+    # op level: odd row length (scalar tail) and a gather; labels through the loss kernel
+    for row_len in (38400, 1003):
+        tab = rng.randint(0, 256, (7, row_len), dtype=np.uint8)
+        sel = np.array([5, 0, 6, 2], np.int32)
+        td, sd = torch.from_numpy(tab).cuda(), torch.from_numpy(sel).cuda()
+        for code, tt in ((milib.MI_F32, torch.float32), (milib.MI_BF16, torch.bfloat16)):
+            out = torch.empty(4, row_len, device="cuda", dtype=tt)
+            L.mi_gather_rows_cast_u8(torch.cuda.current_stream().cuda_stream, code, td.data_ptr(), sd.data_ptr(), 4, row_len, out.data_ptr())
+            want = torch.from_numpy(tab[sel].astype(np.float32) / np.float32(255.0)).to(tt)
+            assert torch.equal(out.cpu(), want), (row_len, code)
+    P, Bq = 38400, 3
+    logits = torch.from_numpy(rng.standard_normal((Bq, P)).astype(np.float32)).cuda()
+    lab8 = torch.from_numpy(rng.randint(0, 256, (5, P), dtype=np.uint8)).cuda()
+    labf = lab8.to(torch.float32) / 255.0
+    gi = torch.from_numpy(np.array([4, 1, 3], np.int32)).cuda()
+    nch = L.mi_recon_loss_chunks(P)
+    outs = []
+    for u in (True, False):
+        dl, part = torch.empty(Bq, P, device="cuda"), torch.empty(Bq * nch, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        if u:
+            L.mi_bce_logits_fwd_bwd_u8(st, milib.MI_F32, logits.data_ptr(), lab8.data_ptr(), gi.data_ptr(), P, Bq, P, 0, 1.0 / Bq, dl.data_ptr(), part.data_ptr())
+        else:
+            L.mi_bce_logits_fwd_bwd(st, milib.MI_F32, logits.data_ptr(), labf.data_ptr(), gi.data_ptr(), P, Bq, P, 0, 1.0 / Bq, dl.data_ptr(), part.data_ptr())
+        outs.append((dl.cpu().numpy(), part.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

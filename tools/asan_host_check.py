@@ -77,7 +77,7 @@ for dtype in (0, 1):
             assert not L.mi_mlpvae_create(ctypes.byref(d), 256, 256, 256, 256, 256, 256, 257, ws)            # workspace misaligned
 for bad in (mlp_desc(2), mlp_desc(1, enc=(500, 256)), mlp_desc(0, enc=()), mlp_desc(0, z=0), mlp_desc(0, S=38402)):
     assert L.mi_mlpvae_workspace_bytes(ctypes.byref(bad)) < 0 and b"unsupported" in L.cdll.mi_last_error()
-assert L.cdll.mi_mlpvae_forward(None, None, None, None, None, 4, 0.25, None, 0, 0, None, 0.0) != 0 and b"null handle" in L.cdll.mi_last_error()
+assert L.cdll.mi_mlpvae_forward(None, None, None, None, 0, None, 4, 0.25, None, 0, 0, None, 0.0) != 0 and b"null handle" in L.cdll.mi_last_error()
 assert L.mi_mlpvae_decoder_offset(None) == -1 and L.mi_mlpvae_buffer(None, 0) is None
 
 # ---- argument checks of the round-4 optimiser / staging launchers (every one of these returns before anything is launched) ----
