@@ -200,8 +200,9 @@ def test_mlp_vae_uint8_frame_tables_equal_the_float_tables(tmp_path, precision):
             assert torch.equal(out.cpu(), want), (row_len, code)
     P, Bq = 38400, 3
     logits = torch.from_numpy(rng.standard_normal((Bq, P)).astype(np.float32)).cuda()
-    lab8 = torch.from_numpy(rng.randint(0, 256, (5, P), dtype=np.uint8)).cuda()
-    labf = lab8.to(torch.float32) / 255.0
+    lab8_np = rng.randint(0, 256, (5, P), dtype=np.uint8)
+    lab8 = torch.from_numpy(lab8_np).cuda()
+    labf = torch.from_numpy(lab8_np.astype(np.float32) / np.float32(255.0)).cuda()      # the HOST quotient (correctly rounded; a device-side `t / 255.0` may multiply by a reciprocal)
     gi = torch.from_numpy(np.array([4, 1, 3], np.int32)).cuda()
     nch = L.mi_recon_loss_chunks(P)
     outs = []

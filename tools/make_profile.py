@@ -68,7 +68,12 @@ NAMES_R04 = [("ares_conv_kernel<4, 1>", None, "conv4.fwd / deconv1.dgrad"), ("ar
              ("adam_tf_layouts_kernel<bf16>", None, "adam (writes both weight layouts)")] \
     + [n for n in NAMES_R03 if n[2] not in R04_GONE]
 # round 5: the latent layers' filter gradients on the LDS-free kernel (both launches have 768 waves: one row, averaged)
-NAMES_R05 = [("dwgs_kernel<false>", None, "dense1.wgrad + heads.wgrad (same kernel and grid: averaged)")] + NAMES_R04
+# round 5: the slab sums of the filter gradients are two launches (the decoder's three layers behind deconv1's filter gradient, the encoder's three at the end of the pass);
+# the latent layers' filter gradients stay on the first-generation kernel (the LDS-free dwgs_kernel serves the MlpVAE's small layers only: DESIGN 3.15)
+NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gradients (mid-pass, filter-gradient queue's idle gap)"),
+             ("reduce_fused_kernel", "1568x1x1", "slab reduce, encoder filter gradients (end of pass)"),
+             ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "1x96x2", "dense1.wgrad (+ bias row)"), ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "49x2x2", "heads.wgrad (+ bias row)")] \
+    + [n for n in NAMES_R04 if n[0] != "reduce_fused_kernel"]
 NAMES = NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic = [], {}
 for kern, grid, op in NAMES:
