@@ -1,0 +1,208 @@
+// enc12_tile.hpp — the encoder head of a FORWARD pass as ONE kernel (round 5): conv1 (3 -> 32 channels, k4 s2, + bias + ReLU,
+// vae/models.py:250) computed straight into LDS and consumed there by conv2 (32 -> 64 channels, k4 s2, + bias + ReLU, vae/models.py:251).
+//
+// Unfused: conv1 (narrow_conv48_kernel) reads the frames (20 MB as camera bytes at batch 512) and writes its activation (111 MB bf16 + 12.6 MB ReLU bit words); conv2
+// (rwconv_conv_kernel) reads those 111 MB back.  Here a block owns a BAND of a frame -- 6 of the 18 output rows of conv2 = 14 rows of conv1's activation -- computes the
+// band's conv1 pixels with the loader / MFMA / epilogue of narrow_conv48_kernel (bit for bit the same activation and bit words), keeps them in LDS, and runs conv2 on
+// them with its 64 KB of weights in REGISTERS (a wave = one 32-output tile over all of K = 16 taps x 32 channels: 32 fragments = 128 VGPRs, the form of rwconv.hip).
+// conv1's activation is still WRITTEN (conv2's filter gradient reads it in the backward pass) -- every pixel by the band that owns it -- but never read back in the
+// forward pass: one launch and 100 MB of reads less on the serial forward chain.
+//
+// LDS: the band's activation as two PLANES (even / odd columns), [plane][row 0 .. 14][column / 2][32 channels] bf16 = 64 bytes per pixel, the 16-byte chunk c of pixel
+// index i stored at c ^ ((i >> 2) & 3): conv2's fragment reads (lane = output pixel, consecutive lanes = consecutive output columns = consecutive entries of ONE plane)
+// then cover all 64 banks per 16-lane group.  2 x 15 x 40 x 64 = 76,800 bytes: two blocks per CU.
+// Band r of a frame: conv2 rows 6 r .. 6 r + 5, conv1 rows 12 r .. 12 r + 13 (band 2 also row 38, which conv2 never reads but the activation tensor holds); rows
+// 12 r + 12, 12 r + 13 are computed twice (they are the next band's first two): 10 % more conv1 work, stored by their owner only.
+#pragma once
+#include "wgrad_tile.hpp"
+
+namespace mi {
+
+typedef uint32_t e12_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int E12_PW = 40;                                // pixels per plane row
+constexpr int E12_ROWS = 15;
+constexpr int E12_PLANE = E12_ROWS * E12_PW * 64;         // bytes
+constexpr int E12_LDS = 2 * E12_PLANE;                    // 76,800
+
+struct Enc12Params {
+    const void* frames; const int* frame_idx; long long frame_stride;   // [*, 80, 160, 3] camera bytes / fp32, elements per frame
+    const bf16_t* w1; const float* b1;                    // conv1: K-contiguous [32][48]
+    const bf16_t* w2; const float* b2;                    // conv2: K-contiguous [64][512], k = (kh * 4 + kw) * 32 + c
+    bf16_t* act1; uint32_t* bits1;                        // [B, 39, 79, 32]; ReLU bit words [B * 39 * 79][2] (may be NULL)
+    bf16_t* act2;                                         // [B, 18, 38, 64]
+    int B, ntiles;                                        // ntiles = 3 B
+};
+
+template <typename TS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc12_fwd_kernel(const Enc12Params p) {
+    constexpr int SSZ = (int)sizeof(TS), GSZ = 4 * SSZ, GDW = GSZ / 4;
+    constexpr int FW = 160, A1H = 39, A1W = 79, A2H = 18, A2W = 38;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[E12_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lgrp = lane >> 5;
+
+    // ---- per wave, once: conv1's weights (3 fragments), conv2's weights of this wave's 32-output tile (32 fragments), the biases as initial accumulators ----
+    const int nt = wave & 1, mh = wave >> 1;              // conv2: output tile (32 of 64 channels), half of the band's 8 position tiles
+    u16x8 wf1[3], wf2[32];
+    {
+        const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 32 * 48 * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 512 * 2, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wf1[s] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW1, (lrow * 48 + s * 16 + lgrp * 8) * 2, 0, 0));
+#pragma unroll
+        for (int f = 0; f < 32; ++f) wf2[f] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW2, ((nt * 32 + lrow) * 512 + f * 16 + lgrp * 8) * 2, 0, 0));
+    }
+    f32x16 acc1_0, acc2_0;                                // register r of a lane = channel (r & 3) + 8 (r >> 2) + 4 lgrp of the 32-channel tile
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 ba = *(const f32x4*)(p.b1 + 8 * qd + 4 * lgrp), bb = *(const f32x4*)(p.b2 + nt * 32 + 8 * qd + 4 * lgrp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc1_0[4 * qd + t] = ba[t]; acc2_0[4 * qd + t] = bb[t]; }
+    }
+    // frame patch of a conv1 pixel (the loader of narrow_conv48_kernel): group j = 2 s + gi of this lane: q = 4 s + gi (+ 2 for the upper half-wave) -> kernel row q / 3,
+    // value offset (q % 3) * 4
+    const uint32_t rowb = (uint32_t)(FW * 3 * SSZ);
+    uint32_t goff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int qa = 4 * (j >> 1) + (j & 1), qb = qa + 2;
+        goff[j] = lgrp ? (uint32_t)(qb / 3) * rowb + (uint32_t)((qb % 3) * GSZ) : (uint32_t)(qa / 3) * rowb + (uint32_t)((qa % 3) * GSZ);
+    }
+    struct Raw { uint32_t d[6][GDW]; };
+
+    const int G = (int)gridDim.x;
+    for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += G) {
+        const int b = tile / 3, band = tile - 3 * b;
+        const int y0 = 12 * band;                          // first conv1 row of the band
+        const int nrows = band == 2 ? 15 : 14;
+        const int npix = nrows * A1W;
+        const int own_rows = band == 2 ? 15 : 12;          // rows this band stores to HBM (the rest belong to the next band)
+        const int ngrp = (npix + 31) >> 5;
+        long long fr = b;
+        if (p.frame_idx) fr = p.frame_idx[b];
+        const unsigned char* fbase = (const unsigned char*)p.frames + fr * p.frame_stride * SSZ;
+
+        // ================= conv1: the band's pixels, 32 per wave step (groups wave, wave + 4, ...), loads two steps ahead =================
+        auto request = [&](int grp, Raw& r) {
+            const int pq = min(grp * 32 + lrow, npix - 1);  // pixels past the band recompute its last one; their stores are skipped
+            const int row = pq / A1W, col = pq - row * A1W;
+            const unsigned char* pix = fbase + (2 * (y0 + row) * FW + 2 * col) * 3 * SSZ;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
+#pragma unroll
+                for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
+            }
+        };
+        Raw r0, r1;
+        request(min(wave, ngrp - 1), r0);
+        request(min(wave + 4, ngrp - 1), r1);
+        for (int grp = wave; grp < ngrp; grp += 4) {
+            Raw cur = r0;
+            r0 = r1;
+            request(min(grp + 8, ngrp - 1), r1);
+            u16x8 xf[3];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                uint32_t* dst = (uint32_t*)&xf[j >> 1] + 2 * (j & 1);
+                float f[4];
+                if constexpr (SSZ == 1) {                  // camera bytes: k * (1 / 255), which rounds to the same bf16 as the exact quotient (common.hpp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = (float)((cur.d[j][0] >> (8 * e)) & 255u) * U8_RCP255;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, cur.d[j][e < GDW ? e : 0]);
+                }
+                const PackN<uint32_t, 2> h = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(f));
+                dst[0] = h.v[0]; dst[1] = h.v[1];
+            }
+            f32x16 acc = acc1_0;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, xf[s]), acc, 0, 0, 0);
+            // epilogue of narrow_conv48_kernel<., 0>: bf16, ReLU, half-wave exchange -> lane (pixel, g) owns channels 16 g .. 16 g + 15 as 8 dwords
+            uint32_t R[4][2];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+                const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+#pragma unroll
+                for (int d = 0; d < 2; ++d) { uint32_t u; asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d])); R[qd][d] = u; }
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
+                auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
+            }
+            const uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
+            const int pq = grp * 32 + lrow;
+            if (pq < npix) {
+                const int row = pq / A1W, col = pq - row * A1W;
+                // LDS: plane col & 1, entry row * 40 + col / 2, chunks 2 g and 2 g + 1 swizzled by the entry index
+                const int idx = col >> 1;
+                unsigned char* q = lds + (col & 1) * E12_PLANE + (row * E12_PW + idx) * 64;
+                const int sw = (idx >> 2) & 3;
+                *(e12_u32x4*)(q + (((2 * lgrp) ^ sw) << 4)) = e12_u32x4{o[0], o[1], o[2], o[3]};
+                *(e12_u32x4*)(q + (((2 * lgrp + 1) ^ sw) << 4)) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                if (row < own_rows) {                      // this band owns the pixel: the activation tensor and its ReLU bit words
+                    const long long m = ((long long)b * A1H + y0 + row) * A1W + col;
+                    unsigned char* g = (unsigned char*)p.act1 + m * 64 + lgrp * 32;
+                    *(e12_u32x4*)g = e12_u32x4{o[0], o[1], o[2], o[3]};
+                    *(e12_u32x4*)(g + 16) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                    if (p.bits1) {                         // bit d / bit 16 + d of the word: the two halves of dword d are non-zero (post-ReLU: positive)
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) { uint32_t nz; asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(o[d]), "v"(0x00010001u)); word |= nz << d; }
+                        p.bits1[m * 2 + lgrp] = word;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // the band's activation is in LDS
+
+        // ================= conv2: 6 x 38 outputs = 8 position tiles of 32 (the last one ragged); this wave: output tile nt, position tiles 4 mh .. 4 mh + 3 =================
+#pragma unroll 1
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oq = (mh * 4 + mt) * 32 + lrow;
+            const int oc = min(oq, 6 * A2W - 1);
+            const int oy = oc / A2W, ox = oc - oy * A2W;
+            f32x16 acc = acc2_0;
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int idx = ox + (kw >> 1);
+                    const unsigned char* q = lds + (kw & 1) * E12_PLANE + ((2 * oy + kh) * E12_PW + idx) * 64;
+                    const int sw = (idx >> 2) & 3;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const u16x8 bfr = *(const u16x8*)(q + (((2 * ks + lgrp) ^ sw) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf2[(kh * 4 + kw) * 2 + ks]), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
+                    }
+                }
+            uint32_t R[4][2];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+                const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+#pragma unroll
+                for (int d = 0; d < 2; ++d) { uint32_t u; asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d])); R[qd][d] = u; }
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
+                auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
+            }
+            if (oq < 6 * A2W) {
+                const long long m2 = ((long long)b * A2H + 6 * band + oy) * A2W + ox;
+                unsigned char* g = (unsigned char*)p.act2 + m2 * 128 + nt * 64 + lgrp * 32;
+                *(e12_u32x4*)g = e12_u32x4{R[0][0], R[0][1], R[2][0], R[2][1]};
+                *(e12_u32x4*)(g + 16) = e12_u32x4{R[1][0], R[1][1], R[3][0], R[3][1]};
+            }
+        }
+        __syncthreads();                                   // every wave is done with the band before the next one's conv1 overwrites it
+    }
+}
+
+}  // namespace mi

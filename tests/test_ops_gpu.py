@@ -1090,6 +1090,70 @@ def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     assert_close(host(db) + 0.25, db64, 2e-3, 5e-4 * float(np.abs(db64).max()), "conv1 bias gradient vs float64")
 
 
+@pytest.mark.parametrize("B", [1, 3, 37, 512])
+def test_encoder_head_forward_fused_equals_the_two_ops(B):
+    """Round 5 (enc12_tile.hpp): mi_conv2d_enc12_fwd -- conv1 computed band by band into LDS and consumed there by conv2, one launch --
+    against the two separately validated layer ops it replaces (mi_conv2d_nhwc_fwd_bits on camera bytes, mi_conv2d_nhwc_fwd on its output), frames gathered through a frame
+    index: conv1's activation and its ReLU bit words BIT FOR BIT (every pixel, incl. the row / column conv2 never reads and the rows two bands compute), conv2's output
+    against the float64 convolution of that stored bf16 activation and against the unfused kernel (same bf16 products, another fp32 summation order: a last-place flip of
+    the bf16 result now and then); garbage in every output buffer beforehand.  Batch 1, a ragged number of bands per resident block, and the benchmarked 512."""
+    import ctypes
+    L = milib.get()
+    code, td = DT["bf16"]
+    rng = np.random.RandomState(100 + B)
+    n_frames = B + 3
+    frames_u8 = rng.randint(0, 256, (n_frames, 80, 160, 3)).astype(np.uint8)
+    idx = rng.permutation(n_frames)[:B].astype(np.int32)
+    fr, idxd = dev(frames_u8, torch.uint8), dev(idx, torch.int32)
+    w1 = (rng.randn(4, 4, 3, 32) / np.sqrt(48)).astype(np.float32)
+    b1 = (0.1 * rng.randn(32)).astype(np.float32)
+    w2 = (rng.randn(4, 4, 32, 64) / np.sqrt(512)).astype(np.float32)
+    b2 = (0.1 * rng.randn(64)).astype(np.float32)
+    w1t = dev(torch.from_numpy(w1).permute(3, 0, 1, 2).reshape(32, -1).contiguous(), td)          # K-contiguous copies [N][K]
+    w2t = dev(torch.from_numpy(w2).permute(3, 0, 1, 2).reshape(64, -1).contiguous(), td)
+    b1d, b2d = dev(b1), dev(b2)
+    # --- the two ops ---
+    act1 = alloc(td, B, 39, 79, 32, fill=3.0)
+    bits = torch.full((B * 39 * 79 * 2,), 0x55, device="cuda", dtype=torch.int32)
+    wrote = np.zeros(1, np.int32)
+    L.mi_conv2d_nhwc_fwd_bits(stream(), code, fr.data_ptr(), idxd.data_ptr(), 2, B, 80, 160, 3, w1t.data_ptr(), 1, b1d.data_ptr(), 4, 4, 32, 1, act1.data_ptr(), bits.data_ptr(), wrote.ctypes.data)
+    torch.cuda.synchronize()
+    assert wrote[0] == 1
+    act2 = alloc(td, B, 18, 38, 64, fill=3.0)
+    L.mi_conv2d_nhwc_fwd(stream(), code, act1.data_ptr(), None, 0, B, 39, 79, 32, w2t.data_ptr(), 1, b2d.data_ptr(), 4, 4, 64, 1, act2.data_ptr())
+    # --- one launch ---
+    f_act1 = alloc(td, B, 39, 79, 32, fill=-7.0)
+    f_bits = torch.full((B * 39 * 79 * 2,), 0x33, device="cuda", dtype=torch.int32)
+    f_act2 = alloc(td, B, 18, 38, 64, fill=-7.0)
+    launched = ctypes.c_int(0)
+    L.mi_conv2d_enc12_fwd(stream(), code, fr.data_ptr(), 2, idxd.data_ptr(), B, 80, 160, w1t.data_ptr(), b1d.data_ptr(), w2t.data_ptr(), b2d.data_ptr(),
+                          f_act1.data_ptr(), f_bits.data_ptr(), f_act2.data_ptr(), ctypes.addressof(launched))
+    torch.cuda.synchronize()
+    assert launched.value == 1
+    assert torch.equal(f_act1.view(torch.int16), act1.view(torch.int16)), "conv1 activation: fused vs layer op, bit for bit"
+    assert torch.equal(f_bits, bits), "ReLU bit words: fused vs layer op"
+    a2, r2 = host(f_act2), host(act2)
+    scale = float(np.abs(r2).max())
+    assert scale > 0.1
+    assert_close(a2, r2, 2.0 ** -7, 2.0 ** -8 * scale, "conv2 output: fused vs layer op (bf16 results of two fp32 summation orders)")
+    assert (a2 >= 0).all() and (a2 == 0).mean() > 0.05, "ReLU"
+    # without the bit words (inference): same tensors
+    g_act1, g_act2 = alloc(td, B, 39, 79, 32, fill=-7.0), alloc(td, B, 18, 38, 64, fill=-7.0)
+    L.mi_conv2d_enc12_fwd(stream(), code, fr.data_ptr(), 2, idxd.data_ptr(), B, 80, 160, w1t.data_ptr(), b1d.data_ptr(), w2t.data_ptr(), b2d.data_ptr(),
+                          g_act1.data_ptr(), None, g_act2.data_ptr(), ctypes.addressof(launched))
+    assert torch.equal(g_act1.view(torch.int16), act1.view(torch.int16)) and torch.equal(g_act2.view(torch.int16), f_act2.view(torch.int16))
+    # not eligible: fp32 frames, another geometry -> nothing launched, nothing touched
+    L.mi_conv2d_enc12_fwd(stream(), code, fr.data_ptr(), 1, idxd.data_ptr(), B, 80, 160, w1t.data_ptr(), b1d.data_ptr(), w2t.data_ptr(), b2d.data_ptr(),
+                          g_act1.data_ptr(), None, g_act2.data_ptr(), ctypes.addressof(launched))
+    assert launched.value == 0
+    if B > 37:
+        return                                              # (the float64 statement is a CPU conv over the whole batch: the small batches carry it)
+    x = torch.from_numpy(host(act1).astype(np.float64)).permute(0, 3, 1, 2)
+    w2b = torch.from_numpy(host(w2t).astype(np.float64)).reshape(64, 4, 4, 32).permute(0, 3, 1, 2)      # [n][kh][kw][c] -> [n][c][kh][kw]
+    ref = torch.nn.functional.conv2d(x, w2b, torch.from_numpy(b2.astype(np.float64)), stride=2).clamp_min(0).permute(0, 2, 3, 1).numpy()
+    assert_close(a2, ref, 2.0 ** -8, 2.0 ** -9 * scale, "conv2 output vs the float64 convolution of the stored activation")
+
+
 @pytest.mark.parametrize("geom", [(39, 79, 32, 64), (18, 38, 64, 128)])
 def test_bf16_partial_sum_slabs_error_bound_at_batch_512(geom):
     """the bf16 engine stores the position-split partial sums of its raw-staged filter gradients rounded to bf16 (mi_set_tuning key 18).  What that costs,
