@@ -6,30 +6,31 @@
 
 using namespace mi;
 
-static int enc12_grid() {
-    static int resident = 0;
-    if (!resident) {
+static int enc12_grid(int u8) {
+    static int resident[2];
+    if (!resident[u8]) {
         int per_cu = 0, dev = 0, cus = 256;
         hipDeviceProp_t pr;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)enc12_fwd_kernel<unsigned char>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        const void* fn = u8 ? (const void*)enc12_fwd_kernel<unsigned char> : (const void*)enc12_fwd_kernel<float>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-        resident = per_cu * cus;
+        resident[u8] = per_cu * cus;
     }
-    return resident;
+    return resident[u8];
 }
 
-// The encoder head of a forward pass in ONE launch (round 5): frames [*, 80, 160, 3] as raw uint8 camera bytes (optionally gathered through frame_idx) -conv1 k4 s2 + bias +
+// The encoder head of a forward pass in ONE launch (round 5): frames [*, 80, 160, 3] as raw uint8 camera bytes (frames_fmt 2) or float32 in [0, 1] (1), optionally gathered through frame_idx, -conv1 k4 s2 + bias +
 // ReLU-> act1 [B, 39, 79, 32] -conv2 k4 s2 + bias + ReLU-> act2 [B, 18, 38, 64], bf16 storage.  w1_t / w2_t: the K-contiguous kernel copies ([32][48] and [64][512]);
 // act1 and (optionally) its ReLU bit words are written exactly as mi_conv2d_nhwc_fwd_bits writes them (bit for bit), act2 as conv2 of that activation with fp32 accumulation
-// (another summation order than the unfused kernel).  *launched = 0: not eligible -- bf16 storage, uint8 frames and this geometry only; nothing was launched: call the two layer ops.
+// (another summation order than the unfused kernel).  *launched = 0: not eligible -- bf16 storage and this geometry only; nothing was launched: call the two layer ops.
 extern "C" int mi_conv2d_enc12_fwd(void* stream, int dtype, const void* frames, int frames_fmt, const int* frame_idx, int B, int FH, int FW, const void* w1_t, const float* b1,
                                    const void* w2_t, const float* b2, void* act1, void* relu_bits1, void* act2, int* launched) {
     if (!launched || !frames || !w1_t || !b1 || !w2_t || !b2 || !act1 || !act2) return mi_fail(MI_ERR_ARG, "mi_conv2d_enc12_fwd: missing buffers");
     *launched = 0;
     static int on = -1;
     if (on < 0) { const char* e = getenv("MI355_ENC12"); on = (e && e[0] == '0') ? 0 : 1; }
-    if (!on || !mi_narrow_enabled() || dtype != MI_BF16 || frames_fmt != 2 || B < 1 || FH != 80 || FW != 160) return MI_OK;
-    if ((((uintptr_t)frames) & 1) || (((uintptr_t)w1_t) | ((uintptr_t)w2_t) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)act1) | ((uintptr_t)act2)) & 15) return MI_OK;
+    if (!on || !mi_narrow_enabled() || dtype != MI_BF16 || (frames_fmt != 1 && frames_fmt != 2) || B < 1 || FH != 80 || FW != 160) return MI_OK;
+    if ((((uintptr_t)frames) & (frames_fmt == 2 ? 1 : 7)) || (((uintptr_t)w1_t) | ((uintptr_t)w2_t) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)act1) | ((uintptr_t)act2)) & 15) return MI_OK;
     if (relu_bits1 && (((uintptr_t)relu_bits1) & 3)) return MI_OK;
     if ((long long)B * 3 >= (1ll << 30)) return MI_OK;
     Enc12Params q = {};
@@ -37,9 +38,10 @@ extern "C" int mi_conv2d_enc12_fwd(void* stream, int dtype, const void* frames, 
     q.w1 = (const bf16_t*)w1_t; q.b1 = b1; q.w2 = (const bf16_t*)w2_t; q.b2 = b2;
     q.act1 = (bf16_t*)act1; q.bits1 = (uint32_t*)relu_bits1; q.act2 = (bf16_t*)act2;
     q.B = B; q.ntiles = 3 * B;
-    int nblocks = enc12_grid();
+    int nblocks = enc12_grid(frames_fmt == 2 ? 1 : 0);
     if (nblocks > q.ntiles) nblocks = q.ntiles;
-    MI_LAUNCH(enc12_fwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    if (frames_fmt == 2) MI_LAUNCH(enc12_fwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    else MI_LAUNCH(enc12_fwd_kernel<float>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     const int rc = mi_check_launch("enc12_fwd_kernel");
     if (rc == MI_OK) *launched = 1;
     return rc;

@@ -96,13 +96,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
             }
         };
+        // (camera bytes: two steps ahead, 6 registers per step; fp32 frames hold 24 per step: one step ahead keeps the kernel at two waves per SIMD without spills)
+        constexpr bool DEEP = SSZ == 1;
         Raw r0, r1;
         request(min(wave, ngrp - 1), r0);
-        request(min(wave + 4, ngrp - 1), r1);
+        if constexpr (DEEP) request(min(wave + 4, ngrp - 1), r1);
         for (int grp = wave; grp < ngrp; grp += 4) {
             Raw cur = r0;
-            r0 = r1;
-            request(min(grp + 8, ngrp - 1), r1);
+            if constexpr (DEEP) { r0 = r1; request(min(grp + 8, ngrp - 1), r1); }
+            else request(min(grp + 4, ngrp - 1), r0);
             u16x8 xf[3];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {

@@ -277,12 +277,12 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
     e->bits1_ok = 0;
     for (int i = 0; i < NCONV; ++i) {
         const void* x = i == 0 ? frames : e->at(e->W.act[i]);
-        if (i == 0 && frames_u8 && d.dtype == MI_BF16 && g.c[1] == 32 && g.c[2] == 64 && e->tm.mode != 1) {
+        if (i == 0 && d.dtype == MI_BF16 && g.c[1] == 32 && g.c[2] == 64 && e->tm.mode != 1) {
             // round 5: conv1 + conv2 as ONE launch (enc12_tile.hpp): conv1's activation stays in LDS for conv2 (it is still written for the backward pass, never read back here).
             // (per-op timing keeps the two layer launches: they are what the profile names)
             const bool bits12 = want_bits && relu_bits_enabled();
             int launched = 0;
-            TOP(e, st, OP_CONV_FWD + 1, mi_conv2d_enc12_fwd(st, d.dtype, frames, 2, idx, B, g.ih[0], g.iw[0], e->wtptr(0), e->bptr(1), e->wtptr(2), e->bptr(3),
+            TOP(e, st, OP_CONV_FWD + 1, mi_conv2d_enc12_fwd(st, d.dtype, frames, frames_u8 ? 2 : 1, idx, B, g.ih[0], g.iw[0], e->wtptr(0), e->bptr(1), e->wtptr(2), e->bptr(3),
                                                          e->at(e->W.act[1]), bits12 ? e->at(e->W.bits_act1) : nullptr, e->at(e->W.act[2]), &launched));
             if (launched) { if (bits12) e->bits1_ok = 1; i = 1; continue; }
         }

@@ -163,11 +163,11 @@ int mi_deconv2d_tail_reduce(void* stream, const void* scratch, int n_partial, fl
  * mi_conv2d_nhwc_dgrad_bits and mi_conv2d_nhwc_wgrad_ws).  scratch: >= mi_conv2d_head_bwd_blocks() * 8320 bytes. */
 int mi_conv2d_head_bwd_blocks(void);
 int mi_conv2d_head_bwd_fused(void* stream, int dtype, const void* frames, int frames_fmt, const int* frame_idx, int B, int FH, int FW, const void* dy2, const void* w2, const void* bits_act1, float* dw1, float* db1, void* scratch, long long scratch_bytes, int* n_blocks);
-/* The encoder head of a FORWARD pass in ONE launch (round 5, csrc/enc12_tile.hpp; replaces the two tf.layers.conv2d of vae/models.py:250-251): uint8 camera frames
- * [*, 80, 160, 3] (frames_fmt 2; optionally gathered through frame_idx) -conv1 k4 s2 + bias + ReLU-> act1 [B, 39, 79, 32] kept in LDS -conv2 k4 s2 + bias + ReLU-> act2
+/* The encoder head of a FORWARD pass in ONE launch (round 5, csrc/enc12_tile.hpp; replaces the two tf.layers.conv2d of vae/models.py:250-251): frames
+ * [*, 80, 160, 3] as uint8 camera bytes (frames_fmt 2) or float32 (1), optionally gathered through frame_idx, -conv1 k4 s2 + bias + ReLU-> act1 [B, 39, 79, 32] kept in LDS -conv2 k4 s2 + bias + ReLU-> act2
  * [B, 18, 38, 64].  w1_t / w2_t: the K-contiguous kernel copies [32][48] / [64][512] (mi_transpose_weights).  act1 and (relu_bits1 != NULL) its ReLU bit words are still
  * written, bit for bit as mi_conv2d_nhwc_fwd_bits writes them (the backward pass reads them); act2 = conv2 of that activation.  *launched = 0: not eligible (bf16 storage,
- * uint8 frames, this geometry only; nothing was launched: call mi_conv2d_nhwc_fwd_bits and mi_conv2d_nhwc_fwd). */
+ * this geometry only; nothing was launched: call mi_conv2d_nhwc_fwd_bits and mi_conv2d_nhwc_fwd). */
 int mi_conv2d_enc12_fwd(void* stream, int dtype, const void* frames, int frames_fmt, const int* frame_idx, int B, int FH, int FW, const void* w1_t, const float* b1, const void* w2_t, const float* b2, void* act1, void* relu_bits1, void* act2, int* launched);
 /* The four SMALL-GRID layers of the ConvVAE on the activation-resident kernels (round 4, csrc/ares_tile.hpp): a block keeps the whole inputs of a group of frames
  * in LDS and streams fragment-ordered weights through registers.  form 0 (conv form, k4 s2, [B,8,18,128] -> [B,3,8,256]): conv4 forward (vae/models.py:253) and
