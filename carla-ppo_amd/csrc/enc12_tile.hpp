@@ -73,38 +73,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     struct Raw { uint32_t d[6][GDW]; };
 
     const int G = (int)gridDim.x;
-    for (int tile = (int)blockIdx.x; tile < p.ntiles; tile += G) {
-        const int b = tile / 3, band = tile - 3 * b;
-        const int y0 = 12 * band;                          // first conv1 row of the band
-        const int nrows = band == 2 ? 15 : 14;
-        const int npix = nrows * A1W;
-        const int own_rows = band == 2 ? 15 : 12;          // rows this band stores to HBM (the rest belong to the next band)
-        const int ngrp = (npix + 31) >> 5;
-        long long fr = b;
-        if (p.frame_idx) fr = p.frame_idx[b];
-        const unsigned char* fbase = (const unsigned char*)p.frames + fr * p.frame_stride * SSZ;
+    // a band: frame b, band index, first conv1 row, rows / pixels / 32-pixel groups, and where its frame starts
+    struct Band { int b, band, y0, npix, own_rows, ngrp; const unsigned char* fbase; };
+    auto band_of = [&](int tile) -> Band {
+        Band q;
+        q.b = tile / 3; q.band = tile - 3 * q.b; q.y0 = 12 * q.band;
+        const int nrows = q.band == 2 ? 15 : 14;
+        q.npix = nrows * A1W; q.own_rows = q.band == 2 ? 15 : 12;      // rows this band stores to HBM (the rest belong to the next band)
+        q.ngrp = (q.npix + 31) >> 5;
+        long long fr = q.b;
+        if (p.frame_idx) fr = p.frame_idx[q.b];
+        q.fbase = (const unsigned char*)p.frames + fr * p.frame_stride * SSZ;
+        return q;
+    };
+    auto request = [&](const Band& q, int grp, Raw& r) {
+        const int pq = min(grp * 32 + lrow, q.npix - 1);   // pixels past the band recompute its last one; their stores are skipped
+        const int row = pq / A1W, col = pq - row * A1W;
+        const unsigned char* pix = q.fbase + (2 * (q.y0 + row) * FW + 2 * col) * 3 * SSZ;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
+#pragma unroll
+            for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
+        }
+    };
+    // (camera bytes: two steps ahead, 6 registers per step; fp32 frames hold 24 per step: one step ahead keeps the kernel at two waves per SIMD without spills)
+    constexpr bool DEEP = SSZ == 1;
+    Raw r0, r1;
+    int tile = (int)blockIdx.x;
+    if (tile >= p.ntiles) return;                          // (block-uniform)
+    Band cb = band_of(tile);
+    request(cb, min(wave, cb.ngrp - 1), r0);
+    if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+    for (; tile < p.ntiles; tile += G) {
+        const int b = cb.b, band = cb.band, y0 = cb.y0, npix = cb.npix, own_rows = cb.own_rows, ngrp = cb.ngrp;
 
-        // ================= conv1: the band's pixels, 32 per wave step (groups wave, wave + 4, ...), loads two steps ahead =================
-        auto request = [&](int grp, Raw& r) {
-            const int pq = min(grp * 32 + lrow, npix - 1);  // pixels past the band recompute its last one; their stores are skipped
-            const int row = pq / A1W, col = pq - row * A1W;
-            const unsigned char* pix = fbase + (2 * (y0 + row) * FW + 2 * col) * 3 * SSZ;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
-#pragma unroll
-                for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
-            }
-        };
-        // (camera bytes: two steps ahead, 6 registers per step; fp32 frames hold 24 per step: one step ahead keeps the kernel at two waves per SIMD without spills)
-        constexpr bool DEEP = SSZ == 1;
-        Raw r0, r1;
-        request(min(wave, ngrp - 1), r0);
-        if constexpr (DEEP) request(min(wave + 4, ngrp - 1), r1);
+        // ================= conv1: the band's pixels, 32 per wave step (groups wave, wave + 4, ...), loads two steps ahead (the first ones were requested before the
+        // previous band's conv2 stage) =================
         for (int grp = wave; grp < ngrp; grp += 4) {
             Raw cur = r0;
-            if constexpr (DEEP) { r0 = r1; request(min(grp + 8, ngrp - 1), r1); }
-            else request(min(grp + 4, ngrp - 1), r0);
+            if constexpr (DEEP) { r0 = r1; if (grp + 8 < ngrp) request(cb, grp + 8, r1); }      // (wave-uniform branches: nothing is requested past the band)
+            else { if (grp + 4 < ngrp) request(cb, grp + 4, r0); }
             u16x8 xf[3];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -162,6 +171,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __syncthreads();                                   // the band's activation is in LDS
+        if (tile + G < p.ntiles) {                         // the NEXT band's first patch loads fly under this band's conv2 stage (block-uniform)
+            cb = band_of(tile + G);
+            request(cb, min(wave, cb.ngrp - 1), r0);
+            if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+        }
 
         // ================= conv2: 6 x 38 outputs = 8 position tiles of 32 (the last one ragged); this wave: output tile nt, position tiles 4 mh .. 4 mh + 3 =================
 #pragma unroll 1
