@@ -380,6 +380,10 @@ constexpr int AL_MAX = 16;
 struct AdamLayoutJobs {
     long long off[AL_MAX]; int K[AL_MAX], N[AL_MAX], tile0[AL_MAX + 1]; int count;          // the 2-D kernels: tiles tile0[t] .. tile0[t + 1]
     unsigned no_shadow, no_wt;                                                              // bit t: kernel t has no storage-type copy / no K-contiguous copy (nobody reads it)
+    // round 5: up to two FRAGMENT-ORDERED bf16 copies per kernel for the activation-resident convolutions (ares_tile.hpp: form 0 conv form / 1 gather form of a
+    // [16 x 128][256] kernel, 2 gather form of a [16 x 64][128] kernel) -- 16-byte granules of the tile this block holds in LDS anyway, written from there: the separate
+    // ares_pack launch (5.6 us + a kernel boundary at the head of every step) is gone.  form < 0: none
+    bf16_t* frag[AL_MAX][2]; signed char fform[AL_MAX][2];
     long long foff[AL_MAX], fn[AL_MAX]; int fblk0[AL_MAX + 1]; int fcount;                 // flat ranges: 1,024 elements per block
 };
 
@@ -449,6 +453,41 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
         for (int q = 0; q < 4; ++q) tile[r * PITCH + c4 + q] = Elem<TT>::from_f32(pv[q]);
     }
     __syncthreads();
+    if constexpr (sizeof(TT) == 2) {
+        // fragment-ordered copies (see AdamLayoutJobs::frag; index maps = ares_pack_kernel's, inverted): 512 granules of 8 values per tile and copy, two per thread
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16_t* const fr = jb.frag[t][q];
+            const int form = jb.fform[t][q];
+            if (!fr || form < 0) continue;                // (block-uniform)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int gi = tid + 256 * it;
+                u16x8 o;
+                long long G;
+                if (form == 0) {                           // 8 consecutive k of one column n: dst granule ((n >> 5) * 128 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)
+                    const int nl = gi & 63, kl = (gi >> 6) << 3;
+                    const int n = n0 + nl, k = k0 + kl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = tile[(kl + e) * PITCH + nl];
+                    G = ((long long)((n >> 5) * 128 + (k >> 4))) * 64 + ((k >> 3) & 1) * 32 + (n & 31);
+                } else {                                   // 8 consecutive n of one row k = (kh * 4 + kw) * C + nt * 32 + lo
+                    const int r = gi >> 3, nl = (gi & 7) << 3;
+                    const int k = k0 + r, n = n0 + nl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = tile[r * PITCH + nl + e];
+                    const int csh = form == 1 ? 7 : 6;     // C = 128 | 64 rows per tap
+                    const int tapi = k >> csh, cc = k & ((1 << csh) - 1);
+                    const int kh = tapi >> 2, kw = tapi & 3;
+                    const int cls = (kh & 1) * 2 + (kw & 1), tap = (kh >> 1) * 2 + (kw >> 1);
+                    const int nt = cc >> 5, lo = cc & 31, l = ((n >> 3) & 1) * 32 + lo;
+                    if (form == 1) G = ((long long)((cls * 4 + nt) * 64 + tap * 16 + (n >> 4))) * 64 + l;
+                    else G = ((long long)(cls * 64 + nt * 32 + tap * 8 + (n >> 4))) * 64 + l;
+                }
+                *(u16x8*)(fr + G * 8) = o;
+            }
+        }
+    }
     if (!wt || ((jb.no_wt >> t) & 1u)) return;
     // wt[off + n * K + k]: thread (n = tid >> 2, quarter = tid & 3) writes 16 consecutive k of its row
     const int nn = tid >> 2, kq = (tid & 3) << 4;
@@ -835,6 +874,13 @@ int mi_u8_to_unit_f32(void* stream, const unsigned char* src, float* dst, long l
 // the first layer of an encoder has no input gradient).  Same arithmetic as mi_adam_tf_flat: bit-identical p / m / v.
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count,
                        float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad) {
+    return mi_adam_tf_layouts_frag(stream, dtype, param, m, v, grad, n, offsets, K, N, skip, count, alpha, alpha_dev, beta1, beta2, epsilon, shadow, wt, clear_grad, nullptr, nullptr);
+}
+
+// same + fragment-ordered bf16 copies of some of the kernels (frag_ptrs[2 * i + q], frag_forms[2 * i + q] for kernel i, q = 0, 1; NULL / -1 = none; bf16 storage only): what
+// mi_ares_pack_weights writes, emitted by the optimiser launch itself (round 5)
+int mi_adam_tf_layouts_frag(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count,
+                            float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad, void* const* frag_ptrs, const int* frag_forms) {
     if (dtype != MI_F32 && dtype != MI_BF16) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: dtype must be MI_F32 or MI_BF16");
     if (count < 0 || count > AL_MAX) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: 0 <= count <= 16");
     if ((((uintptr_t)param) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad)) & 15) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts: buffers must be 16-byte aligned");
@@ -857,6 +903,14 @@ int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v
         jb.off[i] = offsets[i]; jb.K[i] = K[i]; jb.N[i] = N[i]; jb.tile0[i] = tiles;
         if (skip && (skip[i] & 1)) jb.no_shadow |= 1u << i;
         if (skip && (skip[i] & 2)) jb.no_wt |= 1u << i;
+        for (int q = 0; q < 2; ++q) {
+            jb.frag[i][q] = nullptr; jb.fform[i][q] = -1;
+            if (!frag_ptrs || !frag_forms || !frag_ptrs[2 * i + q]) continue;
+            const int form = frag_forms[2 * i + q];
+            const bool shape_ok = (form == 0 || form == 1) ? (K[i] == 2048 && N[i] == 256) : (form == 2 && K[i] == 1024 && N[i] == 128);
+            if (dtype != MI_BF16 || !shape_ok || (((uintptr_t)frag_ptrs[2 * i + q]) & 15)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts_frag: fragment copies are bf16, 16-byte aligned, form 0 | 1 of a [2048, 256] kernel or form 2 of a [1024, 128] kernel");
+            jb.frag[i][q] = (bf16_t*)frag_ptrs[2 * i + q]; jb.fform[i][q] = (signed char)form;
+        }
         tiles += ((K[i] + 63) / 64) * ((N[i] + 63) / 64);
         pos = offsets[i] + sz;
     }

@@ -343,21 +343,30 @@ int kernel_table(const VaeEngine* e, long long* off, int* K, int* N) {
     return n;
 }
 
-// have_wt: the K-contiguous copies were already written (by the optimiser launch itself, mi_adam_tf_layouts)
-int refresh_transposed(VaeEngine* e, void* st, bool have_wt = false) {
+// the activation-resident kernels take this model (bf16 storage, the reference's geometry); *mid: also the mid-layer gather form (conv3's input gradient, deconv2 forward)
+bool ares_eligible(const VaeEngine* e, bool* mid) {
     const Geom& g = e->g; const MiVaeDesc& d = e->d;
+    static int ares_on = -1;
+    if (ares_on < 0) { const char* ev = getenv("MI355_ARES"); ares_on = (ev && ev[0] == '0') ? 0 : 1; }
+    const bool ok = ares_on && d.dtype == MI_BF16 && g.ih[3] == 8 && g.iw[3] == 18 && g.c[3] == 128 && g.c[4] == 256 && g.dh[0] == 3 && g.dw[0] == 8 && g.dc[0] == 256 && g.dc[1] == 128 && DEC_K[0] == 4;
+    if (mid) *mid = ok && g.c[2] == 64 && g.c[3] == 128 && g.dc[1] == 128 && g.dc[2] == 64 && DEC_K[1] == 4;
+    return ok;
+}
+
+// have_wt: the K-contiguous copies were already written (by the optimiser launch itself, mi_adam_tf_layouts); have_frag: ... and the fragment-ordered copies as well (round 5)
+int refresh_transposed(VaeEngine* e, void* st, bool have_wt = false, bool have_frag = false) {
+    const MiVaeDesc& d = e->d;
     long long off[10]; int K[10], N[10];
     const int n = kernel_table(e, off, K, N);
     if (!have_wt) CK(mi_transpose_weights(st, d.dtype, e->params, e->wt, off, K, N, n));
     e->ares_ok = 0; e->ares_mid = 0;
-    static int ares_on = -1;
-    if (ares_on < 0) { const char* ev = getenv("MI355_ARES"); ares_on = (ev && ev[0] == '0') ? 0 : 1; }
-    if (ares_on && d.dtype == MI_BF16 && g.ih[3] == 8 && g.iw[3] == 18 && g.c[3] == 128 && g.c[4] == 256 && g.dh[0] == 3 && g.dw[0] == 8 && g.dc[0] == 256 && g.dc[1] == 128 && DEC_K[0] == 4) {
+    bool mid = false;
+    if (ares_eligible(e, &mid)) {
         // conv4's kernel: HWIO [4][4][128][256]; deconv1's kernel: [kh][kw][out = 128][in = 256] -- the same [16][128][256] shape, read either way (ares.hip)
         // wfrag: 0 conv4 forward, 1 conv4 input gradient, 2 deconv1 forward, 3 deconv1 input gradient -- one launch
-        const bool mid = g.c[2] == 64 && g.c[3] == 128 && g.dc[1] == 128 && g.dc[2] == 64 && DEC_K[1] == 4;      // (4: conv3 input gradient, 5: deconv2 forward)
-        CK(mi_ares_pack_weights6(st, e->params + e->L.off[6], e->params + e->L.off[12], mid ? e->params + e->L.off[4] : nullptr, mid ? e->params + e->L.off[14] : nullptr,
-                                 e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3]), mid ? e->at(e->W.wfrag[4]) : nullptr, mid ? e->at(e->W.wfrag[5]) : nullptr));
+        if (!have_frag)
+            CK(mi_ares_pack_weights6(st, e->params + e->L.off[6], e->params + e->L.off[12], mid ? e->params + e->L.off[4] : nullptr, mid ? e->params + e->L.off[14] : nullptr,
+                                     e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3]), mid ? e->at(e->W.wfrag[4]) : nullptr, mid ? e->at(e->W.wfrag[5]) : nullptr));
         e->ares_mid = mid ? 1 : 0;
         e->ares_ok = 1;
     }
@@ -468,6 +477,7 @@ void* mi_vae_buffer(void* h, int which) {
         case 3: return e->at(e->W.kl_row);
         case 4: return e->at(e->W.dec[4]);
         case 5: return e->at(e->W.z);
+        case 6: case 7: case 8: case 9: case 10: case 11: return e->ares_ok ? e->at(e->W.wfrag[which - 6]) : nullptr;      // the fragment-ordered weight copies (tests)
         default: return nullptr;
     }
 }
@@ -852,9 +862,22 @@ static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alph
     if (layouts_on && e->d.dtype != MI_BF16X3) {
         long long off[10]; int K[10], N[10];
         const int n = kernel_table(e, off, K, N);
-        TOP(e, stream, OP_ADAM, mi_adam_tf_layouts(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, nullptr, n, alpha, alpha_dev, beta1, beta2, epsilon,
-                                                   e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 1));
-        return refresh_transposed(e, stream, true);
+        // round 5: the fragment-ordered copies of conv4 / deconv1 (/ conv3 / deconv2) for the activation-resident kernels come out of the same launch (MI355_ADAM_FRAG=0: the
+        // separate ares_pack launch behind it, 5.6 us + a boundary at the head of the next step)
+        static int frag_on = -1;
+        if (frag_on < 0) { const char* ev = getenv("MI355_ADAM_FRAG"); frag_on = (ev && ev[0] == '0') ? 0 : 1; }
+        void* fp[20]; int ff[20];
+        for (int i = 0; i < 20; ++i) { fp[i] = nullptr; ff[i] = -1; }
+        bool mid = false;
+        const bool frag = frag_on && ares_eligible(e, &mid) && n == 10;
+        if (frag) {      // kernel table: 0-3 conv1-4, 4 heads, 5 dense1, 6-9 deconv1-4
+            fp[2 * 3] = e->at(e->W.wfrag[0]); ff[2 * 3] = 0; fp[2 * 3 + 1] = e->at(e->W.wfrag[1]); ff[2 * 3 + 1] = 1;      // conv4: forward (conv form), input gradient (gather form)
+            fp[2 * 6] = e->at(e->W.wfrag[2]); ff[2 * 6] = 1; fp[2 * 6 + 1] = e->at(e->W.wfrag[3]); ff[2 * 6 + 1] = 0;      // deconv1: forward (gather form), input gradient (conv form)
+            if (mid) { fp[2 * 2] = e->at(e->W.wfrag[4]); ff[2 * 2] = 2; fp[2 * 7] = e->at(e->W.wfrag[5]); ff[2 * 7] = 2; }  // conv3 input gradient, deconv2 forward
+        }
+        TOP(e, stream, OP_ADAM, mi_adam_tf_layouts_frag(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, nullptr, n, alpha, alpha_dev, beta1, beta2, epsilon,
+                                                        e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 1, frag ? fp : nullptr, frag ? ff : nullptr));
+        return refresh_transposed(e, stream, true, frag);
     }
     TOP(e, stream, OP_ADAM, mi_adam_tf_flat_shadow(stream, e->params, e->m, e->v, e->grads, e->L.total, alpha, alpha_dev, beta1, beta2, epsilon,
                                                    e->d.dtype != MI_F32 ? e->shadow : nullptr, e->d.dtype == MI_BF16X3 ? MI_BF16X3 : MI_BF16, 1));

@@ -23,7 +23,7 @@ _CTYPES = {
     "int": ctypes.c_int, "unsigned int": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
     "long long*": ctypes.c_void_p, "const long long*": ctypes.c_void_p, "void": None,
     "unsigned long long": ctypes.c_ulonglong, "unsigned long long*": ctypes.c_void_p,
-    "void**": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
+    "void**": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p, "void* const*": ctypes.c_void_p, "void*const*": ctypes.c_void_p,
     "const MiVaeDesc*": ctypes.c_void_p, "const MiPpoDesc*": ctypes.c_void_p, "const MiMlpVaeDesc*": ctypes.c_void_p,
 }
 

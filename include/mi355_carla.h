@@ -243,6 +243,10 @@ int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float
  * mi_transpose_weights writes; may be NULL).  dtype MI_F32 | MI_BF16 = element type of both copies.  skip (may be NULL): per kernel, bit 0 = do not write its shadow
  * copy, bit 1 = do not write its K-contiguous copy (copies that nobody reads).  Bit-identical p / m / v to mi_adam_tf_flat. */
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
+/* same + FRAGMENT-ORDERED bf16 copies of some kernels for the activation-resident convolutions (round 5): frag_ptrs[2 i + q] / frag_forms[2 i + q], q = 0, 1, for kernel i -- what
+ * mi_ares_pack_weights(form, master kernel) writes (form 0 | 1: a [2048, 256] kernel, 2: a [1024, 128] kernel), emitted by the optimiser launch from the tile it holds anyway;
+ * NULL pointer = none.  Both arrays may be NULL (= mi_adam_tf_layouts). */
+int mi_adam_tf_layouts_frag(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad, void* const* frag_ptrs, const int* frag_forms);
 /* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch (the feed_dict slice of vae/models.py:211-216) gathered and
  * converted in one launch; dtype MI_F32 | MI_BF16.  The table's row count is not an argument: idx[b] must lie inside the table (the host mirror builds every index vector from
  * arange(N) permutations, vae/models.py:207-212) */

@@ -114,3 +114,35 @@ def test_workspace_guards_stay_intact_through_training_and_inference(tmp_path, m
     torch.cuda.synchronize()
     _, bad, _ = m.dev.check_guards()
     assert bad == 1 and "guard 3" in m.dev.L.cdll.mi_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_adam_launch_writes_the_fragment_ordered_weight_copies(tmp_path):
+    """Round 5: the optimiser launch (mi_adam_tf_layouts_frag) also emits the six fragment-ordered bf16 kernel copies of the activation-resident convolutions -- 16-byte granules
+    of the tile it holds in LDS -- instead of a separate ares_pack launch at the head of the next step.  After two SGD steps every copy in the engine's workspace equals, bit for
+    bit, what mi_ares_pack_weights writes from the current master kernel (conv4: conv form + gather form, deconv1: gather form + conv form, conv3 / deconv2: the mid gather form)."""
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    m = make(tmp_path, "bf16", params=trained_like_params(6), seed=0)
+    frames = synth_frames(16, seed=21)
+    eps = np.random.RandomState(2).standard_normal((16, 64)).astype(np.float32)
+    for _ in range(2):
+        m.train_step(frames, frames, eps=eps)
+    torch.cuda.synchronize()
+    dev = m.dev
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = int(L.mi_ares_weight_bytes())
+    lay = dev.layout
+    jobs = [(6, "vae/encoder/conv4/kernel", 0, nbytes), (7, "vae/encoder/conv4/kernel", 1, nbytes), (8, "vae/decoder/deconv1/kernel", 1, nbytes), (9, "vae/decoder/deconv1/kernel", 0, nbytes),
+            (10, "vae/encoder/conv3/kernel", 2, nbytes // 4), (11, "vae/decoder/deconv2/kernel", 2, nbytes // 4)]
+    base = dev.workspace.data_ptr()
+    for which, name, form, nb in jobs:
+        addr = L.mi_vae_buffer(dev.handle, which)
+        assert addr, which
+        got = dev.workspace[addr - base:addr - base + nb].clone()
+        want = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
+        off = lay[name][0]
+        L.mi_ares_pack_weights(st, form, dev.params.data_ptr() + 4 * off, want.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[:nb]), (which, name, form)
