@@ -160,3 +160,54 @@ def test_dp_step_as_one_c_call_equals_the_host_loop(tmp_path, precision):
     assert np.array_equal(l_c, l_h)
     for k in p_h:
         assert np.array_equal(p_c[k], p_h[k]), k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_dp_step_c_call_through_the_real_rccl_at_one_rank(tmp_path, precision):
+    """mi_vae_train_step_dp with a REAL communicator (RCCL bound at run time, world size 1 = what one GPU allows): the three gradient buckets travel through
+    ncclAllReduce on the communicator's side stream (the identity at one rank) and the caller's stream joins them before Adam.  Three SGD steps: parameters and losses are
+    BITWISE those of the same call on the recording communicator (which leaves the buffers alone) -- the collective plumbing (side stream, events, join) neither loses,
+    repeats nor reorders an update -- and equal the single-process step (mi_vae_train_step: one backward pass instead of three parts) to rounding."""
+    import ctypes
+    from mi355 import lib as milib
+    from vae.models import adam_alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON
+    L = milib.get()
+    B = 64
+    frames = synth_frames(B, seed=91)
+    eps = np.random.RandomState(6).standard_normal((3, B, 64)).astype(np.float32)
+    params = trained_like_params(5)
+    res = {}
+    for mode in ("rccl", "recording", "single"):
+        m = make(tmp_path / (precision + mode), precision, params=params, seed=0)
+        dev = m.dev
+        src = m._frames(frames, 38400, "src")
+        h = ctypes.c_void_p()
+        log = np.zeros((32, 4), np.int64)
+        if mode == "rccl":
+            idb = np.zeros(128, np.uint8)
+            L.mi_comm_unique_id(idb.ctypes.data)
+            L.mi_comm_init(ctypes.addressof(h), 0, 1, idb.ctypes.data)
+        elif mode == "recording":
+            L.mi_comm_init_recording(ctypes.addressof(h), 0, 1, log.ctypes.data, 32)
+        try:
+            b1p, b2p = np.float32(ADAM_BETA1), np.float32(ADAM_BETA2)
+            for s in range(3):
+                e = m._eps(B, eps[s])
+                alpha = adam_alpha(1e-4, b1p, b2p)
+                if mode == "single":
+                    dev.train_step(src, src, None, B, 1.0 / B, e, alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+                else:
+                    dev.train_step_dp(h, src, src, None, B, 1.0 / B, e, alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+                b1p, b2p = np.float32(b1p * np.float32(ADAM_BETA1)), np.float32(b2p * np.float32(ADAM_BETA2))
+            torch.cuda.synchronize()
+            res[mode] = (dev.export_params(), dev.losses.cpu().numpy().copy())
+        finally:
+            if mode != "single":
+                L.mi_comm_destroy(h)
+            m.dev.close()
+    (p_r, l_r), (p_c, l_c), (p_s, l_s) = res["rccl"], res["recording"], res["single"]
+    assert np.isfinite(l_r).all() and np.array_equal(l_r, l_c), (l_r, l_c)
+    for k in p_c:
+        assert np.array_equal(p_r[k], p_c[k]), k
+        assert rel_err(p_r[k], p_s[k]) < 1e-5, (k, rel_err(p_r[k], p_s[k]))
+    assert np.allclose(l_r, l_s, rtol=1e-5, atol=1e-6), (l_r, l_s)
