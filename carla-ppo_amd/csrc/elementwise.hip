@@ -50,7 +50,7 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 // the kernel draws eps itself (and stores it in eps_out for the backward pass); the LAST block to finish advances the offset by B * Z, after
 // every block has read it (each block takes its ticket after its reads), so the next launch -- or the next replay of a captured graph --
 // continues the stream.
-template <typename T>
+template <typename T, int U = 8>
 __global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int nsplit, const float* __restrict__ bias_mean,
                                       const float* __restrict__ bias_lv, const float* __restrict__ eps, int sample,
                                       int B, int Z, float* __restrict__ mean, float* __restrict__ logvar,
@@ -65,16 +65,16 @@ __global__ void reparam_kl_fwd_kernel(const float* __restrict__ heads, int nspli
         float klacc = 0.f;
         for (int j = lane; j < Z; j += WAVE) {
             float mu = bias_mean[j], lv = bias_lv[j];
-            for (int s0 = 0; s0 < nsplit; s0 += 8) {       // eight slabs requested together, added in slab order (a plain loop pays one latency per slab)
-                float a[8], b[8];
+            for (int s0 = 0; s0 < nsplit; s0 += U) {       // U (eight) slabs requested together, added in slab order (a plain loop pays one latency per slab)
+                float a[U], b[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const bool ok = s0 + u < nsplit;
                     const float* h = heads + ((long long)(ok ? s0 + u : 0) * B + row) * (2 * Z);
                     a[u] = ok ? h[j] : 0.f; b[u] = ok ? h[Z + j] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { mu += a[u]; lv += b[u]; }
+                for (int u = 0; u < U; ++u) { mu += a[u]; lv += b[u]; }
             }
             mean[(long long)row * Z + j] = mu;
             logvar[(long long)row * Z + j] = lv;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void normal_philox_kernel(unsigned long long s
 
 // reparam + KL backward: dz = sum_s dzs ; dmu = dz + beta*mu*inv_b*act ; dlv = dz*eps*.5*exp(.5lv) + beta*.5*(e^lv-1)*inv_b*act
 // act = 1 unless kl_tolerance clamps the row (tf.maximum passes the gradient to kl_b when kl_b >= tol*Z).
-template <typename T>
+template <typename T, int U = 8>
 __global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit, const float* __restrict__ mean,
                                       const float* __restrict__ logvar, const float* __restrict__ eps,
                                       const float* __restrict__ kl_row, float beta, float kl_floor, float inv_b,
@@ -122,12 +122,12 @@ __global__ void reparam_kl_bwd_kernel(const float* __restrict__ dzs, int nsplit,
     const float act = (kl_floor > 0.f && kl_row[row] < kl_floor) ? 0.f : 1.f;
     for (int j = lane; j < Z; j += WAVE) {
         float dz = 0.f;
-        for (int s0 = 0; s0 < nsplit; s0 += 8) {           // eight slabs requested together, added in slab order
-            float a[8];
+        for (int s0 = 0; s0 < nsplit; s0 += U) {           // U (eight) slabs requested together, added in slab order
+            float a[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = s0 + u < nsplit ? dzs[((long long)(s0 + u) * B + row) * Z + j] : 0.f;
+            for (int u = 0; u < U; ++u) a[u] = s0 + u < nsplit ? dzs[((long long)(s0 + u) * B + row) * Z + j] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dz += a[u];
+            for (int u = 0; u < U; ++u) dz += a[u];
         }
         const float mu = mean[(long long)row * Z + j], lv = logvar[(long long)row * Z + j];
         const float e = eps[(long long)row * Z + j];
@@ -729,6 +729,12 @@ int mi_vae_reparam_kl_fwd(void* stream, int dtype, const float* heads, int nspli
     return mi_vae_reparam_kl_fwd_rng(stream, dtype, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, z, kl_row, nullptr, nullptr);
 }
 
+static bool reparam_wide() {                             // MI355_REPARAM_WIDE=1 (A/B knob, default off): the reparameterisation kernels request up to 32 slabs per element at once
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MI355_REPARAM_WIDE"); on = (e && e[0] == '1') ? 1 : 0; }
+    return on != 0;
+}
+
 // same; eps == NULL with sample != 0: the kernel draws the noise from the Philox stream in rng_state (4 x uint64 on the device: seed, next
 // element offset, 2 words of kernel bookkeeping -- zero them once) and stores what it drew in eps_out [B,Z] for the backward pass
 int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int nsplit, const float* bias_mean, const float* bias_lv,
@@ -736,6 +742,10 @@ int mi_vae_reparam_kl_fwd_rng(void* stream, int dtype, const float* heads, int n
                               unsigned long long* rng_state, float* eps_out) {
     if (sample && !eps && !(rng_state && eps_out)) return mi_fail(MI_ERR_ARG, "mi_vae_reparam_kl_fwd: sampling needs eps or a generator state + eps_out");
     dim3 g((B + 3) / 4), b(256);
+    if (reparam_wide() && nsplit > 8) {                   // MI355_REPARAM_WIDE=1: all (up to 32) slabs of an element requested before the first add -- same order, same sums
+        BY_DTYPE(dtype, hipLaunchKernelGGL((reparam_kl_fwd_kernel<TT, 32>), g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (TT*)z, kl_row, rng_state, eps_out));
+        return mi_check_launch("reparam_kl_fwd");
+    }
     BY_DTYPE(dtype, hipLaunchKernelGGL(reparam_kl_fwd_kernel<TT>, g, b, 0, (hipStream_t)stream, heads, nsplit, bias_mean, bias_lv, eps, sample, B, Z, mean, logvar, (TT*)z, kl_row, rng_state, eps_out));
     return mi_check_launch("reparam_kl_fwd");
 }
@@ -750,6 +760,10 @@ int mi_normal_philox(void* stream, unsigned long long seed, unsigned long long o
 int mi_vae_reparam_kl_bwd(void* stream, int dtype, const float* dz_slabs, int nsplit, const float* mean, const float* logvar,
                           const float* eps, const float* kl_row, float beta, float kl_floor, float inv_batch, int B, int Z, void* dheads) {
     dim3 g((B + 3) / 4), b(256);
+    if (reparam_wide() && nsplit > 8) {
+        BY_DTYPE(dtype, hipLaunchKernelGGL((reparam_kl_bwd_kernel<TT, 32>), g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (TT*)dheads));
+        return mi_check_launch("reparam_kl_bwd");
+    }
     BY_DTYPE(dtype, hipLaunchKernelGGL(reparam_kl_bwd_kernel<TT>, g, b, 0, (hipStream_t)stream, dz_slabs, nsplit, mean, logvar, eps, kl_row, beta, kl_floor, inv_batch, B, Z, (TT*)dheads));
     return mi_check_launch("reparam_kl_bwd");
 }

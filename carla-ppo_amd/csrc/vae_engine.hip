@@ -157,7 +157,9 @@ int pick_split(int M, int N, int K, int bk) {
     const int tiles = ((M + 127) / 128) * (N <= 64 ? 1 : (N + 127) / 128);
     int ns = 256 / (tiles > 0 ? tiles : 1);
     if (ns < 1) ns = 1;
-    if (ns > 32) ns = 32;
+    static int ns_cap = -1;             // MI355_LATENT_SPLIT=<n>: fewer, longer K slices of the latent layers' split-K sums (A/B knob; default 32)
+    if (ns_cap < 0) { const char* ev = getenv("MI355_LATENT_SPLIT"); ns_cap = ev ? atoi(ev) : 32; if (ns_cap < 1 || ns_cap > 32) ns_cap = 32; }
+    if (ns > ns_cap) ns = ns_cap;
     while (ns > 1) {                    // every slab must own at least one K block
         int len = (K + ns - 1) / ns; len = (len + bk - 1) / bk * bk;
         if ((long long)len * (ns - 1) < K) break;
@@ -573,7 +575,14 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     static int two_streams = -1;
     if (two_streams < 0) { const char* ev = getenv("MI355_BWD_STREAMS"); two_streams = (ev && ev[0] == '0') ? 0 : 1; }
     if (two_streams && !e->side_ok) {
-        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
+        // MI355_SIDE_PRIO=-1 / 1: the filter-gradient queue above / below the caller's queue in the hardware scheduler's priority order (default 0: equal; A/B knob)
+        static int side_prio = -99;
+        if (side_prio == -99) { const char* ev = getenv("MI355_SIDE_PRIO"); side_prio = ev ? atoi(ev) : 0; }
+        int prio_lo = 0, prio_hi = 0;
+        if (side_prio != 0) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // (numerically: lowest priority = largest value)
+        const int prio = side_prio < 0 ? prio_hi : prio_lo;
+        if ((side_prio == 0 ? hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio)) == hipSuccess &&
+            hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
             hipEventCreateWithFlags(&e->ev_done, ready_event_flags()) == hipSuccess) e->side_ok = 1;
         else e->side_ok = -1;
     }
