@@ -954,6 +954,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
+    else if (key == 23) { prev = mi_enc12_debug(value); }  // (debug: ablation mask of the fused encoder head's timing instantiation -- results are wrong with any bit set)
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
 }

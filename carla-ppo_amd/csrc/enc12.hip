@@ -6,6 +6,9 @@
 
 using namespace mi;
 
+static int g_enc12_dbg = 0;
+int mi_enc12_debug(int mask) { const int prev = g_enc12_dbg; g_enc12_dbg = mask < 0 ? 0 : mask; return prev; }
+
 static int enc12_grid(int u8) {
     static int resident[2];
     if (!resident[u8]) {
@@ -40,7 +43,24 @@ extern "C" int mi_conv2d_enc12_fwd(void* stream, int dtype, const void* frames, 
     q.B = B; q.ntiles = 3 * B;
     int nblocks = enc12_grid(frames_fmt == 2 ? 1 : 0);
     if (nblocks > q.ntiles) nblocks = q.ntiles;
-    if (frames_fmt == 2) MI_LAUNCH(enc12_fwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    // camera bytes (the production format): the ring form of the conv1 stage's frame loads and conv2's LDS fragment reads pipelined by hand (enc12_tile.hpp; late round 5:
+    // 55.5 -> 53.0 -> 51.1 us for the op alone at batch 512, interleaved medians; step -0.5 ... -0.8 %).  MI355_ENC12_RING=0 / MI355_ENC12_C2=0: the compiler-scheduled forms (A/B).
+    // Both forms issue loads by inline assembly and wait by hand: tools/check_enc12_isa.py (run by tests/test_host_logic.py) proves on the generated code that no
+    // register is read while its load can be outstanding.
+    static int ring = -1;
+    if (ring < 0) { const char* e = getenv("MI355_ENC12_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
+    static int c2 = -1;
+    if (c2 < 0) { const char* e = getenv("MI355_ENC12_C2"); c2 = (e && e[0] == '0') ? 0 : 1; }
+    int use_ring = ring, use_c2 = c2;
+    int dbg = g_enc12_dbg;
+    if (dbg & 4096) { use_ring = (dbg >> 13) & 1; use_c2 = (dbg >> 14) & 1; dbg = 0; }      // (bit 4096: pick a PRODUCT form by mask -- bit 8192 ring, 16384 pipelined conv2 -- for interleaved timing in one process)
+    if (dbg && frames_fmt == 2) {                           // ablation timing (mi_set_tuning key 23; tools/enc12_ablate.py): WRONG results by construction
+        q.dbg = dbg;
+        if (dbg & 2048) MI_LAUNCH((enc12_fwd_kernel<unsigned char, 1, 1, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);      // (bit 2048: the ring + pipelined form)
+        else MI_LAUNCH((enc12_fwd_kernel<unsigned char, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    } else if (use_ring && use_c2 && frames_fmt == 2) MI_LAUNCH((enc12_fwd_kernel<unsigned char, 0, 1, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    else if (use_ring && frames_fmt == 2) MI_LAUNCH((enc12_fwd_kernel<unsigned char, 0, 1>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    else if (frames_fmt == 2) MI_LAUNCH(enc12_fwd_kernel<unsigned char>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     else MI_LAUNCH(enc12_fwd_kernel<float>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     const int rc = mi_check_launch("enc12_fwd_kernel");
     if (rc == MI_OK) *launched = 1;

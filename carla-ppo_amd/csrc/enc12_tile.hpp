@@ -32,10 +32,39 @@ struct Enc12Params {
     bf16_t* act1; uint32_t* bits1;                        // [B, 39, 79, 32]; ReLU bit words [B * 39 * 79][2] (may be NULL)
     bf16_t* act2;                                         // [B, 18, 38, 64]
     int B, ntiles;                                        // ntiles = 3 B
+    int dbg;                                              // ablation mask of the DBG instantiation (tools/enc12_ablate.py; results are WRONG with any bit set): 1 no act1 / bit-word stores, 2 no bit words,
+                                                          // 4 no conv2 stage, 8 no act2 stores, 16 no frame loads, 32 no LDS writes of conv1, 64 no LDS reads in conv2, 128 conflict-free (wrong) read addresses in the pipelined conv2
 };
 
-template <typename TS>
+// conv2 stage, pipelined form (C2 = 1): the 32 (tap, channel half) fragments of a position tile are read from LDS by hand, NF of them in flight, in the order the MFMAs
+// consume them (the compiler sinks every ds_read next to its MFMA: "two reads, s_waitcnt lgkmcnt(1), v_mfma" -- a full LDS latency in front of every other MFMA; measured
+// with the reads taken out: 17 of the kernel's 73 us).  LDS returns in order: fragment F has landed when at most (reads issued after it) are outstanding; the fragment
+// passes THROUGH the wait statement, so its MFMA cannot move above it.  Buffer (F - 1) % NF is refilled behind MFMA F: its reader issued a whole MFMA earlier.
+template <int IMM> __device__ __forceinline__ void e12_lds_read(u16x8& d, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(IMM)); }
+template <int N> __device__ __forceinline__ void e12_lds_wait(u16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int F> __device__ __forceinline__ void e12_frag_read(u16x8& d, const uint32_t (&base)[2][2]) {      // F = (kh * 4 + kw) * 2 + ks
+    constexpr int kh = F >> 3, kw = (F >> 1) & 3, ks = F & 1;
+    e12_lds_read<(kw & 1) * E12_PLANE + kh * E12_PW * 64>(d, base[kw >> 1][ks]);
+}
+template <int F, int NF> struct E12Conv2Pipe {
+    static __device__ __forceinline__ void run(u16x8 (&fb)[NF], const u16x8 (&wf2)[32], f32x16& acc, const uint32_t (&base)[2][2]) {
+        constexpr int issued = F == 0 ? NF - 1 : (F - 2 + NF < 31 ? F - 2 + NF : 31);      // highest fragment requested so far
+        e12_lds_wait<issued - F>(fb[F % NF]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf2[F]), __builtin_bit_cast(bf16x8, fb[F % NF]), acc, 0, 0, 0);
+        if constexpr (F >= 1 && F - 1 + NF < 32) e12_frag_read<F - 1 + NF>(fb[(F - 1) % NF], base);
+        if constexpr (F + 1 < 32) E12Conv2Pipe<F + 1, NF>::run(fb, wf2, acc, base);
+    }
+};
+template <int F, int NF> struct E12Conv2Prologue {
+    static __device__ __forceinline__ void run(u16x8 (&fb)[NF], const uint32_t (&base)[2][2]) {
+        e12_frag_read<F>(fb[F], base);
+        if constexpr (F + 1 < NF) E12Conv2Prologue<F + 1, NF>::run(fb, base);
+    }
+};
+
+template <typename TS, int DBG = 0, int RING = 0, int C2 = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void enc12_fwd_kernel(const Enc12Params p) {
+    const int dbg = DBG ? p.dbg : 0;                      // (DBG = 0, the product: every `dbg &` test below folds away)
     constexpr int SSZ = (int)sizeof(TS), GSZ = 4 * SSZ, GDW = GSZ / 4;
     constexpr int FW = 160, A1H = 39, A1W = 79, A2H = 18, A2W = 38;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[E12_LDS];
@@ -82,108 +111,247 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         q.npix = nrows * A1W; q.own_rows = q.band == 2 ? 15 : 12;      // rows this band stores to HBM (the rest belong to the next band)
         q.ngrp = (q.npix + 31) >> 5;
         long long fr = q.b;
-        if (p.frame_idx) fr = p.frame_idx[q.b];
+        if constexpr (RING && SSZ == 1) {                  // (ring form: a SCALAR load by hand -- a vector load here would be the one load the compiler sees next to the stores, and it
+            if (p.frame_idx) {                             // answers its use with s_waitcnt vmcnt(0): every request in flight drained at the head of every band)
+                int v;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p.frame_idx + q.b));
+                fr = v;
+            }
+        } else if (p.frame_idx) fr = p.frame_idx[q.b];
         q.fbase = (const unsigned char*)p.frames + fr * p.frame_stride * SSZ;
         return q;
     };
-    auto request = [&](const Band& q, int grp, Raw& r) {
-        const int pq = min(grp * 32 + lrow, q.npix - 1);   // pixels past the band recompute its last one; their stores are skipped
+    auto request3 = [&](const unsigned char* fbase, int y0r, int npixr, int grp, Raw& r) {
+        const int pq = min(grp * 32 + lrow, npixr - 1);    // pixels past the band recompute its last one; their stores are skipped
         const int row = pq / A1W, col = pq - row * A1W;
-        const unsigned char* pix = q.fbase + (2 * (q.y0 + row) * FW + 2 * col) * 3 * SSZ;
+        const unsigned char* pix = fbase + (2 * (y0r + row) * FW + 2 * col) * 3 * SSZ;
+        if constexpr (RING && SSZ == 1) {
+            // ring form on camera bytes: the six loads are INLINE ASSEMBLY, i.e. invisible to the compiler's s_waitcnt placement.  On gfx9-family targets loads and stores share
+            // vmcnt and may retire out of order with respect to each other, so LLVM answers every use of a loaded register with s_waitcnt vmcnt(0) while ANY store is
+            // pending (SIInsertWaitcnts: mixed pending events) -- in a loop that stores what it computes that is every step: no load is ever in flight across a step.
+            // The wait is written by hand instead (ring_wait: vmcnt(6 x the younger requests); loads retire in order among themselves and younger STORES are not counted,
+            // which errs on the waiting side whatever order they retire in).  Nothing may read r between this request and its ring_wait (no copies, no spills: the build's
+            // resource line must say 0 spills for this instantiation; tools/check_enc12_isa.py reads the listing).
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (dbg & 16) { r.d[j][0] = 0x40404040u + (uint32_t)pq; continue; }
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(r.d[j][0]) : "v"(pix + goff[j]));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
+            if (dbg & 16) {
+#pragma unroll
+                for (int e = 0; e < GDW; ++e) r.d[j][e] = 0x40404040u + (uint32_t)pq;
+                continue;
+            }
             const PackU<uint32_t, GDW, 2> v = *(const PackU<uint32_t, GDW, 2>*)(pix + goff[j]);
 #pragma unroll
             for (int e = 0; e < GDW; ++e) r.d[j][e] = v.v[e];
         }
     };
+    auto request = [&](const Band& q, int grp, Raw& r) { request3(q.fbase, q.y0, q.npix, grp, r); };
+    // the hand-written wait of the ring form: the request of `r` is complete when at most 6 x (NB - 1) younger loads are outstanding; r's registers pass THROUGH the
+    // statement, so no use of them can be scheduled above it
+    auto ring_wait = [&](Raw& r) {
+        if constexpr (RING && SSZ == 1)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r.d[0][0]), "+v"(r.d[1][0]), "+v"(r.d[2][0]), "+v"(r.d[3][0]), "+v"(r.d[4][0]), "+v"(r.d[5][0]) : "n"(6 * ((SSZ == 1 ? 3 : 2) - 1)));
+    };
     // (camera bytes: two steps ahead, 6 registers per step; fp32 frames hold 24 per step: one step ahead keeps the kernel at two waves per SIMD without spills)
     constexpr bool DEEP = SSZ == 1;
-    Raw r0, r1;
+    constexpr int NB = DEEP ? 3 : 2;                      // ring form: request buffers = steps a load is ahead of its use
+    Raw r0, r1, ra, rb, rc;
     int tile = (int)blockIdx.x;
     if (tile >= p.ntiles) return;                          // (block-uniform)
     Band cb = band_of(tile);
-    request(cb, min(wave, cb.ngrp - 1), r0);
-    if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+    if constexpr (RING) {
+        request(cb, wave, ra); request(cb, wave + 4, rb);
+        if constexpr (NB == 3) request(cb, wave + 8, rc);
+    } else {
+        request(cb, min(wave, cb.ngrp - 1), r0);
+        if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+    }
     for (; tile < p.ntiles; tile += G) {
         const int b = cb.b, band = cb.band, y0 = cb.y0, npix = cb.npix, own_rows = cb.own_rows, ngrp = cb.ngrp;
 
         // ================= conv1: the band's pixels, 32 per wave step (groups wave, wave + 4, ...), loads two steps ahead (the first ones were requested before the
         // previous band's conv2 stage) =================
-        for (int grp = wave; grp < ngrp; grp += 4) {
-            Raw cur = r0;
-            if constexpr (DEEP) { r0 = r1; if (grp + 8 < ngrp) request(cb, grp + 8, r1); }      // (wave-uniform branches: nothing is requested past the band)
-            else { if (grp + 4 < ngrp) request(cb, grp + 4, r0); }
-            u16x8 xf[3];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                uint32_t* dst = (uint32_t*)&xf[j >> 1] + 2 * (j & 1);
-                float f[4];
-                if constexpr (SSZ == 1) {                  // camera bytes: k * (1 / 255), which rounds to the same bf16 as the exact quotient (common.hpp)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] = (float)((cur.d[j][0] >> (8 * e)) & 255u) * U8_RCP255;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, cur.d[j][e < GDW ? e : 0]);
+        if constexpr (RING) {
+            // ---- ring form (round 5, late): NB statically named request buffers, step k of this wave (group wave + 4 k) consumes buffer k % NB and re-requests it for step
+            // k + NB right after its conversion -- no register rotation (the `cur = r0; r0 = r1` copies made every step wait for the loads issued ONE step earlier, and the
+            // conditional request left an s_waitcnt vmcnt(0) behind it: no prefetch at all in the generated code), no conditional requests (every wave runs a multiple of NB
+            // steps; steps past the band recompute its last pixel and store nothing; requests past the band are the NEXT band's first steps, so the stream of loads never stops)
+            const int nsteps = (ngrp - wave + 3) >> 2, nsp = (nsteps + NB - 1) / NB * NB;      // (wave-uniform)
+            const bool more = tile + G < p.ntiles;
+            const Band nb = more ? band_of(tile + G) : cb;
+            auto step = [&](Raw& cur, int k) {
+                const int grp = wave + 4 * k;
+                ring_wait(cur);
+                u16x8 xf[3];
+    #pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    uint32_t* dst = (uint32_t*)&xf[j >> 1] + 2 * (j & 1);
+                    float f[4];
+                    if constexpr (SSZ == 1) {                  // camera bytes: k * (1 / 255), which rounds to the same bf16 as the exact quotient (common.hpp)
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = (float)((cur.d[j][0] >> (8 * e)) & 255u) * U8_RCP255;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, cur.d[j][e < GDW ? e : 0]);
+                    }
+                    const PackN<uint32_t, 2> h = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(f));
+                    dst[0] = h.v[0]; dst[1] = h.v[1];
                 }
-                const PackN<uint32_t, 2> h = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(f));
-                dst[0] = h.v[0]; dst[1] = h.v[1];
+                {   // (selects, not a branch: both sides issue the same six loads)
+                    const int j = k + NB; const bool nx = j >= nsp;
+                    request3(nx ? nb.fbase : cb.fbase, nx ? nb.y0 : y0, nx ? nb.npix : npix, wave + 4 * (nx ? j - nsp : j), cur);
+                }
+                f32x16 acc = acc1_0;
+    #pragma unroll
+                for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, xf[s]), acc, 0, 0, 0);
+                // epilogue of narrow_conv48_kernel<., 0>: bf16, ReLU, half-wave exchange -> lane (pixel, g) owns channels 16 g .. 16 g + 15 as 8 dwords
+                uint32_t R[4][2];
+    #pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+                    const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+    #pragma unroll
+                    for (int d = 0; d < 2; ++d) { uint32_t u; asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d])); R[qd][d] = u; }
+                }
+    #pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
+                    auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
+                }
+                const uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
+                const int pq = grp * 32 + lrow;
+                if (pq < npix) {
+                    const int row = pq / A1W, col = pq - row * A1W;
+                    // LDS: plane col & 1, entry row * 40 + col / 2, chunks 2 g and 2 g + 1 swizzled by the entry index
+                    const int idx = col >> 1;
+                    unsigned char* q = lds + (col & 1) * E12_PLANE + (row * E12_PW + idx) * 64;
+                    const int sw = (idx >> 2) & 3;
+                    if (!(dbg & 32)) {
+                        *(e12_u32x4*)(q + (((2 * lgrp) ^ sw) << 4)) = e12_u32x4{o[0], o[1], o[2], o[3]};
+                        *(e12_u32x4*)(q + (((2 * lgrp + 1) ^ sw) << 4)) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                    }
+                    if (row < own_rows && !(dbg & 1)) {                      // this band owns the pixel: the activation tensor and its ReLU bit words
+                        const long long m = ((long long)b * A1H + y0 + row) * A1W + col;
+                        unsigned char* g = (unsigned char*)p.act1 + m * 64 + lgrp * 32;
+                        *(e12_u32x4*)g = e12_u32x4{o[0], o[1], o[2], o[3]};
+                        *(e12_u32x4*)(g + 16) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                        if (p.bits1 && !(dbg & 2)) {            // bit d / bit 16 + d of the word: the two halves of dword d are non-zero (post-ReLU: positive)
+                            uint32_t word = 0;
+    #pragma unroll
+                            for (int d = 0; d < 8; ++d) { uint32_t nz; asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(o[d]), "v"(0x00010001u)); word |= nz << d; }
+                            p.bits1[m * 2 + lgrp] = word;
+                        }
+                    }
+                }
+            };
+            for (int k = 0; k < nsp; k += NB) {
+                step(ra, k); step(rb, k + 1);
+                if constexpr (NB == 3) step(rc, k + 2);
             }
-            f32x16 acc = acc1_0;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, xf[s]), acc, 0, 0, 0);
-            // epilogue of narrow_conv48_kernel<., 0>: bf16, ReLU, half-wave exchange -> lane (pixel, g) owns channels 16 g .. 16 g + 15 as 8 dwords
-            uint32_t R[4][2];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
-                const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
-#pragma unroll
-                for (int d = 0; d < 2; ++d) { uint32_t u; asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d])); R[qd][d] = u; }
-            }
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
-                auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
-            }
-            const uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
-            const int pq = grp * 32 + lrow;
-            if (pq < npix) {
-                const int row = pq / A1W, col = pq - row * A1W;
-                // LDS: plane col & 1, entry row * 40 + col / 2, chunks 2 g and 2 g + 1 swizzled by the entry index
-                const int idx = col >> 1;
-                unsigned char* q = lds + (col & 1) * E12_PLANE + (row * E12_PW + idx) * 64;
-                const int sw = (idx >> 2) & 3;
-                *(e12_u32x4*)(q + (((2 * lgrp) ^ sw) << 4)) = e12_u32x4{o[0], o[1], o[2], o[3]};
-                *(e12_u32x4*)(q + (((2 * lgrp + 1) ^ sw) << 4)) = e12_u32x4{o[4], o[5], o[6], o[7]};
-                if (row < own_rows) {                      // this band owns the pixel: the activation tensor and its ReLU bit words
-                    const long long m = ((long long)b * A1H + y0 + row) * A1W + col;
-                    unsigned char* g = (unsigned char*)p.act1 + m * 64 + lgrp * 32;
-                    *(e12_u32x4*)g = e12_u32x4{o[0], o[1], o[2], o[3]};
-                    *(e12_u32x4*)(g + 16) = e12_u32x4{o[4], o[5], o[6], o[7]};
-                    if (p.bits1) {                         // bit d / bit 16 + d of the word: the two halves of dword d are non-zero (post-ReLU: positive)
-                        uint32_t word = 0;
-#pragma unroll
-                        for (int d = 0; d < 8; ++d) { uint32_t nz; asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(o[d]), "v"(0x00010001u)); word |= nz << d; }
-                        p.bits1[m * 2 + lgrp] = word;
+            __syncthreads();                               // the band's activation is in LDS
+            if (more) cb = nb;
+        } else {
+            for (int grp = wave; grp < ngrp; grp += 4) {
+                Raw cur = r0;
+                if constexpr (DEEP) { r0 = r1; if (grp + 8 < ngrp) request(cb, grp + 8, r1); }      // (wave-uniform branches: nothing is requested past the band)
+                else { if (grp + 4 < ngrp) request(cb, grp + 4, r0); }
+                u16x8 xf[3];
+    #pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    uint32_t* dst = (uint32_t*)&xf[j >> 1] + 2 * (j & 1);
+                    float f[4];
+                    if constexpr (SSZ == 1) {                  // camera bytes: k * (1 / 255), which rounds to the same bf16 as the exact quotient (common.hpp)
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = (float)((cur.d[j][0] >> (8 * e)) & 255u) * U8_RCP255;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, cur.d[j][e < GDW ? e : 0]);
+                    }
+                    const PackN<uint32_t, 2> h = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(f));
+                    dst[0] = h.v[0]; dst[1] = h.v[1];
+                }
+                f32x16 acc = acc1_0;
+    #pragma unroll
+                for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, xf[s]), acc, 0, 0, 0);
+                // epilogue of narrow_conv48_kernel<., 0>: bf16, ReLU, half-wave exchange -> lane (pixel, g) owns channels 16 g .. 16 g + 15 as 8 dwords
+                uint32_t R[4][2];
+    #pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+                    const PackN<uint32_t, 2> w = __builtin_bit_cast(PackN<uint32_t, 2>, pack4<bf16_t>(v));
+    #pragma unroll
+                    for (int d = 0; d < 2; ++d) { uint32_t u; asm("v_pk_max_i16 %0, %1, 0" : "=v"(u) : "v"(w.v[d])); R[qd][d] = u; }
+                }
+    #pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
+                    auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
+                }
+                const uint32_t o[8] = {R[0][0], R[0][1], R[2][0], R[2][1], R[1][0], R[1][1], R[3][0], R[3][1]};       // dword d: channels 16 g + 2 d, + 1
+                const int pq = grp * 32 + lrow;
+                if (pq < npix) {
+                    const int row = pq / A1W, col = pq - row * A1W;
+                    // LDS: plane col & 1, entry row * 40 + col / 2, chunks 2 g and 2 g + 1 swizzled by the entry index
+                    const int idx = col >> 1;
+                    unsigned char* q = lds + (col & 1) * E12_PLANE + (row * E12_PW + idx) * 64;
+                    const int sw = (idx >> 2) & 3;
+                    if (!(dbg & 32)) {
+                        *(e12_u32x4*)(q + (((2 * lgrp) ^ sw) << 4)) = e12_u32x4{o[0], o[1], o[2], o[3]};
+                        *(e12_u32x4*)(q + (((2 * lgrp + 1) ^ sw) << 4)) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                    }
+                    if (row < own_rows && !(dbg & 1)) {                      // this band owns the pixel: the activation tensor and its ReLU bit words
+                        const long long m = ((long long)b * A1H + y0 + row) * A1W + col;
+                        unsigned char* g = (unsigned char*)p.act1 + m * 64 + lgrp * 32;
+                        *(e12_u32x4*)g = e12_u32x4{o[0], o[1], o[2], o[3]};
+                        *(e12_u32x4*)(g + 16) = e12_u32x4{o[4], o[5], o[6], o[7]};
+                        if (p.bits1 && !(dbg & 2)) {            // bit d / bit 16 + d of the word: the two halves of dword d are non-zero (post-ReLU: positive)
+                            uint32_t word = 0;
+    #pragma unroll
+                            for (int d = 0; d < 8; ++d) { uint32_t nz; asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(o[d]), "v"(0x00010001u)); word |= nz << d; }
+                            p.bits1[m * 2 + lgrp] = word;
+                        }
                     }
                 }
             }
-        }
-        __syncthreads();                                   // the band's activation is in LDS
-        if (tile + G < p.ntiles) {                         // the NEXT band's first patch loads fly under this band's conv2 stage (block-uniform)
-            cb = band_of(tile + G);
-            request(cb, min(wave, cb.ngrp - 1), r0);
-            if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+            __syncthreads();                                   // the band's activation is in LDS
+            if (tile + G < p.ntiles) {                         // the NEXT band's first patch loads fly under this band's conv2 stage (block-uniform)
+                cb = band_of(tile + G);
+                request(cb, min(wave, cb.ngrp - 1), r0);
+                if constexpr (DEEP) request(cb, min(wave + 4, cb.ngrp - 1), r1);
+            }
         }
 
         // ================= conv2: 6 x 38 outputs = 8 position tiles of 32 (the last one ragged); this wave: output tile nt, position tiles 4 mh .. 4 mh + 3 =================
 #pragma unroll 1
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = (dbg & 4) ? 4 : 0; mt < 4; ++mt) {
             const int oq = (mh * 4 + mt) * 32 + lrow;
             const int oc = min(oq, 6 * A2W - 1);
             const int oy = oc / A2W, ox = oc - oy * A2W;
             f32x16 acc = acc2_0;
+            if constexpr (C2) {
+                constexpr int NF = 4;
+                uint32_t base[2][2];                       // LDS address of (row 2 oy, entry ox + kwh, chunk 2 ks + lane group) of plane 0; taps = immediates on top
+#pragma unroll
+                for (int kwh = 0; kwh < 2; ++kwh) {
+                    const int idx = ox + kwh, sw = (idx >> 2) & 3;
+                    const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (uint32_t)((2 * oy * E12_PW + idx) * 64);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) base[kwh][ks] = pb + (uint32_t)((((2 * ks + lgrp) ^ sw)) << 4);
+                }
+                if (dbg & 128) {                           // (ablation: every lane its own 16 bytes of one KiB -- the reads without any bank conflict)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) base[i >> 1][i & 1] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (uint32_t)(lane * 16 + i * 1024);
+                }
+                u16x8 fb[NF];
+                E12Conv2Prologue<0, NF>::run(fb, base);
+                E12Conv2Pipe<0, NF>::run(fb, wf2, acc, base);
+            } else
 #pragma unroll
             for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
@@ -193,7 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int sw = (idx >> 2) & 3;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const u16x8 bfr = *(const u16x8*)(q + (((2 * ks + lgrp) ^ sw) << 4));
+                        const u16x8 bfr = (dbg & 64) ? wf1[ks] : *(const u16x8*)(q + (((2 * ks + lgrp) ^ sw) << 4));
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf2[(kh * 4 + kw) * 2 + ks]), __builtin_bit_cast(bf16x8, bfr), acc, 0, 0, 0);
                     }
                 }
@@ -210,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 auto s0 = __builtin_amdgcn_permlane32_swap(R[0][d], R[2][d], false, false); R[0][d] = s0[0]; R[2][d] = s0[1];
                 auto s1 = __builtin_amdgcn_permlane32_swap(R[1][d], R[3][d], false, false); R[1][d] = s1[0]; R[3][d] = s1[1];
             }
-            if (oq < 6 * A2W) {
+            if (oq < 6 * A2W && !(dbg & 8)) {
                 const long long m2 = ((long long)b * A2H + 6 * band + oy) * A2W + ox;
                 unsigned char* g = (unsigned char*)p.act2 + m2 * 128 + nt * 64 + lgrp * 32;
                 *(e12_u32x4*)g = e12_u32x4{R[0][0], R[0][1], R[2][0], R[2][1]};
@@ -219,6 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __syncthreads();                                   // every wave is done with the band before the next one's conv1 overwrites it
     }
+    if constexpr (RING && SSZ == 1) asm volatile("s_waitcnt vmcnt(0)");      // (the last band's look-ahead requests: nothing reads them, nothing is left in flight)
 }
 
 }  // namespace mi

@@ -157,8 +157,10 @@ int pick_split(int M, int N, int K, int bk) {
     const int tiles = ((M + 127) / 128) * (N <= 64 ? 1 : (N + 127) / 128);
     int ns = 256 / (tiles > 0 ? tiles : 1);
     if (ns < 1) ns = 1;
-    static int ns_cap = -1;             // MI355_LATENT_SPLIT=<n>: fewer, longer K slices of the latent layers' split-K sums (A/B knob; default 32)
-    if (ns_cap < 0) { const char* ev = getenv("MI355_LATENT_SPLIT"); ns_cap = ev ? atoi(ev) : 32; if (ns_cap < 1 || ns_cap > 32) ns_cap = 32; }
+    // MI355_LATENT_SPLIT=<n>: at most n K slices in the latent layers' split-K sums.  16 since late round 5 (32 before): half the slab traffic between the tall-K kernels and the
+    // reparameterisation kernels that sum them, one block per CU instead of two; step 0.8225 -> 0.8179 / 0.8153 -> 0.8125 ms on two boxes (12: the same, 8 and 24: slower)
+    static int ns_cap = -1;
+    if (ns_cap < 0) { const char* ev = getenv("MI355_LATENT_SPLIT"); ns_cap = ev ? atoi(ev) : 16; if (ns_cap < 1 || ns_cap > 32) ns_cap = 16; }
     if (ns > ns_cap) ns = ns_cap;
     while (ns > 1) {                    // every slab must own at least one K block
         int len = (K + ns - 1) / ns; len = (len + bk - 1) / bk * bk;

@@ -111,7 +111,8 @@ int mi_device_probe(void* stream, void* scratch, long long scratch_bytes, int mi
  * key 15: register-weight kernel of the conv-form layers (rwconv.hip): 0 off, 1 deconv3 dgrad (32 -> 64 channels, k = 5), 2 also conv2 fwd (k = 4),
  * 3 also the 64 -> 128 channel k = 4 shape, conv3 fwd / deconv2 dgrad (default; MI355_RWCONV_CONV); subject to key 13's off / auto / always; key 16: persistent blocks per XCD of the
  * register-weight kernels, 0 = as many as stay resident (tests use 1: every block then walks several chunks); key 22: the LDS-free one-wave-per-tile dense filter
- * gradient of round 5 (csrc/dwgs_tile.hpp; MI355_DWGS) on / off.  Returns the previous value. */
+ * gradient of round 5 (csrc/dwgs_tile.hpp; MI355_DWGS) on / off; key 23 (debug): ablation mask of the fused encoder-head forward kernel's timing instantiation
+ * (tools/enc12_ablate.py; any bit set = wrong results; 0 = the product kernel).  Returns the previous value. */
 int mi_set_tuning(int key, int value);
 /* debug only: s_memtime stamps of the tapconv kernel (32 int64 per wave per block) into a caller-provided device buffer; NULL = off */
 int mi_debug_set_trace(void* dev_ptr, int capacity_entries);

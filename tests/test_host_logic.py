@@ -573,3 +573,19 @@ def test_device_probe_argument_validation_without_a_gpu():
     for scratch, nbytes, out in ((None, 1 << 30, out8.ctypes.data), (4096, 1 << 20, out8.ctypes.data), (4096 + 8, 1 << 30, out8.ctypes.data), (4096, 1 << 30, None)):
         with pytest.raises(milib.MiError):
             L.mi_device_probe(None, scratch, nbytes, 5, out)
+
+
+def test_hand_scheduled_loads_of_the_fused_encoder_head_are_never_read_early():
+    """csrc/enc12_tile.hpp (ring form, pipelined conv2): the frame loads and the LDS fragment reads of the production instantiations are inline assembly with hand-written
+    s_waitcnt, so the compiler's own hazard tracking does not cover them.  tools/check_enc12_isa.py compiles enc12.hip to a gfx950 listing (no GPU needed) and replays
+    both kernels under the hardware's rule -- loads retire in order, a wait leaves at most N outstanding -- twice around the band loop: no instruction reads a register
+    whose load may still be in flight, no spills, the expected number of loads and waits.  (A register copy or a spill the compiler might one day place between a load and
+    its wait would read stale data silently; this is the test that would notice.)"""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("needs hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_enc12_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 violations") == 2, r.stdout
