@@ -75,7 +75,7 @@ NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gr
              ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "1x96x2", "dense1.wgrad (+ bias row)"), ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "49x2x2", "heads.wgrad (+ bias row)"),
              # the encoder head of the forward pass is one kernel (conv1's activation never leaves LDS on its way into conv2); the two kernels it replaces
              # still run twice in a profile (bench.py's isolated per-op table): not listed
-             ("enc12_fwd_kernel<unsigned char>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
+             ("enc12_fwd_kernel<unsigned char, 0, 1, 1>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
     + [n for n in NAMES_R04 if n[0] != "reduce_fused_kernel" and n[2] not in ("conv1.fwd", "conv2.fwd")]
 NAMES = NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic = [], {}
