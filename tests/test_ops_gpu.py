@@ -1025,6 +1025,8 @@ def test_encoder_head_backward_fused_equals_the_two_ops(u8, B, FH, FW):
     and two ragged ones (8 x 16 tiles overhanging the image, odd slot counts), camera bytes and fp32 frames, gathered through a frame index, ACCUMULATING into the
     gradient buffers; and against the float64 statement of the same two contractions (bf16 operands, the intermediate rounded to bf16 like the stored tensor)."""
     import ctypes
+    if os.environ.get("MI355_ENC12") == "0":
+        pytest.skip("MI355_ENC12=0 switches the fused op off (A/B runs): nothing to compare")
     if B == 512 and not u8:
         pytest.skip("the benchmarked batch runs once, on camera bytes (the production configuration)")
     L = milib.get()
