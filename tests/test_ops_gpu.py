@@ -1,5 +1,7 @@
 """Op-level parity: every C-ABI kernel launcher vs a float64 torch-CPU statement of the same TF op, on the layer
 geometries of the ConvVAE (odd sizes, k=5, C=3 and C=1 edge layers, fused minibatch gather) and the PPO MLP."""
+import os
+
 import numpy as np
 import pytest
 import torch
