@@ -469,6 +469,27 @@ def box_probe(dev, local=0, millis=5):
     return box
 
 
+def condition_clocks(step, target_ms, world, device, chunk=20, sync=None):
+    """Untimed steps in chunks of `chunk` until `target_ms` of wall time have passed; returns how many ran.  step(i) runs step number i.
+    Every step of a data-parallel run is a collective, so the ranks must leave this WALL-CLOCK loop after the same number of steps: each rank reading only its own clock,
+    one rank could run a chunk more than another -- whose all-reduces then wait forever (the two-rank bench test hung on exactly that, once in seven runs).  The ranks
+    therefore agree after every chunk -- a float sum through the same transport as the gradients; any rank past the target ends the loop for all."""
+    sync = sync or torch.cuda.synchronize
+    done_steps = 0
+    t_c = time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            step(done_steps); done_steps += 1
+        sync()
+        done = (time.perf_counter() - t_c) * 1e3 >= target_ms
+        if world > 1:
+            flag = torch.tensor([1.0 if done else 0.0], dtype=torch.float32, device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.SUM)
+            done = bool(flag.item() > 0.0)
+        if done:
+            return done_steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -532,13 +553,7 @@ def main():
 
     # ---- clock conditioning (untimed, in front of the counted warm-up): the driver's command is 5 + 20 steps = 25 ms of GPU work from an idle
     # box, i.e. measured on the DVFS ramp; >= --condition-ms of the very same steps first, then the box calibration, then the counted warm-up ----
-    conditioned = 0
-    if args.condition_ms > 0:
-        t_c = time.perf_counter()
-        while (time.perf_counter() - t_c) * 1e3 < args.condition_ms:
-            for _ in range(20):
-                step(conditioned); conditioned += 1
-            torch.cuda.synchronize()
+    conditioned = condition_clocks(step, args.condition_ms, world, device) if args.condition_ms > 0 else 0
     box = None
     if not args.no_box:
         try:

@@ -102,7 +102,7 @@ def test_bench_data_parallel_path_with_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", MI355_BENCH_BACKEND="gloo", MI355_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--batch", "64", "--pool", "256"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=300)      # (seconds: a rank-count mismatch in any loop of the bench is a hang, and must fail here, fast)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -589,3 +589,19 @@ def test_hand_scheduled_loads_of_the_fused_encoder_head_are_never_read_early():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_enc12_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 violations") == 2, r.stdout
+
+
+def test_bench_clock_conditioning_leaves_every_rank_after_the_same_number_of_steps(tmp_path):
+    """bench.py's clock conditioning is a WALL-CLOCK loop of SGD steps, and in a data-parallel run every step is a collective: ranks that each read their own clock leave it
+    after different numbers of steps and the job hangs (the two-rank bench test on the GPU did, once in seven runs -- and the driver's --gpus 8 launch would).
+    bench.condition_clocks lets the ranks agree after every chunk.  Two gloo ranks on the CPU, one of them 3 ms per step slower: both return, after the same number of steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29561",
+                        os.path.join(root, "tests", "condition_worker.py"), str(tmp_path)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = (json.load(open(os.path.join(str(tmp_path), "cond_rank%d.json" % k))) for k in (0, 1))
+    assert a["steps"] == b["steps"] and a["steps"] >= 5 and a["steps"] % 5 == 0, (a, b)
