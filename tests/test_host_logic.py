@@ -589,6 +589,10 @@ def test_hand_scheduled_loads_of_the_fused_encoder_head_are_never_read_early():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_enc12_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 violations") == 2, r.stdout
+    # the same replay over the activation-resident kernels (ares_tile.hpp: LDS fragment reads and their waits by hand -- the idiom the fused encoder head took over)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_enc12_isa.py"), "--generic", os.path.join(root, "carla-ppo_amd", "csrc", "ares.hip"),
+                        "ares_(conv|gather|gather2)_kernel"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 violations" in r.stdout, r.stdout + r.stderr
 
 
 def test_bench_clock_conditioning_leaves_every_rank_after_the_same_number_of_steps(tmp_path):

@@ -4,7 +4,8 @@ their s_waitcnt is written by hand, so nothing protects a register between `glob
 enc12.hip (compiled here if no path is given), walks the kernel in layout order -- once from the top, then the band loop a second time for the loop-carried
 requests -- with the hardware's rule (loads retire in order; a wait vmcnt(N) leaves at most N of them outstanding; stores only ever make a wait stricter) and fails if any
 instruction READS a register whose load may still be outstanding, or if the kernel spills.
-    python tools/check_enc12_isa.py [listing.s]"""
+    python tools/check_enc12_isa.py [listing.s]
+    python tools/check_enc12_isa.py --generic carla-ppo_amd/csrc/ares.hip "ares_(conv|gather|gather2)_kernel"      (any file / kernels: the replay alone)"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -101,7 +102,45 @@ def check(kernel, path):
     return path, bool(errors) or spills != 0 or n_loads < 36 or n_waits < 3
 
 
+def check_generic(hip_path, pattern, listing_path=None):
+    """Any kernel of `hip_path` whose mangled name matches `pattern`: the same replay (hand-written LDS reads / waits of the ar_lds_read idiom of ares_tile.hpp and rwconv.hip are covered by
+    the LGKM half of the rule), no expectation about counts.  Returns True when a violation was found."""
+    if listing_path is None:
+        listing_path = os.path.join(tempfile.mkdtemp(), "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        hip_path, "-o", listing_path], check=True, capture_output=True)
+    txt = open(listing_path).read().split("\n")
+    starts = {}
+    for i, ln in enumerate(txt):
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", ln)
+        if m and re.search(pattern, m.group(1)):
+            starts[m.group(1)] = i
+    bad, n_asm = False, 0
+    for k, i0 in starts.items():
+        out = []
+        for ln in txt[i0:]:
+            out.append(ln)
+            if "s_endpgm" in ln:
+                break
+        num = list(enumerate(out, 1))
+        errors, outstanding, lds = [], [], []
+        walk(num, outstanding, errors, "pass 1", lds)
+        heads = [i for i, l in enumerate(out) if "Loop Header: Depth=1" in l]
+        if heads:
+            walk(num[heads[0] - 1:], outstanding, errors, "pass 2", lds)
+        n_asm += sum(1 for l in out if "ASMSTART" in l)
+        if errors:
+            bad = True
+            print("kernel %s: %d violations" % (k[:80], len(errors)))
+            for e in errors[:5]:
+                print("  " + e)
+    print("%s: %d kernels matching /%s/, %d inline-assembly statements, %s" % (os.path.basename(hip_path), len(starts), pattern, n_asm, "VIOLATIONS" if bad else "0 violations"))
+    return bad or not starts
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--generic":          # --generic file.hip name-regex [listing.s]
+        raise SystemExit(1 if check_generic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None) else 0)
     path, bad = sys.argv[1] if len(sys.argv) > 1 else None, False
     for k in KERNELS:
         path, b = check(k, path)
