@@ -285,8 +285,19 @@ def ppo_extra(tmp, steps=5):
         update()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # a PPO minibatch step moves 284 B per sample + 369,505 parameters x 24 B (theta, m, v, g read; theta, m, v written) and does 2,441,600 FLOP per sample:
+    # at minibatch 32 both floors are ~1 us -- the step is bound by the latency of its five dependent launches, priced here against HBM as SURVEY says to
+    step_s = dt / 16
+    step_bytes = 369505 * 24.0 + 284.0 * 32
+    step_flops = 2441600.0 * 32
     return {"config": "PPO update, horizon 128, 4 epochs x 4 minibatches of 32, fp32, 1 GPU", "samples_per_s": T / dt, "ms_per_update": dt * 1e3,
-            "ms_per_sgd_step": dt * 1e3 / 16}
+            "ms_per_sgd_step": dt * 1e3 / 16,
+            "roofline": {"kernel": "PPO minibatch SGD step (five dependent launches: mi_ppo_train_step_idx)", "bound": "launch latency (priced against HBM, SURVEY 8d)",
+                         "algorithmic_bytes_per_step": step_bytes, "algorithmic_flops_per_step": step_flops, "achieved": step_bytes / step_s / 1e9, "peak": PEAK["hbm"] / 1e9,
+                         "unit": "GB/s", "frac": step_bytes / step_s / PEAK["hbm"], "floor_ms": {"hbm": step_bytes / PEAK["hbm"] * 1e3, "mfma_f32": step_flops / PEAK["mfma_f32"] * 1e3},
+                         "launches_per_step": 5, "us_per_launch": step_s * 1e6 / 5,
+                         "note": "a dependent kernel boundary in this chain costs 1.5-1.6 us (profiles/r05_ppo.md): five launches = ~8 us of the step are boundaries, the rest "
+                                 "is five kernels of 32-row matrices on an empty chip"}}
 
 
 def fp32_extra(tmp, B, pool_u8, idx, steps=40, warm=5, precision="fp32"):
@@ -401,8 +412,98 @@ def replay_extra(tmp, rows, T=128, batch=2048, epochs=4):
     res["seconds"], res["samples_per_s"] = dt_r, n / dt_r
     if "sgd" in stages_r:
         res["ppo_sgd_samples_per_s"] = n * epochs / stages_r["sgd"]
+        # the large-minibatch PPO step: 2,441,600 FLOP per sample in exact fp32 (157 TFLOP/s) against 8.87 MB of optimiser traffic + 284 B per sample per step
+        sgd_steps = max(len(out_r["losses"]), 1)
+        step_s = stages_r["sgd"] / sgd_steps
+        res["ppo_sgd_roofline"] = {"minibatch": batch, "ms_per_step": step_s * 1e3, "mfma_f32_frac": 2441600.0 * batch / step_s / PEAK["mfma_f32"],
+                                   "hbm_frac": (369505 * 24.0 + 284.0 * batch) / step_s / PEAK["hbm"], "bound": "launch latency / exact-fp32 MFMA (SURVEY 8d)"}
+    efps = res["resident"].get("encode_frames_per_s")
+    if efps:
+        # 118,778,880 FLOP per encoded frame (bf16 MFMA), 38,400 camera bytes in + 256 B out
+        res["encode_roofline"] = {"frames_per_s": efps, "achieved_tflops": efps * 118778880.0 / 1e12, "mfma_bf16_frac": efps * 118778880.0 / PEAK["mfma_bf16"],
+                                  "hbm_frac_algorithmic": efps * (38400.0 + 256.0) / PEAK["hbm"], "bound": "mfma (AI = 3,073 FLOP / B on uint8 frames)"}
     del out_r
     return res
+
+
+def step_traffic(B):
+    """HBM bytes of one WHOLE SGD step (PMC FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of a step, from the committed rocprofv3 passes of this round) next to SURVEY
+    8(d)'s two reference points: the algorithmic bytes (frames + noise + optimiser traffic) and the practical un-fused activation traffic (every activation written in forward and
+    read in backward, the same for the gradients, bf16).  Counters cannot be read from inside the bench: the figure is the profile's, for batch 512."""
+    alg = B * (38400.0 + 256.0) + 2584387 * 24.0
+    practical = B * 3.0e6 + 2584387 * 24.0
+    out = {"algorithmic_gb": alg / 1e9, "practical_unfused_gb": practical / 1e9, "pmc_gb_per_step": None, "source": None}
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            st = tj.get("step")
+            if st:
+                out["pmc_gb_per_step"], out["source"] = st["hbm_bytes"] / 1e9, "profiles/%s (%d kernels of one step, batch %d)" % (fn, st["kernels"], st.get("batch", 512))
+            else:                                      # (older files: per-op records only -- every op runs once per step except the two averaged pairs)
+                tot = sum(r["hbm_bytes_per_launch"] * (2 if "averaged" in op else 1) for op, r in tj["ops"].items())
+                out["pmc_gb_per_step"], out["source"] = tot / 1e9, "profiles/%s (sum of its per-op records)" % fn
+            break
+        except Exception:
+            continue
+    if out["pmc_gb_per_step"]:
+        out["x_algorithmic"], out["x_practical"] = out["pmc_gb_per_step"] / out["algorithmic_gb"], out["pmc_gb_per_step"] / out["practical_unfused_gb"]
+    return out
+
+
+def _watchdog(seconds, last_words):
+    """A timer that ends THIS process (exit code 0) after `seconds` unless cancelled; rank 0 passes `last_words` (prints the result line it already has)."""
+    import threading
+
+    def fire():
+        try:
+            if last_words is not None:
+                last_words()
+        finally:
+            os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def dp_schedules(step, n_steps, world, rank, device):
+    """Data-parallel runs only: the same SGD steps under BOTH gradient-bucket schedules of the library communicator -- ncclAllReduce and one-hop reduce-scatter + all-gather
+    (csrc/comm.hip) -- timed the same way in one run, and the number of ranks RCCL itself reports (the first multi-GPU run has something to compare).
+    A schedule that has never moved a byte between two devices must not be able to take the headline down with it: a watchdog ends every rank of a leg that does not come
+    back (rank 0 has printed nothing yet; main() prints the line without this object in that case -- see _watchdog)."""
+    from mi355 import dist as midist
+    from mi355 import lib as milib
+    c = midist.mi_comm()
+    if c is None:
+        return {"schedules": None, "schedules_note": "torch.distributed carries the buckets (no library communicator): one schedule only"}
+    L = milib.get()
+    out = {"ranks_seen": int(L.mi_comm_ranks(c.handle))}
+    has = torch.tensor([int(L.mi_comm_has_rsag())], dtype=torch.int32, device=device)
+    torch.distributed.all_reduce(has, op=torch.distributed.ReduceOp.MIN)
+    start_algo = 1 if "reduce-scatter" in midist.comm_note else 0
+    res = {}
+    for algo, name in ((0, "ncclAllReduce"), (1, "reduce_scatter_all_gather")):
+        if algo == 1 and not int(has.item()):
+            res[name] = None
+            continue
+        torch.cuda.synchronize(); midist.barrier()
+        L.mi_comm_set_algo(c.handle, algo)                # (every rank, at the same point of the program: the schedule is a property of the communicator)
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize(); midist.barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i)
+        torch.cuda.synchronize()
+        midist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        res[name] = float(t[0].item()) / n_steps * 1e3
+    torch.cuda.synchronize(); midist.barrier()
+    L.mi_comm_set_algo(c.handle, start_algo)
+    out["schedules_ms_per_step"] = res
+    out["schedule_of_the_timed_region"] = "reduce_scatter_all_gather" if start_algo else "ncclAllReduce"
+    return out
 
 
 def _library_stamp():
@@ -509,6 +610,8 @@ def main():
     ap.add_argument("--condition-ms", type=float, default=300.0, help="untimed steps in FRONT of the counted warm-up until this much wall time has passed: the box reaches its "
                                                                     "sustained clocks / power state before anything is measured (0 = off)")
     ap.add_argument("--no-box", action="store_true", help="skip the in-run box calibration (mi_device_probe)")
+    ap.add_argument("--long-steps", type=int, default=200, help="a second, longer timed leg of the same step behind the counted one (`value_200`): shows whether the driver's "
+                                                                "20-step sample (16 ms) is representative; 0 = off")
     args = ap.parse_args()
 
     from mi355 import dist as midist
@@ -651,6 +754,22 @@ def main():
             except Exception:
                 pass
 
+    # ---- a longer leg of the very same step, same run (the driver's --steps 20 is a 16 ms sample): barrier + synchronize on both sides, MAX over ranks ----
+    long_leg = None
+    if args.long_steps > args.steps:
+        midist.barrier()
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        for i in range(args.long_steps):
+            step(total + i)
+        torch.cuda.synchronize()
+        midist.barrier()
+        tl = torch.tensor([time.perf_counter() - tl0], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(tl, op=torch.distributed.ReduceOp.MAX)
+        long_leg = {"steps": args.long_steps, "ms_per_step": float(tl[0].item()) / args.long_steps * 1e3, "frames_per_s": B * world * args.long_steps / float(tl[0].item()),
+                    "note": "the same step, %d more steps timed the same way right behind the counted region (not the headline: `value` is the counted K steps)" % args.long_steps}
+
     # data parallel: what one rank spends per step, and how much of it is gradient all-reduce that nothing overlaps
     dp = None
     if world > 1:
@@ -697,7 +816,10 @@ def main():
             "per_op_ms": {k: round(v, 4) for k, v in sorted(per_op.items(), key=lambda kv: -kv[1])},
             "final_losses": {"reconstruction": float(losses[0]), "kl": float(losses[1])},
             "data_parallel": dp,
+            "value_200": long_leg,
         }
+        if roofline is not None and args.precision == "bf16":
+            roofline["step_traffic"] = step_traffic(B)
         out["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(B)
@@ -732,6 +854,16 @@ def main():
                 out["replay"] = {"error": repr(e)}
         if box and "error" not in box and box.get("mfma_bf16_tflops", 0) > 0 and args.precision == "bf16":
             out["step_model_flops_utilisation"]["frac_of_box_mfma_rate"] = out["step_model_flops_utilisation"]["achieved_tflops"] / box["mfma_bf16_tflops"]
+    if world > 1:
+        # both bucket schedules, timed in this run -- behind a watchdog: the headline line exists by now and must get out even if a collective schedule that has never run
+        # on this many devices does not come back (rank 0 prints it without the schedule object; every rank leaves)
+        wd = _watchdog(180.0, (lambda: print(json.dumps(dict(out, data_parallel=dict(out["data_parallel"] or {}, schedules_note="watchdog: the schedule leg did not return"))), flush=True))
+                       if rank == 0 else None)
+        extra = dp_schedules(step, min(args.steps, 50), world, rank, device)
+        wd.cancel()
+        if rank == 0 and out.get("data_parallel") is not None:
+            out["data_parallel"].update(extra)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     midist.barrier()
     if world > 1:

@@ -30,6 +30,7 @@ struct Rccl {
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);    // optional (mi_comm_ranks)
 };
 
 Rccl g_rccl;                                              // function table, filled once (idempotent; same values from any thread)
@@ -49,6 +50,7 @@ int load_rccl() {
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
     r.ReduceScatter = (decltype(r.ReduceScatter))dlsym(lib, "ncclReduceScatter");      // optional: the two-phase schedule below is skipped without them
     r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+    r.CommCount = (decltype(r.CommCount))dlsym(lib, "ncclCommCount");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GetErrorString)
         return mi_fail(MI_ERR_STATE, "mi_comm: librccl.so.1 lacks an entry point");
     r.lib = lib;
@@ -71,8 +73,8 @@ struct MiComm {
 enum { REC_ALLREDUCE = 1, REC_REDUCE_SCATTER = 2, REC_ALLGATHER = 3, REC_BROADCAST = 4, REC_WAIT = 5 };
 void rec_add(MiComm* c, int op, long long count, int async, const void* buf) {
     if (c->rec_n < c->rec_cap) { long long* e = c->rec + 4ll * c->rec_n; e[0] = op; e[1] = count; e[2] = async; e[3] = (long long)(uintptr_t)buf; }
-    c->rec_n += 1;                                        // (counts past the capacity too: the caller sees that its log was too short)
-}
+    if (c->rec_n < (1 << 30)) c->rec_n += 1;              // (counts past the capacity too: the caller sees that its log was too short; saturates -- a recording communicator kept
+}                                                         //  for a whole benchmark run adds ~7 entries per step)
 
 // Gradient-bucket schedule: 0 = ncclAllReduce (RCCL picks ring / tree / one-shot itself), 1 = reduce-scatter + all-gather: on the
 // fully connected xGMI mesh of one node every rank owns 1/W of the bucket, receives the other ranks' pieces of ITS slice over the seven direct
@@ -182,6 +184,17 @@ int mi_comm_init_recording(void** comm_out, int rank, int world, long long* log,
     return MI_OK;
 }
 int mi_comm_recorded(void* comm) { MiComm* c = (MiComm*)comm; return (c && c->rec) ? c->rec_n : -1; }
+// how many ranks the communicator spans as RCCL itself reports it (ncclCommCount; a recording communicator: the world it was created for); < 0: error / entry point missing.
+// bench.py prints it next to the data-parallel timings: the all-reduce really went over that many devices.
+int mi_comm_ranks(void* comm) {
+    MiComm* c = (MiComm*)comm;
+    if (!c) return mi_fail(MI_ERR_ARG, "mi_comm_ranks: null communicator");
+    if (c->rec) return c->world;
+    if (!g_rccl.CommCount) return mi_fail(MI_ERR_STATE, "mi_comm_ranks: the bound RCCL lacks ncclCommCount");
+    int n = 0;
+    const ncclResult_t r = g_rccl.CommCount(c->comm, &n);
+    return r == ncclSuccess ? n : rccl_fail("ncclCommCount", r);
+}
 
 // the gradient-bucket schedule of this communicator: 0 = ncclAllReduce, 1 = reduce-scatter + all-gather (needs both entry points in the bound library).  Every rank
 // must set the SAME value (the caller agrees on it first: mi355/dist.py, which also agrees on whether EVERY rank's library has both entry points); returns MI_OK

@@ -322,6 +322,8 @@ static int nw_depth_env() { const char* e = getenv("MI355_NW_DEPTH"); return e ?
 int g_nw_depth = nw_depth_env();                          // narrow_wgrad (uint8 conv1 shape): steps in flight per wave (3 | 5 | 6); mi_set_tuning key 19
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
+static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); return (e && e[0] == '0') ? 0 : 1; }
+int g_tw_ldec = tw_ldec_env();                             // raw-staged filter gradients: a step's DMA rows decoded once per wave, one row per lane (tapwgrad_tile.hpp, round 6); mi_set_tuning key 24
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
     if (g_tapwgrad_on < 0) { const char* e = getenv("MI355_TAPWGRAD"); g_tapwgrad_on = (e && e[0] == '0') ? 0 : 1; }
@@ -388,7 +390,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW); q.div_n = make_fastdiv(N);
     q.div_2c = make_fastdiv(2 * C); q.div_c = make_fastdiv(C);
     q.out = out;
-    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg_cheap_addr = g_wgrad_skip == 2;
+    q.trace = g_trace; q.trace_cap = g_trace_cap; q.dbg_cheap_addr = (g_wgrad_skip >= 2 && g_wgrad_skip <= 5) ? g_wgrad_skip : 0;
     // partial sums per split in the caller's scratch (accumulator-order 16-byte stores + one reduce that does the dW index decode)
     // when it is large enough; otherwise fp32 atomics straight into dW (~1 element per clock per CU: 35-45 % of the kernel at 256 splits)
     const int kt_tiles = taps == 2 ? 4 : 2;
@@ -405,17 +407,22 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     }
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
+    const bool ldec = g_tw_ldec && !q.dbg_cheap_addr && !q.trace;
     if (mode == TC_CONV) {
-        if (split) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
+        else if (split) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
         else MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     } else if (taps == 2) {
-        if (split) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
+        if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
+        else if (split) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
         else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     }
     else {
         if (q.npairs > 32) return 0;
         // k = 5 with caller scratch: a wave per (parity class, tap row), the shifted slot fragments formed in registers (mi_set_tuning key 14 = 0: the pair layout)
-        if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) MI_LAUNCH(tapwgrad_cw_kernel, g, dim3(TWC_NT), 0, st, q);
+        if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) {
+            if (ldec) MI_LAUNCH(tapwgrad_cw_kernel<true>, g, dim3(TWC_NT), 0, st, q); else MI_LAUNCH(tapwgrad_cw_kernel<false>, g, dim3(TWC_NT), 0, st, q);
+        }
         else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
     int rc = mi_check_launch("tapwgrad_kernel");
@@ -954,6 +961,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
+    else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value ? 1 : 0; }
     else if (key == 23) { prev = mi_enc12_debug(value); }  // (debug: ablation mask of the fused encoder head's timing instantiation -- results are wrong with any bit set)
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;

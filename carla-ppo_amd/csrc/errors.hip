@@ -21,7 +21,7 @@ extern "C" const char* mi_last_error(void) { return g_err; }
 
 thread_local hipEvent_t mi_tl_stop_event = nullptr;     // mi_internal.hpp, MI_LAUNCH
 
-extern "C" int mi_abi_version(void) { return 6; }          // 2: frames_u8 arguments, engine-side noise, mi_vae_train_step; 3: split storage (MI_BF16X3), fused decoder tail, mi_ppo_train_step_idx, mi_comm_probe; 4: ordered (atomic-free) gradient reductions: mi_colsum_ws / mi_gemm_wgrad_ws, mi_ppo_fused_shape_ok; 5: MlpVAE engine (mi_mlpvae_*), mi_adam_tf_layouts, mi_gather_rows_cast, mi_gemm_wgrad_bias_set; 6: mi_device_probe (box calibration), mi_vae_train_step_dp, mi_vae_reparam_kl_fwd_bwd, frames_u8 on the mi_mlpvae_* entry points, MiVaeDesc.inference_only
+extern "C" int mi_abi_version(void) { return 7; }          // 2: frames_u8 arguments, engine-side noise, mi_vae_train_step; 3: split storage (MI_BF16X3), fused decoder tail, mi_ppo_train_step_idx, mi_comm_probe; 4: ordered (atomic-free) gradient reductions: mi_colsum_ws / mi_gemm_wgrad_ws, mi_ppo_fused_shape_ok; 5: MlpVAE engine (mi_mlpvae_*), mi_adam_tf_layouts, mi_gather_rows_cast, mi_gemm_wgrad_bias_set; 6: mi_device_probe (box calibration), mi_vae_train_step_dp, mi_vae_reparam_kl_fwd_bwd, frames_u8 on the mi_mlpvae_* entry points, MiVaeDesc.inference_only; 7: mi_ppo_train_step_dp, mi_mlpvae_train_step_dp / mi_mlpvae_dp_buckets (one-call data-parallel steps of PPO and the MlpVAE)
 
 // device properties the host side reports in bench output (no torch needed)
 extern "C" int mi_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len) {

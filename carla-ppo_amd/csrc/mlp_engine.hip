@@ -405,6 +405,38 @@ int mi_mlpvae_train_step(void* h, void* stream, const void* src, const void* tgt
     return mi_mlpvae_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
 }
 
+// One whole DATA-PARALLEL SGD step of the MlpVAE in ONE call (round 6): forward + ELBO of this rank's rows (inv_batch = 1 / B_global), the
+// decoder half of the backward pass, its gradients' all-reduce queued on the communicator's own stream (it runs under the encoder half), the encoder half, its all-reduce,
+// the join, TF-Adam -- what vae/models.py's host loop issued as two backward calls + two Python-side collectives.  Buckets (mi_mlpvae_dp_buckets): {part 1: floats
+// [decoder_offset, total)} then {part 2: [0, decoder_offset)} -- the order the backward pass completes them.  comm: mi_comm_init (or a recording communicator).
+int mi_mlpvae_dp_buckets(void* h, long long* out6) {
+    MlpEngine* e = (MlpEngine*)h;
+    if (!e || !out6) return mi_fail(MI_ERR_ARG, "mi_mlpvae_dp_buckets: null handle or output");
+    const long long b[6] = {1, e->decoder_offset, e->total, 2, 0, e->decoder_offset};
+    for (int i = 0; i < 6; ++i) out6[i] = b[i];
+    return MI_OK;
+}
+
+int mi_mlpvae_train_step_dp(void* h, void* comm, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps,
+                            float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight) {
+    MlpEngine* e = (MlpEngine*)h;
+    CK(check_batch(e, B));
+    if (!comm) return mi_fail(MI_ERR_ARG, "mi_mlpvae_train_step_dp: null communicator (single rank: mi_mlpvae_train_step)");
+    if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_mlpvae_train_step_dp: engine created without a gradient buffer");
+    long long bk[6];
+    CK(mi_mlpvae_dp_buckets(h, bk));
+    CK(mi_mlpvae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
+    int rc = MI_OK;                                       // (a local failure still joins what was queued; it is fatal for the job all the same: mi_vae_train_step_dp)
+    for (int i = 0; i < 2 && rc == MI_OK; ++i) {
+        rc = mi_mlpvae_backward(h, stream, eps, inv_batch, (int)bk[3 * i]);
+        if (rc == MI_OK) rc = mi_allreduce_sum_f32_async(comm, stream, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]);
+    }
+    const int rcw = mi_comm_wait(comm, stream);
+    if (rc != MI_OK) return rc;
+    CK(rcw);
+    return mi_mlpvae_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
+}
+
 // VAE.encode (vae/models.py:199-202): frames -> mean [B, Z] fp32
 int mi_mlpvae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out) {
     MlpEngine* e = (MlpEngine*)h;

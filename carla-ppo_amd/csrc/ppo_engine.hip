@@ -235,7 +235,7 @@ int mi_ppo_forward_backward(void* h, void* stream, const float* states, const fl
     if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
     if (M < 1 || M > e->d.max_batch) return mi_fail(MI_ERR_ARG, "mi_ppo_forward_backward: batch outside [1, max_batch]");
     if (!e->grads) return mi_fail(MI_ERR_STATE, "mi_ppo_forward_backward: engine created without a gradient buffer");
-    if (fused_enabled(e)) {                                // 5 launches; gradients written (not accumulated) into the flat buffer (M > 256: zeroed, then row chunks meet in atomics)
+    if (fused_enabled(e)) {                                // 5 launches; gradients written (not accumulated) into the flat buffer (M > 256: the row chunks' partial sums are added in a fixed order, round 4)
         PpoFusedParams q; fill_fused(e, q, states, M);
         q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
         e->last_M = M;
@@ -309,7 +309,7 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
     if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step: engine created without optimiser buffers");
     if (M > 256 || !fused_enabled(e)) {
         // large minibatches (the synthetic replay: 2048 rows per GPU): the weight-gradient launch splits the rows into chunks of 256 whose partial
-        // sums meet in atomics, so the Adam update is its own (flat) launch; everything before it is the same five-kernel chain
+        // sums are added in a fixed order (round 4: no atomics), so the Adam update is its own (flat) launch; everything before it is the same five-kernel chain
         if (!fused_enabled(e)) { CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale)); }
         else {
             PpoFusedParams q; fill_fused(e, q, states, M);
@@ -358,6 +358,34 @@ int mi_ppo_train_step_idx(void* h, void* stream, const float* states, const floa
     }
     q.alpha = alpha; q.omb1 = 1.0f - beta1; q.omb2 = 1.0f - beta2; q.epsilon = epsilon;
     return mi_ppo_fused_step((hipStream_t)stream, q, 1);
+}
+
+// One DATA-PARALLEL SGD step of PPO.train (ppo.py:218-229 behind train.py:193-207) in ONE call (round 6): the fused five-launch chain of
+// mi_ppo_train_step[_idx] with the gradients left in the flat buffer (sums over this rank's M rows / M_global: inv_m = 1 / M_global, grad_scale = M / M_global), ONE
+// all-reduce of that buffer (1.48 MB: one bucket, in stream order -- nothing of this step is left to overlap it with), tf.train.AdamOptimizer.  row_idx != NULL: the
+// minibatch gather of train.py:199-204 stays inside the kernels (states / actions / returns / advantage / logp_old are this rank's horizon-batch tables of n_rows rows);
+// row_idx == NULL: contiguous minibatch tensors (n_rows ignored).  comm: mi_comm_init (or a recording communicator).  Before round 6 the host issued
+// forward_backward -> a blocking Python-side all-reduce -> apply_adam and gathered the rows itself whenever world_size > 1.
+int mi_ppo_train_step_dp(void* h, void* comm, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old,
+                         const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon) {
+    PpoEngine* e = (PpoEngine*)h;
+    if (!e) return mi_fail(MI_ERR_STATE, "ppo engine: null handle");
+    if (!comm) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step_dp: null communicator (single rank: mi_ppo_train_step)");
+    if (M < 1 || M > e->d.max_batch || (row_idx && n_rows < 1)) return mi_fail(MI_ERR_ARG, "mi_ppo_train_step_dp: batch outside [1, max_batch] or empty tables");
+    if (!e->grads || !e->m || !e->v) return mi_fail(MI_ERR_STATE, "mi_ppo_train_step_dp: engine created without optimiser buffers");
+    if (fused_enabled(e)) {
+        PpoFusedParams q; fill_fused(e, q, states, M);
+        q.actions = actions; q.returns = returns; q.adv = advantage; q.inv_m = inv_m; q.grad_scale = grad_scale;
+        q.logp_old = logp_old; q.n_nets = logp_old ? 2 : 3;
+        if (row_idx) { q.row_idx = row_idx; q.n_rows = n_rows; q.s_gath = (float*)e->at(e->s_pad); }
+        e->last_M = M;
+        CK(mi_ppo_fused_step((hipStream_t)stream, q, 0));      // gradients written into the flat buffer (M > 256: ordered row chunks)
+    } else {
+        if (row_idx) return mi_fail(MI_ERR_SHAPE, "mi_ppo_train_step_dp: the in-kernel gather needs the fused kernels (shape outside their range or MI355_PPO_FUSED=0): gather on the host side and pass row_idx = NULL");
+        CK(mi_ppo_forward_backward(h, stream, states, actions, returns, advantage, M, inv_m, grad_scale));
+    }
+    CK(mi_allreduce_sum_f32(comm, stream, e->grads, e->total));
+    return mi_ppo_apply_adam(h, stream, alpha, beta1, beta2, epsilon);
 }
 
 // log pi_old(a | s) of M samples under theta_old -> out [M] (the per-horizon cache for mi_ppo_train_step)

@@ -634,8 +634,18 @@ int mi_ppo_fused_trunks(hipStream_t st, const PpoFusedParams& q) {
 // Measurement aid (round 5; profiles/r05_ppo.md): MI355_PPO_PAD=n issues n trivial one-wave launches behind layer 2 and n behind the layer-1
 // input gradient -- 2 n extra dependent kernel boundaries on the step's stream.  (wall(n) - wall(0)) / 2 n is what ONE boundary costs inside THIS launch chain on this
 // box, i.e. the most a fusion that removes a boundary can win before it has paid for any recomputation.  Default 0: nothing is launched.
+// Compiled only with -DMI355_PPO_PAD_PROBE (HIPCC_EXTRA=-DMI355_PPO_PAD_PROBE python -m mi355.build --force): the production step carries no measurement code.
+#ifdef MI355_PPO_PAD_PROBE
 __global__ void ppo_boundary_probe_kernel(float* sink) { if (threadIdx.x == 1024) sink[0] = 0.f; }
 static int ppo_pad_launches() { static int n = -1; if (n < 0) { const char* e = getenv("MI355_PPO_PAD"); n = e ? atoi(e) : 0; if (n < 0 || n > 64) n = 0; } return n; }
+static int ppo_pad(hipStream_t st, float* sink) {
+    const int pad = ppo_pad_launches();
+    for (int i = 0; i < pad; ++i) hipLaunchKernelGGL(ppo_boundary_probe_kernel, dim3(1), dim3(64), 0, st, sink);
+    return pad ? mi_check_launch("ppo_boundary_probe") : MI_OK;
+}
+#else
+static inline int ppo_pad(hipStream_t, float*) { return MI_OK; }
+#endif
 
 // the whole minibatch step; fuse_adam = 0: gradients to q.grads instead of the in-place optimiser update
 int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
@@ -644,12 +654,13 @@ int mi_ppo_fused_step(hipStream_t st, PpoFusedParams& q, int fuse_adam) {
     q.n_loss_blocks = (q.M + 31) / 32;
     int rc = mi_ppo_fused_trunks(st, q);
     if (rc != MI_OK) return rc;
-    const int pad = ppo_pad_launches();
-    for (int i = 0; i < pad; ++i) hipLaunchKernelGGL(ppo_boundary_probe_kernel, dim3(1), dim3(64), 0, st, q.losses);
+    rc = ppo_pad(st, q.losses);
+    if (rc != MI_OK) return rc;
     if (q.A == 2) hipLaunchKernelGGL(ppo_head_loss_kernel<2>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);     // (action loops are compile-time unrolled)
     else hipLaunchKernelGGL(ppo_head_loss_kernel<PF_MAX_ACT>, dim3(q.n_loss_blocks), dim3(256), 0, st, q);
     hipLaunchKernelGGL(ppo_dh1_kernel, dim3((q.H1 + 31) / 32, 2, (q.M + 31) / 32), dim3(256), 0, st, q);
-    for (int i = 0; i < pad; ++i) hipLaunchKernelGGL(ppo_boundary_probe_kernel, dim3(1), dim3(64), 0, st, q.losses);
+    rc = ppo_pad(st, q.losses);
+    if (rc != MI_OK) return rc;
     const int nt1 = (q.H1 + 31) / 32, nt2 = (q.H2 + 31) / 32, kt1 = (q.kin + 31) / 32;
     const int tiles = 2 * (nt1 * nt2 + kt1 * nt1 + nt2) + 1;         // + the wave that finalises the loss scalars
     q.m_chunk = 0;

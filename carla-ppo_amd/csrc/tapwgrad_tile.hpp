@@ -51,7 +51,9 @@ struct TapWgradParams {
                                      // element, each 2^-9 relative with independent signs, add ~1e-4 of the element's own scale to a gradient whose operands
                                      // were bf16 to begin with -- and halve the 211 MB written + 214 MB read per step that the slabs cost
     long long* trace; int trace_cap;   // debug stamps (mi_debug_set_trace)
-    int dbg_cheap_addr;                // debug (mi_set_tuning key 2 == 2): trivial DMA addresses, wrong results, shows the cost of the address arithmetic
+    int dbg_cheap_addr;                // TIMING INSTANTIATIONS (mi_set_tuning key 2; wrong results, honest durations -- tools/wgrad_ablate.py): 2 = trivial DMA addresses inside ONE
+                                       // megabyte (every load an L2 hit: NOT "the cost of the address arithmetic" as round 1 read it, but the kernel without its HBM traffic), 3 = no
+                                       // loads at all (stale LDS), 4 = no fragment reads / MFMAs (loads, barriers and stores only), 5 = no slab stores
 };
 
 // LDS-DMA issued through inline asm: hipcc drains every builtin LDS-DMA (s_waitcnt vmcnt(0)) in front of the next
@@ -105,7 +107,16 @@ __device__ __forceinline__ bool tw_dw_index(const TapWgradParams& p, int kc0, in
 // SPLIT (needs 4 taps x NTB == 2, PPW == NTB): wave = (tap, position half); a wave keeps the KT x NTB tiles of its tap over its 64
 // positions of every step, so a slot fragment is read from LDS once for both output tiles (48 instead of 80 transpose reads per
 // 32 MFMAs); the two halves meet in LDS at the end.
-template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false>
+// LDEC (round 6, VERDICT r05 item 1 -- the VALU diet): the source offset of a DMA row is a function of its POSITION only, and the 64 lanes of a DMA instruction cover 4 or 8
+// rows: decoding it per lane and per instruction (two magic-number divisions = 6 quarter-rate multiplies, the image bounds, the address: ~25 VALU instructions, ~200 issue
+// cycles, nine times per wave and 128-position step -- as many VALU cycles per SIMD as the step's MFMAs take) computed every row's offset 8 or 16 times over.  Here each wave decodes
+// ALL the rows it is going to request for a step at once, one row per LANE (28 + 16 or 32 + 16 rows: 44 / 48 lanes), two steps ahead (at the top of a step, while its first
+// fragment reads are in flight), and a DMA instruction fetches its rows'
+// offsets with ONE ds_bpermute_b32 (crossbar only, no LDS banks); what depends on the lane's 16-byte chunk rides along: the channel offset is added,
+// and the two "this pixel's odd row / column is outside the image" bits of the 2 x 2 forms travel in the low bits of the row offset (rows are >= 64 bytes apart) and are tested
+// against the chunk's own (ph, pw).  Same addresses, same zero fill, bit-identical sums (tests/test_ops_gpu.py runs both forms).  Measured upper bound of the whole address cost
+// (mi_set_tuning key 2 = 2: trivial addresses, wrong results): -3.0 % of the ConvVAE step; this form: DESIGN 3.16.
+template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false, bool LDEC = false>
 __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p) {
     static_assert(!SPLIT || (TAPS == 2 && NTB == 2 && PPW == NTB), "split layout: 4 taps x 2 position halves = 8 waves");
     typedef bf16_t T;
@@ -177,7 +188,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
         const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
-        if (p.dbg_cheap_addr) {
+        if (p.dbg_cheap_addr == 3) return;
+        if (p.dbg_cheap_addr == 2) {
             const int t = wave + 8 * (idx < NIA ? idx : idx - NIA);
             if (idx < NIA && t >= ninstrA) return;
             const uint32_t vo = (uint32_t)((Ps * 64 + t * 1024 + lane * 16) & 0xFFFFF);
@@ -223,6 +235,56 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         }
     };
     constexpr int NDMA = NIA + NID, NKS = SPLIT ? TW_BP / 32 : TW_BP / 16;   // k16-steps a wave runs per position step
+    // ---------------- LDEC: one row per lane (see the kernel's header) ----------------
+    constexpr int RA = NIA * SPI_A, RD = NID * SPI_D;     // rows this wave requests per step: slot tile, gradient tile
+    static_assert(!LDEC || RA + RD <= 64, "lane-parallel row decode: one lane per requested row");
+    const bool lpA = lane < RA;
+    const int lpj = lpA ? lane : lane - RA;
+    const int lpt = wave + 8 * (lpA ? lpj / SPI_A : lpj / SPI_D);
+    const int lprow = lpA ? SPI_A * lpt + lpj % SPI_A : SPI_D * lpt + lpj % SPI_D;
+    const bool lplive = lane < RA + RD && (!lpA || lpt < ninstrA);
+    auto decode_rows = [&](int step) -> uint32_t {        // this lane's row of step `step`: byte offset of its pixel (| edge bits) or G2_OOB
+        const int P = Pbeg + step * TW_BP + lprow;
+        const bool ok = lplive && P < (lpA ? p.MP : Pend);
+        uint32_t g, gx, b, gy;
+        p.div_gw.divmod((uint32_t)(ok ? P : 0), g, gx);
+        p.div_g.divmod(g, b, gy);
+        if constexpr (MODE == TC_CONV) {                  // slot rows: the 2 x 2 pixel block at (2 gy, 2 gx); gradient rows: pixel (gy, gx)
+            const int yy = lpA ? 2 * (int)gy : (int)gy, xx = lpA ? 2 * (int)gx : (int)gx;
+            const int H = lpA ? p.IH : p.OH, W = lpA ? p.IW : p.OW, CB = (lpA ? p.C : p.N) * ESZ;
+            const bool v = ok && yy < H && xx < W;
+            const uint32_t edge = lpA ? (uint32_t)(yy + 1 >= H) | ((uint32_t)(xx + 1 >= W) << 1) : 0u;
+            return v ? (uint32_t)(((int)b * H + yy) * W + xx) * (uint32_t)CB | edge : G2_OOB;
+        } else {                                          // slot rows: pixel (gy - HY, gx - HX); gradient rows: the 2 x 2 output block at (2 gy, 2 gx)
+            const int yy = lpA ? (int)gy - p.HY : 2 * (int)gy, xx = lpA ? (int)gx - p.HX : 2 * (int)gx;
+            const int H = lpA ? p.IH : p.OH, W = lpA ? p.IW : p.OW, CB = (lpA ? p.C : p.N) * ESZ;
+            const bool v = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const uint32_t edge = lpA ? 0u : (uint32_t)(yy + 1 >= H) | ((uint32_t)(xx + 1 >= W) << 1);
+            return v ? (uint32_t)(((int)b * H + yy) * W + xx) * (uint32_t)CB | edge : G2_OOB;
+        }
+    };
+    // which odd row / column this lane's chunk needs (tested against the row's edge bits)
+    const uint32_t a_edge = MODE == TC_CONV ? (uint32_t)((a_sub >> 1) | ((a_sub & 1) << 1)) : 0u;
+    const uint32_t d_edge = MODE == TC_CONV ? 0u : (uint32_t)((d_cls >> 1) | ((d_cls & 1) << 1));
+    uint32_t lp_offs = 0;                                 // the decoded rows of the step whose loads are issued next
+    auto fetch_row = [&](int idx) -> uint32_t {           // the row offset DMA instruction idx of that step needs in this lane
+        const int src = idx < NIA ? idx * SPI_A + rA : RA + (idx - NIA) * SPI_D + rD;
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, (int)lp_offs);
+    };
+    auto issue_row = [&](int buf, int idx, uint32_t row) {
+        const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (idx < NIA) {
+            const int t = wave + 8 * idx;
+            if (t >= ninstrA) return;                     // wave-uniform
+            const bool bad = (row & a_edge) != 0u || !a_kok;
+            dma16_asm(rsA, As + t * 1024, bad ? G2_OOB : (row & ~3u) + a_koff);
+        } else {
+            const int t = wave + 8 * (idx - NIA);
+            const bool bad = (row & d_edge) != 0u || !d_kok;
+            dma16_asm(rsD, Ds + t * 1024, bad ? G2_OOB : (row & ~3u) + d_koff);
+        }
+    };
+    uint32_t lp_nn = 0;                                   // ... and of the step after that: decoded at the TOP of a step, while the step's first fragment reads are in flight
 
     // ---------------- this wave's (tap, output tile) pairs and their per-lane transpose-read offsets ----------------
     // transpose read (see tr_fragment in wgrad_tile.hpp): lane l supplies row r0 + (l>>5)*8 + ((l&15)>>2) (+4 for the high half),
@@ -283,8 +345,15 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     const u16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
+    if constexpr (LDEC) {
+        lp_offs = decode_rows(0);
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+        for (int i = 0; i < NDMA; ++i) issue_row(0, i, fetch_row(i));
+        lp_offs = decode_rows(1);                         // (past the last step: nothing is issued from it)
+    } else {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+    }
     TW_STAMP();
     // One "unit" = the fragments one group of MFMAs needs: (k16-step, pair) in the pair layout (1 gradient + KT slot fragments,
     // KT MFMAs), a whole k16-step in the split layout (NTB gradient + KT slot fragments, NTB KT MFMAs).  The fragments of unit
@@ -321,13 +390,27 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
             const uint32_t sbase = (uint32_t)(cur * STAGE);
             Frag fr[2];
             if constexpr (PIPE) load_unit(fr[0], sbase, 0);
+            if constexpr (LDEC) {                             // in the latency shadow of the reads just issued (behind the last MFMAs of a step the same ~300 cycles delayed the
+                lp_nn = decode_rows(step + 2);                // barrier: +2.7 % on the ConvVAE step, measured)
+                asm volatile("" : "+v"(lp_nn));
+            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int ks = SPLIT ? u : u / PPW, q0 = SPLIT ? 0 : u % PPW;
+                if constexpr (LDEC) {
+                    if (more && (SPLIT || q0 == 0) && ks < NKI) {   // next step's loads: the row offsets come out of lp_offs (one ds_bpermute_b32 each, under the previous group's MFMAs)
+                        uint32_t rows[(NDMA + NKI - 1) / NKI];
+#pragma unroll
+                        for (int i = ks, g = 0; i < NDMA; i += NKI, ++g) rows[g] = fetch_row(i);
+#pragma unroll
+                        for (int i = ks, g = 0; i < NDMA; i += NKI, ++g) issue_row(cur ^ 1, i, rows[g]);
+                    }
+                } else
                 if (more && (SPLIT || q0 == 0) && ks < NKI) { // next step's loads, a few per k16-step
 #pragma unroll
                     for (int i = ks; i < NDMA; i += NKI) issue_one(step + 1, cur ^ 1, i);
                 }
+                if (p.dbg_cheap_addr == 4) continue;          // (timing instantiation: loads and barriers only)
                 if constexpr (!PIPE) load_unit(fr[u & 1], sbase, u);
                 else if (u + 1 < NU) load_unit(fr[(u + 1) & 1], sbase, u + 1);
                 const Frag& f = fr[u & 1];
@@ -353,6 +436,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
                             acc[q][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.d[j]), __builtin_bit_cast(bf16x8, f.a[kt]), acc[q][kt], 0, 0, 0);
                     }
                 }
+                if constexpr (LDEC) {
+                    if (u == NU - 1) lp_offs = lp_nn;          // every load of step + 1 is out: the next step issues from the rows of step + 2
+                }
             }
         }
     };
@@ -375,6 +461,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     // [lane][4 rows] (one contiguous 1 KiB store per wave-instruction); reduce_tiled_kernel sums the slabs and does the decode.
     // Without scratch: fp32 atomics straight into dW.
     auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
+        if (p.dbg_cheap_addr == 5) return;
         if (p.slabs) {
             const long long eoff = (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
             if (p.slab_bf16) {
@@ -454,6 +541,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 // Staging (LDS-DMA of the slot range and the gradient rows, two stages), the slab layout and the reduce are tapwgrad_kernel's.
 // =====================================================================================================================
 constexpr int TWC_NW = 10, TWC_NT = TWC_NW * 64;
+template <bool LDEC>                                      // LDEC: the rows of a step decoded once per wave, one row per lane (tapwgrad_kernel's header)
 __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParams p) {
     constexpr int TAPS = 3, KT = 2, NTB = 4;
     constexpr int ESZ = 2, VE = 8;
@@ -501,6 +589,14 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
     auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
         const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (p.dbg_cheap_addr == 3) return;
+        if (p.dbg_cheap_addr == 2) {                      // (timing instantiation: every load inside one megabyte)
+            const int t = wave + TWC_NW * (idx < NIA ? idx : idx - NIA);
+            if (idx < NIA ? t >= ninstrA : t >= NINSD) return;
+            const uint32_t vo = (uint32_t)((Ps * 64 + t * 1024 + lane * 16) & 0xFFFFF);
+            if (idx < NIA) dma16_asm(rsA, As + t * 1024, vo); else dma16_asm(rsD, Ds + t * 1024, vo);
+            return;
+        }
         if (idx < NIA) {
             const int t = wave + TWC_NW * idx;
             if (t >= ninstrA) return;                     // wave-uniform
@@ -527,6 +623,45 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
     };
     constexpr int NDMA = NIA + NID, NKS = TW_BP / 16;    // 8 k16-steps per position step; at most one DMA instruction per wave and k-step
     static_assert(NDMA <= NKS, "DMA schedule");
+    // ---------------- LDEC: one requested row per lane, decoded a step ahead; a DMA instruction fetches its rows with one ds_bpermute_b32, one k-step ahead ----------------
+    constexpr int RA = NIA * SPI_A, RD = NID * SPI_D;     // 24 + 16 rows per wave and step
+    static_assert(RA + RD <= 64, "lane-parallel row decode: one lane per requested row");
+    const bool lpA = lane < RA;
+    const int lpj = lpA ? lane : lane - RA;
+    const int lpt = wave + TWC_NW * (lpA ? lpj / SPI_A : lpj / SPI_D);
+    const int lprow = lpA ? SPI_A * lpt + lpj % SPI_A : SPI_D * lpt + lpj % SPI_D;
+    const bool lplive = lane < RA + RD && (lpA ? lpt < ninstrA : lpt < NINSD);
+    auto decode_rows = [&](int step) -> uint32_t {
+        const int P = Pbeg + step * TW_BP + lprow;
+        const bool ok = lplive && P < (lpA ? p.MP : Pend);
+        uint32_t g, gx, b, gy;
+        p.div_gw.divmod((uint32_t)(ok ? P : 0), g, gx);
+        p.div_g.divmod(g, b, gy);
+        const int yy = lpA ? (int)gy - p.HY : 2 * (int)gy, xx = lpA ? (int)gx - p.HX : 2 * (int)gx;
+        const int H = lpA ? p.IH : p.OH, W = lpA ? p.IW : p.OW, CB = (lpA ? p.C : p.N) * ESZ;
+        const bool v = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const uint32_t edge = lpA ? 0u : (uint32_t)(yy + 1 >= H) | ((uint32_t)(xx + 1 >= W) << 1);      // the 2 x 2 output block's odd row / column outside the image
+        return v ? (uint32_t)(((int)b * H + yy) * W + xx) * (uint32_t)CB | edge : G2_OOB;
+    };
+    const uint32_t d_edge = (uint32_t)((d_cls >> 1) | ((d_cls & 1) << 1));
+    uint32_t lp_offs = 0, lp_nn = 0;                     // rows of the step whose loads are issued next / of the one after it
+    auto fetch_row = [&](int idx) -> uint32_t {
+        const int src = idx < NIA ? idx * SPI_A + rA : RA + (idx - NIA) * SPI_D + rD;
+        return (uint32_t)__builtin_amdgcn_ds_bpermute(src * 4, (int)lp_offs);
+    };
+    auto issue_row = [&](int buf, int idx, uint32_t row) {
+        const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
+        if (idx < NIA) {
+            const int t = wave + TWC_NW * idx;
+            if (t >= ninstrA) return;                     // wave-uniform
+            dma16_asm(rsA, As + t * 1024, a_kok ? row + a_koff : G2_OOB);
+        } else {
+            const int t = wave + TWC_NW * (idx - NIA);
+            if (t >= NINSD) return;                       // wave-uniform
+            const bool bad = (row & d_edge) != 0u || !d_kok;
+            dma16_asm(rsD, Ds + t * 1024, bad ? G2_OOB : (row & ~3u) + d_koff);
+        }
+    };
 
     // ---------------- role: (class, tap row) -- k = 5: class (ph, pw) keeps tap rows ta >= ph and taps tb >= pw ----------------
     //   SIMD 0: w0 (c0, row 2)  w4 (c1, row 0)         w8 (c1, row 1)       6 + 4 + 4       = 14
@@ -566,8 +701,15 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
         return u32x4_f{lo[0], lo[1], hi[0], hi[1]};
     };
 
+    if constexpr (LDEC) {
+        lp_offs = decode_rows(0);
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+        for (int i = 0; i < NDMA; ++i) issue_row(0, i, fetch_row(i));
+        lp_offs = decode_rows(1);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) issue_one(0, 0, i);
+    }
 
     // The position loop and the epilogue, specialised on the first live tap of the row (tb >= TB0): every tap loop is a literal loop
     auto run = [&](auto tb0_c) {
@@ -593,9 +735,17 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) { Fa[kt][0] = tr_full(sb + aoff[kt], PA); Fa[kt][1] = tr_full(sb + aoff[kt] + 8 * PA, PA); }
             Dq[0] = tr_full(sb + doff, PD); Dq[1] = tr_full(sb + doff + 8 * PD, PD);
+            if constexpr (LDEC) {                             // the rows of step + 2, decoded in the latency shadow of the twelve reads just issued
+                lp_nn = decode_rows(step + 2);
+                asm volatile("" : "+v"(lp_nn));
+            }
 #pragma unroll
             for (int j = 0; j < NKS; ++j) {
+                if constexpr (LDEC) {
+                    if (more && j < NDMA) issue_row(cur ^ 1, j, fetch_row(j));
+                } else
                 if (more && j < NDMA) issue_one(step + 1, cur ^ 1, j);
+                if (p.dbg_cheap_addr == 4) continue;          // (timing instantiation: loads and barriers only)
                 const bf16x8 dfrag = __builtin_bit_cast(bf16x8, Dq[j & 1]);
                 if (bias_on) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), dfrag, accb, 0, 0, 0);
 #pragma unroll
@@ -615,6 +765,9 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
                     else if (j + 2 == NKS) { const u32x2_t lo = tr_half(sb + aoff[kt] + (j + 2) * 8 * PA); Fa[kt][j & 1] = u32x4_f{lo[0], lo[1], 0u, 0u}; }
                 }
                 if (j + 2 < NKS) Dq[j & 1] = tr_full(sb + doff + (j + 2) * 8 * PD, PD);
+                if constexpr (LDEC) {
+                    if (j == NKS - 1) lp_offs = lp_nn;       // every load of step + 1 is out
+                }
             }
         }
         if (bias_on && lane < 32) {                       // bias gradient: row 0 of (ones x D) = register 0 of lanes 0..31
@@ -624,7 +777,7 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
                 else atomicAdd(&p.dbias[ne - (int)p.div_n.div((uint32_t)ne) * p.N], accb[0]);
             }
         }
-        if (!cls_live) return;
+        if (!cls_live || p.dbg_cheap_addr == 5) return;
         // dW tiles: same accumulator order / slab layout as tapwgrad_kernel (pair index looked up in the host's (tap, output tile) list)
 #pragma unroll
         for (int tb = TB0; tb < TAPS; ++tb) {

@@ -138,6 +138,9 @@ struct VaeEngine {
     int ares_mid;                       // ... and the mid-layer copies (conv3's input gradient, deconv2 forward)
     int ares_ok;                        // the fragment-ordered weight copies exist (bf16 engine, the model's geometry): the four small-grid layers run on the activation-resident kernels
     int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
+    hipStream_t main2;                  // MI355_CU_SPLIT=N (measurement aid, round 6): the caller-side half of the backward pass on an engine stream bound to compute units [0, N), the filter-gradient stream to [N, 256)
+    hipEvent_t ev_in, ev_out;
+    int main2_ok;
     hipStream_t third;                  // latent-layer gradients + loss finalisation of a full two-stream backward (small launches with early operands)
     hipEvent_t ev_lat, ev_third;
     int third_ok;
@@ -258,6 +261,12 @@ int check_batch(const VaeEngine* e, int B) {
     return MI_OK;
 }
 
+static int cu_split_env() {                            // MI355_CU_SPLIT=N, 8 <= N <= 248: compute units of the caller-side backward queue (0 / unset: no masks)
+    static int n = -1;
+    if (n < 0) { const char* ev = getenv("MI355_CU_SPLIT"); n = ev ? atoi(ev) : 0; if (n < 8 || n > 248) n = 0; }
+    return n;
+}
+
 unsigned ready_event_flags() {                         // MI355_KEVENT=2: the hand-over event with timing enabled (A/B: what hipExtLaunchKernelGGL's stop event wants)
     const char* ev = getenv("MI355_KEVENT");
     unsigned f = (ev && atoi(ev) == 2) ? hipEventDefault : hipEventDisableTiming;
@@ -281,7 +290,7 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
     e->bits1_ok = 0;
     for (int i = 0; i < NCONV; ++i) {
         const void* x = i == 0 ? frames : e->at(e->W.act[i]);
-        if (i == 0 && d.dtype == MI_BF16 && g.c[1] == 32 && g.c[2] == 64 && e->tm.mode != 1) {
+        if (i == 0 && d.dtype == MI_BF16 && g.c[0] == 3 && g.c[1] == 32 && g.c[2] == 64 && e->tm.mode != 1) {      // (the fused kernel reads 3-channel frames: frame stride FH FW 3, w1 as [32][48])
             // round 5: conv1 + conv2 as ONE launch (enc12_tile.hpp): conv1's activation stays in LDS for conv2 (it is still written for the backward pass, never read back here).
             // (per-op timing keeps the two layer launches: they are what the profile names)
             const bool bits12 = want_bits && relu_bits_enabled();
@@ -457,6 +466,7 @@ void mi_vae_destroy(void* h) {
     VaeEngine* e = (VaeEngine*)h;
     if (e && e->side_ok == 1) { hipStreamDestroy(e->side); hipEventDestroy(e->ev_ready); hipEventDestroy(e->ev_done); }
     if (e && e->third_ok == 1) { hipStreamDestroy(e->third); hipEventDestroy(e->ev_lat); hipEventDestroy(e->ev_third); }
+    if (e && e->main2_ok == 1) { hipStreamDestroy(e->main2); hipEventDestroy(e->ev_in); hipEventDestroy(e->ev_out); }
     free(h);
 }
 
@@ -583,7 +593,19 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         int prio_lo = 0, prio_hi = 0;
         if (side_prio != 0) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // (numerically: lowest priority = largest value)
         const int prio = side_prio < 0 ? prio_hi : prio_lo;
-        if ((side_prio == 0 ? hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio)) == hipSuccess &&
+        // MI355_CU_SPLIT=N (measurement aid): the two queues of the backward pass on DISJOINT compute units -- mask bits [0, N) for the caller-side queue (an
+        // engine stream the pass forks to and joins from), [N, 256) for the filter-gradient queue; KFD deals the mask bits round-robin over the eight XCDs, so both halves
+        // span all of them.  Tells time-slicing of whole CUs (147 KB-LDS blocks) from HBM / L2 interference: DESIGN 3.16.
+        const int cu_split = cu_split_env();
+        uint32_t mask_side[8], mask_main[8];
+        for (int w = 0; w < 8; ++w) { mask_side[w] = 0; mask_main[w] = 0; }
+        for (int b = 0; b < 256; ++b) { if (b < cu_split) mask_main[b >> 5] |= 1u << (b & 31); else mask_side[b >> 5] |= 1u << (b & 31); }
+        if (cu_split > 0 && !e->main2_ok) {
+            if (hipExtStreamCreateWithCUMask(&e->main2, 8, mask_main) == hipSuccess && hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) == hipSuccess) e->main2_ok = 1;
+            else e->main2_ok = -1;
+        }
+        if ((cu_split > 0 ? hipExtStreamCreateWithCUMask(&e->side, 8, mask_side) : side_prio == 0 ? hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) : hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio)) == hipSuccess &&
             hipEventCreateWithFlags(&e->ev_ready, ready_event_flags()) == hipSuccess &&
             hipEventCreateWithFlags(&e->ev_done, ready_event_flags()) == hipSuccess) e->side_ok = 1;
         else e->side_ok = -1;
@@ -596,6 +618,9 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         else e->third_ok = -1;
     }
     const bool fork = two_streams && e->side_ok == 1 && e->tm.mode != 1;      // per-op timing (mode 1) wants one op at a time
+    const bool split_cus = fork && cu_split_env() > 0 && e->main2_ok == 1 && part == 0;
+    if (split_cus) { hipEventRecord(e->ev_in, (hipStream_t)stream); hipStreamWaitEvent(e->main2, e->ev_in, 0); st = (void*)e->main2; }
+    struct SplitGuard { bool on; VaeEngine* e; void* caller; ~SplitGuard() { if (on) { hipEventRecord(e->ev_out, e->main2); hipStreamWaitEvent((hipStream_t)caller, e->ev_out, 0); } } } split_guard{split_cus, e, stream};
     struct StopEventGuard { ~StopEventGuard() { mi_tl_stop_event = nullptr; } } stop_guard;      // (see mi_vae_forward)
     void* sw = fork ? (void*)e->side : st;                                     // stream of the filter gradients
     // Hand-over of a gradient tensor from the caller's stream to the filter-gradient stream.  Round 3 form: hipEventRecord behind the producing kernel -- a marker
@@ -955,11 +980,17 @@ int mi_vae_train_step_dp(void* h, void* comm, void* stream, const void* src, con
     long long bk[9];
     CK(mi_vae_dp_buckets(&e->d, bk));
     CK(mi_vae_forward(h, stream, src, tgt, frames_u8, idx, B, inv_batch, eps, 1, 1, metrics3, metric_weight));
-    for (int i = 0; i < 3; ++i) {
-        CK(mi_vae_backward(h, stream, src, idx, eps, inv_batch, (int)bk[3 * i]));
-        CK(mi_allreduce_sum_f32_async(comm, stream, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]));
+    // A LOCAL failure between two buckets must not leave all-reduces queued with nothing joined behind them: whatever was queued is joined to `stream` before
+    // the error is returned, so the caller's buffers are quiescent once `stream` drains.  The collective schedule of THIS rank is broken all the same -- its peers are
+    // inside (or about to enter) collectives it will never issue: a non-OK return is FATAL for the job (the host mirror raises; the launcher tears every rank down).
+    int rc = MI_OK;
+    for (int i = 0; i < 3 && rc == MI_OK; ++i) {
+        rc = mi_vae_backward(h, stream, src, idx, eps, inv_batch, (int)bk[3 * i]);
+        if (rc == MI_OK) rc = mi_allreduce_sum_f32_async(comm, stream, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]);
     }
-    CK(mi_comm_wait(comm, stream));
+    const int rcw = mi_comm_wait(comm, stream);
+    if (rc != MI_OK) return rc;
+    CK(rcw);
     return apply_adam(e, stream, alpha, nullptr, beta1, beta2, epsilon);
 }
 

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OBJ = os.path.join(ROOT, "build", "obj")
 LIB = os.path.join(HERE, "libmi355_carla.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")]
+FLAGS += os.environ.get("HIPCC_EXTRA", "").split()        # e.g. -DMI355_PPO_PAD_PROBE (the boundary-cost probe of profiles/r05_ppo.md); never set by the product build
 
 
 def sources():

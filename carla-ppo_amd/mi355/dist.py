@@ -154,7 +154,7 @@ _recording = [None]
 
 def recording_comm():
     """A communicator of the C ABI that records instead of communicating (mi_comm_init_recording): bench.py times the data-parallel step WITHOUT its collectives
-    through the very same C call (mi_vae_train_step_dp) by handing it this one.  The log is a small ring nobody reads."""
+    through the very same C call (mi_vae_train_step_dp) by handing it this one.  The log holds the first 64 entries; the library's counter saturates (nobody reads either)."""
     if _recording[0] is None:
         import ctypes
         import numpy as np
@@ -175,6 +175,12 @@ def shutdown():
     global _mi_comm, _mi_comm_tried, comm_note
     c, _mi_comm, _mi_comm_tried = _mi_comm, None, False
     comm_note = "single process"
+    rec, _recording[0] = _recording[0], None            # the recording communicator was created for THIS process group's rank / world: a later group gets a fresh one
+    if rec is not None:
+        try:
+            rec.L.mi_comm_destroy(rec.handle)
+        except Exception:
+            pass
     if c is not None:
         try:
             if torch.cuda.is_available():

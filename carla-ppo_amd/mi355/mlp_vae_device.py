@@ -232,6 +232,15 @@ class MlpVaeDevice:
         self.L.mi_mlpvae_train_step(self.handle, self.stream(), p(self._tab(src, "the source table")), p(self._tab(tgt, "the target table")), self._u8(src, tgt), p(idx), int(B), float(inv_batch),
                                     p(eps), float(alpha), float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
 
+    def train_step_dp(self, comm_handle, src, tgt, idx, B, inv_batch, eps, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8, accumulate_metrics=True):
+        """One whole DATA-PARALLEL SGD step in one C call (mi_mlpvae_train_step_dp, round 6): forward, the decoder half of backward, its all-reduce on the library
+        communicator's stream under the encoder half, that half's all-reduce, join, Adam.  comm_handle: the C-ABI communicator (mi355/dist.py)."""
+        self.ensure_batch(B)
+        p = milib.ptr
+        self.L.mi_mlpvae_train_step_dp(self.handle, comm_handle, self.stream(), p(self._tab(src, "the source table")), p(self._tab(tgt, "the target table")), self._u8(src, tgt), p(idx), int(B),
+                                       float(inv_batch), p(eps), float(alpha), float(beta1), float(beta2), float(epsilon), p(self.metrics) if accumulate_metrics else None, float(B * inv_batch))
+        self._last_src = None
+
     def encode(self, src, idx, B, out):
         self.ensure_batch(B)
         self.L.mi_mlpvae_encode(self.handle, self.stream(), milib.ptr(self._tab(src, "the source table")), self._u8(src), milib.ptr(idx), int(B), milib.ptr(out))

@@ -156,6 +156,15 @@ class PpoDevice:
         self.L.mi_ppo_train_step_idx(self.handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), p(row_idx), int(states.shape[0]), int(M),
                                      float(inv_m), float(grad_scale), float(alpha), float(beta1), float(beta2), float(epsilon))
 
+    def train_step_dp(self, comm_handle, states, actions, returns, advantage, logp_old, row_idx, M, inv_m, grad_scale, alpha, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """One DATA-PARALLEL minibatch step in one C call (mi_ppo_train_step_dp, round 6): the fused chain on this rank's M rows, one all-reduce of the flat gradient
+        buffer through the library communicator, Adam.  row_idx (int32 device tensor [M]) names rows of the horizon-batch tables (gather inside the kernels) or is None
+        (contiguous minibatch tensors)."""
+        self.ensure_batch(M)
+        p = milib.ptr
+        self.L.mi_ppo_train_step_dp(self.handle, comm_handle, self.stream(), p(states), p(actions), p(returns), p(advantage), p(logp_old), p(row_idx),
+                                    int(states.shape[0]), int(M), float(inv_m), float(grad_scale), float(alpha), float(beta1), float(beta2), float(epsilon))
+
     def fused_ok(self):
         """True when the fused kernels (in-kernel minibatch gather, cached log pi_old) take this engine's shape; else only the per-layer path runs."""
         return bool(self.L.mi_ppo_fused_shape_ok(self.handle))

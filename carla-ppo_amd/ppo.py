@@ -152,8 +152,12 @@ class PPO():
         data parallel: gradients, all-reduce, Adam.  logp_old: cached log pi_old(a|s) of these samples (PpoDevice.logp_old), optional."""
         dev = self.dev
         alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
+        comm = self._dp_comm()
         if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0":
             dev.train_step(s, a, r, adv, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON, logp_old=logp_old)
+        elif comm is not None:
+            # data parallel with the library's communicator live: the step is ONE C call -- the fused chain, the all-reduce of the flat gradient buffer, Adam (round 6)
+            dev.train_step_dp(comm.handle, s, a, r, adv, logp_old, None, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
         else:
             dev.forward_backward(s, a, r, adv, m_local, 1.0 / m_global, m_local / float(m_global))
             if midist.world_size() > 1:
@@ -161,6 +165,17 @@ class PPO():
             dev.apply_adam(alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
         self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
+
+    def _dp_comm(self):
+        """The C-ABI communicator that carries this process's gradient all-reduce inside the one-call data-parallel step (mi_ppo_train_step_dp), or None: single
+        rank, torch.distributed as the transport (gloo in the CPU tests, a rank without a usable RCCL), or MI355_DP_HOST_LOOP=1 (the host-sequenced form, A/B runs).
+        MI355_DP_SKIP_ALLREDUCE=1 (bench.py only): the recording communicator -- the same C call with its collective recorded instead of issued."""
+        if midist.world_size() == 1 or os.environ.get("MI355_DP_HOST_LOOP") == "1":
+            return None
+        comm = midist.mi_comm()
+        if comm is not None and os.environ.get("MI355_DP_SKIP_ALLREDUCE") == "1":
+            comm = midist.recording_comm()
+        return comm
 
     def _step_rows(self, s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, m_global):
         """One SGD step on rows `rows` (int32 device tensor) of device-resident horizon-batch tables: the minibatch gather of train.py:199-204 runs inside
@@ -171,6 +186,15 @@ class PPO():
         if midist.world_size() == 1 and os.environ.get("MI355_PPO_FUSED", "1") != "0" and os.environ.get("MI355_PPO_IDX", "1") != "0" and dev.fused_ok():
             alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
             dev.train_step_idx(s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+            self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
+            self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
+            return
+        comm = self._dp_comm()
+        if comm is not None and os.environ.get("MI355_PPO_FUSED", "1") != "0" and os.environ.get("MI355_PPO_IDX", "1") != "0" and dev.fused_ok():
+            # data parallel: the in-kernel gather is kept -- `rows` index THIS rank's tables -- and the step stays one C call (round 6; before, world_size > 1 gathered here
+            # and sequenced forward_backward -> all-reduce -> Adam from Python)
+            alpha = _adam_alpha(self.current_learning_rate(), self.beta1_power, self.beta2_power)
+            dev.train_step_dp(comm.handle, s_all, a_all, r_all, adv_all, logp_old_all, rows, m_local, 1.0 / m_global, m_local / float(m_global), alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
             self.beta1_power = np.float32(self.beta1_power * np.float32(ADAM_BETA1))
             self.beta2_power = np.float32(self.beta2_power * np.float32(ADAM_BETA2))
             return

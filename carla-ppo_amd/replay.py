@@ -125,13 +125,15 @@ def replay_update(vae, ppo, frames, measurements, actions, rewards, dones, gamma
     # theta_old is now fixed for the whole update: log pi_old(a | s) of every sample is computed ONCE (the reference's graph recomputes the old
     # policy's forward pass in every minibatch step, ppo.py:112-121 -- same numbers)
     logp_old = None
-    if world == 1 and hasattr(pdev, "logp_old") and pdev.fused_ok():
+    if hasattr(pdev, "logp_old") and pdev.fused_ok():      # (data parallel too: theta_old is replicated, every rank caches the values of ITS samples)
         logp_old = torch.empty(n_loc, device=device)
         for lo_ in range(0, n_loc, 4096):
             hi_ = min(lo_ + 4096, n_loc)
             pdev.logp_old(s[lo_:hi_], a[lo_:hi_], hi_ - lo_, logp_old[lo_:hi_])
     records = []
-    fused_rows = world == 1 and hasattr(ppo, "_step_rows") and hasattr(pdev, "train_step_idx") and pdev.fused_ok()
+    # the minibatch gather inside the step's kernels: single rank, and (round 6) data parallel -- PPO._step_rows keeps it in the one-call step mi_ppo_train_step_dp when the
+    # library's communicator carries the all-reduce, and gathers the rows itself otherwise (torch.distributed as the transport)
+    fused_rows = hasattr(ppo, "_step_rows") and hasattr(pdev, "train_step_idx") and pdev.fused_ok()
     for _ in range(num_epochs):
         indices = np.arange(n_loc)
         np.random.shuffle(indices)                                               # legacy numpy RNG, as train.py:194-195

@@ -390,6 +390,8 @@ class VAE():
             step = self.get_step_idx()
             self.val_writer.add_scalar("vae/kl_loss", self.last_val_metrics[1], step)
             self.val_writer.add_scalar("vae/reconstruction_loss", self.last_val_metrics[0], step)
+            # the reference's merge_summary holds the three scalars and evaluate() writes all of it: the val log carries the (decayed, logged-only) learning rate too (vae/models.py:147-151,230)
+            self.val_writer.add_scalar("vae/learning_rate", self.learning_rate_value * self.lr_decay ** step, step)
             self.val_writer.flush()
         return list(self.last_val_metrics)
 

@@ -346,6 +346,11 @@ int mi_mlpvae_forward(void* h, void* stream, const void* src, const void* tgt, i
 int mi_mlpvae_backward(void* h, void* stream, const float* eps, float inv_batch, int part);
 int mi_mlpvae_apply_adam(void* h, void* stream, float alpha, float beta1, float beta2, float epsilon);
 int mi_mlpvae_train_step(void* h, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
+/* round 6 (ABI 7): one DATA-PARALLEL SGD step of the MlpVAE (vae/models.py:271-299 behind :140-142,213-216) in ONE call -- forward + ELBO of this rank's rows (inv_batch =
+ * 1 / B_global), the decoder half of the backward pass, its gradients' all-reduce on the communicator's own stream under the encoder half, that half's all-reduce, the join,
+ * TF-Adam.  mi_mlpvae_dp_buckets: out6 = 2 x {part, first float, one past the last float of the flat gradient buffer} in completion order. */
+int mi_mlpvae_dp_buckets(void* h, long long* out6);
+int mi_mlpvae_train_step_dp(void* h, void* comm, void* stream, const void* src, const void* tgt, int frames_u8, const int* idx, int B, float inv_batch, const float* eps, float alpha, float beta1, float beta2, float epsilon, float* metrics3, float metric_weight);
 int mi_mlpvae_encode(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, float* mean_out);
 int mi_mlpvae_decode(void* h, void* stream, const float* z, int B, float* recon_out);
 int mi_mlpvae_reconstruct(void* h, void* stream, const void* src, int frames_u8, const int* idx, int B, const float* eps, int sample, float* recon_out);
@@ -378,6 +383,8 @@ int mi_comm_has_rsag(void);
  * left alone (the sum over one rank).  mi_comm_recorded: entries issued so far, -1 for a real communicator.  mi_comm_set_algo / mi_comm_destroy work on it as usual. */
 int mi_comm_init_recording(void** comm_out, int rank, int world, long long* log, int log_capacity);
 int mi_comm_recorded(void* comm);
+/* round 6: the number of ranks the communicator spans as RCCL reports it (ncclCommCount); recording communicator: the world it was created for */
+int mi_comm_ranks(void* comm);
 int mi_comm_set_algo(void* comm, int algo);
 int mi_comm_allreduce_plan(int algo, int world, int rank, long long n, long long* out5);
 int mi_comm_id_bytes(void);
@@ -418,6 +425,11 @@ int mi_ppo_train_step(void* h, void* stream, const float* states, const float* a
 /* the same step with the minibatch gather fused in — train.py:199-204 (`states[mb_idx]`, ...): the five operands are the horizon-batch tables (n_rows rows,
  * device resident for the whole update) and row_idx [M] (int32, device) names this minibatch's rows */
 int mi_ppo_train_step_idx(void* h, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
+/* round 6 (ABI 7): one DATA-PARALLEL SGD step of PPO.train (ppo.py:218-229 under the minibatch loop of train.py:193-207) in ONE call: the fused chain of
+ * mi_ppo_train_step[_idx] with the gradients of this rank's M rows (inv_m = 1 / M_global, grad_scale = M / M_global) left in the flat buffer, ONE all-reduce of that
+ * buffer through `comm` in stream order, tf.train.AdamOptimizer.  row_idx != NULL: the operands are this rank's horizon-batch tables (n_rows rows) and the gather of
+ * train.py:199-204 stays inside the kernels; row_idx == NULL: contiguous minibatch tensors. */
+int mi_ppo_train_step_dp(void* h, void* comm, void* stream, const float* states, const float* actions, const float* returns, const float* advantage, const float* logp_old, const int* row_idx, int n_rows, int M, float inv_m, float grad_scale, float alpha, float beta1, float beta2, float epsilon);
 /* 1: this engine's shape (1 <= num_actions <= 8, h2 <= 320 and a multiple of 4, padded input width <= 96) is inside the range of the fused kernels and they are
  * switched on, i.e. mi_ppo_train_step_idx / mi_ppo_logp_old will run; 0: only the per-layer path exists for it (mi_ppo_train_step and mi_ppo_forward_backward fall
  * back by themselves; gather the minibatch on the host side instead of calling the _idx form).  Row indices are clamped into [0, n_rows) by the kernels. */

@@ -211,3 +211,173 @@ def test_dp_step_c_call_through_the_real_rccl_at_one_rank(tmp_path, precision):
         assert np.array_equal(p_r[k], p_c[k]), k
         assert rel_err(p_r[k], p_s[k]) < 1e-5, (k, rel_err(p_r[k], p_s[k]))
     assert np.allclose(l_r, l_s, rtol=1e-5, atol=1e-6), (l_r, l_s)
+
+
+def _ppo_pair(tmp_path, tag):
+    from oracle import ppo_oracle as po
+    from ppo import PPO
+    space = po.ActionSpace()
+    hp = dict(learning_rate=1e-4, lr_decay=1.0, epsilon=0.2, value_scale=1.0, entropy_scale=0.01, initial_std=1.0)
+    o = po.OraclePPO([67], space, seed=2, **hp)
+    rng = np.random.RandomState(3)
+    for k in o.params:                                   # theta != theta_old: ratio != 1, some samples clipped
+        o.params[k] = o.params[k] + (0.02 * rng.standard_normal(o.params[k].shape)).astype(np.float32)
+    m = PPO(np.array([67]), space, model_dir=str(tmp_path / tag), seed=2, **hp)
+    m.set_weights(o.params)
+    m.init_session(init_logging=False)
+    return m
+
+
+@pytest.mark.parametrize("M,gather", [(32, True), (32, False), (77, True), (300, True)])
+def test_ppo_dp_step_as_one_c_call_equals_the_host_sequence(tmp_path, M, gather):
+    """Round 6: mi_ppo_train_step_dp -- the fused launch chain with the gradients of this rank's rows left in the flat buffer, ONE all-reduce of that buffer
+    through the communicator, tf.train.AdamOptimizer -- as ONE C call, with the minibatch gather of train.py:199-204 kept inside the kernels (row_idx) as in the single-rank step.
+    Driven with a RECORDING communicator as rank 1 of 2 (what one GPU allows: the data stays the sum over one rank): two SGD steps give BITWISE the parameters, Adam slots and
+    loss scalars of the sequence ppo.py issued from Python before (forward_backward on host-gathered rows -> all-reduce -> apply_adam), and the log is one in-stream all-reduce
+    of the whole gradient buffer per step."""
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    T = 512
+    rng = np.random.RandomState(M)
+    s = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    R, A = rng.randn(T).astype(np.float32), rng.randn(T).astype(np.float32)
+    rows = [rng.permutation(T)[:M].astype(np.int32) for _ in range(2)]
+    res = []
+    for mode in ("c_call", "host"):
+        m = _ppo_pair(tmp_path, mode)
+        d = m.dev
+        d.ensure_batch(T)
+        sd, ad, Rd, Ad = (m._to_dev(x, x.shape) for x in (s, a, R, A))
+        log = np.zeros((8, 4), np.int64)
+        h = ctypes.c_void_p()
+        L.mi_comm_init_recording(ctypes.addressof(h), 1, 2, log.ctypes.data, 8)
+        for step in range(2):
+            rd = torch.from_numpy(rows[step]).to(d.device)
+            mb = rd.long()
+            alpha = 1e-4 * (1.0 + step)
+            if mode == "c_call" and gather:
+                d.train_step_dp(h, sd, ad, Rd, Ad, None, rd, M, 0.5 / M, 0.5, alpha)
+            elif mode == "c_call":
+                d.train_step_dp(h, sd[mb].contiguous(), ad[mb].contiguous(), Rd[mb].contiguous(), Ad[mb].contiguous(), None, None, M, 0.5 / M, 0.5, alpha)
+            else:
+                d.forward_backward(sd[mb].contiguous(), ad[mb].contiguous(), Rd[mb].contiguous(), Ad[mb].contiguous(), M, 0.5 / M, 0.5)
+                d.apply_adam(alpha)
+        torch.cuda.synchronize()
+        n = L.mi_comm_recorded(h)
+        L.mi_comm_destroy(h)
+        res.append((d.params.cpu().numpy().copy(), d.adam_m.cpu().numpy().copy(), d.adam_v.cpu().numpy().copy(), d.losses.cpu().numpy()[:5].copy(), log[:max(n, 0)].copy(),
+                    d.grads.data_ptr(), d.grads.numel()))
+    (p_c, m_c, v_c, l_c, log_c, gptr, gn), (p_h, m_h, v_h, l_h, log_h, _, _) = res
+    assert len(log_h) == 0
+    assert [tuple(int(x) for x in e) for e in log_c] == [(1, gn, 0, gptr)] * 2
+    assert np.array_equal(p_c, p_h) and np.array_equal(m_c, m_h) and np.array_equal(v_c, v_h), float(np.abs(p_c - p_h).max())
+    assert np.array_equal(l_c, l_h), (l_c, l_h)
+    assert not np.array_equal(p_c, _ppo_pair(tmp_path, "fresh").dev.params.cpu().numpy())      # (the steps did something)
+
+
+def test_ppo_dp_step_through_the_real_rccl_at_one_rank(tmp_path):
+    """mi_ppo_train_step_dp with a REAL communicator (RCCL bound at run time, world size 1): the all-reduce is the identity, so three steps through it give bitwise the
+    parameters of the recording communicator, and -- inv_m = 1 / M, grad_scale = 1 -- those of the single-rank fused step (mi_ppo_train_step_idx: Adam inside the
+    filter-gradient launch instead of a flat launch behind the all-reduce) to rounding."""
+    import ctypes
+    from mi355 import lib as milib
+    L = milib.get()
+    T, M = 256, 64
+    rng = np.random.RandomState(11)
+    s = (0.5 * rng.standard_normal((T, 67))).astype(np.float32)
+    a = rng.uniform(-1, 1, (T, 2)).astype(np.float32)
+    R, A = rng.randn(T).astype(np.float32), rng.randn(T).astype(np.float32)
+    rows = [rng.permutation(T)[:M].astype(np.int32) for _ in range(3)]
+    res = {}
+    for mode in ("rccl", "recording", "single"):
+        m = _ppo_pair(tmp_path, mode)
+        d = m.dev
+        d.ensure_batch(T)
+        sd, ad, Rd, Ad = (m._to_dev(x, x.shape) for x in (s, a, R, A))
+        h = ctypes.c_void_p()
+        log = np.zeros((8, 4), np.int64)
+        if mode == "rccl":
+            idb = np.zeros(128, np.uint8)
+            L.mi_comm_unique_id(idb.ctypes.data)
+            L.mi_comm_init(ctypes.addressof(h), 0, 1, idb.ctypes.data)
+        elif mode == "recording":
+            L.mi_comm_init_recording(ctypes.addressof(h), 0, 1, log.ctypes.data, 8)
+        try:
+            for step in range(3):
+                rd = torch.from_numpy(rows[step]).to(d.device)
+                if mode == "single":
+                    d.train_step_idx(sd, ad, Rd, Ad, None, rd, M, 1.0 / M, 1.0, 1e-4)
+                else:
+                    d.train_step_dp(h, sd, ad, Rd, Ad, None, rd, M, 1.0 / M, 1.0, 1e-4)
+            torch.cuda.synchronize()
+            res[mode] = (d.params.cpu().numpy().copy(), d.losses.cpu().numpy()[:5].copy())
+        finally:
+            if mode != "single":
+                L.mi_comm_destroy(h)
+    assert np.array_equal(res["rccl"][0], res["recording"][0]) and np.array_equal(res["rccl"][1], res["recording"][1])
+    assert rel_err(res["rccl"][0], res["single"][0]) < 1e-6 and np.allclose(res["rccl"][1], res["single"][1], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_mlp_vae_dp_step_as_one_c_call_equals_the_host_loop(tmp_path, precision):
+    """Round 6: mi_mlpvae_train_step_dp -- forward, the decoder half of the backward pass, its all-reduce queued on the communicator under the encoder
+    half, that half's all-reduce, the join, Adam -- as ONE C call.  RECORDING communicator (rank 0 of 2), two SGD steps through an index vector: parameters, both Adam slots
+    and losses bitwise those of the host-sequenced loop vae/models.py ran for the MlpVAE (forward, backward(part 1), backward(part 2), Adam); the log is the two buckets of
+    mi_mlpvae_dp_buckets as async all-reduces + one join per step; and the same call through the real RCCL at one rank gives the same bits."""
+    import ctypes
+    from mi355 import lib as milib
+    from vae.models import adam_alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON
+    L = milib.get()
+    src_shape, enc, dec, B = (80, 160, 3), (512, 256), (256, 512), 37
+    rng = np.random.RandomState(4)
+    table = (rng.randint(0, 256, (50,) + src_shape).astype(np.float32) / 255.0)
+    eps = rng.standard_normal((2, B, 64)).astype(np.float32)
+    idx = rng.permutation(50)[:B].astype(np.int32)
+    params = _mlp_params(9, src_shape, src_shape, enc, dec)
+    res = {}
+    for mode in ("c_call", "host_loop", "rccl"):
+        m = MlpVAE(np.array(src_shape), z_dim=64, model_dir=str(tmp_path / (precision + mode)), precision=precision, learning_rate=1e-4)
+        m.set_weights(params)
+        m.init_session(init_logging=False)
+        d = m.dev
+        s_dev, i_dev = m._frames(table, 38400, "src"), torch.from_numpy(idx).cuda()
+        log = np.zeros((16, 4), np.int64)
+        h = ctypes.c_void_p()
+        if mode == "rccl":
+            idb = np.zeros(128, np.uint8)
+            L.mi_comm_unique_id(idb.ctypes.data)
+            L.mi_comm_init(ctypes.addressof(h), 0, 1, idb.ctypes.data)
+        else:
+            L.mi_comm_init_recording(ctypes.addressof(h), 0, 2, log.ctypes.data, 16)
+        try:
+            b1p, b2p = np.float32(ADAM_BETA1), np.float32(ADAM_BETA2)
+            for s in range(2):
+                e_dev = m._eps(B, eps[s])
+                alpha = adam_alpha(1e-4, b1p, b2p)
+                if mode == "host_loop":
+                    d.forward(s_dev, s_dev, i_dev, B, 0.5 / B, e_dev, 1, 1)
+                    for part, lo, hi in d.grad_buckets:
+                        d.backward(s_dev, i_dev, e_dev, 0.5 / B, part=part)
+                    d.apply_adam(alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+                else:
+                    d.train_step_dp(h, s_dev, s_dev, i_dev, B, 0.5 / B, e_dev, alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+                b1p, b2p = np.float32(b1p * np.float32(ADAM_BETA1)), np.float32(b2p * np.float32(ADAM_BETA2))
+            torch.cuda.synchronize()
+            n = L.mi_comm_recorded(h)
+            bk = np.zeros(6, np.int64)
+            L.mi_mlpvae_dp_buckets(d.handle, bk.ctypes.data)                  # the library's own table = the host mirror's
+            assert [tuple(int(x) for x in bk[3 * i:3 * i + 3]) for i in range(2)] == [tuple(b) for b in d.grad_buckets]
+            res[mode] = (d.params.clone(), d.adam_m.clone(), d.adam_v.clone(), d.losses.cpu().numpy().copy(), log[:max(n, 0)].copy(), d.grads.data_ptr(), list(d.grad_buckets))
+        finally:
+            L.mi_comm_destroy(h)
+    p_c, m_c, v_c, l_c, log_c, gptr, buckets = res["c_call"]
+    p_h, m_h, v_h, l_h, log_h, _, _ = res["host_loop"]
+    want = [(1, hi - lo, 1, gptr + 4 * lo) for (_, lo, hi) in buckets] + [(5, 2, 0, 0)]
+    assert len(log_h) == 0 and [tuple(int(x) for x in e) for e in log_c] == want + want
+    assert [int(p_) for p_, _, _ in buckets] == [1, 2]
+    for x, y in ((p_c, p_h), (m_c, m_h), (v_c, v_h)):
+        assert torch.equal(x, y)
+    assert np.array_equal(l_c, l_h)
+    assert torch.equal(res["rccl"][0], p_c) and np.array_equal(res["rccl"][3], l_c)

@@ -20,7 +20,7 @@ def test_shared_library_exports_every_declared_symbol():
     L = milib.get()                                   # raises if the .so is missing or lacks a declared symbol
     for name in protos:
         assert hasattr(L.cdll, name), name
-    assert L.mi_abi_version() == 6
+    assert L.mi_abi_version() == 7
     assert L.mi_vae_desc_size() == ctypes.sizeof(milib.MiVaeDesc) and L.mi_ppo_desc_size() == ctypes.sizeof(milib.MiPpoDesc)
     # every public entry point cites the reference op it replaces
     text = open(milib.HEADER).read()
@@ -609,3 +609,99 @@ def test_bench_clock_conditioning_leaves_every_rank_after_the_same_number_of_ste
     assert r.returncode == 0, r.stderr[-3000:]
     a, b = (json.load(open(os.path.join(str(tmp_path), "cond_rank%d.json" % k))) for k in (0, 1))
     assert a["steps"] == b["steps"] and a["steps"] >= 5 and a["steps"] % 5 == 0, (a, b)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ppo_and_mlp_vae_dp_steps_are_one_c_call_with_the_same_collectives_on_every_rank(tmp_path, monkeypatch, world):
+    """Round 6.  With the library's communicator live, a data-parallel PPO minibatch step is ONE call of the device (mi_ppo_train_step_dp) that keeps
+    the in-kernel minibatch gather (before: forward_backward -> a blocking Python-side all-reduce -> apply_adam, rows gathered on the host whenever world_size > 1), and the
+    MlpVAE step is one call as the ConvVAE's (before: the host loop).  No GPU here: stand-in devices record what the host mirror asks of them per rank; the collectives the C calls
+    issue are replayed on RECORDING communicators (no RCCL) for every rank under both bucket schedules: same ops, same element counts everywhere."""
+    import ctypes
+    import torch
+    from mi355 import dist as midist
+    from mi355 import lib as milib
+    import ppo as ppo_mod
+    from oracle import ppo_oracle as po
+    from vae.models import MlpVAE
+    L = milib.get()
+
+    class _Comm:
+        handle = 0xC0FFEE
+    monkeypatch.setattr(midist, "world_size", lambda: world)
+    monkeypatch.setattr(midist, "mi_comm", lambda: _Comm)
+
+    class _PpoDev:
+        def __init__(self): self.calls = []; self.losses = torch.zeros(16); self.device = torch.device("cpu")
+        def fused_ok(self): return True
+        def train_step_dp(self, comm, s, a, r, adv, lp, rows, m, inv_m, gs, alpha, *rest): self.calls.append(("dp", comm, tuple(s.shape), None if rows is None else tuple(rows.shape), m, inv_m, gs))
+        def train_step(self, *a, **k): self.calls.append(("single",))
+        def train_step_idx(self, *a, **k): self.calls.append(("single_idx",))
+        def forward_backward(self, *a, **k): self.calls.append(("fb",))
+        def apply_adam(self, *a, **k): self.calls.append(("adam",))
+    per_rank = []
+    for r in range(world):
+        monkeypatch.setattr(midist, "rank", lambda r=r: r)
+        m = ppo_mod.PPO(np.array([67]), po.ActionSpace(), model_dir=str(tmp_path / ("p%d" % r)), seed=1)
+        m.dev = _PpoDev()
+        T, mb = 128, 32 // world if world <= 8 else 4
+        s, a, R, A = torch.zeros(T, 67), torch.zeros(T, 2), torch.zeros(T), torch.zeros(T)
+        rows = torch.arange(mb, dtype=torch.int32)
+        b1 = m.beta1_power
+        m._step_rows(s, a, R, A, None, rows, mb, mb * world)             # the replay's / train()'s resident form: rows of THIS rank's tables
+        m._step_resident(s[:mb], a[:mb], R[:mb], A[:mb], mb, mb * world)   # PPO.train's host-minibatch form
+        assert m.beta1_power == np.float32(np.float32(b1 * np.float32(0.9)) * np.float32(0.9))
+        per_rank.append(m.dev.calls)
+    want = [("dp", 0xC0FFEE, (128, 67), (32 // world,), 32 // world, 1.0 / 32, 1.0 / world), ("dp", 0xC0FFEE, (32 // world, 67), None, 32 // world, 1.0 / 32, 1.0 / world)]
+    assert all(c == want for c in per_rank), per_rank[0]
+    # MI355_DP_HOST_LOOP=1 and a process group without the library communicator (gloo) keep the host-sequenced form
+    monkeypatch.setattr(midist, "mi_comm", lambda: None)
+    monkeypatch.setattr(midist, "all_reduce_sum", lambda t, async_op=False: None)
+    m = ppo_mod.PPO(np.array([67]), po.ActionSpace(), model_dir=str(tmp_path / "ph"), seed=1)
+    m.dev = _PpoDev(); m.dev.grads = torch.zeros(4)
+    m._step_resident(torch.zeros(4, 67), torch.zeros(4, 2), torch.zeros(4), torch.zeros(4), 4, 4 * world)
+    assert m.dev.calls == [("fb",), ("adam",)]
+    monkeypatch.setattr(midist, "mi_comm", lambda: _Comm)
+
+    # the MlpVAE takes the one-call branch of VAE._train_minibatch as soon as its device offers train_step_dp
+    class _MlpDev:
+        def __init__(self): self.calls = []
+        def train_step_dp(self, comm, src, tgt, idx, B, inv_batch, eps, alpha, *rest): self.calls.append(("dp", comm, B, inv_batch))
+        def forward(self, *a, **k): self.calls.append(("fwd",))
+    mv = MlpVAE(np.array([80, 160, 3]), z_dim=64, model_dir=str(tmp_path / "mlp"), precision="bf16", seed=0)
+    mv.dev = _MlpDev()
+    mv._train_minibatch(None, None, None, 512 // world, 1.0 / 512, None)
+    assert mv.dev.calls == [("dp", 0xC0FFEE, 512 // world, 1.0 / 512)]
+    from mi355.mlp_vae_device import MlpVaeDevice
+    from mi355.ppo_device import PpoDevice
+    assert hasattr(MlpVaeDevice, "train_step_dp") and hasattr(PpoDevice, "train_step_dp")
+
+    # what those C calls issue, per rank and bucket schedule: PPO = ONE in-stream all-reduce of the flat gradient buffer; MlpVAE = decoder bucket, encoder bucket (async), one join
+    dp = milib.MiPpoDesc(256, 67, 2, 500, 300, 0.2, 1.0, 0.01)
+    n_ppo = int(L.mi_ppo_param_floats(ctypes.byref(dp)))
+    assert n_ppo >= 369505
+    dm = milib.MiMlpVaeDesc()
+    dm.dtype, dm.max_batch, dm.source_size, dm.target_size, dm.z_dim, dm.n_enc, dm.n_dec = 1, 512, 38400, 38400, 64, 2, 2
+    dm.enc[0], dm.enc[1], dm.dec[0], dm.dec[1] = 512, 256, 256, 512
+    dm.loss_kind, dm.with_optimizer, dm.beta, dm.kl_tolerance = 0, 1, 1.0, 0.0
+    n_mlp = int(L.mi_mlpvae_param_floats(ctypes.byref(dm)))
+    dec_off = n_mlp // 2                                  # (any split: the plan only depends on the bucket sizes)
+    for sizes, asyncs in (([n_ppo], 0), ([n_mlp - dec_off, dec_off], 1)):
+        for algo in (0, 1):
+            logs = []
+            for r in range(world):
+                log = np.zeros((16, 4), np.int64)
+                h = ctypes.c_void_p()
+                L.mi_comm_init_recording(ctypes.addressof(h), r, world, log.ctypes.data, 16)
+                L.mi_comm_set_algo(h, algo)
+                for n in sizes:
+                    (L.mi_allreduce_sum_f32_async if asyncs else L.mi_allreduce_sum_f32)(h, None, 1 << 20, n)
+                L.mi_comm_wait(h, None)
+                cnt = L.mi_comm_recorded(h)
+                L.mi_comm_destroy(h)
+                logs.append([(int(e[0]), int(e[1]), int(e[2])) for e in log[:cnt]])
+            assert all(lg == logs[0] for lg in logs[1:]), (world, algo, sizes)
+            if algo == 0:
+                assert logs[0] == [(1, n, asyncs) for n in sizes] + ([(5, len(sizes), 0)] if asyncs else [])
+            else:
+                assert sum(e[1] * (world if e[0] == 2 else 1) for e in logs[0] if e[0] in (1, 2)) == sum(sizes)      # reduce-scatter slices x W + tails tile every bucket

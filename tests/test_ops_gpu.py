@@ -1238,3 +1238,58 @@ def test_split_storage_filter_gradient_on_the_doubled_channel_bf16_kernel(form, 
         assert_close(host(db) + 1.0, dbref, 2e-5, 2e-5 * sb, "bias gradient")
     finally:
         L.mi_set_tuning(21, prev)
+
+
+@pytest.mark.parametrize("B", [5, 37])
+@pytest.mark.parametrize("form,geom,k", [("conv", (39, 79, 32, 64), 4), ("conv", (18, 38, 64, 128), 4), ("conv", (8, 18, 128, 256), 4),
+                                         ("deconv", (3, 8, 256, 128), 4), ("deconv", (8, 18, 128, 64), 4), ("deconv", (18, 38, 64, 32), 5)])
+def test_filter_gradient_dma_rows_decoded_once_per_wave(form, geom, k, B):
+    """Round 6 (tapwgrad_tile.hpp, LDEC): the raw-staged filter-gradient kernels decode the source offsets of a step's DMA rows ONCE per wave -- one row per
+    lane, a step ahead -- and every DMA instruction fetches its rows with one ds_bpermute_b32, instead of two magic-number divisions + the image bounds per lane and instruction.
+    Same addresses, same zero fill, same summation order: all six layers of the model (both 2 x 2-tap forms and the k = 5 class-wave kernel, image edges, a ragged last step,
+    several position splits) give BITWISE the filter and bias gradient of the per-instruction decode (mi_set_tuning key 24 = 0), and both meet the float64 product."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    IH, IW, Ci, Co = geom
+    rng = np.random.RandomState(IH + Ci + B)
+    ws = torch.empty(128 << 20, device="cuda", dtype=torch.uint8)
+    x = rng.randn(B, IH, IW, Ci).astype(np.float32)
+    if form == "conv":
+        OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
+        wshape = (k, k, Ci, Co)
+    else:
+        OH, OW = (IH - 1) * 2 + k, (IW - 1) * 2 + k
+        wshape = (k, k, Co, Ci)
+    dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+    xr, dyr = rounded(x, td), rounded(dy, td)
+    if form == "conv":
+        w = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(_nchw(xr), w, stride=2).backward(_nchw(dyr))
+    else:
+        w = torch.zeros(Ci, Co, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(_nchw(xr), w, stride=2).backward(_nchw(dyr))
+    dwref = w.grad.permute(2, 3, 1, 0).numpy()
+    dbref = dyr.sum((0, 1, 2)).numpy()
+    xd, dyd = dev(x, td), dev(dy, td)
+    res = {}
+    prev_blocks = L.mi_set_tuning(9, 64)                                   # 64 target blocks: several position splits even at these small batches
+    try:
+        for mode in (0, 1):
+            prev = L.mi_set_tuning(24, mode)
+            try:
+                dw, db = torch.full(wshape, 0.25, device="cuda"), torch.full((Co,), -2.0, device="cuda")
+                ws.fill_(0x7f)                                               # (stale scratch must not matter)
+                if form == "conv":
+                    L.mi_conv2d_nhwc_wgrad_ws(stream(), code, xd.data_ptr(), None, 0, B, IH, IW, Ci, dyd.data_ptr(), k, k, Co, dw.data_ptr(), ws.data_ptr(), ws.numel(), db.data_ptr())
+                else:
+                    L.mi_deconv2d_nhwc_wgrad_ws(stream(), code, dyd.data_ptr(), B, OH, OW, Co, xd.data_ptr(), k, k, Ci, dw.data_ptr(), ws.data_ptr(), ws.numel(), db.data_ptr())
+                torch.cuda.synchronize()
+                res[mode] = (host(dw), host(db))
+            finally:
+                L.mi_set_tuning(24, prev)
+    finally:
+        L.mi_set_tuning(9, prev_blocks)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    sw, sb = float(np.abs(dwref).max()), float(np.abs(dbref).max())
+    assert_close(res[1][0] - 0.25, dwref, 1e-4, 1e-4 * sw, "filter gradient (rows decoded once per wave)")
+    assert_close(res[1][1] + 2.0, dbref, 1e-4, 1e-4 * sb, "bias gradient")

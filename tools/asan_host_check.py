@@ -9,7 +9,7 @@ import numpy as np
 from mi355 import lib as milib
 
 L = milib.get()
-assert L.mi_abi_version() == 6
+assert L.mi_abi_version() == 7
 print("library:", milib.LIB_PATH)
 
 # ---- VAE descriptor arithmetic for every dtype / loss / geometry the models use, with and without the guard mode ----
