@@ -737,7 +737,7 @@ def main():
         roofline["timing"] = how
         # HBM traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 read correction),
         # measured offline on this same workload and committed under profiles/ (PMC counters cannot be read from inside the bench)
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 for op, rec in tj["ops"].items():

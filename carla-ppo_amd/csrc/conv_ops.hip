@@ -322,6 +322,9 @@ static int nw_depth_env() { const char* e = getenv("MI355_NW_DEPTH"); return e ?
 int g_nw_depth = nw_depth_env();                          // narrow_wgrad (uint8 conv1 shape): steps in flight per wave (3 | 5 | 6); mi_set_tuning key 19
 int g_nw_waves = 12;                                       // narrow_wgrad: waves per block (4 | 8 | 12); mi_set_tuning key 10
 int g_tapwgrad_cw = 1;                                     // k = 5 filter gradient: class-wave layout (tapwgrad_cw_kernel); mi_set_tuning key 14
+static int dectail_split5_env() { const char* e = getenv("MI355_DECTAIL_SPLIT5"); return (e && e[0] == '1') ? 1 : 0; }      // measured neutral (74.4-77.4 vs 76.2-77.6 us alone, 0.8440 = 0.8440 ms per step): off
+int g_dectail_split5 = dectail_split5_env();               // decoder tail: the fifth slot group's loss shared by three waves (dectail_tile.hpp, round 6); mi_set_tuning key 26
+int g_dectail_dbg = 0;                                     // ablation mask of the decoder tail's timing instantiation (wrong results); mi_set_tuning key 25
 static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); return (e && e[0] == '0') ? 0 : 1; }
 int g_tw_ldec = tw_ldec_env();                             // raw-staged filter gradients: a step's DMA rows decoded once per wave, one row per lane (tapwgrad_tile.hpp, round 6); mi_set_tuning key 24
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
@@ -962,6 +965,8 @@ int mi_set_tuning(int key, int value) {
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
     else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value ? 1 : 0; }
+    else if (key == 25) { prev = g_dectail_dbg; g_dectail_dbg = value; }
+    else if (key == 26) { prev = g_dectail_split5; g_dectail_split5 = value ? 1 : 0; }
     else if (key == 23) { prev = mi_enc12_debug(value); }  // (debug: ablation mask of the fused encoder head's timing instantiation -- results are wrong with any bit set)
     else return mi_fail(MI_ERR_ARG, "mi_set_tuning: unknown key");
     return prev;
@@ -1152,7 +1157,9 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     if (nblocks >= 16) nblocks &= ~7;                       // whole rounds of the eight XCDs (the kernel's tile order)
     if (nblocks > partial_capacity || scratch_bytes < (long long)nblocks * DT_SLAB * 4) return MI_OK;
     q.slabs = (float*)scratch;
-    if (fast) MI_LAUNCH(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
+    q.dbg = g_dectail_dbg; q.fifth_split = g_dectail_split5;
+    if (fast && q.dbg) MI_LAUNCH((dectail_kernel<true, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);      // (timing instantiation: tools/dectail_ablate.py)
+    else if (fast) MI_LAUNCH(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     else MI_LAUNCH(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     int rc = mi_check_launch("dectail_kernel");
     if (rc != MI_OK) return rc;

@@ -18,6 +18,7 @@
 // v_mfma_f32_32x32x16_bf16; the summation orders of the logits and of the input gradient are those of gather_narrow_kernel / narrow_conv48_kernel, so
 // both are bit-identical to the unfused path (tests/test_ops_gpu.py::test_decoder_tail_fused_equals_the_three_ops).
 #pragma once
+#include <type_traits>
 #include "narrow_tile.hpp"
 
 namespace mi {
@@ -53,6 +54,10 @@ struct DecTailParams {
     int OH, OW, GH, GW, tiles_x, tiles_per_frame, ntiles;
     int edge_own;                                        // 1: tiles cover the PIXEL grid; the last slot row / column (index IH / IW) is owned by the last tile row / column
     FastDiv div_tpf, div_tx;
+    int fifth_split;                                     // 1 (MI355_DECTAIL_SPLIT5=1, mi_set_tuning key 26; default 0: measured neutral): the fifth slot group's loss is shared by waves 0 .. 2, a logit pair each
+    int dbg;                                             // TIMING INSTANTIATION only (dectail_kernel<.., true>, mi_set_tuning key 25; wrong results, honest durations -- tools/dectail_ablate.py):
+                                                         // 1 no transcendentals in the loss, 2 no input-gradient phase, 4 no filter-gradient phase, 8 no gradient stores,
+                                                         // 16 no loads (the first tile's data stay), 32 no slot groups at all (phase 1 off), 64 only ONE slot group per wave (no fifth group)
 };
 
 // two fp32 values -> two bf16 in one dword (low half = a): one v_cvt_pk_bf16_f32, round-to-nearest-even like f32_to_bf16
@@ -67,8 +72,9 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
 // software prefetch of the next tile wait at the first barrier it meets
 __device__ __forceinline__ void dt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool FASTBCE>
+template <bool FASTBCE, bool DBG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dectail_kernel(const DecTailParams p) {
+    const int dbg = DBG ? p.dbg : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[DT_XS + 4 * DT_PT + 3840 + 4 * 13 * 64 + DT_LBBYTES];
     unsigned char* const xs = lds;                        // staged input pixels
     unsigned char* const pt = lds + DT_XS;                // 4 wave-private patch tiles (the cross-wave reduction at the very end reuses them)
@@ -218,6 +224,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         return L;
     };
     const SlotLane own = slot_lane(wave);
+    // the fifth group: slots 128 .. 152 = slot row 7, columns 9 .. 16 and slot row 8 (set up once: the generic decode inside the tile loop was 49 VALU instructions per tile)
+    SlotLane fifth;
+    {
+        const int sidx = min(128 + lrow, DT_NSLOT - 1);
+        fifth.sv = 128 + lrow < DT_NSLOT;
+        fifth.sy = sidx >= 8 * DT_SX ? 8 : 7; fifth.sx = sidx - fifth.sy * DT_SX;
+        fifth.xa = (uint32_t)((fifth.sy * DT_PC + fifth.sx) * DT_XP + lgrp * 16);
+        fifth.la = (uint32_t)(((2 * fifth.sy + lgrp) * DT_LBC + fifth.sx * 6) * 4);
+        fifth.da = (uint32_t)((2 * fifth.sy + lgrp) * DT_DLPITCH + fifth.sx * 12);
+    }
+    static_assert(DT_SY == 9 && DT_SX == 17, "fifth group: slot rows 7 and 8");
     const uint32_t wa = (uint32_t)(wrow * 64 + lgrp * 16);
     for (int tile = vb; tile < p.ntiles; tile += G) {
         uint32_t b, rem, ty, tx;
@@ -226,11 +243,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         const int y0 = (int)ty * DT_TY, x0 = (int)tx * DT_TX;
         commit(cur);
         dt_lds_barrier();                                 // LDS only: __syncthreads() also waited for the ACKNOWLEDGEMENTS of the previous tile's gradient stores (vmcnt counts stores too)
-        request(t_nxt, frame_of(t_nxt), cur);
+        if (!(dbg & 16)) request(t_nxt, frame_of(t_nxt), cur);
         t_nxt = min(t_nxt + G, p.ntiles - 1);
 
         // ---- phase 1: logits of the 9 x 17 slots, loss, dlogits into the LDS tile ----
-        auto slot_group = [&](const SlotLane& L) {
+        // PAIR < 0: the whole group (all six logits of the lane's output row).  PAIR = 0 | 1 | 2 (round 6): only logit pair PAIR -- the FIFTH group (25 of its 32 slots live) used to
+        // be wave 0's second group while three waves waited at the barrier: 12.9 of the kernel's 76.7 us (tools/dectail_ablate.py).  Its eight MFMAs and four half-wave swaps are
+        // cheap; the ~110 VALU instructions + 18 transcendentals of the loss are not: with p.fifth_split waves 0, 1, 2 each run the MFMAs of the fifth group and the loss of ONE of
+        // its three logit pairs (same values, same dlogits tile; the loss / bias partial sums are regrouped: fp32 summation order).  MEASURED NEUTRAL (one box, three interleaved
+        // rounds: 74.4 / 77.4 / 74.9 us one wave, 77.2 / 76.2 / 77.6 us shared; step 0.8440 = 0.8440 ms): what the fifth group costs its wave is not the loss arithmetic but the
+        // LATENCY CHAIN in front of it -- sixteen LDS reads feeding eight MFMAs on ONE accumulator, each waiting for the one before -- and three waves now pay that chain instead of
+        // one.  Kept behind the knob (default off) with its test; the lever that is left is two accumulators per group (changes the logits' summation order: DESIGN 7).
+        auto slot_group = [&](const SlotLane& L, auto pair_c) {
+            constexpr int PAIR = decltype(pair_c)::value;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -273,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             uint32_t gw[3];
 #pragma unroll
             for (int jp = 0; jp < 3; ++jp) {                // two logits at a time: one v_cvt_pk_bf16_f32 rounds both (logits as STORED, dlogits as STORED)
+                if (PAIR >= 0 && jp != PAIR) continue;
                 const int ja = 2 * jp, jb = 2 * jp + 1;
                 const float xa_ = xr[ja] + (ja % 3 == 0 ? bias0 : (ja % 3 == 1 ? bias1 : bias2));
                 const float xb_ = xr[jb] + (jb % 3 == 0 ? bias0 : (jb % 3 == 1 ? bias1 : bias2));
@@ -284,6 +310,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                     const int j = 2 * jp + h;
                     const float xv = xv2[h];
                     float l, gr;
+                    if (DBG && (dbg & 1)) { l = xv * yv[j]; gr = xv - yv[j]; }
+                    else
                     if constexpr (FASTBCE) {               // loss_kind 0 on the hardware transcendentals (gather_narrow_kernel, FASTBCE)
                         const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * 1.44269504f);
                         const float s1 = 1.0f + e;
@@ -313,15 +341,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             if (L.sv) {
                 uint32_t* drow = (uint32_t*)(dl + L.da);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) drow[j] = gw[j];
+                for (int j = 0; j < 3; ++j) if (PAIR < 0 || j == PAIR) drow[j] = gw[j];
             }
         };
-        slot_group(own);
-        if (wave == 0) slot_group(slot_lane(4));
+        if (!(dbg & 32)) {
+            slot_group(own, std::integral_constant<int, -1>{});
+            if (!(dbg & 64)) {
+                if (p.fifth_split) {
+                    if (wave == 0) slot_group(fifth, std::integral_constant<int, 0>{});
+                    else if (wave == 1) slot_group(fifth, std::integral_constant<int, 1>{});
+                    else if (wave == 2) slot_group(fifth, std::integral_constant<int, 2>{});
+                } else if (wave == 0) slot_group(fifth, std::integral_constant<int, -1>{});
+            }
+        }
         dt_lds_barrier();                                 // dlogits tile complete (LDS only: the next tile's global loads stay in flight)
 
         // ---- phase 2: input gradient of this wave's 32 pixels: rows yl = 2 wave, 2 wave + 1, columns xl = 0 .. 15 ----
         const int yl = 2 * wave + (lrow >> 4), xl = lrow & 15;
+        if (DBG && (dbg & 2) && (dbg & 4)) { dt_lds_barrier(); continue; }
         u16x8 xf[3];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                      // group j = 2 s + gi: q4 = 4 s + gi (+ 2 for the upper half-wave) -> kernel row q4 / 3, values (q4 % 3) * 4 ..
@@ -334,9 +371,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        if (!(DBG && (dbg & 2))) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wtf[s]), __builtin_bit_cast(bf16x8, xf[s]), acc2, 0, 0, 0);
-        {
+        }
+        if (!(DBG && (dbg & 2))) {
             uint32_t R[4][2];
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -362,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 o[d] &= nz * 0xffffu;
             }
             const int y = y0 + yl, x = x0 + xl;
-            if (y < p.IH && x < p.IW) {
+            if (y < p.IH && x < p.IW && !(DBG && (dbg & 8))) {
                 bf16_t* out = p.dx + (((long long)b * p.IH + y) * p.IW + x) * 32 + lgrp * 16;
                 *(PackN<uint32_t, 4>*)out = PackN<uint32_t, 4>{{o[0], o[1], o[2], o[3]}};
                 *(PackN<uint32_t, 4>*)(out + 8) = PackN<uint32_t, 4>{{o[4], o[5], o[6], o[7]}};
@@ -371,6 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 
         // ---- phase 3: filter gradient  dW[k][ci] += sum over this wave's pixels of patch[pixel][k] * x[pixel][ci] ----
         // patches: this lane's 24 values -> row lrow of the wave's transposed-read tile; the activations are read transposed from the staged tile
+        if (DBG && (dbg & 4)) { dt_lds_barrier(); continue; }
 #pragma unroll
         for (int s = 0; s < 3; ++s) *(u16x8*)(ptw + lrow * 128 + (((2 * s + lgrp) ^ (lrow & 7)) << 4)) = xf[s];
         __builtin_amdgcn_wave_barrier();                  // same wave, in-order LDS queue

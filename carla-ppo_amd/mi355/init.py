@@ -145,6 +145,13 @@ def seed_from_numpy_state():
     train.py seeds TensorFlow and numpy from the same --seed (train.py:50-53) and TensorFlow's graph seed then drives initialisation and
     sampling; here `np.random.seed(seed)` is the only one of the two that still exists, so it drives both -- and because the state is only
     peeked, the minibatch permutations the reference draws from that generator (vae/models.py:209, train.py:195) stay bit-identical."""
+    import sys
     import zlib
+    # ... unless the script DID seed "TensorFlow": with carla-ppo_amd's stub in place tf.random.set_random_seed(seed) is remembered there, and -- as in the reference, where the
+    # graph seed drives initialisation and sampling -- it decides alone: a script that seeds only TensorFlow gets reproducible models whatever numpy's state is (ADVICE r05)
+    tf = sys.modules.get("tensorflow")
+    gs = tf.get_graph_seed() if tf is not None and hasattr(tf, "get_graph_seed") else None
+    if gs is not None:
+        return int(zlib.crc32(b"graph-seed" + int(gs).to_bytes(8, "little", signed=True)) & 0x7FFFFFFF)
     st = np.random.get_state()
     return int(zlib.crc32(np.asarray(st[1], np.uint32).tobytes() + int(st[2]).to_bytes(4, "little")) & 0x7FFFFFFF)

@@ -3,14 +3,34 @@ import it and touch exactly two symbols -- tf.random.set_random_seed(seed) and t
 vae/models.py, ppo.py and utils.py, which this directory replaces.  With carla-ppo_amd/ ahead of the reference checkout on PYTHONPATH the unchanged scripts import
 this module and INTEGRATION.md's command line works without TensorFlow installed.
 
-  tf.random.set_random_seed(seed)   the graph-level seed of the reference (train.py:50-51): here the default seed of the engines' own noise sources
-                                    (mi_vae_set_seed / the PPO exploration noise): mi355.seed.graph_seed() returns it to models created afterwards
+  tf.random.set_random_seed(seed)   the graph-level seed of the reference (train.py:50-51): remembered here (get_graph_seed) and CONSUMED by mi355.init.seed_from_numpy_state --
+                                    the default seed of models built without an explicit one (weight initialisation, mi_vae_set_seed, the PPO exploration noise): a script
+                                    that seeds only TensorFlow gets reproducible models, as it did with the reference
   tf.reset_default_graph()          nothing to reset: there is no global graph (train.py:273)
 Anything else raises AttributeError naming this file, so that a script that really needs TensorFlow fails loudly instead of half-working.
 """
+import os
+import sys
 import types
+import warnings
 
 _graph_seed = [None]
+
+
+def _warn_if_shadowing():
+    """A real TensorFlow elsewhere on sys.path is hidden from EVERY importer of this process (tensorboard.compat, ...) while this directory is ahead of it: say so once, by name."""
+    try:
+        from importlib.machinery import PathFinder
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        other = PathFinder.find_spec("tensorflow", [p for p in sys.path if p and os.path.abspath(p) != here])
+        if other is not None and other.origin and os.path.abspath(other.origin) != os.path.abspath(__file__):
+            warnings.warn("carla-ppo_amd's two-symbol `tensorflow` stub (%s) shadows a real TensorFlow at %s for every import in this process; put carla-ppo_amd behind it on "
+                          "PYTHONPATH (and import vae.models / ppo from carla-ppo_amd explicitly) if anything else here needs the real one" % (__file__, other.origin), RuntimeWarning)
+    except Exception:
+        pass
+
+
+_warn_if_shadowing()
 
 
 def _set_random_seed(seed):

@@ -1293,3 +1293,46 @@ def test_filter_gradient_dma_rows_decoded_once_per_wave(form, geom, k, B):
     sw, sb = float(np.abs(dwref).max()), float(np.abs(dbref).max())
     assert_close(res[1][0] - 0.25, dwref, 1e-4, 1e-4 * sw, "filter gradient (rows decoded once per wave)")
     assert_close(res[1][1] + 2.0, dbref, 1e-4, 1e-4 * sb, "bias gradient")
+
+
+@pytest.mark.parametrize("B,IH,IW", [(3, 39, 79), (37, 39, 79), (2, 7, 15)])
+def test_decoder_tail_fifth_slot_group_shared_by_three_waves(B, IH, IW):
+    """Round 6 (dectail_tile.hpp; VERDICT r05 item 1: the ablation of tools/dectail_ablate.py named it): a tile computes 9 x 17 = 153 slots = FIVE groups of 32 for four waves; the fifth
+    (25 live slots) was wave 0's second group while three waves waited at the barrier -- 12.9 of 76.7 us.  Waves 0, 1, 2 now each run the fifth group's MFMAs and the loss of ONE
+    of its three logit pairs.  Same logits, same dlogits tile: the input gradient is BITWISE that of the one-wave form (mi_set_tuning key 26 = 0), the filter gradient too (same
+    patches, same order); loss and bias-gradient partial sums are regrouped (fp32 summation order)."""
+    import ctypes
+    L = milib.get()
+    code, td = DT["bf16"]
+    Ci, Co, k = 32, 3, 4
+    OH, OW = 2 * IH + 2, 2 * IW + 2
+    rng = np.random.RandomState(B + IH)
+    x = np.maximum(rng.randn(B, IH, IW, Ci), 0).astype(np.float32)
+    w = (rng.randn(k, k, Co, Ci) / np.sqrt(4 * Ci)).astype(np.float32)
+    b = (0.1 * rng.randn(Co)).astype(np.float32)
+    frames_u8 = rng.randint(0, 256, (B + 2, OH * OW * Co)).astype(np.uint8)
+    idx = rng.permutation(B + 2)[:B].astype(np.int32)
+    labels = dev(frames_u8, torch.uint8)
+    xd, wd, bd, idxd = dev(x, td), dev(w, td), dev(b), dev(idx, torch.int32)
+    wt = torch.zeros(k * k * Co * Ci, device="cuda", dtype=td)
+    offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
+    L.mi_transpose_weights(stream(), code, P(dev(w)), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+    nb = L.mi_deconv2d_tail_blocks()
+    res = {}
+    for mode in (0, 1):
+        prev = L.mi_set_tuning(26, mode)
+        try:
+            scratch = torch.empty(nb * 6144, device="cuda", dtype=torch.uint8)
+            lp, bp = torch.zeros(16384, device="cuda"), torch.zeros(16384, 4, device="cuda")
+            dx = alloc(td, B, IH, IW, Ci, fill=5.0)
+            dw = torch.zeros(k, k, Co, Ci, device="cuda")
+            n = ctypes.c_int(0)
+            L.mi_deconv2d_tail_fused(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), wt.data_ptr(), bd.data_ptr(), k, k, Co, labels.data_ptr(), 1, idxd.data_ptr(),
+                                     OH * OW * Co, 0, 1.0 / 16, dx.data_ptr(), dw.data_ptr(), lp.data_ptr(), bp.data_ptr(), 16384, ctypes.addressof(n), scratch.data_ptr(), scratch.numel(), 1)
+            torch.cuda.synchronize()
+            res[mode] = (dx.view(torch.int16).clone(), dw.clone(), float(lp[:n.value].double().sum()), bp[:n.value, :Co].double().sum(0).cpu().numpy())
+        finally:
+            L.mi_set_tuning(26, prev)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert abs(res[1][2] / res[0][2] - 1) < 2e-6
+    assert_close(res[1][3], res[0][3], 1e-5, 1e-5 * float(np.abs(res[0][3]).max()) + 1e-7, "bias gradient sums")

@@ -139,6 +139,17 @@ def test_tensorflow_stub_is_exactly_what_the_scripts_touch():
         assert "carla-ppo_amd" in tf.__file__
         tf.random.set_random_seed(7)
         assert tf.get_graph_seed() == 7
+        # ... and it is consumed: a model built without an explicit seed takes it, whatever numpy's global state is (a script that seeds only TensorFlow)
+        from mi355.init import seed_from_numpy_state
+        st = np.random.get_state()
+        try:
+            np.random.seed(1); a = seed_from_numpy_state()
+            np.random.seed(2); b = seed_from_numpy_state()
+            tf.random.set_random_seed(8); c = seed_from_numpy_state()
+            tf.random.set_random_seed(None); np.random.seed(1); d = seed_from_numpy_state(); np.random.seed(2); e = seed_from_numpy_state()
+        finally:
+            np.random.set_state(st)
+        assert a == b and c != a and d != e
         assert tf.reset_default_graph() is None
         with pytest.raises(AttributeError, match="stub"):
             tf.layers

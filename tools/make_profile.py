@@ -77,19 +77,30 @@ NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gr
              # still run twice in a profile (bench.py's isolated per-op table): not listed
              ("enc12_fwd_kernel<unsigned char, 0, 1, 1>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
     + [n for n in NAMES_R04 if n[0] != "reduce_fused_kernel" and n[2] not in ("conv1.fwd", "conv2.fwd")]
-NAMES = NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
-lines, traffic = [], {}
+# round 6: the raw-staged filter gradients decode a step's DMA rows once per wave (template flag LDEC: new kernel names)
+_R06_RENAME = {"tapwgrad_cw_kernel": "tapwgrad_cw_kernel<true>", "tapwgrad_kernel<0, 2, 4, 2, 2, true>": "tapwgrad_kernel<0, 2, 4, 2, 2, true, true>",
+               "tapwgrad_kernel<1, 2, 4, 2, 2, true>": "tapwgrad_kernel<1, 2, 4, 2, 2, true, true>"}
+NAMES_R06 = [(_R06_RENAME.get(k, k), g, o) for (k, g, o) in NAMES_R05] + [n for n in NAMES_R05 if n[0] in _R06_RENAME]      # (the round-5 names too: a profile taken with MI355_TW_LDEC=0)
+NAMES = NAMES_R06 if tag.startswith("r06") else NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
+lines, traffic, seen_ops = [], {}, set()
+step_bytes, step_kernels = 0.0, 0
 for kern, grid, op in NAMES:
     keys = [k for k in sqr if k[0].strip("`") == kern and (grid is None or k[1] == grid)]
-    if not keys:
+    if not keys or op in seen_ops:
         continue
+    seen_ops.add(op)
     key = keys[0]
     d = sqr[key]; us = float(d["us"]); gui = float(d["GRBM_GUI_ACTIVE"]) / 8.0
     util = float(d["VALU_MFMA_BUSY_CYCLES"]) / (gui * 1024.0) if gui > 0 else 0.0
     f, w = fer.get(key), wrr.get(key)
     fmb = 2 * f / 1e3 if f else 0.0; wmb = w / 1e3 if w else 0.0
-    lines.append("| %s | `%s` %s | %.1f | %.1f%% | %.1f | %.1f | %.2f |" % (op, kern, key[1], us, 100 * util, fmb, wmb, (fmb + wmb) / us))
-    traffic[op] = {"kernel": kern, "grid": key[1], "us": us, "fetch_mb_corrected": fmb, "write_mb": wmb, "hbm_bytes_per_launch": (fmb + wmb) * 1e6, "mfma_util": util}
+    nmf, nva = float(d.get("INSTS_MFMA", 0) or 0), float(d.get("INSTS_VALU", 0) or 0)
+    vpm = nva / nmf if nmf > 0 else float("nan")
+    lines.append("| %s | `%s` %s | %.1f | %.1f%% | %.1f | %.1f | %.1f | %.2f |" % (op, kern, key[1], us, 100 * util, vpm, fmb, wmb, (fmb + wmb) / us))
+    traffic[op] = {"kernel": kern, "grid": key[1], "us": us, "fetch_mb_corrected": fmb, "write_mb": wmb, "hbm_bytes_per_launch": (fmb + wmb) * 1e6, "mfma_util": util,
+                   "valu_per_mfma": None if nmf <= 0 else vpm}
+    mult = 2 if "averaged" in op else 1                   # (two layers of a step share kernel and grid: one averaged row, two launches per step)
+    step_bytes += mult * (fmb + wmb) * 1e6; step_kernels += mult
 doc = """# %s
 
 ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  ONE `gpurun` call = one box, one library (stamp and the box's own calibration: `config.library` / `box` in the bench line below).  Sources: `rocprofv3 --kernel-trace --stats` of
@@ -108,9 +119,12 @@ MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 S
 MI355X_MICROARCH.md: wide coalesced reads are tallied at half their size; calibrated for 16-byte-per-lane reads, the 8-byte fp32 frame reads of the
 conv1 kernels of round 1 may be over-counted) + WRITE_SIZE, both reported in KB by rocprofv3.  Last column: (read + write) / duration; 8 TB/s spec, ~6.3 achievable.
 
-| op | kernel, grid | us | MFMA util | HBM read MB | HBM write MB | HBM TB/s |
-|---|---|---:|---:|---:|---:|---:|
+| op | kernel, grid | us (alone: the counter pass serialises) | MFMA util | VALU / MFMA instructions | HBM read MB | HBM write MB | HBM TB/s |
+|---|---|---:|---:|---:|---:|---:|---:|
 %s
+
+Whole step (every row above once, the two averaged rows twice; the small latent-layer / reparameterisation / loss kernels are not in the table): **%.2f GB of HBM traffic in %d kernels**
+against SURVEY 8(d)'s 1.54 GB "practical un-fused" and 0.141 GB algorithmic.
 
 ## Kernel time table (every step of the profiled run: clock conditioning + warm-up + timed steps; the averages are IN-STEP times)
 
@@ -131,8 +145,8 @@ conv1 kernels of round 1 may be over-counted) + WRITE_SIZE, both reported in KB 
 ## PMC pass 3 (WRITE_SIZE, KB)
 
 %s
-""" % (title, json.dumps(bench), "\n".join(lines), stats, timeline, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
+""" % (title, json.dumps(bench), "\n".join(lines), step_bytes / 1e9, step_kernels, stats, timeline, "\n".join(sq.splitlines()[:32]), "\n".join(fe.splitlines()[:26]), "\n".join(wr.splitlines()[:26]))
 open(R + "profiles/%s.md" % outname, "w").write(doc)
 json.dump({"provenance": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, batch 512 bf16; FETCH_SIZE doubled per MI355X_MICROARCH.md",
-           "ops": traffic}, open(R + "profiles/%s_pmc_traffic.json" % tag[:3], "w"), indent=1)
+           "ops": traffic, "step": {"hbm_bytes": step_bytes, "kernels": step_kernels, "batch": 512}}, open(R + "profiles/%s_pmc_traffic.json" % tag[:3], "w"), indent=1)
 print("\n".join(lines))
