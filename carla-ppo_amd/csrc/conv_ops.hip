@@ -325,7 +325,7 @@ int g_tapwgrad_cw = 1;                                     // k = 5 filter gradi
 static int dectail_split5_env() { const char* e = getenv("MI355_DECTAIL_SPLIT5"); return (e && e[0] == '1') ? 1 : 0; }      // measured neutral (74.4-77.4 vs 76.2-77.6 us alone, 0.8440 = 0.8440 ms per step): off
 int g_dectail_split5 = dectail_split5_env();               // decoder tail: the fifth slot group's loss shared by three waves (dectail_tile.hpp, round 6); mi_set_tuning key 26
 int g_dectail_dbg = 0;                                     // ablation mask of the decoder tail's timing instantiation (wrong results); mi_set_tuning key 25
-static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); return (e && e[0] == '0') ? 0 : 1; }
+static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }      // bit 0: the 2 x 2-tap kernels (default), bit 1: the k = 5 class-wave kernel (measured neutral in the step, 6 us slower alone: off)
 int g_tw_ldec = tw_ldec_env();                             // raw-staged filter gradients: a step's DMA rows decoded once per wave, one row per lane (tapwgrad_tile.hpp, round 6); mi_set_tuning key 24
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
@@ -410,7 +410,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     }
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
-    const bool ldec = g_tw_ldec && !q.dbg_cheap_addr && !q.trace;
+    const bool ldec = (g_tw_ldec & 1) && !q.dbg_cheap_addr && !q.trace, ldec_cw = (g_tw_ldec & 2) && !q.dbg_cheap_addr && !q.trace;
     if (mode == TC_CONV) {
         if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
         else if (split) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
@@ -424,7 +424,7 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
         if (q.npairs > 32) return 0;
         // k = 5 with caller scratch: a wave per (parity class, tap row), the shifted slot fragments formed in registers (mi_set_tuning key 14 = 0: the pair layout)
         if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) {
-            if (ldec) MI_LAUNCH(tapwgrad_cw_kernel<true>, g, dim3(TWC_NT), 0, st, q); else MI_LAUNCH(tapwgrad_cw_kernel<false>, g, dim3(TWC_NT), 0, st, q);
+            if (ldec_cw) MI_LAUNCH(tapwgrad_cw_kernel<true>, g, dim3(TWC_NT), 0, st, q); else MI_LAUNCH(tapwgrad_cw_kernel<false>, g, dim3(TWC_NT), 0, st, q);
         }
         else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
@@ -964,7 +964,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
-    else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value ? 1 : 0; }
+    else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value < 0 || value > 3 ? 1 : value; }
     else if (key == 25) { prev = g_dectail_dbg; g_dectail_dbg = value; }
     else if (key == 26) { prev = g_dectail_split5; g_dectail_split5 = value ? 1 : 0; }
     else if (key == 23) { prev = mi_enc12_debug(value); }  // (debug: ablation mask of the fused encoder head's timing instantiation -- results are wrong with any bit set)

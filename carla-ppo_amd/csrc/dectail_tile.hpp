@@ -72,6 +72,9 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
 // software prefetch of the next tile wait at the first barrier it meets
 __device__ __forceinline__ void dt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (Round 6, measured and dropped -- DESIGN 3.16: the same body at TWO waves per SIMD with the forward weights in registers and all eight activation fragments of a slot group
+//  requested before its first MFMA -- the generated code here is "two ds_read_b128, s_waitcnt lgkmcnt(0), MFMA" eight times per group, 165 of 170 registers leave no room to read
+//  ahead -- 197 registers, two blocks per CU: 78.2 / 76.9 / 77.3 us against 74.7 / 75.6 / 74.9, step 0.8220 against 0.8199 ms.)
 template <bool FASTBCE, bool DBG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dectail_kernel(const DecTailParams p) {
     const int dbg = DBG ? p.dbg : 0;
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // cheap; the ~110 VALU instructions + 18 transcendentals of the loss are not: with p.fifth_split waves 0, 1, 2 each run the MFMAs of the fifth group and the loss of ONE of
         // its three logit pairs (same values, same dlogits tile; the loss / bias partial sums are regrouped: fp32 summation order).  MEASURED NEUTRAL (one box, three interleaved
         // rounds: 74.4 / 77.4 / 74.9 us one wave, 77.2 / 76.2 / 77.6 us shared; step 0.8440 = 0.8440 ms): what the fifth group costs its wave is not the loss arithmetic but the
-        // LATENCY CHAIN in front of it -- sixteen LDS reads feeding eight MFMAs on ONE accumulator, each waiting for the one before -- and three waves now pay that chain instead of
-        // one.  Kept behind the knob (default off) with its test; the lever that is left is two accumulators per group (changes the logits' summation order: DESIGN 7).
+        // LATENCY CHAIN in front of it -- eight times two LDS reads, a wait, an MFMA -- and three waves now pay that chain instead of one.  Kept behind the knob (default off)
+        // with its test.
         auto slot_group = [&](const SlotLane& L, auto pair_c) {
             constexpr int PAIR = decltype(pair_c)::value;
             f32x16 acc;
@@ -267,6 +270,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                     const u32x4 wv = *(const u32x4*)(wl + wa + tap * 13 * 64 + kk * 32);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
                 }
+            // (round 6, measured and dropped: two accumulators -- two chains of four MFMAs instead of one of eight -- 77.3 / 77.8 / 76.2 us against 76.0 / 75.5 / 74.8; the
+            //  generated code is "two ds_read_b128, s_waitcnt lgkmcnt(0), MFMA" eight times: what a lone group waits for is the LDS latency in front of every MFMA, and with
+            //  three waves per SIMD at 165 of 170 registers there is no room to read further ahead: DESIGN 3.16)
             // D rows: register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h; rows 0 .. 11 = class * 3 + channel are live: h = 0 holds rows 0..3
             // (registers 0..3) and 8..11 (registers 4..7), h = 1 rows 4..7 (registers 0..3).  Four half-wave swaps give every lane ONE output row of its
             // slot -- h = 0: rows 0..5 = output row 2 sy (pixels 2 sx, 2 sx + 1 x 3 channels), h = 1: rows 6..11 = output row 2 sy + 1 -- six consecutive

@@ -1274,7 +1274,7 @@ def test_filter_gradient_dma_rows_decoded_once_per_wave(form, geom, k, B):
     res = {}
     prev_blocks = L.mi_set_tuning(9, 64)                                   # 64 target blocks: several position splits even at these small batches
     try:
-        for mode in (0, 1):
+        for mode in (0, 3):
             prev = L.mi_set_tuning(24, mode)
             try:
                 dw, db = torch.full(wshape, 0.25, device="cuda"), torch.full((Co,), -2.0, device="cuda")
@@ -1289,10 +1289,10 @@ def test_filter_gradient_dma_rows_decoded_once_per_wave(form, geom, k, B):
                 L.mi_set_tuning(24, prev)
     finally:
         L.mi_set_tuning(9, prev_blocks)
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1])
     sw, sb = float(np.abs(dwref).max()), float(np.abs(dbref).max())
-    assert_close(res[1][0] - 0.25, dwref, 1e-4, 1e-4 * sw, "filter gradient (rows decoded once per wave)")
-    assert_close(res[1][1] + 2.0, dbref, 1e-4, 1e-4 * sb, "bias gradient")
+    assert_close(res[3][0] - 0.25, dwref, 1e-4, 1e-4 * sw, "filter gradient (rows decoded once per wave)")
+    assert_close(res[3][1] + 2.0, dbref, 1e-4, 1e-4 * sb, "bias gradient")
 
 
 @pytest.mark.parametrize("B,IH,IW", [(3, 39, 79), (37, 39, 79), (2, 7, 15)])

@@ -78,8 +78,8 @@ NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gr
              ("enc12_fwd_kernel<unsigned char, 0, 1, 1>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
     + [n for n in NAMES_R04 if n[0] != "reduce_fused_kernel" and n[2] not in ("conv1.fwd", "conv2.fwd")]
 # round 6: the raw-staged filter gradients decode a step's DMA rows once per wave (template flag LDEC: new kernel names)
-_R06_RENAME = {"tapwgrad_cw_kernel": "tapwgrad_cw_kernel<true>", "tapwgrad_kernel<0, 2, 4, 2, 2, true>": "tapwgrad_kernel<0, 2, 4, 2, 2, true, true>",
-               "tapwgrad_kernel<1, 2, 4, 2, 2, true>": "tapwgrad_kernel<1, 2, 4, 2, 2, true, true>"}
+_R06_RENAME = {"tapwgrad_cw_kernel": "tapwgrad_cw_kernel<false>", "tapwgrad_kernel<0, 2, 4, 2, 2, true>": "tapwgrad_kernel<0, 2, 4, 2, 2, true, true>",
+               "tapwgrad_kernel<1, 2, 4, 2, 2, true>": "tapwgrad_kernel<1, 2, 4, 2, 2, true, true>", "dectail_kernel<true>": "dectail_kernel<true, false>"}
 NAMES_R06 = [(_R06_RENAME.get(k, k), g, o) for (k, g, o) in NAMES_R05] + [n for n in NAMES_R05 if n[0] in _R06_RENAME]      # (the round-5 names too: a profile taken with MI355_TW_LDEC=0)
 NAMES = NAMES_R06 if tag.startswith("r06") else NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic, seen_ops = [], {}, set()
