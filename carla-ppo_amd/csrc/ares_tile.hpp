@@ -27,6 +27,13 @@
 #include "gemm_tile.hpp"
 #include "gemm2_tile.hpp"
 
+// the timing switches of these kernels (MI355_ARES_DBG: bit 0 no MFMA loop, bit 1 no staging) exist only in a -DMI355_ARES_DBG build: as run-time values they made the trip counts of
+// the staging loops run-time values too (round 6: the same class of cost as the filter-gradient kernels' run-time debug branch)
+#ifdef MI355_ARES_DBG
+#define AR_DBG(p) ((p).dbg)
+#else
+#define AR_DBG(p) 0
+#endif
 namespace mi {
 
 struct AresParams {
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
         int f = 0, y = 0, x = 4 * wave + pq;              // q < 16 < IW on the first iteration
         uint32_t vq = (uint32_t)((f0 * AC_PIX + 4 * wave + pq) * 256);
 #pragma unroll 4
-        for (int t = wave; t < ((p.dbg & 2) ? 0 : F * AC_PIX / 4); t += 4) {
+        for (int t = wave; t < ((AR_DBG(p) & 2) ? 0 : F * AC_PIX / 4); t += 4) {
             const int s = (8 * f + 8 * (y >> 1) + (x >> 1)) & 15;
             const int jc = (pc - s) & 15;                 // logical chunk that lives at physical position pc
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, WPE) void ares_conv_kernel(const AresParams p)
 #pragma unroll
     for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tb[i] + q0);
 #pragma unroll 1
-    for (int t2 = 0; t2 < ((p.dbg & 1) ? 0 : 8); ++t2) {
+    for (int t2 = 0; t2 < ((AR_DBG(p) & 1) ? 0 : 8); ++t2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                     // tap number tl of this block's order; its fragments sit in ring half h
             const int tl = 2 * t2 + h;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams 
         int f = 0, y = 0;
         uint32_t vq = (uint32_t)((f0 * AG_PIX + 2 * wave + pq) * 512);
 #pragma unroll 4
-        for (int t = wave; t < ((p.dbg & 2) ? 0 : F * AG_PIX / 2); t += 4) {
+        for (int t = wave; t < ((AR_DBG(p) & 2) ? 0 : F * AG_PIX / 2); t += 4) {
             const int s = (4 * f + 9 * y + x) & 15;
             const int jc = (pc & 16) | ((pc - s) & 15);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256, WPE) void ares_gather_kernel(const AresParams 
         for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], abase[i] + r);
     }
 #pragma unroll 1
-    for (int t8 = 0; t8 < ((p.dbg & 1) ? 0 : 8); ++t8) {
+    for (int t8 = 0; t8 < ((AR_DBG(p) & 1) ? 0 : 8); ++t8) {
         const int o = (o0 + t8) & 7, on = (o0 + t8 + 1) & 7;
         const uint32_t hoff = (uint32_t)(o & 1) * 256u;
 #pragma unroll
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void ares_gather2_kernel(const AresParams p
         int y = 0, x = 4 * wave + pq;                     // pixel q = 4 t + pq, 16 pixels further per iteration; rotation s(y, x) = (19 y + x) & 15
         uint32_t vq = (uint32_t)((frame * G2_PIX + 4 * wave + pq) * 256);
 #pragma unroll 3
-        for (int t = wave; t < ((p.dbg & 2) ? 0 : G2_PIX / 4); t += 4) {
+        for (int t = wave; t < ((AR_DBG(p) & 2) ? 0 : G2_PIX / 4); t += 4) {
             const int s = (3 * y + x) & 15;
             const int jc = (pc - s) & 15;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_vptr)(lds + t * 1024), 16, (int)(vq + (uint32_t)jc * 16u), 0, 0, 0);
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void ares_gather2_kernel(const AresParams p
     for (int i = 0; i < TM; ++i) ar_lds_read(A[0][i], lds0 + tb[i] + q0);
     const int mlim = min(p.M, (frame + 1) * G2_RPF);
 #pragma unroll 1
-    for (int G = 0; G < ((p.dbg & 1) ? 0 : 16); ++G) {    // group = (class in this block's order, tap): 8 channel steps
+    for (int G = 0; G < ((AR_DBG(p) & 1) ? 0 : 16); ++G) {    // group = (class in this block's order, tap): 8 channel steps
         const int cls = (cls0 + (G >> 2)) & 3, tap = G & 3;
         const int Gn = (G + 1) & 15, clsn = (cls0 + (Gn >> 2)) & 3;
         uint32_t tbn[TM], q0n;

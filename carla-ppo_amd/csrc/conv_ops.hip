@@ -249,9 +249,10 @@ static int launch_fold(hipStream_t st, const PendingFold& f) {
 }
 static thread_local PendingReduce g_pending[16];
 static thread_local int g_npending = 0, g_defer_reduces = 0, g_defer_pause = 0;
+static unsigned reduce_ry_cap() { static int c = -1; if (c < 0) { const char* e = getenv("MI355_REDUCE_RY_CAP"); c = e ? atoi(e) : 16; if (c < 1 || c > 64) c = 16; } return (unsigned)c; }      // (16: 0.7900 / 0.7923 against 0.7929 / 0.7949 ms per step at 64, two interleaved A/B runs of four rounds)
 static unsigned reduce_ry(const PendingReduce& r) {       // slab chains per element (a power of two <= 64, from the shape only): about 512 blocks in flight, at most ~16 slabs per thread
-    unsigned ry = 1;
-    while (((unsigned)(r.ngroups / 512 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < 64) ry *= 2;
+    unsigned ry = 1;                                        // (MI355_REDUCE_RY_CAP: A/B knob -- fewer chains = longer contiguous pieces per slab and block, fewer blocks)
+    while (((unsigned)(r.ngroups / 512 + 1) * ry < 512 || r.splits / (int)ry > 16) && (int)(ry * 2) <= r.splits / 4 && ry < reduce_ry_cap()) ry *= 2;
     return ry;
 }
 static unsigned reduce_blocks(const PendingReduce& r, unsigned ry) { const unsigned upb = 256 / ry, nunits = (unsigned)r.ngroups / 2; return (nunits + upb - 1) / upb; }      // units = pairs of 16-byte groups
@@ -325,7 +326,7 @@ int g_tapwgrad_cw = 1;                                     // k = 5 filter gradi
 static int dectail_split5_env() { const char* e = getenv("MI355_DECTAIL_SPLIT5"); return (e && e[0] == '1') ? 1 : 0; }      // measured neutral (74.4-77.4 vs 76.2-77.6 us alone, 0.8440 = 0.8440 ms per step): off
 int g_dectail_split5 = dectail_split5_env();               // decoder tail: the fifth slot group's loss shared by three waves (dectail_tile.hpp, round 6); mi_set_tuning key 26
 int g_dectail_dbg = 0;                                     // ablation mask of the decoder tail's timing instantiation (wrong results); mi_set_tuning key 25
-static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }      // bit 0: the 2 x 2-tap kernels (default), bit 1: the k = 5 class-wave kernel (measured neutral in the step, 6 us slower alone: off)
+static int tw_ldec_env() { const char* e = getenv("MI355_TW_LDEC"); const int v = e ? atoi(e) : 0; return v < 0 || v > 3 ? 0 : v; }      // bit 0: the 2 x 2-tap kernels, bit 1: the k = 5 class-wave kernel.  Default 0: once the product kernels lost their run-time debug branch (below) the two forms are equal (0.7929 / 0.7932 / 0.7942 ms for 0 / 1 / 3)
 int g_tw_ldec = tw_ldec_env();                             // raw-staged filter gradients: a step's DMA rows decoded once per wave, one row per lane (tapwgrad_tile.hpp, round 6); mi_set_tuning key 24
 int g_tapwgrad_blocks = 256;                               // tapwgrad: target number of blocks (position splits x block columns); mi_set_tuning key 9
 bool tapwgrad_enabled() {
@@ -411,12 +412,15 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
     q.gx = splits; q.gy = gy;
     dim3 g((unsigned)((splits + 7) / 8 * 8 * gy), 1, 1);   // 1-D: the column blocks of a position split share an XCD (tapwgrad_tile.hpp)
     const bool ldec = (g_tw_ldec & 1) && !q.dbg_cheap_addr && !q.trace, ldec_cw = (g_tw_ldec & 2) && !q.dbg_cheap_addr && !q.trace;
+    const bool dbg = q.dbg_cheap_addr != 0;                // timing instantiations (tools/wgrad_ablate.py): their own kernels, the split layouts and the k = 5 kernel only
     if (mode == TC_CONV) {
-        if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
+        if (split && dbg) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true, false, true>), g, dim3(TW_NT), 0, st, q);
+        else if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
         else if (split) MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
         else MI_LAUNCH((tapwgrad_kernel<TC_CONV, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     } else if (taps == 2) {
-        if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
+        if (split && dbg) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true, false, true>), g, dim3(TW_NT), 0, st, q);
+        else if (split && ldec) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true, true>), g, dim3(TW_NT), 0, st, q);
         else if (split) MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 2, true>), g, dim3(TW_NT), 0, st, q);
         else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 2, 4, 2, 1>), g, dim3(TW_NT), 0, st, q);
     }
@@ -424,7 +428,8 @@ int try_tapwgrad(hipStream_t st, int dtype, int mode, const void* a, const void*
         if (q.npairs > 32) return 0;
         // k = 5 with caller scratch: a wave per (parity class, tap row), the shifted slot fragments formed in registers (mi_set_tuning key 14 = 0: the pair layout)
         if (g_tapwgrad_cw && KH == 5 && C == 64 && q.NE == 128 && q.KC == 64 && q.slabs) {
-            if (ldec_cw) MI_LAUNCH(tapwgrad_cw_kernel<true>, g, dim3(TWC_NT), 0, st, q); else MI_LAUNCH(tapwgrad_cw_kernel<false>, g, dim3(TWC_NT), 0, st, q);
+            if (dbg) MI_LAUNCH((tapwgrad_cw_kernel<false, true>), g, dim3(TWC_NT), 0, st, q);
+            else if (ldec_cw) MI_LAUNCH(tapwgrad_cw_kernel<true>, g, dim3(TWC_NT), 0, st, q); else MI_LAUNCH(tapwgrad_cw_kernel<false>, g, dim3(TWC_NT), 0, st, q);
         }
         else MI_LAUNCH((tapwgrad_kernel<TC_GATHER, 3, 2, 4, 4>), g, dim3(TW_NT), 0, st, q);
     }
@@ -964,7 +969,7 @@ int mi_set_tuning(int key, int value) {
     else if (key == 20) { prev = g_gemm2_stages; g_gemm2_stages = value; }
     else if (key == 21) { prev = g_x3_tapwgrad; g_x3_tapwgrad = value; }
     else if (key == 22) { prev = g_dwgs_on; g_dwgs_on = value ? 1 : 0; }
-    else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value < 0 || value > 3 ? 1 : value; }
+    else if (key == 24) { prev = g_tw_ldec; g_tw_ldec = value < 0 || value > 3 ? 0 : value; }
     else if (key == 25) { prev = g_dectail_dbg; g_dectail_dbg = value; }
     else if (key == 26) { prev = g_dectail_split5; g_dectail_split5 = value ? 1 : 0; }
     else if (key == 23) { prev = mi_enc12_debug(value); }  // (debug: ablation mask of the fused encoder head's timing instantiation -- results are wrong with any bit set)
@@ -1157,8 +1162,9 @@ int mi_deconv2d_tail_fused(void* stream, int dtype, const void* x, int B, int IH
     if (nblocks >= 16) nblocks &= ~7;                       // whole rounds of the eight XCDs (the kernel's tile order)
     if (nblocks > partial_capacity || scratch_bytes < (long long)nblocks * DT_SLAB * 4) return MI_OK;
     q.slabs = (float*)scratch;
-    q.dbg = g_dectail_dbg; q.fifth_split = g_dectail_split5;
+    q.dbg = g_dectail_dbg;
     if (fast && q.dbg) MI_LAUNCH((dectail_kernel<true, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);      // (timing instantiation: tools/dectail_ablate.py)
+    else if (fast && g_dectail_split5) MI_LAUNCH((dectail_kernel<true, false, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     else if (fast) MI_LAUNCH(dectail_kernel<true>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     else MI_LAUNCH(dectail_kernel<false>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, q);
     int rc = mi_check_launch("dectail_kernel");

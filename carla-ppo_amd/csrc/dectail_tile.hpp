@@ -54,7 +54,6 @@ struct DecTailParams {
     int OH, OW, GH, GW, tiles_x, tiles_per_frame, ntiles;
     int edge_own;                                        // 1: tiles cover the PIXEL grid; the last slot row / column (index IH / IW) is owned by the last tile row / column
     FastDiv div_tpf, div_tx;
-    int fifth_split;                                     // 1 (MI355_DECTAIL_SPLIT5=1, mi_set_tuning key 26; default 0: measured neutral): the fifth slot group's loss is shared by waves 0 .. 2, a logit pair each
     int dbg;                                             // TIMING INSTANTIATION only (dectail_kernel<.., true>, mi_set_tuning key 25; wrong results, honest durations -- tools/dectail_ablate.py):
                                                          // 1 no transcendentals in the loss, 2 no input-gradient phase, 4 no filter-gradient phase, 8 no gradient stores,
                                                          // 16 no loads (the first tile's data stay), 32 no slot groups at all (phase 1 off), 64 only ONE slot group per wave (no fifth group)
@@ -75,7 +74,7 @@ __device__ __forceinline__ void dt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // (Round 6, measured and dropped -- DESIGN 3.16: the same body at TWO waves per SIMD with the forward weights in registers and all eight activation fragments of a slot group
 //  requested before its first MFMA -- the generated code here is "two ds_read_b128, s_waitcnt lgkmcnt(0), MFMA" eight times per group, 165 of 170 registers leave no room to read
 //  ahead -- 197 registers, two blocks per CU: 78.2 / 76.9 / 77.3 us against 74.7 / 75.6 / 74.9, step 0.8220 against 0.8199 ms.)
-template <bool FASTBCE, bool DBG = false>
+template <bool FASTBCE, bool DBG = false, bool SPLIT5 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void dectail_kernel(const DecTailParams p) {
     const int dbg = DBG ? p.dbg : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[DT_XS + 4 * DT_PT + 3840 + 4 * 13 * 64 + DT_LBBYTES];
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // ---- phase 1: logits of the 9 x 17 slots, loss, dlogits into the LDS tile ----
         // PAIR < 0: the whole group (all six logits of the lane's output row).  PAIR = 0 | 1 | 2 (round 6): only logit pair PAIR -- the FIFTH group (25 of its 32 slots live) used to
         // be wave 0's second group while three waves waited at the barrier: 12.9 of the kernel's 76.7 us (tools/dectail_ablate.py).  Its eight MFMAs and four half-wave swaps are
-        // cheap; the ~110 VALU instructions + 18 transcendentals of the loss are not: with p.fifth_split waves 0, 1, 2 each run the MFMAs of the fifth group and the loss of ONE of
+        // cheap; the ~110 VALU instructions + 18 transcendentals of the loss are not: in the SPLIT5 instantiation (MI355_DECTAIL_SPLIT5=1, mi_set_tuning key 26) waves 0, 1, 2 each run the MFMAs of the fifth group and the loss of ONE of
         // its three logit pairs (same values, same dlogits tile; the loss / bias partial sums are regrouped: fp32 summation order).  MEASURED NEUTRAL (one box, three interleaved
         // rounds: 74.4 / 77.4 / 74.9 us one wave, 77.2 / 76.2 / 77.6 us shared; step 0.8440 = 0.8440 ms): what the fifth group costs its wave is not the loss arithmetic but the
         // LATENCY CHAIN in front of it -- eight times two LDS reads, a wait, an MFMA -- and three waves now pay that chain instead of one.  Kept behind the knob (default off)
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         if (!(dbg & 32)) {
             slot_group(own, std::integral_constant<int, -1>{});
             if (!(dbg & 64)) {
-                if (p.fifth_split) {
+                if constexpr (SPLIT5) {                       // (its own instantiation: no run-time switch inside the product kernel's tile loop)
                     if (wave == 0) slot_group(fifth, std::integral_constant<int, 0>{});
                     else if (wave == 1) slot_group(fifth, std::integral_constant<int, 1>{});
                     else if (wave == 2) slot_group(fifth, std::integral_constant<int, 2>{});

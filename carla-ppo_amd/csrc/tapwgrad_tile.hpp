@@ -116,8 +116,11 @@ __device__ __forceinline__ bool tw_dw_index(const TapWgradParams& p, int kc0, in
 // and the two "this pixel's odd row / column is outside the image" bits of the 2 x 2 forms travel in the low bits of the row offset (rows are >= 64 bytes apart) and are tested
 // against the chunk's own (ph, pw).  Same addresses, same zero fill, bit-identical sums (tests/test_ops_gpu.py runs both forms).  Measured upper bound of the whole address cost
 // (mi_set_tuning key 2 = 2: trivial addresses, wrong results): -3.0 % of the ConvVAE step; this form: DESIGN 3.16.
-template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false, bool LDEC = false>
+template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false, bool LDEC = false, bool DBG = false>
 __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p) {
+    // the timing instantiations (DBG) are their own kernels: a wave-uniform `if (p.dbg...) continue;` inside the unrolled MFMA loop of the PRODUCT kernel cuts its basic
+    // blocks at every k-step and cost the k = 5 kernel 6 us of 57 (round 6, found in the counter pass)
+    const int dbgm = DBG ? p.dbg_cheap_addr : 0;
     static_assert(!SPLIT || (TAPS == 2 && NTB == 2 && PPW == NTB), "split layout: 4 taps x 2 position halves = 8 waves");
     typedef bf16_t T;
     constexpr int ESZ = 2, VE = 8;
@@ -141,6 +144,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     if (bx >= p.gx) return;
     long long* const tr = p.trace ? p.trace + ((long long)(by * p.gx + bx) * 8 + (tid >> 6)) * 32 : nullptr;
     const bool tr_on = tr && ((long long)(by * p.gx + bx) * 8 + 8) * 32 <= p.trace_cap && lane == 0;
+// (round 6: compiling the stamps of this file, rwconv.hip and tapconv_tile.hpp out of the product build -- per-lane `if (tr_on)` branches at the phase boundaries -- measured
+//  SLOWER, 0.8142 against 0.8080 ms per step over four interleaved rounds: the hand-scheduled loops were tuned with those block boundaries in place.  They stay.)
 #define TW_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     TW_STAMP();
     const int kb = by % p.nkb, nb = by / p.nkb;
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
         const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
-        if (p.dbg_cheap_addr == 3) return;
-        if (p.dbg_cheap_addr == 2) {
+        if (dbgm == 3) return;
+        if (dbgm == 2) {
             const int t = wave + 8 * (idx < NIA ? idx : idx - NIA);
             if (idx < NIA && t >= ninstrA) return;
             const uint32_t vo = (uint32_t)((Ps * 64 + t * 1024 + lane * 16) & 0xFFFFF);
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
                     for (int i = ks; i < NDMA; i += NKI) issue_one(step + 1, cur ^ 1, i);
                 }
-                if (p.dbg_cheap_addr == 4) continue;          // (timing instantiation: loads and barriers only)
+                if (dbgm == 4) continue;                      // (timing instantiation: loads and barriers only)
                 if constexpr (!PIPE) load_unit(fr[u & 1], sbase, u);
                 else if (u + 1 < NU) load_unit(fr[(u + 1) & 1], sbase, u + 1);
                 const Frag& f = fr[u & 1];
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     // [lane][4 rows] (one contiguous 1 KiB store per wave-instruction); reduce_tiled_kernel sums the slabs and does the decode.
     // Without scratch: fp32 atomics straight into dW.
     auto emit = [&](const f32x16 (&tiles)[KT], int tap, int nt, int pi) {
-        if (p.dbg_cheap_addr == 5) return;
+        if (dbgm == 5) return;
         if (p.slabs) {
             const long long eoff = (long long)bx * p.slab_stride + ((long long)(by * p.npairs + pi) * KT) * 1024 + lane * 4;
             if (p.slab_bf16) {
@@ -541,8 +546,9 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 // Staging (LDS-DMA of the slot range and the gradient rows, two stages), the slab layout and the reduce are tapwgrad_kernel's.
 // =====================================================================================================================
 constexpr int TWC_NW = 10, TWC_NT = TWC_NW * 64;
-template <bool LDEC>                                      // LDEC: the rows of a step decoded once per wave, one row per lane (tapwgrad_kernel's header)
+template <bool LDEC, bool DBG = false>                    // LDEC: the rows of a step decoded once per wave, one row per lane (tapwgrad_kernel's header); DBG: timing instantiation
 __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParams p) {
+    const int dbgm = DBG ? p.dbg_cheap_addr : 0;
     constexpr int TAPS = 3, KT = 2, NTB = 4;
     constexpr int ESZ = 2, VE = 8;
     constexpr int KCB = 32 * KT, NEB = 32 * NTB;
@@ -589,8 +595,8 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
     auto issue_one = [&](int step, int buf, int idx) {
         const int Ps = Pbeg + step * TW_BP;
         const uint32_t As = lds0 + buf * STAGE, Ds = As + ASTAGE;
-        if (p.dbg_cheap_addr == 3) return;
-        if (p.dbg_cheap_addr == 2) {                      // (timing instantiation: every load inside one megabyte)
+        if (dbgm == 3) return;
+        if (dbgm == 2) {                                  // (timing instantiation: every load inside one megabyte)
             const int t = wave + TWC_NW * (idx < NIA ? idx : idx - NIA);
             if (idx < NIA ? t >= ninstrA : t >= NINSD) return;
             const uint32_t vo = (uint32_t)((Ps * 64 + t * 1024 + lane * 16) & 0xFFFFF);
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
                     if (more && j < NDMA) issue_row(cur ^ 1, j, fetch_row(j));
                 } else
                 if (more && j < NDMA) issue_one(step + 1, cur ^ 1, j);
-                if (p.dbg_cheap_addr == 4) continue;          // (timing instantiation: loads and barriers only)
+                if (dbgm == 4) continue;                      // (timing instantiation: loads and barriers only)
                 const bf16x8 dfrag = __builtin_bit_cast(bf16x8, Dq[j & 1]);
                 if (bias_on) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), dfrag, accb, 0, 0, 0);
 #pragma unroll
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
                 else atomicAdd(&p.dbias[ne - (int)p.div_n.div((uint32_t)ne) * p.N], accb[0]);
             }
         }
-        if (!cls_live || p.dbg_cheap_addr == 5) return;
+        if (!cls_live || dbgm == 5) return;
         // dW tiles: same accumulator order / slab layout as tapwgrad_kernel (pair index looked up in the host's (tap, output tile) list)
 #pragma unroll
         for (int tb = TB0; tb < TAPS; ++tb) {

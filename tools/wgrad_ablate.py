@@ -57,7 +57,7 @@ for name, (call, flops, nbytes) in ops.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); run(call, args.iters); e1.record(); torch.cuda.synchronize()
             samples[(dbg, ldec)].append(e0.elapsed_time(e1) / args.iters * 1e3)
-    L.mi_set_tuning(2, 0); L.mi_set_tuning(24, 1)
+    L.mi_set_tuning(2, 0); L.mi_set_tuning(24, 0)
     print("%s.wgrad  (%.1f GFLOP = %.1f us at 2.5 PF; %.1f MB of operands = %.1f us at 8 TB/s)" % (name, flops / 1e9, flops / 2.5e15 * 1e6, nbytes / 1e6, nbytes / 8e12 * 1e6))
     for (m, nm) in MODES:
         v = sorted(samples[m])
