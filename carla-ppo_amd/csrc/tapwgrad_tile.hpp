@@ -114,8 +114,8 @@ __device__ __forceinline__ bool tw_dw_index(const TapWgradParams& p, int kc0, in
 // fragment reads are in flight), and a DMA instruction fetches its rows'
 // offsets with ONE ds_bpermute_b32 (crossbar only, no LDS banks); what depends on the lane's 16-byte chunk rides along: the channel offset is added,
 // and the two "this pixel's odd row / column is outside the image" bits of the 2 x 2 forms travel in the low bits of the row offset (rows are >= 64 bytes apart) and are tested
-// against the chunk's own (ph, pw).  Same addresses, same zero fill, bit-identical sums (tests/test_ops_gpu.py runs both forms).  Measured upper bound of the whole address cost
-// (mi_set_tuning key 2 = 2: trivial addresses, wrong results): -3.0 % of the ConvVAE step; this form: DESIGN 3.16.
+// against the chunk's own (ph, pw).  Same addresses, same zero fill, bit-identical sums (tests/test_ops_gpu.py runs both forms).  VALU instructions per MFMA 7.3 -> 4.5 -- and
+// the step time is EQUAL to the per-instruction decode (0.7929 / 0.7932 ms, DESIGN_HISTORY 3.16c): these kernels are not VALU-issue bound.  Default off (MI355_TW_LDEC, key 24).
 template <int MODE, int TAPS, int KT, int NTB, int PPW, bool SPLIT = false, bool LDEC = false, bool DBG = false>
 __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p) {
     // the timing instantiations (DBG) are their own kernels: a wave-uniform `if (p.dbg...) continue;` inside the unrolled MFMA loop of the PRODUCT kernel cuts its basic
