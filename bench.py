@@ -430,9 +430,10 @@ def step_traffic(B):
     """HBM bytes of one WHOLE SGD step (PMC FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of a step, from the committed rocprofv3 passes of this round) next to SURVEY
     8(d)'s two reference points: the algorithmic bytes (frames + noise + optimiser traffic) and the practical un-fused activation traffic (every activation written in forward and
     read in backward, the same for the gradients, bf16).  Counters cannot be read from inside the bench: the figure is the profile's, for batch 512."""
-    alg = B * (38400.0 + 256.0) + 2584387 * 24.0
+    alg = B * (38400.0 + 256.0) + 2584387 * 24.0         # this path: uint8 camera bytes + noise per frame, 24 B of optimiser traffic per parameter
+    alg_survey = B * (153600.0 + 256.0) + 2584387 * 24.0  # SURVEY 8(d) as written: float32 frames (0.141 GB at batch 512)
     practical = B * 3.0e6 + 2584387 * 24.0
-    out = {"algorithmic_gb": alg / 1e9, "practical_unfused_gb": practical / 1e9, "pmc_gb_per_step": None, "source": None}
+    out = {"algorithmic_gb": alg / 1e9, "algorithmic_gb_survey_fp32_frames": alg_survey / 1e9, "practical_unfused_gb": practical / 1e9, "pmc_gb_per_step": None, "source": None}
     for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
@@ -446,7 +447,7 @@ def step_traffic(B):
         except Exception:
             continue
     if out["pmc_gb_per_step"]:
-        out["x_algorithmic"], out["x_practical"] = out["pmc_gb_per_step"] / out["algorithmic_gb"], out["pmc_gb_per_step"] / out["practical_unfused_gb"]
+        out["x_algorithmic"], out["x_practical"] = out["pmc_gb_per_step"] / out["algorithmic_gb_survey_fp32_frames"], out["pmc_gb_per_step"] / out["practical_unfused_gb"]
     return out
 
 

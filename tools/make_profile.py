@@ -78,14 +78,15 @@ NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gr
              ("enc12_fwd_kernel<unsigned char, 0, 1, 1>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
     + [n for n in NAMES_R04 if n[0] != "reduce_fused_kernel" and n[2] not in ("conv1.fwd", "conv2.fwd")]
 # round 6: the raw-staged filter gradients decode a step's DMA rows once per wave (template flag LDEC: new kernel names)
-_R06_RENAME = {"tapwgrad_cw_kernel": "tapwgrad_cw_kernel<false>", "tapwgrad_kernel<0, 2, 4, 2, 2, true>": "tapwgrad_kernel<0, 2, 4, 2, 2, true, true>",
-               "tapwgrad_kernel<1, 2, 4, 2, 2, true>": "tapwgrad_kernel<1, 2, 4, 2, 2, true, true>", "dectail_kernel<true>": "dectail_kernel<true, false>"}
-NAMES_R06 = [(_R06_RENAME.get(k, k), g, o) for (k, g, o) in NAMES_R05] + [n for n in NAMES_R05 if n[0] in _R06_RENAME]      # (the round-5 names too: a profile taken with MI355_TW_LDEC=0)
+NAMES_R06 = NAMES_R05                                     # (same ops; the kernels' template signatures grew: matched by prefix below)
 NAMES = NAMES_R06 if tag.startswith("r06") else NAMES_R05 if tag.startswith("r05") else NAMES_R01 if tag.startswith("r01") else (NAMES_R02 if tag.startswith("r02") else (NAMES_R03 if tag.startswith("r03") else NAMES_R04))
 lines, traffic, seen_ops = [], {}, set()
 step_bytes, step_kernels = 0.0, 0
 for kern, grid, op in NAMES:
-    keys = [k for k in sqr if k[0].strip("`") == kern and (grid is None or k[1] == grid)]
+    def same(name):                                       # later rounds append template flags (LDEC, DBG, ...) behind the round-5 signature: `k<a, b>` also matches `k<a, b, false>`; `k` matches `k<false>`
+        name = name.strip("`")
+        return name == kern or (kern.endswith(">") and name.startswith(kern[:-1] + ", ")) or (not kern.endswith(">") and name.startswith(kern + "<"))
+    keys = [k for k in sqr if same(k[0]) and (grid is None or k[1] == grid)]
     if not keys or op in seen_ops:
         continue
     seen_ops.add(op)
@@ -96,6 +97,7 @@ for kern, grid, op in NAMES:
     fmb = 2 * f / 1e3 if f else 0.0; wmb = w / 1e3 if w else 0.0
     nmf, nva = float(d.get("INSTS_MFMA", 0) or 0), float(d.get("INSTS_VALU", 0) or 0)
     vpm = nva / nmf if nmf > 0 else float("nan")
+    kern = key[0].strip("`")
     lines.append("| %s | `%s` %s | %.1f | %.1f%% | %.1f | %.1f | %.1f | %.2f |" % (op, kern, key[1], us, 100 * util, vpm, fmb, wmb, (fmb + wmb) / us))
     traffic[op] = {"kernel": kern, "grid": key[1], "us": us, "fetch_mb_corrected": fmb, "write_mb": wmb, "hbm_bytes_per_launch": (fmb + wmb) * 1e6, "mfma_util": util,
                    "valu_per_mfma": None if nmf <= 0 else vpm}
