@@ -705,3 +705,32 @@ def test_ppo_and_mlp_vae_dp_steps_are_one_c_call_with_the_same_collectives_on_ev
                 assert logs[0] == [(1, n, asyncs) for n in sizes] + ([(5, len(sizes), 0)] if asyncs else [])
             else:
                 assert sum(e[1] * (world if e[0] == 2 else 1) for e in logs[0] if e[0] in (1, 2)) == sum(sizes)      # reduce-scatter slices x W + tails tile every bucket
+
+
+def test_bench_line_helpers_step_traffic_and_watchdog():
+    """bench.py round 6: `roofline.step_traffic` prices the committed PMC total of one whole step against SURVEY 8(d)'s two reference points, and the watchdog
+    that guards the never-run-on-hardware collective schedule of an N > 1 bench fires its last words exactly once unless cancelled."""
+    import importlib
+    import threading
+    bench = importlib.import_module("bench")
+    st = bench.step_traffic(512)
+    assert st["algorithmic_gb_survey_fp32_frames"] == pytest.approx(0.1408, rel=1e-3)          # 512 x (153,600 + 256) B + 2,584,387 x 24 B
+    assert st["algorithmic_gb"] == pytest.approx(0.0818, rel=1e-3) and st["practical_unfused_gb"] == pytest.approx(1.598, rel=1e-3)
+    assert st["pmc_gb_per_step"] and 1.5 < st["pmc_gb_per_step"] < 2.5 and st["source"].startswith("profiles/r06_pmc_traffic.json")
+    assert st["x_practical"] == pytest.approx(st["pmc_gb_per_step"] / st["practical_unfused_gb"]) and st["x_algorithmic"] > 10
+    # the watchdog: cancelled -> silent
+    said = []
+    t = bench._watchdog(0.2, lambda: said.append("line"))
+    t.cancel()
+    threading.Event().wait(0.4)
+    assert said == []
+    # ... and firing: last words, then os._exit (patched: the test process must survive)
+    import os as _os
+    real_exit, codes = _os._exit, []
+    try:
+        _os._exit = lambda c: codes.append(c)
+        t = bench._watchdog(0.05, lambda: said.append("line"))
+        t.join(2.0)
+    finally:
+        _os._exit = real_exit
+    assert said == ["line"] and codes == [0]
