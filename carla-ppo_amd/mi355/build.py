@@ -22,6 +22,20 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def build_variant(tag, extra_flags, verbose=True):
+    """A second build of the library with extra compiler flags into build/lib_<tag>.so (objects in build/obj_<tag>): compiler-flag A/B runs load it with MI355_LIB=build/lib_<tag>.so
+    next to the product build (tools/ab_env.sh).  Never loaded by the product."""
+    global OBJ, LIB, FLAGS
+    saved = (OBJ, LIB, FLAGS)
+    OBJ = os.path.join(ROOT, "build", "obj_" + tag)
+    LIB = os.path.join(ROOT, "build", "lib_%s.so" % tag)
+    FLAGS = FLAGS + list(extra_flags)
+    try:
+        return _build(False, verbose, [])
+    finally:
+        OBJ, LIB, FLAGS = saved
+
+
 def build(force=False, verbose=True, asan=False):
     """asan=True: the HOST side of the library with AddressSanitizer (-fsanitize=address is ignored for the gfx950 code objects) into build/asan/ -- the
     checker build of tools/asan_host_check.sh (sanitizer row); never loaded by the product."""
@@ -71,4 +85,8 @@ def _build(force, verbose, link_extra):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, asan="--asan" in sys.argv)
+    if "--variant" in sys.argv:                           # python -m mi355.build --variant <tag> <flag> <flag> ...
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv, asan="--asan" in sys.argv)
