@@ -29,7 +29,9 @@ long long mi_ares_weight_bytes(void) { return 16ll * 128 * 256 * 2; }
 // [kh,kw,out = 128,in = 256] kernel for deconv1's INPUT gradient.  form 1 (gather form): w is [kh][kw][128][256] read as [kh][kw][n][c] -- deconv1's kernel
 // for its forward pass, or conv4's HWIO kernel for conv4's INPUT gradient.  (vae/models.py:253,261 and their gradients behind :142)
 int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out) {
-    if (!w_fp32 || !wf_out || form < 0 || form > 2) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
+    // round 6: forms 3 ([1024][128] mid-layer kernel, conv form of the register-weight kernel), 4 (deconv3's [5][5][32][64] kernel, gather form of the register-weight kernel: 144 KB),
+    // 5 (conv2's [512][64] kernel for the fused encoder head: 64 KB) -- the orders those kernels' prologues load their weight registers in
+    if (!w_fp32 || !wf_out || form < 0 || form > 5) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
     if ((((uintptr_t)w_fp32) | ((uintptr_t)wf_out)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
     AresPackJobs j = {};
     j.src[0] = w_fp32; j.dst[0] = (bf16_t*)wf_out; j.form[0] = form; j.n = 1;
@@ -47,6 +49,13 @@ int mi_ares_pack_weights4(void* stream, const float* conv4_w, const float* decon
 // for deconv2's forward pass (form 2, 256 KB each)
 int mi_ares_pack_weights6(void* stream, const float* conv4_w, const float* deconv1_w, const float* conv3_w, const float* deconv2_w,
                           void* wf0, void* wf1, void* wf2, void* wf3, void* wf4, void* wf5) {
+    return mi_ares_pack_weights8(stream, conv4_w, deconv1_w, conv3_w, deconv2_w, wf0, wf1, wf2, wf3, wf4, wf5, nullptr, nullptr);
+}
+
+// ... plus (optional, round 6) the two conv-form copies of the SAME mid-layer kernels for the register-weight kernel (form 3, 256 KB each): conv3_w -> wf6 for conv3's forward
+// pass, deconv2_w -> wf7 for deconv2's input gradient -- the order rwconv_conv_kernel<4, 2>'s prologue loads its 64 weight fragments in, 1 KB contiguous per wave load
+int mi_ares_pack_weights8(void* stream, const float* conv4_w, const float* deconv1_w, const float* conv3_w, const float* deconv2_w,
+                          void* wf0, void* wf1, void* wf2, void* wf3, void* wf4, void* wf5, void* wf6, void* wf7) {
     if (!conv4_w || !deconv1_w || !wf0 || !wf1 || !wf2 || !wf3) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
     if ((((uintptr_t)conv4_w) | ((uintptr_t)deconv1_w) | ((uintptr_t)conv3_w) | ((uintptr_t)deconv2_w) | ((uintptr_t)wf0) | ((uintptr_t)wf1) | ((uintptr_t)wf2) | ((uintptr_t)wf3) |
          ((uintptr_t)wf4) | ((uintptr_t)wf5)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
@@ -58,6 +67,9 @@ int mi_ares_pack_weights6(void* stream, const float* conv4_w, const float* decon
     j.src[3] = deconv1_w; j.dst[3] = (bf16_t*)wf3; j.form[3] = 0;
     if (conv3_w && wf4) { j.src[j.n] = conv3_w; j.dst[j.n] = (bf16_t*)wf4; j.form[j.n] = 2; ++j.n; }
     if (deconv2_w && wf5) { j.src[j.n] = deconv2_w; j.dst[j.n] = (bf16_t*)wf5; j.form[j.n] = 2; ++j.n; }
+    if ((((uintptr_t)wf6) | ((uintptr_t)wf7)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
+    if (conv3_w && wf6) { j.src[j.n] = conv3_w; j.dst[j.n] = (bf16_t*)wf6; j.form[j.n] = 3; ++j.n; }
+    if (deconv2_w && wf7) { j.src[j.n] = deconv2_w; j.dst[j.n] = (bf16_t*)wf7; j.form[j.n] = 3; ++j.n; }
     hipLaunchKernelGGL(ares_pack_kernel, dim3(256 * j.n), dim3(256), 0, (hipStream_t)stream, j);
     return mi_check_launch("ares_pack_kernel");
 }

@@ -443,6 +443,26 @@ __global__ __launch_bounds__(256) void ares_pack_kernel(const AresPackJobs jobs)
         const float* s = src + ((long long)((kh * 4 + kw) * 64 + nt * 32 + (l & 31))) * 128 + (ks & 7) * 16 + (l >> 5) * 8;
         const f32x4 a = *(const f32x4*)s, c = *(const f32x4*)(s + 4);
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = c[0]; v[5] = c[1]; v[6] = c[2]; v[7] = c[3];
+    } else if (form == 4) {                               // gather form of the register-weight kernel, k = 5 (deconv3 forward; round 6): kernel [5][5][n = 32][c = 64] ->
+        if (frag >= 144) return;                          // [class (ph, pw)][tap (ta, tb) of 3 x 3][k-step kk (4)][lane (lgrp, n)]: kernel position (ph + 2 (2 - ta), pw + 2 (2 - tb)); taps past the 5 x 5 kernel: zeros
+        const int kk = frag & 3, tap = (frag >> 2) % 9, cls = frag / 36;
+        const int kh = (cls >> 1) + 2 * (2 - tap / 3), kw = (cls & 1) + 2 * (2 - tap % 3);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (kh < 5 && kw < 5) ? src[((long long)((kh * 5 + kw) * 32 + (l & 31))) * 64 + kk * 16 + (l >> 5) * 8 + e] : 0.f;
+    } else if (form == 5) {                               // conv2's kernel for the fused encoder head (enc12_tile.hpp; round 6): HWIO [k = 512][n = 64] -> [tile nt (2)][k-step f (32)][lane]
+        if (frag >= 64) return;
+        const int f = frag & 31, nt = frag >> 5;
+        const int k = f * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 64 + n];
+    } else if (form == 3) {                               // conv form of the register-weight kernel (rwconv_conv_kernel<4, 2>: conv3 forward, deconv2's input gradient; round 6):
+        if (frag >= 256) return;                          // [k = (kh, kw, c = 64)][n = 128] -> [tile nt (4)][k-step (tap 4 x s 16)][lane]: lane (lgrp, n & 31) holds channels 16 (s & 3) + 8 lgrp .. + 7
+        const int kidx = frag & 63, nt = frag >> 6;       // of kernel position kh = 2 (tap >> 1) + (s >> 3), kw = 2 (tap & 1) + ((s >> 2) & 1): the order the kernel's prologue loads its 64 fragments in
+        const int tap = kidx >> 4, st = kidx & 15;
+        const int kh = 2 * (tap >> 1) + (st >> 3), kw = 2 * (tap & 1) + ((st >> 2) & 1);
+        const int k = (kh * 4 + kw) * 64 + (st & 3) * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 128 + n];
     } else {
         const int ks = frag & 63, nt = (frag >> 6) & 3, cls = frag >> 8;
         const int tap = ks >> 4, th = tap >> 1, tw = tap & 1;

@@ -40,6 +40,7 @@ extern "C" int mi_conv2d_enc12_fwd(void* stream, int dtype, const void* frames, 
     q.frames = frames; q.frame_idx = frame_idx; q.frame_stride = (long long)FH * FW * 3;
     q.w1 = (const bf16_t*)w1_t; q.b1 = b1; q.w2 = (const bf16_t*)w2_t; q.b2 = b2;
     q.act1 = (bf16_t*)act1; q.bits1 = (uint32_t*)relu_bits1; q.act2 = (bf16_t*)act2;
+    q.w2f = (const bf16_t*)mi_tl_rc_wfrag; mi_tl_rc_wfrag = nullptr;      // (announced by mi_rwconv_next_weights_fragment_ordered; consumed by this launch)
     q.B = B; q.ntiles = 3 * B;
     int nblocks = enc12_grid(frames_fmt == 2 ? 1 : 0);
     if (nblocks > q.ntiles) nblocks = q.ntiles;

@@ -29,6 +29,7 @@ struct Enc12Params {
     const void* frames; const int* frame_idx; long long frame_stride;   // [*, 80, 160, 3] camera bytes / fp32, elements per frame
     const bf16_t* w1; const float* b1;                    // conv1: K-contiguous [32][48]
     const bf16_t* w2; const float* b2;                    // conv2: K-contiguous [64][512], k = (kh * 4 + kw) * 32 + c
+    const bf16_t* w2f;                                    // optional: conv2's kernel in fragment order (mi_ares_pack_weights form 5): the prologue's 32 loads per wave are then 1 KB contiguous each
     bf16_t* act1; uint32_t* bits1;                        // [B, 39, 79, 32]; ReLU bit words [B * 39 * 79][2] (may be NULL)
     bf16_t* act2;                                         // [B, 18, 38, 64]
     int B, ntiles;                                        // ntiles = 3 B
@@ -77,11 +78,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u16x8 wf1[3], wf2[32];
     {
         const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 32 * 48 * 2, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 64 * 512 * 2, 0x00020000);
+        const bool w2frag = p.w2f != nullptr;               // (wave-uniform: an address select per load, no branch)
+        const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc((void*)(w2frag ? p.w2f : p.w2), 0, 64 * 512 * 2, 0x00020000);
 #pragma unroll
         for (int s = 0; s < 3; ++s) wf1[s] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW1, (lrow * 48 + s * 16 + lgrp * 8) * 2, 0, 0));
 #pragma unroll
-        for (int f = 0; f < 32; ++f) wf2[f] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW2, ((nt * 32 + lrow) * 512 + f * 16 + lgrp * 8) * 2, 0, 0));
+        for (int f = 0; f < 32; ++f)                       // (round 6) p.w2f: conv2's kernel in fragment order (pack form 5), 1 KB contiguous per load instead of 32 rows x 32 B at a 1 KB pitch
+            wf2[f] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW2, w2frag ? ((nt * 32 + f) * 64 + lane) * 16 : ((nt * 32 + lrow) * 512 + f * 16 + lgrp * 8) * 2, 0, 0));
     }
     f32x16 acc1_0, acc2_0;                                // register r of a lane = channel (r & 3) + 8 (r >> 2) + 4 lgrp of the 32-channel tile
 #pragma unroll

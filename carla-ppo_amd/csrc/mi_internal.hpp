@@ -16,6 +16,7 @@ extern thread_local hipEvent_t mi_tl_stop_event;
             hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, ev__, 0, __VA_ARGS__); } \
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
+extern thread_local const void* mi_tl_rc_wfrag;  // rwconv.hip: fragment-ordered weights for the next conv-form register-weight launch of this thread (mi_rwconv_next_weights_fragment_ordered)
 int mi_enc12_debug(int mask);                    // enc12.hip: ablation mask of the fused encoder-head forward kernel (tools/enc12_ablate.py); returns the previous one
 int mi_fail(int code, const char* msg);          // records msg (thread-local) and returns code
 int mi_check_launch(const char* what);           // hipGetLastError() -> MI_OK / MI_ERR_LAUNCH

@@ -143,6 +143,16 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
 
     // ---- weights: fragment (tap, kk) = 8 consecutive input channels (kk*16 + lgrp*8) of output channel lrow, straight from L2, ONCE ----
     freg wf[NT][KS];
+    if (p.bfrag) {                                         // (round 6; k = 5, CK = 1: deconv3 forward) the fragment-ordered copy, 1 KB contiguous per load: [class][tap][kk][lane] (pack form 4)
+        const bf16_t* __restrict__ F = (const bf16_t*)p.bfrag;
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+            const int ta = tap / TAPS, tb = tap % TAPS;
+            if (PH + 2 * (H - ta) >= KH || PW + 2 * (H - tb) >= KH) continue;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) wf[tap][kk] = *(const freg*)(F + ((size_t)((CLS * NT + tap) * KS + kk) * 64 + lane) * 8);
+        }
+    } else
     {
         const bf16_t* __restrict__ W = (const bf16_t*)p.b;
 #pragma unroll
@@ -419,7 +429,7 @@ template <int CK> struct RcWalk {
     }
 };
 
-template <int KH, int CK, bool RELU, bool MASK>
+template <int KH, int CK, bool RELU, bool MASK, bool WFRAG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rwconv_conv_kernel(const TapParams p, const int nchunks) {
     static_assert(CK == 1 || (CK == 2 && KH == 4), "64 -> 128 channels: k = 4 only");
     typedef RcCfg<KH, CK> Cfg;
@@ -490,7 +500,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int k = 0; k < ST.n; ++k) {
             const int tap = ST.id[k] / SPT, s = ST.id[k] % SPT;
             const int kh = 2 * (tap / TAPS) + s / (4 * CK), kw = 2 * (tap % TAPS) + (s / (2 * CK)) % 2;
-            wf[k] = *(const freg*)(wrow + (kh * KH + kw) * (32 * CK) + (s % (2 * CK)) * 16);
+            // WFRAG (round 6): the fragment-ordered copy -- fragment (nt, k) is 1 KB contiguous, lane-linear -- instead of 32 rows x 32 B at a 2 KB pitch per load:
+            // conv3 forward 35.5 -> 30.9 us, deconv2's input gradient 35.6 -> 32.7 us, step -1.5 % (timing build with coalesced but wrong addresses, three interleaved rounds)
+            if constexpr (WFRAG) wf[k] = *(const freg*)((const bf16_t*)p.bfrag + ((size_t)(nt * ST.n + k) * 64 + lane) * 8);
+            else wf[k] = *(const freg*)(wrow + (kh * KH + kw) * (32 * CK) + (s % (2 * CK)) * 16);
         }
     }
     RC_STAMP();
@@ -635,6 +648,8 @@ int mi_rwconv_mode(int set) {                            // set < 0: query
 // returns 1 launched, 0 not eligible, < 0 error.  x [B,IH,IW,64] bf16, w [KH][KW][32][64] bf16, out / mask [B,OH,OW,32] bf16.
 int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                          int KH, int KW, void* out, const float* bias, const void* mask, int relu, const void* mask_bits, void* bits_out) {
+    const void* const wfrag = mi_tl_rc_wfrag;              // fragment-ordered weights announced for this launch (mi_rwconv_next_weights_fragment_ordered; pack form 4: k = 5, 64 -> 32 channels)
+    mi_tl_rc_wfrag = nullptr;
     mi_rwconv_mode(-1);
     static int wide = -1;                                 // MI355_RWCONV_WIDE=0: the 128 -> 64 channel layers stay on tapconv (A/B runs)
     if (wide < 0) { const char* ev = getenv("MI355_RWCONV_WIDE"); wide = (ev && ev[0] == '0') ? 0 : 1; }
@@ -655,6 +670,7 @@ int mi_try_rwconv_gather(hipStream_t st, int dtype, const void* a, const void* w
     q.B = B; q.IH = IH; q.IW = IW; q.C = C; q.OH = OH; q.OW = OW; q.N = N; q.KH = KH; q.KW = KW; q.MP = (int)MP;
     q.KC = C; q.NE = 4 * N;
     q.div_g = make_fastdiv(q.GH); q.div_gw = make_fastdiv(q.GW);
+    q.bfrag = (KH == 5 && ck == 1) ? wfrag : nullptr;
     q.out = out; q.bias = bias; q.mask = mask; q.relu = relu;
     q.mask_bits = mask ? (const uint32_t*)mask_bits : nullptr; q.bits_out = relu ? (uint32_t*)bits_out : nullptr;
     if ((bits_out && !q.bits_out) || ((((uintptr_t)mask_bits) | ((uintptr_t)bits_out)) & 7)) return 0;
@@ -703,6 +719,16 @@ int mi_rwconv_blocks(int set) {                          // mi_set_tuning key 16
     if (set >= 0) g_rwconv_blocks = set;
     return prev;
 }
+// The NEXT register-weight launch issued by this thread reads its weights from `wf`, the same kernel in the fragment order its prologue loads registers in (mi_ares_pack_weights forms
+// 3 / 4 / 5): conv form 64 -> 128 channels k = 4 (mi_conv2d_nhwc_fwd[_bits] = conv3 forward, mi_deconv2d_nhwc_dgrad[_bits] = deconv2's input gradient; form 3), gather form
+// 64 -> 32 channels k = 5 (mi_deconv2d_nhwc_fwd[_bits] = deconv3 forward; form 4), the fused encoder head (mi_conv2d_enc12_fwd: conv2's kernel, form 5).  Consumed by that call
+// whether or not such a kernel takes the layer; NULL clears.  The VAE engine sets it in front of those four launches (round 6).
+thread_local const void* mi_tl_rc_wfrag = nullptr;
+extern "C" int mi_rwconv_next_weights_fragment_ordered(const void* wf) {
+    if (((uintptr_t)wf) & 15) return mi_fail(MI_ERR_ARG, "mi_rwconv_next_weights_fragment_ordered: the copy must be 16-byte aligned");
+    mi_tl_rc_wfrag = wf;
+    return MI_OK;
+}
 int g_rwconv_conv = -1;                                  // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 k = 5 only, 2 also k = 4, 3 also the 64 -> 128 channel shape (default)
 int mi_rwconv_conv_mode(int set) {                       // set < 0: query
     if (g_rwconv_conv < 0) { const char* e = getenv("MI355_RWCONV_CONV"); g_rwconv_conv = e ? atoi(e) : 3; if (g_rwconv_conv < 0 || g_rwconv_conv > 3) g_rwconv_conv = 3; }
@@ -716,6 +742,8 @@ int mi_rwconv_conv_mode(int set) {                       // set < 0: query
 // mi_set_tuning key 15 / MI355_RWCONV_CONV: 0 off, 1 the k = 5 layer, 2 also 32 -> 64 channels k = 4, 3 also 64 -> 128 channels (default).
 int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, int B, int IH, int IW, int C, int OH, int OW, int N,
                        int KH, int KW, int ldb, void* out, const float* bias, const void* mask, int relu) {
+    const void* const wfrag = mi_tl_rc_wfrag;              // (consumed by THIS call whatever it dispatches to)
+    mi_tl_rc_wfrag = nullptr;
     const int on = mi_rwconv_conv_mode(-1);
     mi_rwconv_mode(-1);
     const int ck = (C == 64 && N == 128) ? 2 : 1;
@@ -749,7 +777,14 @@ int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, 
         else if (relu) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, true, false>), g, t, 0, st, q, nchunks); \
         else if (mask) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, true>), g, t, 0, st, q, nchunks); \
         else MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, false>), g, t, 0, st, q, nchunks); } while (0)
-    if (KH == 5) RC_LAUNCH(5, 1); else if (ck == 1) RC_LAUNCH(4, 1); else RC_LAUNCH(4, 2);
+    if (KH == 5) RC_LAUNCH(5, 1); else if (ck == 1) RC_LAUNCH(4, 1);
+    else if (wfrag) {                                      // 64 -> 128 channels with the caller's fragment-ordered weight copy (mi_rwconv_next_weights_fragment_ordered)
+        q.bfrag = wfrag;
+        if (relu && mask) MI_LAUNCH((rwconv_conv_kernel<4, 2, true, true, true>), g, t, 0, st, q, nchunks);
+        else if (relu) MI_LAUNCH((rwconv_conv_kernel<4, 2, true, false, true>), g, t, 0, st, q, nchunks);
+        else if (mask) MI_LAUNCH((rwconv_conv_kernel<4, 2, false, true, true>), g, t, 0, st, q, nchunks);
+        else MI_LAUNCH((rwconv_conv_kernel<4, 2, false, false, true>), g, t, 0, st, q, nchunks);
+    } else RC_LAUNCH(4, 2);
 #undef RC_LAUNCH
     const int rc = mi_check_launch("rwconv_conv_kernel");
     return rc == MI_OK ? 1 : rc;

@@ -36,6 +36,7 @@ struct TapParams {
     int GH, GW, TH, TW, HY, HX;      // slot grid per image, taps, gather-form halos
     int KC, NE, MP;                  // channels per slot (4C | C), effective outputs (N | 4N), B*GH*GW
     int ldb;                         // conv form: row pitch (elements) of the K-contiguous weight copy [N][KH*KW*C]
+    const void* bfrag;               // rwconv_conv_kernel<4, 2, .., WFRAG>: the same weights in the kernel's own fragment order (mi_ares_pack_weights8 form 3), 1 KB contiguous per wave load
     FastDiv div_g, div_gw, div_n, div_2c, div_c;
     void* out; const float* bias; const void* mask; int relu;
     const uint32_t* mask_bits; uint32_t* bits_out;    // rwconv.hip only: ReLU bit words read instead of `mask` / written next to `out` (mi355_carla.h)

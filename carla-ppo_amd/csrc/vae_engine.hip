@@ -76,7 +76,7 @@ struct Workspace {
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64)
-    long long wfrag[6];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
+    long long wfrag[10];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
                               // gradient, deconv1 forward, deconv1 input gradient (1 MB each), conv3 input gradient, deconv2 forward (256 KB each); rewritten behind every optimiser step with the K-contiguous copies
     long long total;
     // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
@@ -225,7 +225,7 @@ void make_workspace(VaeEngine& e) {
         W.roll = add(W.roll_bytes);
     }
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256);
-    for (int i = 0; i < 6; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());
+    for (int i = 0; i < 10; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());     // (round 6 -- 6, 7: the conv-form copies of conv3 / deconv2 for the register-weight kernel, 256 KB used; 8: deconv3 for its gather form, 144 KB; 9: conv2 for the fused encoder head, 64 KB)
     W.total = o;
 }
 
@@ -277,6 +277,18 @@ unsigned ready_event_flags() {                         // MI355_KEVENT=2: the ha
     return f;
 }
 
+bool rc_wfrag_enabled() {                              // MI355_RC_WFRAG=0: the conv-form register-weight kernels of the mid layers read the K-contiguous weight copy (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* ev = getenv("MI355_RC_WFRAG"); on = (ev && ev[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+
+// conv2 is 32 -> 64 channels k = 4 and deconv3 64 -> 32 channels k = 5 (the reference's geometry): their fragment-ordered copies (pack forms 5 / 4) exist next to the activation-resident ones
+bool rc_small_frag_ok(const VaeEngine* e) {
+    const Geom& g = e->g;
+    return g.c[1] == 32 && g.c[2] == 64 && g.dc[2] == 64 && g.dc[3] == 32 && DEC_K[2] == 5;
+}
+
 bool relu_bits_enabled() {                             // MI355_RELU_BITS=0: the input gradients read the activation tensors as ReluGrad masks (A/B runs)
     static int on = -1;
     if (on < 0) { const char* ev = getenv("MI355_RELU_BITS"); on = (ev && ev[0] == '0') ? 0 : 1; }
@@ -295,6 +307,8 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
             // (per-op timing keeps the two layer launches: they are what the profile names)
             const bool bits12 = want_bits && relu_bits_enabled();
             int launched = 0;
+            if (e->ares_ok && rc_small_frag_ok(e) && rc_wfrag_enabled()) mi_tl_rc_wfrag = e->at(e->W.wfrag[9]);      // conv2's kernel in fragment order (consumed by the launch below)
+            struct WfragGuard0 { ~WfragGuard0() { mi_tl_rc_wfrag = nullptr; } } wfrag_guard0;
             TOP(e, st, OP_CONV_FWD + 1, mi_conv2d_enc12_fwd(st, d.dtype, frames, frames_u8 ? 2 : 1, idx, B, g.ih[0], g.iw[0], e->wtptr(0), e->bptr(1), e->wtptr(2), e->bptr(3),
                                                          e->at(e->W.act[1]), bits12 ? e->at(e->W.bits_act1) : nullptr, e->at(e->W.act[2]), &launched));
             if (launched) { if (bits12) e->bits1_ok = 1; i = 1; continue; }
@@ -306,6 +320,9 @@ int run_encoder(VaeEngine* e, void* st, const void* frames, int frames_u8, const
             TOP(e, st, OP_CONV_FWD + i, mi_ares_conv(st, d.dtype, 0, x, B, e->at(e->W.wfrag[0]), e->bptr(7), 1, nullptr, e->at(e->W.act[4]), &launched));
             if (launched) continue;
         }
+        // conv3 (64 -> 128 channels, k = 4): the register-weight kernel loads its weights from their fragment-ordered copy (round 6; MI355_RC_WFRAG=0: from the K-contiguous one)
+        if (i == 2 && e->ares_ok && e->ares_mid && rc_wfrag_enabled()) mi_tl_rc_wfrag = e->at(e->W.wfrag[6]);
+        struct WfragGuard { ~WfragGuard() { mi_tl_rc_wfrag = nullptr; } } wfrag_guard;
         TOP(e, st, OP_CONV_FWD + i, mi_conv2d_nhwc_fwd_bits(st, d.dtype, x, i == 0 ? idx : nullptr, i == 0 ? (frames_u8 ? 2 : 1) : 0, B, g.ih[i], g.iw[i], g.c[i],
                               e->wtptr(2 * i), 1, e->bptr(2 * i + 1), 4, 4, g.c[i + 1], 1, e->at(e->W.act[i + 1]), bits ? e->at(e->W.bits_act1) : nullptr, bits ? &e->bits1_ok : nullptr));
     }
@@ -338,6 +355,8 @@ int run_decoder(VaeEngine* e, void* st, int B, int last = 4, int want_bits = 0) 
             TOP(e, st, OP_DECONV_FWD + i, mi_ares_conv(st, d.dtype, 2, e->at(e->W.dec[1]), B, e->at(e->W.wfrag[5]), e->bptr(15), 1, nullptr, e->at(e->W.dec[2]), &launched));
             if (launched) continue;
         }
+        if (i == 2 && e->ares_ok && rc_small_frag_ok(e) && rc_wfrag_enabled()) mi_tl_rc_wfrag = e->at(e->W.wfrag[8]);      // deconv3: its kernel in the gather form's fragment order (round 6)
+        struct WfragGuard3 { ~WfragGuard3() { mi_tl_rc_wfrag = nullptr; } } wfrag_guard3;
         TOP(e, st, OP_DECONV_FWD + i, mi_deconv2d_nhwc_fwd_bits(st, d.dtype, e->at(e->W.dec[i]), B, g.dh[i], g.dw[i], g.dc[i], e->wptr(12 + 2 * i), e->bptr(13 + 2 * i),
                                 DEC_K[i], DEC_K[i], g.dc[i + 1], i < 3 ? 1 : 0, e->at(e->W.dec[i + 1]), bits ? e->at(e->W.bits_dec3) : nullptr, bits ? &e->bits3_ok : nullptr));
     }
@@ -378,8 +397,13 @@ int refresh_transposed(VaeEngine* e, void* st, bool have_wt = false, bool have_f
         // conv4's kernel: HWIO [4][4][128][256]; deconv1's kernel: [kh][kw][out = 128][in = 256] -- the same [16][128][256] shape, read either way (ares.hip)
         // wfrag: 0 conv4 forward, 1 conv4 input gradient, 2 deconv1 forward, 3 deconv1 input gradient -- one launch
         if (!have_frag)
-            CK(mi_ares_pack_weights6(st, e->params + e->L.off[6], e->params + e->L.off[12], mid ? e->params + e->L.off[4] : nullptr, mid ? e->params + e->L.off[14] : nullptr,
-                                     e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3]), mid ? e->at(e->W.wfrag[4]) : nullptr, mid ? e->at(e->W.wfrag[5]) : nullptr));
+            CK(mi_ares_pack_weights8(st, e->params + e->L.off[6], e->params + e->L.off[12], mid ? e->params + e->L.off[4] : nullptr, mid ? e->params + e->L.off[14] : nullptr,
+                                     e->at(e->W.wfrag[0]), e->at(e->W.wfrag[1]), e->at(e->W.wfrag[2]), e->at(e->W.wfrag[3]), mid ? e->at(e->W.wfrag[4]) : nullptr, mid ? e->at(e->W.wfrag[5]) : nullptr,
+                                     mid ? e->at(e->W.wfrag[6]) : nullptr, mid ? e->at(e->W.wfrag[7]) : nullptr));
+        if (!have_frag && rc_small_frag_ok(e)) {           // (round 6) deconv3's kernel for the gather-form register-weight kernel, conv2's for the fused encoder head
+            CK(mi_ares_pack_weights(st, 4, e->params + e->L.off[16], e->at(e->W.wfrag[8])));
+            CK(mi_ares_pack_weights(st, 5, e->params + e->L.off[2], e->at(e->W.wfrag[9])));
+        }
         e->ares_mid = mid ? 1 : 0;
         e->ares_ok = 1;
     }
@@ -491,7 +515,7 @@ void* mi_vae_buffer(void* h, int which) {
         case 3: return e->at(e->W.kl_row);
         case 4: return e->at(e->W.dec[4]);
         case 5: return e->at(e->W.z);
-        case 6: case 7: case 8: case 9: case 10: case 11: return e->ares_ok ? e->at(e->W.wfrag[which - 6]) : nullptr;      // the fragment-ordered weight copies (tests)
+        case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: return e->ares_ok ? e->at(e->W.wfrag[which - 6]) : nullptr;      // the fragment-ordered weight copies (tests)
         default: return nullptr;
     }
 }
@@ -632,6 +656,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     const int kev = kev_env;
     bool produced = fork && kev && e->fwd_produced && (part == 0 || part == 1);      // ev_ready already rides on the last kernel issued on st
     e->fwd_produced = 0;
+    bool mid_flush_pending = false;
     auto release = [&]() {                                                     // "everything issued on st so far is an input of the next sw op"
         if (fork) { if (!produced) hipEventRecord(e->ev_ready, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_ready, 0); }
         produced = false;
@@ -723,6 +748,8 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
                 if (launched) continue;
             }
             if (i > 0) arm();                                // its output is the next layer's filter-gradient operand
+            if (i == 1 && e->ares_ok && e->ares_mid && rc_wfrag_enabled()) mi_tl_rc_wfrag = e->at(W.wfrag[7]);      // deconv2's input gradient: conv form, fragment-ordered weights
+            struct WfragGuard2 { ~WfragGuard2() { mi_tl_rc_wfrag = nullptr; } } wfrag_guard2;
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
             if (i > 0) armed_ok();
@@ -735,7 +762,12 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             // shrinks from six layers to three.  MI355_MID_FLUSH=0: one reduce at the end (A/B runs).
             static int mid_flush = -1;
             if (mid_flush < 0) { const char* ev = getenv("MI355_MID_FLUSH"); mid_flush = (ev && ev[0] == '0') ? 0 : 1; }
-            if (defer && part == 0 && mid_flush) CK(mi_tapwgrad_flush(sw));
+            // MI355_MID_FLUSH_LATE=1 (round 6 A/B): the same launch on the same queue behind the same kernel, but SUBMITTED behind the latent chain's launches (dense1.dgrad,
+            // reparam.bwd, heads.dgrad) -- on boxes whose dispatcher serves the older submission first the chain's 128-block kernels otherwise queue behind the reduce's 1,864 blocks
+            static int mid_late = -1;
+            if (mid_late < 0) { const char* ev = getenv("MI355_MID_FLUSH_LATE"); mid_late = (ev && ev[0] == '1') ? 1 : 0; }
+            mid_flush_pending = defer && part == 0 && mid_flush && mid_late;
+            if (defer && part == 0 && mid_flush && !mid_late) CK(mi_tapwgrad_flush(sw));
         }
         if (e->tail_nblk > 0 && !late_dense) {               // deconv4's filter gradient: the fused tail's per-block sums -> the gradient buffer
             CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18)));      // (full two-stream backward: at the tail of the caller's stream, below)
@@ -766,6 +798,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         if (!use_third) arm();                               // gact4: conv4's filter-gradient operand
         TOP(e, st, OP_HEADS_DGRAD, mi_gemm_bias_act(st, d.dtype, e->at(W.dheads), B, 2 * d.z_dim, e->wptr(8), 1, g.flat, nullptr, 0, e->at(W.act[4]), e->at(W.gact[4]), 0, 1));
         if (!use_third) armed_ok();
+        if (mid_flush_pending) { mid_flush_pending = false; CK(mi_tapwgrad_flush(sw)); }
         if (use_third) {
             // everything the latent layers' gradients read exists from here on (gdec0, z, dheads, act4; the tail's slabs and loss partials since the forward pass): they run on
             // their own stream under the encoder half instead of serialising ~70 us of small launches at the end of the caller's stream
@@ -910,6 +943,8 @@ static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alph
             fp[2 * 3] = e->at(e->W.wfrag[0]); ff[2 * 3] = 0; fp[2 * 3 + 1] = e->at(e->W.wfrag[1]); ff[2 * 3 + 1] = 1;      // conv4: forward (conv form), input gradient (gather form)
             fp[2 * 6] = e->at(e->W.wfrag[2]); ff[2 * 6] = 1; fp[2 * 6 + 1] = e->at(e->W.wfrag[3]); ff[2 * 6 + 1] = 0;      // deconv1: forward (gather form), input gradient (conv form)
             if (mid) { fp[2 * 2] = e->at(e->W.wfrag[4]); ff[2 * 2] = 2; fp[2 * 7] = e->at(e->W.wfrag[5]); ff[2 * 7] = 2; }  // conv3 input gradient, deconv2 forward
+            if (mid) { fp[2 * 2 + 1] = e->at(e->W.wfrag[6]); ff[2 * 2 + 1] = 3; fp[2 * 7 + 1] = e->at(e->W.wfrag[7]); ff[2 * 7 + 1] = 3; }      // (round 6) conv3 forward, deconv2 input gradient: conv form of the register-weight kernel
+            if (rc_small_frag_ok(e)) { fp[2 * 8] = e->at(e->W.wfrag[8]); ff[2 * 8] = 4; fp[2 * 1] = e->at(e->W.wfrag[9]); ff[2 * 1] = 5; }      // (round 6) deconv3 forward (gather form), conv2 inside the fused encoder head
         }
         TOP(e, stream, OP_ADAM, mi_adam_tf_layouts_frag(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, nullptr, n, alpha, alpha_dev, beta1, beta2, epsilon,
                                                         e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 1, frag ? fp : nullptr, frag ? ff : nullptr));

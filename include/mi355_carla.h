@@ -185,6 +185,17 @@ int mi_ares_pack_weights4(void* stream, const float* conv4_w, const float* decon
  * gradient): w is [4][4][64][128] read as [kh][kw][n][c] (deconv2's [kh,kw,out,in] kernel, or conv3's HWIO kernel); its fragment copy is 256 KB.
  * mi_ares_pack_weights6 = mi_ares_pack_weights4 + those two copies (conv3_w -> wf4, deconv2_w -> wf5; either pair may be NULL) in one launch. */
 int mi_ares_pack_weights6(void* stream, const float* conv4_w, const float* deconv1_w, const float* conv3_w, const float* deconv2_w, void* wf0, void* wf1, void* wf2, void* wf3, void* wf4, void* wf5);
+/* round 6: ... plus the conv-form copies of the same two mid-layer kernels for the register-weight kernel (form 3: the order rwconv_conv_kernel<4, 2> loads its 64 weight fragments in, 256 KB
+ * each): conv3_w -> wf6 (conv3 forward, vae/models.py:252), deconv2_w -> wf7 (deconv2's input gradient, Conv2D of dy behind :262).  NULL pairs are skipped. */
+int mi_ares_pack_weights8(void* stream, const float* conv4_w, const float* deconv1_w, const float* conv3_w, const float* deconv2_w, void* wf0, void* wf1, void* wf2, void* wf3, void* wf4, void* wf5, void* wf6, void* wf7);
+/* The NEXT register-weight launch of the calling thread reads its weights from `wf` instead of the K-contiguous copy: 1 KB contiguous per wave load in the kernel's prologue
+ * (the K-contiguous copy gives 16 B per lane at a 1-2 KB lane stride).  Which form `wf` must hold follows from the call:
+ *   form 3 (above)  mi_conv2d_nhwc_fwd[_bits] of a 64 -> 128 channel k = 4 layer (conv3), mi_deconv2d_nhwc_dgrad[_bits] of a 128 -> 64 channel one (deconv2)
+ *   form 4          mi_deconv2d_nhwc_fwd of the k = 5, 64 -> 32 channel layer (deconv3, vae/models.py:263): mi_ares_pack_weights(form 4) of its [5][5][32][64] kernel,
+ *                   144 fragments of 1 KB ordered (output-parity class, tap of the 3 x 3 class window, 16-channel K step); fragments of taps outside the 5 x 5 kernel are never read
+ *   form 5          mi_conv2d_enc12_fwd: conv2's [4][4][32][64] HWIO kernel (vae/models.py:251), mi_ares_pack_weights(form 5), 64 fragments (32-wide output half, K step)
+ * Consumed by that call whether or not the kernel it picks uses it; NULL clears.  Same values in the same registers: results are bit-identical either way. */
+int mi_rwconv_next_weights_fragment_ordered(const void* wf);
 int mi_ares_conv(void* stream, int dtype, int form, const void* x, int B, const void* wf, const float* bias, int relu, const void* mask, void* out, int* launched);
 /* backward of conv2d_transpose wrt its input (= a plain s2 conv of dy) with fused ReluGrad mask */
 int mi_deconv2d_nhwc_dgrad(void* stream, int dtype, const void* dy, int B, int OH, int OW, int Cout, const void* w, int w_transposed, int KH, int KW, int Cin, const void* mask, void* dx);
@@ -245,7 +256,7 @@ int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float
  * copy, bit 1 = do not write its K-contiguous copy (copies that nobody reads).  Bit-identical p / m / v to mi_adam_tf_flat. */
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
 /* same + FRAGMENT-ORDERED bf16 copies of some kernels for the activation-resident convolutions (round 5): frag_ptrs[2 i + q] / frag_forms[2 i + q], q = 0, 1, for kernel i -- what
- * mi_ares_pack_weights(form, master kernel) writes (form 0 | 1: a [2048, 256] kernel, 2: a [1024, 128] kernel), emitted by the optimiser launch from the tile it holds anyway;
+ * mi_ares_pack_weights(form, master kernel) writes (form 0 | 1: a [2048, 256] kernel, 2 | 3: a [1024, 128] kernel, 4: deconv3's [800, 64], 5: conv2's [512, 64]), emitted by the optimiser launch from the tile it holds anyway;
  * NULL pointer = none.  Both arrays may be NULL (= mi_adam_tf_layouts). */
 int mi_adam_tf_layouts_frag(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad, void* const* frag_ptrs, const int* frag_forms);
 /* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch (the feed_dict slice of vae/models.py:211-216) gathered and

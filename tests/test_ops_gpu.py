@@ -1336,3 +1336,130 @@ def test_decoder_tail_fifth_slot_group_shared_by_three_waves(B, IH, IW):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert abs(res[1][2] / res[0][2] - 1) < 2e-6
     assert_close(res[1][3], res[0][3], 1e-5, 1e-5 * float(np.abs(res[0][3]).max()) + 1e-7, "bias gradient sums")
+
+
+@pytest.mark.parametrize("B", [3, 40])
+@pytest.mark.parametrize("which", ["conv3.fwd", "deconv2.dgrad"])
+def test_register_weight_conv_reads_fragment_ordered_weights(which, B):
+    """Round 6 (rwconv.hip, WFRAG): rwconv_conv_kernel<4, 2> (64 -> 128 channels, k = 4: conv3's forward pass, deconv2's input gradient) loads its 64 weight fragments per wave ONCE per
+    block; from the K-contiguous copy every load touches 32 rows x 32 B at a 2 KB pitch, from the fragment-ordered copy (mi_ares_pack_weights8 form 3; the optimiser launch emits it)
+    1 KB contiguous.  Same values in the same registers: the output is BITWISE that of the K-contiguous form, with ReLU + bias (forward) and with a ReluGrad mask (input gradient)."""
+    L = milib.get()
+    code, td = DT["bf16"]
+    rng = np.random.RandomState(B + len(which))
+    prev = {k: L.mi_set_tuning(k, v) for k, v in ((13, 2), (15, 3))}          # the register-weight kernels whenever eligible (auto takes them only on chip-filling grids)
+    try:
+        if which == "conv3.fwd":
+            IH, IW, Ci, Co, k = 18, 38, 64, 128, 4
+            OH, OW = 8, 18
+            x = np.maximum(rng.randn(B, IH, IW, Ci), 0).astype(np.float32)
+            w = (rng.randn(k, k, Ci, Co) / np.sqrt(k * k * Ci)).astype(np.float32)           # HWIO = [K = 1024][N = 128]
+            b = (0.1 * rng.randn(Co)).astype(np.float32)
+            xd, bd, wmaster = dev(x, td), dev(b), dev(w)
+            wt = alloc(td, k * k * Ci * Co, fill=0.0)
+            offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Ci], np.int32), np.array([Co], np.int32)
+            L.mi_transpose_weights(stream(), code, wmaster.data_ptr(), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+            outs = []
+            for frag in (False, True):
+                out = alloc(td, B, OH, OW, Co, fill=3.0)
+                if frag:
+                    L.mi_rwconv_next_weights_fragment_ordered(wfrag.data_ptr())
+                L.mi_conv2d_nhwc_fwd(stream(), code, xd.data_ptr(), None, 0, B, IH, IW, Ci, wt.data_ptr(), 1, bd.data_ptr(), k, k, Co, 1, out.data_ptr())
+                torch.cuda.synchronize()
+                outs.append(out.view(torch.int16).clone())
+                if not frag:
+                    wfrag = torch.zeros(1 << 20, device="cuda", dtype=torch.uint8)
+                    junk = [torch.zeros(1 << 20, device="cuda", dtype=torch.uint8) for _ in range(4)]
+                    big = dev(np.zeros((4, 4, 128, 256), np.float32))
+                    L.mi_ares_pack_weights8(stream(), big.data_ptr(), big.data_ptr(), wmaster.data_ptr(), None, junk[0].data_ptr(), junk[1].data_ptr(), junk[2].data_ptr(), junk[3].data_ptr(),
+                                            None, None, wfrag.data_ptr(), None)
+        else:
+            IH, IW, Ci, Co, k = 8, 18, 128, 64, 4                                              # deconv2: x [B, 8, 18, 128] -> y [B, 18, 38, 64]; its input gradient is a k4 s2 conv of dy
+            OH, OW = 18, 38
+            dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+            xmask = rng.randn(B, IH, IW, Ci).astype(np.float32)
+            w = (rng.randn(k, k, Co, Ci) / np.sqrt(k * k * Co)).astype(np.float32)           # [kh, kw, out = 64, in = 128] = [K = 1024][N = 128]
+            dyd, md, wmaster = dev(dy, td), dev(xmask, td), dev(w)
+            wt = alloc(td, k * k * Co * Ci, fill=0.0)
+            offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
+            L.mi_transpose_weights(stream(), code, wmaster.data_ptr(), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+            outs = []
+            for frag in (False, True):
+                dx = alloc(td, B, IH, IW, Ci, fill=3.0)
+                if frag:
+                    L.mi_rwconv_next_weights_fragment_ordered(wfrag.data_ptr())
+                L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, md.data_ptr(), dx.data_ptr())
+                torch.cuda.synchronize()
+                outs.append(dx.view(torch.int16).clone())
+                if not frag:
+                    wfrag = torch.zeros(1 << 20, device="cuda", dtype=torch.uint8)
+                    junk = [torch.zeros(1 << 20, device="cuda", dtype=torch.uint8) for _ in range(4)]
+                    big = dev(np.zeros((4, 4, 128, 256), np.float32))
+                    L.mi_ares_pack_weights8(stream(), big.data_ptr(), big.data_ptr(), None, wmaster.data_ptr(), junk[0].data_ptr(), junk[1].data_ptr(), junk[2].data_ptr(), junk[3].data_ptr(),
+                                            None, None, None, wfrag.data_ptr())
+        assert torch.equal(outs[0], outs[1])
+        assert float(outs[0].float().abs().max()) > 0 and not bool((outs[0] == outs[0].flatten()[0]).all())      # (something was computed)
+        L.mi_rwconv_next_weights_fragment_ordered(None)
+    finally:
+        for k_, v in prev.items():
+            L.mi_set_tuning(k_, v)
+
+
+@pytest.mark.parametrize("B", [2, 24])
+def test_deconv3_forward_and_fused_encoder_head_read_fragment_ordered_weights(B):
+    """Round 6: the gather-form register-weight kernel of deconv3's forward pass (k = 5, 64 -> 32 channels; pack form 4) and the fused encoder head's conv2 stage (pack form 5) load their
+    weight registers from fragment-ordered copies when one is announced (mi_rwconv_next_weights_fragment_ordered): 1 KB contiguous per wave load in the prologue.  Same values in the
+    same registers: outputs BITWISE equal to the K-contiguous / TF-layout forms."""
+    import ctypes
+    L = milib.get()
+    code, td = DT["bf16"]
+    rng = np.random.RandomState(B)
+    prev = L.mi_set_tuning(13, 2)                          # the gather-form register-weight kernel whenever eligible
+    try:
+        # ---- deconv3 forward: x [B, 18, 38, 64] -> y [B, 39, 79, 32], kernel [5, 5, 32, 64] ----
+        IH, IW, Ci, Co, k = 18, 38, 64, 32, 5
+        OH, OW = 39, 79
+        x = np.maximum(rng.randn(B, IH, IW, Ci), 0).astype(np.float32)
+        w = (rng.randn(k, k, Co, Ci) / np.sqrt(k * k * Ci / 4)).astype(np.float32)
+        b = (0.1 * rng.randn(Co)).astype(np.float32)
+        xd, wd, wmaster, bd = dev(x, td), dev(w, td), dev(w), dev(b)
+        wfrag = torch.zeros(1 << 20, device="cuda", dtype=torch.uint8)
+        L.mi_ares_pack_weights(stream(), 4, wmaster.data_ptr(), wfrag.data_ptr())
+        outs = []
+        for frag in (False, True):
+            out = alloc(td, B, OH, OW, Co, fill=3.0)
+            if frag:
+                L.mi_rwconv_next_weights_fragment_ordered(wfrag.data_ptr())
+            L.mi_deconv2d_nhwc_fwd(stream(), code, xd.data_ptr(), B, IH, IW, Ci, wd.data_ptr(), bd.data_ptr(), k, k, Co, 1, out.data_ptr())
+            torch.cuda.synchronize()
+            outs.append(out.view(torch.int16).clone())
+        assert torch.equal(outs[0], outs[1]) and float(outs[0].float().abs().max()) > 0
+        L.mi_rwconv_next_weights_fragment_ordered(None)
+    finally:
+        L.mi_set_tuning(13, prev)
+    # ---- the fused encoder head: conv2's kernel [4, 4, 32, 64] in fragment order ----
+    frames = torch.from_numpy(rng.randint(0, 256, (B + 3, 80, 160, 3)).astype(np.uint8)).cuda()
+    idx = torch.from_numpy(rng.permutation(B + 3)[:B].astype(np.int32)).cuda()
+    w1 = (rng.randn(4, 4, 3, 32) / 7).astype(np.float32); w2 = (rng.randn(4, 4, 32, 64) / 22).astype(np.float32)
+    b1d, b2d = dev((0.1 * rng.randn(32)).astype(np.float32)), dev((0.1 * rng.randn(64)).astype(np.float32))
+    w1t, w2t = alloc(td, 32 * 48, fill=0.0), alloc(td, 64 * 512, fill=0.0)
+    for wm, wt_, K_, N_ in ((w1, w1t, 48, 32), (w2, w2t, 512, 64)):
+        offs, Ks, Ns = np.array([0], np.int64), np.array([K_], np.int32), np.array([N_], np.int32)
+        L.mi_transpose_weights(stream(), code, P(dev(wm)), wt_.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+    w2master = dev(w2)
+    w2frag = torch.zeros(1 << 17, device="cuda", dtype=torch.uint8)
+    L.mi_ares_pack_weights(stream(), 5, w2master.data_ptr(), w2frag.data_ptr())
+    res = []
+    for frag in (False, True):
+        act1 = alloc(td, B, 39, 79, 32, fill=0.0); bits = torch.zeros(B * 39 * 79 * 2, device="cuda", dtype=torch.int32); act2 = alloc(td, B, 18, 38, 64, fill=0.0)
+        launched = ctypes.c_int(0)
+        if frag:
+            L.mi_rwconv_next_weights_fragment_ordered(w2frag.data_ptr())
+        L.mi_conv2d_enc12_fwd(stream(), code, frames.data_ptr(), 2, idx.data_ptr(), B, 80, 160, w1t.data_ptr(), b1d.data_ptr(), w2t.data_ptr(), b2d.data_ptr(),
+                              act1.data_ptr(), bits.data_ptr(), act2.data_ptr(), ctypes.addressof(launched))
+        torch.cuda.synchronize()
+        assert launched.value == 1
+        res.append((act1.view(torch.int16).clone(), bits.clone(), act2.view(torch.int16).clone()))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    assert float(res[0][2].float().abs().max()) > 0
