@@ -31,7 +31,7 @@ long long mi_ares_weight_bytes(void) { return 16ll * 128 * 256 * 2; }
 int mi_ares_pack_weights(void* stream, int form, const float* w_fp32, void* wf_out) {
     // round 6: forms 3 ([1024][128] mid-layer kernel, conv form of the register-weight kernel), 4 (deconv3's [5][5][32][64] kernel, gather form of the register-weight kernel: 144 KB),
     // 5 (conv2's [512][64] kernel for the fused encoder head: 64 KB) -- the orders those kernels' prologues load their weight registers in
-    if (!w_fp32 || !wf_out || form < 0 || form > 5) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
+    if (!w_fp32 || !wf_out || form < 0 || form > 6) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: bad arguments");
     if ((((uintptr_t)w_fp32) | ((uintptr_t)wf_out)) & 15) return mi_fail(MI_ERR_ARG, "mi_ares_pack_weights: buffers must be 16-byte aligned");
     AresPackJobs j = {};
     j.src[0] = w_fp32; j.dst[0] = (bf16_t*)wf_out; j.form[0] = form; j.n = 1;

@@ -455,6 +455,19 @@ __global__ __launch_bounds__(256) void ares_pack_kernel(const AresPackJobs jobs)
         const int k = f * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 64 + n];
+    } else if (form == 6) {                               // conv form of the register-weight kernel, k = 5, 32 -> 64 channels (rwconv_conv_kernel<5, 1>: deconv3's input gradient; round 6): deconv3's
+        if (frag >= 100) return;                          // [k = (kh, kw, c = 32)][n = 64] kernel -> [tile nt (2)][live k-step (50)][lane]; the 50 live (tap, s) pairs in the prologue's issue order:
+        const int nt = frag / 50;                         // tap (ta, tb) of 3 x 3, s = 4 ph + 2 pw + kk with kh = 2 ta + ph < 5, kw = 2 tb + pw < 5
+        int r = frag - nt * 50;
+        const int ta = r < 20 ? 0 : r < 40 ? 1 : 2; r -= ta < 2 ? 20 * ta : 40;
+        const int nph = ta < 2 ? 2 : 1;
+        const int tb = r < nph * 4 ? 0 : r < nph * 8 ? 1 : 2; r -= tb * nph * 4;
+        const int npw = tb < 2 ? 2 : 1;
+        const int ph = r / (npw * 2); r -= ph * npw * 2;
+        const int pw = r >> 1, kk = r & 1;
+        const int k = ((2 * ta + ph) * 5 + 2 * tb + pw) * 32 + kk * 16 + (l >> 5) * 8, n = nt * 32 + (l & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)(k + e) * 64 + n];
     } else if (form == 3) {                               // conv form of the register-weight kernel (rwconv_conv_kernel<4, 2>: conv3 forward, deconv2's input gradient; round 6):
         if (frag >= 256) return;                          // [k = (kh, kw, c = 64)][n = 128] -> [tile nt (4)][k-step (tap 4 x s 16)][lane]: lane (lgrp, n & 31) holds channels 16 (s & 3) + 8 lgrp .. + 7
         const int kidx = frag & 63, nt = frag >> 6;       // of kernel position kh = 2 (tap >> 1) + (s >> 3), kw = 2 (tap & 1) + ((s >> 2) & 1): the order the kernel's prologue loads its 64 fragments in

@@ -465,6 +465,17 @@ __global__ __launch_bounds__(256) void adam_tf_layouts_kernel(float* __restrict_
                 const int gi = tid + 256 * it;
                 u16x8 o;
                 long long G;
+                if (form == 6) {                           // (round 6) deconv3's [800][64] kernel for its input gradient (conv form, k = 5): 8 consecutive k = channels of one kernel position, column n
+                    const int nl = gi & 63, kl = (gi >> 6) << 3;
+                    const int n = n0 + nl, k = k0 + kl;
+                    if (k >= K) continue;                  // (K = 800: the last tile is 32 rows)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = tile[(kl + e) * PITCH + nl];
+                    const int kq = k >> 5, kh = kq / 5, kw = kq - kh * 5, c = k & 31;
+                    const int ta = kh >> 1, tb = kw >> 1, nph = ta < 2 ? 2 : 1, npw = tb < 2 ? 2 : 1;
+                    const int ord = (ta < 2 ? 20 * ta : 40) + tb * nph * 4 + (kh & 1) * npw * 2 + (kw & 1) * 2 + (c >> 4);       // ares_pack_kernel form 6, inverted
+                    G = ((long long)((n >> 5) * 50 + ord)) * 64 + ((c >> 3) & 1) * 32 + (n & 31);
+                } else
                 if (form == 5) {                           // (round 6) conv2's [512][64] kernel for the fused encoder head: 8 consecutive k of one column n
                     const int nl = gi & 63, kl = (gi >> 6) << 3;
                     const int n = n0 + nl, k = k0 + kl;
@@ -947,7 +958,7 @@ int mi_adam_tf_layouts_frag(void* stream, int dtype, float* param, float* m, flo
             jb.frag[i][q] = nullptr; jb.fform[i][q] = -1;
             if (!frag_ptrs || !frag_forms || !frag_ptrs[2 * i + q]) continue;
             const int form = frag_forms[2 * i + q];
-            const bool shape_ok = (form == 0 || form == 1) ? (K[i] == 2048 && N[i] == 256) : (form == 2 || form == 3) ? (K[i] == 1024 && N[i] == 128) : form == 4 ? (K[i] == 800 && N[i] == 64) : (form == 5 && K[i] == 512 && N[i] == 64);
+            const bool shape_ok = (form == 0 || form == 1) ? (K[i] == 2048 && N[i] == 256) : (form == 2 || form == 3) ? (K[i] == 1024 && N[i] == 128) : (form == 4 || form == 6) ? (K[i] == 800 && N[i] == 64) : (form == 5 && K[i] == 512 && N[i] == 64);
             if (dtype != MI_BF16 || !shape_ok || (((uintptr_t)frag_ptrs[2 * i + q]) & 15)) return mi_fail(MI_ERR_ARG, "mi_adam_tf_layouts_frag: fragment copies are bf16, 16-byte aligned, form 0 | 1 of a [2048, 256] kernel, 2 | 3 of a [1024, 128], 4 of a [800, 64], 5 of a [512, 64] kernel");
             jb.frag[i][q] = (bf16_t*)frag_ptrs[2 * i + q]; jb.fform[i][q] = (signed char)form;
         }

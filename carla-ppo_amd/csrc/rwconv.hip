@@ -777,6 +777,13 @@ int mi_try_rwconv_conv(hipStream_t st, int dtype, const void* a, const void* w, 
         else if (relu) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, true, false>), g, t, 0, st, q, nchunks); \
         else if (mask) MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, true>), g, t, 0, st, q, nchunks); \
         else MI_LAUNCH((rwconv_conv_kernel<KH_, CK_, false, false>), g, t, 0, st, q, nchunks); } while (0)
+    if (KH == 5 && wfrag) {                                // k = 5, 32 -> 64 channels (deconv3's input gradient) with the fragment-ordered copy (pack form 6: [tile nt (2)][live k-step (50)][lane])
+        q.bfrag = wfrag;
+        if (relu && mask) MI_LAUNCH((rwconv_conv_kernel<5, 1, true, true, true>), g, t, 0, st, q, nchunks);
+        else if (relu) MI_LAUNCH((rwconv_conv_kernel<5, 1, true, false, true>), g, t, 0, st, q, nchunks);
+        else if (mask) MI_LAUNCH((rwconv_conv_kernel<5, 1, false, true, true>), g, t, 0, st, q, nchunks);
+        else MI_LAUNCH((rwconv_conv_kernel<5, 1, false, false, true>), g, t, 0, st, q, nchunks);
+    } else
     if (KH == 5) RC_LAUNCH(5, 1); else if (ck == 1) RC_LAUNCH(4, 1);
     else if (wfrag) {                                      // 64 -> 128 channels with the caller's fragment-ordered weight copy (mi_rwconv_next_weights_fragment_ordered)
         q.bfrag = wfrag;

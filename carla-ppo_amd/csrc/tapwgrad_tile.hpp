@@ -59,6 +59,11 @@ struct TapWgradParams {
 // LDS-DMA issued through inline asm: hipcc drains every builtin LDS-DMA (s_waitcnt vmcnt(0)) in front of the next
 // ds_read_b64_tr_b16 it cannot prove disjoint, which would serialise prefetch and compute; asm loads are invisible to that
 // pass, so the step barrier carries an explicit vmcnt(0).  m0 = LDS byte address of lane 0's 16 bytes (wave-uniform).
+#ifdef MI355_TW_SLAB_PLAIN                                 // (variant build: the bf16 slab stores without the streaming hint)
+#define TW_SLAB_STORE(v, ptr) (*(ptr) = (v))
+#else
+#define TW_SLAB_STORE(v, ptr) __builtin_nontemporal_store((v), (ptr))
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t tw_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
@@ -148,6 +153,11 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 //  SLOWER, 0.8142 against 0.8080 ms per step over four interleaved rounds: the hand-scheduled loops were tuned with those block boundaries in place.  They stay.)
 #define TW_STAMP() do { if (tr_on && tr_n < 32) tr[tr_n++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     TW_STAMP();
+#ifdef MI355_TW_EPI_STAMPS                                // (variant build of tools/trace_tapwgrad.py: the phases of the epilogue; the product kernel keeps its stamp sites as they are, see above)
+#define TW_EPI_STAMP() TW_STAMP()
+#else
+#define TW_EPI_STAMP() do {} while (0)
+#endif
     const int kb = by % p.nkb, nb = by / p.nkb;
     const int kc0 = kb * KCB, ne0 = nb * NEB;
     const int Pbeg = bx * p.pos_per_split;
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const float v[4] = {tiles[kt][4 * g4], tiles[kt][4 * g4 + 1], tiles[kt][4 * g4 + 2], tiles[kt][4 * g4 + 3]};
-                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + (kt * 4 + g4) * 256));
+                        TW_SLAB_STORE(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + (kt * 4 + g4) * 256));
                     }
                 return;
             }
@@ -507,17 +517,21 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
         constexpr int WSZ = KT * 16 * 64;                 // floats per wave (16 KB at KT = 4)
         static_assert(8 * WSZ * 4 <= 2 * STAGE, "reduction scratch");
         __syncthreads();                                  // the stage tiles are dead
+        TW_EPI_STAMP();
         float* const red = (float*)lds;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[wave * WSZ + (kt * 16 + r) * 64 + lane] = half ? acc[0][kt][r] : acc[1][kt][r];
+        TW_EPI_STAMP();
         __syncthreads();
+        TW_EPI_STAMP();
         f32x16 fin[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) fin[kt][r] = (half ? acc[1][kt][r] : acc[0][kt][r]) + red[(wave ^ 1) * WSZ + (kt * 16 + r) * 64 + lane];
+        TW_EPI_STAMP();
         emit(fin, wave >> 1, half, (wave >> 1) * 2 + half);
     } else {
 #pragma unroll
@@ -528,6 +542,7 @@ __global__ __launch_bounds__(TW_NT) void tapwgrad_kernel(const TapWgradParams p)
     }
     TW_STAMP();
 #undef TW_STAMP
+#undef TW_EPI_STAMP
 }
 
 // =====================================================================================================================
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(TWC_NT) void tapwgrad_cw_kernel(const TapWgradParam
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const float v[4] = {t[4 * g4], t[4 * g4 + 1], t[4 * g4 + 2], t[4 * g4 + 3]};
-                        __builtin_nontemporal_store(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + g4 * 256));
+                        TW_SLAB_STORE(__builtin_bit_cast(tw_u32x2, pack4<bf16_t>(v)), (tw_u32x2*)(dst + g4 * 256));
                     }
                     continue;
                 }

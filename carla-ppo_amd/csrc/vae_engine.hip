@@ -76,7 +76,7 @@ struct Workspace {
     long long bits_act1, bits_dec3;    // ReLU bit words of conv1's / deconv3's output (bf16 engine: 8 bytes per pixel; read by conv2's / deconv4's input gradient)
     long long roll, roll_bytes;        // rollout step (B = 1): act1 | raw sums of conv2..4 and of the mean head (zeroed per step)
     long long eps_buf, rng;   // noise drawn by the engine [B,Z] fp32; generator state (4 x uint64)
-    long long wfrag[10];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
+    long long wfrag[11];       // fragment-ordered bf16 copies of conv4's / deconv1's kernels for the activation-resident kernels (ares_tile.hpp): conv4 forward, conv4 input
                               // gradient, deconv1 forward, deconv1 input gradient (1 MB each), conv3 input gradient, deconv2 forward (256 KB each); rewritten behind every optimiser step with the K-contiguous copies
     long long total;
     // debug (MI355_DEBUG_GUARDS=1 at mi_vae_workspace_bytes AND mi_vae_create time): 256 bytes of a known pattern behind every region; mi_vae_debug_check_guards
@@ -225,7 +225,7 @@ void make_workspace(VaeEngine& e) {
         W.roll = add(W.roll_bytes);
     }
     W.eps_buf = add(B * d.z_dim * 4); W.rng = add(256);
-    for (int i = 0; i < 10; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());     // (round 6 -- 6, 7: the conv-form copies of conv3 / deconv2 for the register-weight kernel, 256 KB used; 8: deconv3 for its gather form, 144 KB; 9: conv2 for the fused encoder head, 64 KB)
+    for (int i = 0; i < 11; ++i) W.wfrag[i] = add(mi_ares_weight_bytes());     // (round 6 -- 6, 7: the conv-form copies of conv3 / deconv2 for the register-weight kernel, 256 KB used; 8: deconv3 for its gather form, 144 KB; 9: conv2 for the fused encoder head, 64 KB; 10: deconv3 for its input gradient, conv form k = 5, 100 KB)
     W.total = o;
 }
 
@@ -283,7 +283,12 @@ bool rc_wfrag_enabled() {                              // MI355_RC_WFRAG=0: the 
     return on != 0;
 }
 
-// conv2 is 32 -> 64 channels k = 4 and deconv3 64 -> 32 channels k = 5 (the reference's geometry): their fragment-ordered copies (pack forms 5 / 4) exist next to the activation-resident ones
+bool rc_wfrag6_enabled() {                             // MI355_RC_WFRAG6=0: deconv3's input gradient alone back on the K-contiguous copy (A/B runs)
+    static int on = -1;
+    if (on < 0) { const char* ev = getenv("MI355_RC_WFRAG6"); on = (ev && ev[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+// conv2 is 32 -> 64 channels k = 4 and deconv3 64 -> 32 channels k = 5 (the reference's geometry): their fragment-ordered copies (pack forms 5 / 4, 6) exist next to the activation-resident ones
 bool rc_small_frag_ok(const VaeEngine* e) {
     const Geom& g = e->g;
     return g.c[1] == 32 && g.c[2] == 64 && g.dc[2] == 64 && g.dc[3] == 32 && DEC_K[2] == 5;
@@ -403,6 +408,7 @@ int refresh_transposed(VaeEngine* e, void* st, bool have_wt = false, bool have_f
         if (!have_frag && rc_small_frag_ok(e)) {           // (round 6) deconv3's kernel for the gather-form register-weight kernel, conv2's for the fused encoder head
             CK(mi_ares_pack_weights(st, 4, e->params + e->L.off[16], e->at(e->W.wfrag[8])));
             CK(mi_ares_pack_weights(st, 5, e->params + e->L.off[2], e->at(e->W.wfrag[9])));
+            CK(mi_ares_pack_weights(st, 6, e->params + e->L.off[16], e->at(e->W.wfrag[10])));     // deconv3's input gradient: conv form, k = 5
         }
         e->ares_mid = mid ? 1 : 0;
         e->ares_ok = 1;
@@ -515,7 +521,7 @@ void* mi_vae_buffer(void* h, int which) {
         case 3: return e->at(e->W.kl_row);
         case 4: return e->at(e->W.dec[4]);
         case 5: return e->at(e->W.z);
-        case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: return e->ares_ok ? e->at(e->W.wfrag[which - 6]) : nullptr;      // the fragment-ordered weight copies (tests)
+        case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: return e->ares_ok ? e->at(e->W.wfrag[which - 6]) : nullptr;      // the fragment-ordered weight copies (tests)
         default: return nullptr;
     }
 }
@@ -749,6 +755,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             }
             if (i > 0) arm();                                // its output is the next layer's filter-gradient operand
             if (i == 1 && e->ares_ok && e->ares_mid && rc_wfrag_enabled()) mi_tl_rc_wfrag = e->at(W.wfrag[7]);      // deconv2's input gradient: conv form, fragment-ordered weights
+            if (i == 2 && e->ares_ok && rc_small_frag_ok(e) && rc_wfrag_enabled() && rc_wfrag6_enabled()) mi_tl_rc_wfrag = e->at(W.wfrag[10]);   // deconv3's: conv form, k = 5 (pack form 6)
             struct WfragGuard2 { ~WfragGuard2() { mi_tl_rc_wfrag = nullptr; } } wfrag_guard2;
             TOP(e, st, OP_DECONV_DGRAD + i, mi_deconv2d_nhwc_dgrad_bits(st, d.dtype, gy, B, g.dh[i + 1], g.dw[i + 1], g.dc[i + 1], e->wtptr(12 + 2 * i), 1, DEC_K[i], DEC_K[i], g.dc[i],
                                       i > 0 ? e->at(W.dec[i]) : nullptr, (i == 3 && e->bits3_ok) ? e->at(W.bits_dec3) : nullptr, e->at(W.gdec[i])));
@@ -944,7 +951,7 @@ static int apply_adam(VaeEngine* e, void* stream, float alpha, const float* alph
             fp[2 * 6] = e->at(e->W.wfrag[2]); ff[2 * 6] = 1; fp[2 * 6 + 1] = e->at(e->W.wfrag[3]); ff[2 * 6 + 1] = 0;      // deconv1: forward (gather form), input gradient (conv form)
             if (mid) { fp[2 * 2] = e->at(e->W.wfrag[4]); ff[2 * 2] = 2; fp[2 * 7] = e->at(e->W.wfrag[5]); ff[2 * 7] = 2; }  // conv3 input gradient, deconv2 forward
             if (mid) { fp[2 * 2 + 1] = e->at(e->W.wfrag[6]); ff[2 * 2 + 1] = 3; fp[2 * 7 + 1] = e->at(e->W.wfrag[7]); ff[2 * 7 + 1] = 3; }      // (round 6) conv3 forward, deconv2 input gradient: conv form of the register-weight kernel
-            if (rc_small_frag_ok(e)) { fp[2 * 8] = e->at(e->W.wfrag[8]); ff[2 * 8] = 4; fp[2 * 1] = e->at(e->W.wfrag[9]); ff[2 * 1] = 5; }      // (round 6) deconv3 forward (gather form), conv2 inside the fused encoder head
+            if (rc_small_frag_ok(e)) { fp[2 * 8] = e->at(e->W.wfrag[8]); ff[2 * 8] = 4; fp[2 * 1] = e->at(e->W.wfrag[9]); ff[2 * 1] = 5; fp[2 * 8 + 1] = e->at(e->W.wfrag[10]); ff[2 * 8 + 1] = 6; }      // (round 6) deconv3 forward (gather form), conv2 inside the fused encoder head
         }
         TOP(e, stream, OP_ADAM, mi_adam_tf_layouts_frag(stream, e->d.dtype, e->params, e->m, e->v, e->grads, e->L.total, off, K, N, nullptr, n, alpha, alpha_dev, beta1, beta2, epsilon,
                                                         e->d.dtype == MI_BF16 ? e->shadow : nullptr, e->wt, 1, frag ? fp : nullptr, frag ? ff : nullptr));

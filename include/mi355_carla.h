@@ -193,6 +193,8 @@ int mi_ares_pack_weights8(void* stream, const float* conv4_w, const float* decon
  *   form 3 (above)  mi_conv2d_nhwc_fwd[_bits] of a 64 -> 128 channel k = 4 layer (conv3), mi_deconv2d_nhwc_dgrad[_bits] of a 128 -> 64 channel one (deconv2)
  *   form 4          mi_deconv2d_nhwc_fwd of the k = 5, 64 -> 32 channel layer (deconv3, vae/models.py:263): mi_ares_pack_weights(form 4) of its [5][5][32][64] kernel,
  *                   144 fragments of 1 KB ordered (output-parity class, tap of the 3 x 3 class window, 16-channel K step); fragments of taps outside the 5 x 5 kernel are never read
+ *   form 6          mi_deconv2d_nhwc_dgrad[_bits] of the k = 5, 32 -> 64 channel layer (deconv3's input gradient): mi_ares_pack_weights(form 6) of deconv3's kernel read as [800][64],
+ *                   2 x 50 fragments (32-wide output tile, the 50 live (tap, k-step) pairs of the 3 x 3 slot taps in the prologue's order)
  *   form 5          mi_conv2d_enc12_fwd: conv2's [4][4][32][64] HWIO kernel (vae/models.py:251), mi_ares_pack_weights(form 5), 64 fragments (32-wide output half, K step)
  * Consumed by that call whether or not the kernel it picks uses it; NULL clears.  Same values in the same registers: results are bit-identical either way. */
 int mi_rwconv_next_weights_fragment_ordered(const void* wf);
@@ -256,7 +258,7 @@ int mi_adam_tf_flat_shadow(void* stream, float* param, float* m, float* v, float
  * copy, bit 1 = do not write its K-contiguous copy (copies that nobody reads).  Bit-identical p / m / v to mi_adam_tf_flat. */
 int mi_adam_tf_layouts(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad);
 /* same + FRAGMENT-ORDERED bf16 copies of some kernels for the activation-resident convolutions (round 5): frag_ptrs[2 i + q] / frag_forms[2 i + q], q = 0, 1, for kernel i -- what
- * mi_ares_pack_weights(form, master kernel) writes (form 0 | 1: a [2048, 256] kernel, 2 | 3: a [1024, 128] kernel, 4: deconv3's [800, 64], 5: conv2's [512, 64]), emitted by the optimiser launch from the tile it holds anyway;
+ * mi_ares_pack_weights(form, master kernel) writes (form 0 | 1: a [2048, 256] kernel, 2 | 3: a [1024, 128] kernel, 4 | 6: deconv3's [800, 64], 5: conv2's [512, 64]), emitted by the optimiser launch from the tile it holds anyway;
  * NULL pointer = none.  Both arrays may be NULL (= mi_adam_tf_layouts). */
 int mi_adam_tf_layouts_frag(void* stream, int dtype, float* param, float* m, float* v, float* grad, long long n, const long long* offsets, const int* K, const int* N, const int* skip, int count, float alpha, const float* alpha_dev, float beta1, float beta2, float epsilon, void* shadow, void* wt, int clear_grad, void* const* frag_ptrs, const int* frag_forms);
 /* out[b, :] = storage_type(src[idx[b], :]) for b < B (idx NULL: rows 0 .. B-1): the frame rows of a minibatch (the feed_dict slice of vae/models.py:211-216) gathered and

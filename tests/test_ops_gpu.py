@@ -1339,7 +1339,7 @@ def test_decoder_tail_fifth_slot_group_shared_by_three_waves(B, IH, IW):
 
 
 @pytest.mark.parametrize("B", [3, 40])
-@pytest.mark.parametrize("which", ["conv3.fwd", "deconv2.dgrad"])
+@pytest.mark.parametrize("which", ["conv3.fwd", "deconv2.dgrad", "deconv3.dgrad"])
 def test_register_weight_conv_reads_fragment_ordered_weights(which, B):
     """Round 6 (rwconv.hip, WFRAG): rwconv_conv_kernel<4, 2> (64 -> 128 channels, k = 4: conv3's forward pass, deconv2's input gradient) loads its 64 weight fragments per wave ONCE per
     block; from the K-contiguous copy every load touches 32 rows x 32 B at a 2 KB pitch, from the fragment-ordered copy (mi_ares_pack_weights8 form 3; the optimiser launch emits it)
@@ -1373,6 +1373,26 @@ def test_register_weight_conv_reads_fragment_ordered_weights(which, B):
                     big = dev(np.zeros((4, 4, 128, 256), np.float32))
                     L.mi_ares_pack_weights8(stream(), big.data_ptr(), big.data_ptr(), wmaster.data_ptr(), None, junk[0].data_ptr(), junk[1].data_ptr(), junk[2].data_ptr(), junk[3].data_ptr(),
                                             None, None, wfrag.data_ptr(), None)
+        elif which == "deconv3.dgrad":
+            IH, IW, Ci, Co, k = 18, 38, 64, 32, 5                                              # deconv3: x [B, 18, 38, 64] -> y [B, 39, 79, 32]; its input gradient is a k5 s2 conv of dy (rwconv_conv_kernel<5, 1>, pack form 6)
+            OH, OW = 39, 79
+            dy = rng.randn(B, OH, OW, Co).astype(np.float32)
+            xmask = rng.randn(B, IH, IW, Ci).astype(np.float32)
+            w = (rng.randn(k, k, Co, Ci) / np.sqrt(k * k * Co / 4)).astype(np.float32)       # [kh, kw, out = 32, in = 64] = [K = 800][N = 64]
+            dyd, md, wmaster = dev(dy, td), dev(xmask, td), dev(w)
+            wt = alloc(td, k * k * Co * Ci, fill=0.0)
+            offs, Ks, Ns = np.array([0], np.int64), np.array([k * k * Co], np.int32), np.array([Ci], np.int32)
+            L.mi_transpose_weights(stream(), code, wmaster.data_ptr(), wt.data_ptr(), offs.ctypes.data, Ks.ctypes.data, Ns.ctypes.data, 1)
+            wfrag = torch.zeros(1 << 20, device="cuda", dtype=torch.uint8)
+            L.mi_ares_pack_weights(stream(), 6, wmaster.data_ptr(), wfrag.data_ptr())
+            outs = []
+            for frag in (False, True):
+                dx = alloc(td, B, IH, IW, Ci, fill=3.0)
+                if frag:
+                    L.mi_rwconv_next_weights_fragment_ordered(wfrag.data_ptr())
+                L.mi_deconv2d_nhwc_dgrad(stream(), code, dyd.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, md.data_ptr(), dx.data_ptr())
+                torch.cuda.synchronize()
+                outs.append(dx.view(torch.int16).clone())
         else:
             IH, IW, Ci, Co, k = 8, 18, 128, 64, 4                                              # deconv2: x [B, 8, 18, 128] -> y [B, 18, 38, 64]; its input gradient is a k4 s2 conv of dy
             OH, OW = 18, 38

@@ -139,7 +139,8 @@ def test_adam_launch_writes_the_fragment_ordered_weight_copies(tmp_path):
             # round 6: the conv-form copies of the same two kernels for the register-weight kernel (conv3 forward, deconv2's input gradient): form 3
             (12, "vae/encoder/conv3/kernel", 3, nbytes // 4), (13, "vae/decoder/deconv2/kernel", 3, nbytes // 4),
             # ... deconv3's kernel for the gather-form register-weight kernel (form 4, 144 fragments) and conv2's for the fused encoder head (form 5, 64 fragments)
-            (14, "vae/decoder/deconv3/kernel", 4, 144 * 1024), (15, "vae/encoder/conv2/kernel", 5, 64 * 1024)]
+            (14, "vae/decoder/deconv3/kernel", 4, 144 * 1024), (15, "vae/encoder/conv2/kernel", 5, 64 * 1024),
+            (16, "vae/decoder/deconv3/kernel", 6, 100 * 1024)]                                # ... and deconv3's again for its input gradient (conv form, k = 5: 2 x 50 fragments)
     base = dev.workspace.data_ptr()
     scratch4 = [torch.zeros(nbytes, device="cuda", dtype=torch.uint8) for _ in range(4)]
     for which, name, form, nb in jobs:
@@ -148,7 +149,7 @@ def test_adam_launch_writes_the_fragment_ordered_weight_copies(tmp_path):
         got = dev.workspace[addr - base:addr - base + nb].clone()
         want = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
         off = lay[name][0]
-        if form in (4, 5):
+        if form in (4, 5, 6):
             L.mi_ares_pack_weights(st, form, dev.params.data_ptr() + 4 * off, want.data_ptr())
             if form == 4:                                    # (fragments of taps past the 5 x 5 kernel are never written by the optimiser launch and never read by the kernel: compare the live ones)
                 live = torch.zeros(144, dtype=torch.bool)

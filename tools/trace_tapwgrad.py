@@ -55,5 +55,7 @@ for nm, (kind, IH, IW, Ci, Co, k) in LAYERS.items():
     for i in range((nst - 3) // 2):
         lab += ["s%d.barrier" % i if i == 0 else "s%d.compute(prev)+barrier" % i, "s%d.issue" % i]
     lab += ["remaining steps", "dW stores"]
+    if os.environ.get("MI355_LIB", "").endswith("lib_epi.so"):      # python -m mi355.build --variant epi -DMI355_TW_EPI_STAMPS: the epilogue's phases
+        lab = lab[:-1] + ["wait for the block", "LDS writes", "barrier", "LDS reads + adds", "slab stores"]
     print("%s: %.1f us/launch, %d blocks, lifetime mean %.0f (min %.0f max %.0f) cycles" % (nm, us, t.shape[0], tot.mean(), tot.min(), tot.max()))
     print("   " + "  ".join("%s=%.0f" % (n, v) for n, v in zip(lab, d)))
