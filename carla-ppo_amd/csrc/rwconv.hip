@@ -21,6 +21,9 @@
 #include "tapconv_tile.hpp"
 #include "mi_internal.hpp"
 
+#ifndef MI_RW_STORE_AUX                                     // cache policy of the output stores (variant builds: 2 = nt, the streaming hint)
+#define MI_RW_STORE_AUX 0
+#endif
 namespace mi {
 
 // packed 16-bit integer ops on dwords of two bf16 (hipcc lowers the ext-vector formulations to compare / select chains)
@@ -325,8 +328,8 @@ __device__ __forceinline__ void rw_class(const TapParams& p, unsigned char* lds,
                     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
                     const bool st_ok = ok[h] && (DBG != 1 || w[0][0] == 0x12345678u);       // debug 1: (practically) nothing stored
                     const uint32_t bo = st_ok ? e0[h] * 2u : G2_OOB;                         // byte offset; out of range = dropped
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, MI_RW_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, MI_RW_STORE_AUX);
                 }
             }
         }
@@ -617,8 +620,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             const uint32_t bo = ok[h] ? e0[h] * 2u : G2_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[0][0], w[0][1], w[1][0], w[1][1]}, rsO, (int)bo, 0, MI_RW_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[2][0], w[2][1], w[3][0], w[3][1]}, rsO, (int)bo, 32, MI_RW_STORE_AUX);
         }
         RC_STAMP();
         // the next chunk's instalment was requested before this chunk's mask loads (consumed above) and 4 stores: everything but the stores has landed

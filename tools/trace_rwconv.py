@@ -25,6 +25,18 @@ elif name == "deconv3.dgrad":                      # conv-form register-weight k
     dy = torch.randn(B, OH, OW, Co, device="cuda", generator=g).to(bf); wt = (torch.randn(Ci, k * k * Co, device="cuda", generator=g) * 0.05).to(bf)
     mask = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).relu().to(bf); dx = torch.empty(B, IH, IW, Ci, device="cuda", dtype=bf)
     f = lambda: L.mi_deconv2d_nhwc_dgrad(st, 1, dy.data_ptr(), B, OH, OW, Co, wt.data_ptr(), 1, k, k, Ci, mask.data_ptr(), dx.data_ptr())
+elif name == "conv3.fwd":                          # conv-form register-weight kernel, 64 -> 128 channels (rwconv_conv_kernel<4, 2>): 4 stamps per chunk
+    IH, IW, Ci, Co, k = 18, 38, 64, 128, 4
+    OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
+    L.mi_set_tuning(15, 3)
+    x = torch.randn(B, IH, IW, Ci, device="cuda", generator=g).relu().to(bf); wt = (torch.randn(Co, k * k * Ci, device="cuda", generator=g) * 0.05).to(bf)
+    b = torch.zeros(Co, device="cuda"); out = torch.empty(B, OH, OW, Co, device="cuda", dtype=bf)
+    wf = torch.zeros(1 << 20, device="cuda", dtype=torch.uint8)
+    use_frag = os.environ.get("FRAG", "1") == "1"      # (timing only: the fragment-ordered copy holds zeros)
+    def f():
+        if use_frag:
+            L.mi_rwconv_next_weights_fragment_ordered(wf.data_ptr())
+        L.mi_conv2d_nhwc_fwd(st, 1, x.data_ptr(), None, 0, B, IH, IW, Ci, wt.data_ptr(), 1, b.data_ptr(), k, k, Co, 1, out.data_ptr())
 else:
     IH, IW, Ci, Co, k = 39, 79, 32, 64, 4
     OH, OW = (IH - k) // 2 + 1, (IW - k) // 2 + 1
@@ -52,7 +64,7 @@ t = raw.astype(np.float64); t[:, :, 31] = 0
 nb = t.shape[0]
 nw = int((t[0, :, 0] != 0).sum())
 print("%s: %.1f us / launch alone; %d blocks traced, %d waves per block" % (name, us, nb, nw))
-if name == "deconv3.dgrad":
+if name in ("deconv3.dgrad", "conv3.fwd"):
     for c in range(nw):
         w_ = t[:, c, :31]
         n = int((w_ > 0).sum(axis=1).min())
