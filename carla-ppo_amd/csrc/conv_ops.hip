@@ -809,7 +809,8 @@ static int wgrad_splits(int dtype, int M, int Kc, int N, int target_blocks, int*
 
 // scratch (optional): the pixel splits store per-split slabs there and one ordered pass adds them to out -- two runs are bitwise equal; without
 // scratch (or with too little of it) the splits meet in fp32 atomics on out (run-to-run differences in the last bit)
-int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0, int overwrite = 0) {
+// grid, row splits and slab placement of a gen-1 filter-gradient launch (shared by the single and the pair launch)
+static int prepare_wgrad(int dtype, WgradParams& p, int target_blocks, void* scratch, long long scratch_bytes, int overwrite, dim3* grid, bool* wide_out) {
     const int Kce = p.Kc + (p.ones_row ? 1 : 0);          // rows of the result incl. the bias row
     const bool wide = Kce > 64;                           // 128 kc rows per block: halves the re-reads of the small tensor
     const int gx = wide ? (Kce + 127) / 128 : 1, gy = (p.N + 63) / 64;
@@ -822,7 +823,14 @@ int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int targ
     // overwrite: out = result (no zeroed buffer, no atomics): plain stores from the single split, or the ordered slab sum storing instead of adding
     if (overwrite && splits > 1 && !p.slabs) return mi_fail(MI_ERR_ARG, "wgrad: the overwriting form needs scratch for its row splits (mi_gemm_wgrad_scratch_bytes)");
     p.overwrite = overwrite && splits == 1 ? 1 : 0;
-    dim3 g(gx, gy, splits);
+    *grid = dim3(gx, gy, splits); *wide_out = wide;
+    return MI_OK;
+}
+
+int launch_wgrad(hipStream_t st, int dtype, int in_f32, WgradParams& p, int target_blocks, void* scratch = nullptr, long long scratch_bytes = 0, int overwrite = 0) {
+    dim3 g; bool wide = false;
+    { const int rc0 = prepare_wgrad(dtype, p, target_blocks, scratch, scratch_bytes, overwrite, &g, &wide); if (rc0 != MI_OK) return rc0; }
+    const int splits = (int)g.z;
     const bool a16 = (((uintptr_t)p.big) & 15) == 0;
     const bool mergedok = p.merged && (p.KW * p.C) % 4 == 0 && (p.IW * p.C) % 2 == 0 && (p.stride * p.C) % 2 == 0 && (p.frame_stride % 2) == 0;
 #define WG_LAUNCH(T_, TIn_, VA_, AL_) do { \
@@ -1353,6 +1361,46 @@ int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* d
     if (K % vb != 0) return mi_fail(MI_ERR_SHAPE, "mi_gemm_wgrad: K must be a multiple of the 16-byte vector (pad K)");
     p.N = N; p.small = dy; p.s_vec = vec_ok(dy, N, dtype); p.out = dw;
     return launch_wgrad((hipStream_t)stream, dtype, 0, p, g_dense_wgrad_blocks, scratch, scratch_bytes, overwrite);
+}
+
+// TWO dense filter gradients (+ bias rows) as ONE launch: what mi_gemm_wgrad_bias_ws(problem 0) followed by mi_gemm_wgrad_bias_ws(problem 1) computes, bit for bit, when both take the
+// first-generation kernel in its bf16 / 128-row configuration (the latent layers of the ConvVAE: dense1 [B, 64] x [B, 6144] and the heads [B, 6144] x [B, 128]); any other pair of
+// shapes: the two single calls.  Round 6: the two ~190-block grids sat back to back at the very end of the backward pass.
+int mi_gemm_wgrad_bias_pair_ws(void* stream, int dtype, const void* a0, const void* dy0, int M0, int K0, int N0, float* dw0, float* db0, void* scratch0, long long scratch_bytes0,
+                               const void* a1, const void* dy1, int M1, int K1, int N1, float* dw1, float* db1, void* scratch1, long long scratch_bytes1) {
+    static int pair_on = -1;
+    if (pair_on < 0) { const char* e = getenv("MI355_DENSE_PAIR"); pair_on = (e && e[0] == '0') ? 0 : 1; }
+    const void* A[2] = {a0, a1}; const void* DY[2] = {dy0, dy1}; const int M[2] = {M0, M1}, K[2] = {K0, K1}, N[2] = {N0, N1};
+    float* DW[2] = {dw0, dw1}; float* DB[2] = {db0, db1}; void* WS[2] = {scratch0, scratch1}; const long long NB[2] = {scratch_bytes0, scratch_bytes1};
+    bool ok = pair_on && dtype == MI_BF16;
+    WgradPair q = {};
+    dim3 g[2];
+    for (int i = 0; i < 2 && ok; ++i) {
+        if (dwgs_eligible(dtype, M[i], K[i], N[i]) || K[i] % 8 != 0 || (((uintptr_t)A[i]) & 15)) { ok = false; break; }
+        WgradParams& p = q.p[i];
+        p.ones_row = DB[i] ? 1 : 0; p.dbias = DB[i];
+        p.big = A[i]; p.frame_idx = nullptr;
+        fill_wgrad_geom(p, M[i], 1, 1, K[i], 1, 1, 1, 1, 1, false);
+        p.N = N[i]; p.small = DY[i]; p.s_vec = vec_ok(DY[i], N[i], dtype); p.out = DW[i];
+        bool wide = false;
+        if (prepare_wgrad(dtype, p, g_dense_wgrad_blocks, WS[i], NB[i], 0, &g[i], &wide) != MI_OK || !wide || p.C % 8 != 0) ok = false;
+    }
+    if (!ok) {
+        const int rc = mi_gemm_wgrad_bias_ws(stream, dtype, a0, dy0, M0, K0, N0, dw0, db0, scratch0, scratch_bytes0);
+        return rc != MI_OK ? rc : mi_gemm_wgrad_bias_ws(stream, dtype, a1, dy1, M1, K1, N1, dw1, db1, scratch1, scratch_bytes1);
+    }
+    q.n0 = (int)(g[0].x * g[0].y * g[0].z);
+    for (int i = 0; i < 2; ++i) { q.gx[i] = (int)g[i].x; q.gy[i] = (int)g[i].y; }
+    const unsigned nblk = (unsigned)q.n0 + g[1].x * g[1].y * g[1].z;
+    MI_LAUNCH((wgrad_pair_kernel<bf16_t, bf16_t, 8, 16, 128>), dim3(nblk), dim3(GEMM_NT), 0, (hipStream_t)stream, q);
+    int rc = mi_check_launch("wgrad_pair_kernel");
+    for (int i = 0; i < 2 && rc == MI_OK; ++i) {
+        const WgradParams& p = q.p[i];
+        if (!p.slabs) continue;
+        rc = mi_reduce_slabs((hipStream_t)stream, p.slabs, p.slab_stride, (int)g[i].z, (long long)p.Kc * p.N, p.out, 0);
+        if (rc == MI_OK && p.ones_row) rc = mi_reduce_slabs((hipStream_t)stream, p.slabs + (long long)p.Kc * p.N, p.slab_stride, (int)g[i].z, (long long)p.N, p.dbias, 0);
+    }
+    return rc;
 }
 
 }  // extern "C"

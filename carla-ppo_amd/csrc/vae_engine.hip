@@ -825,7 +825,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         }
     }
     if (upper || lower) {
-        bool enc_fused = false, dense_done = false;
+        bool enc_fused = false, dense_done = false, pair_used = false;
         for (int i = NCONV - 1; i >= 0; --i) {               // conv(i+1): input act[i] -> output act[i+1]
             if (i == NCONV - 1 ? !upper : !lower) continue;
             const void* gy = e->at(W.gact[i + 1]);
@@ -896,6 +896,18 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
         else
         if (late_dense && !use_third) {                      // the tails of both streams: dense1 + the decoder tail's slab sums here, the heads on the other one
             if (tail_fuse_on && !tail_defer) { mi_small_reduce_defer(1); mi_small_reduce_bind(st); tail_defer = true; }
+            // round 6: dense1's and the heads' filter + bias gradients as ONE launch when both are issued here on the caller's stream (a fused encoder head in front): the two
+            // ~190-block grids of a latency-bound kernel ran back to back on the step's critical tail (MI355_DENSE_PAIR=0: two launches; per-op timing keeps them apart)
+            const bool pair = !dense_done && bias_fused && enc_fused && heads_main && e->tm.mode != 1;
+            long long nb0 = 0, nb1 = 0;
+            void* ws0 = pair ? small_ws(st, mi_gemm_wgrad_scratch_bytes(d.dtype, B, d.z_dim, g.flat), &nb0) : nullptr;
+            void* ws1 = pair ? small_ws(st, mi_gemm_wgrad_scratch_bytes(d.dtype, B, g.flat, 2 * d.z_dim), &nb1) : nullptr;
+            // (both launches' slabs are live at once: two DISJOINT pieces of the tail scratch, which its bump allocator hands out while the slab sums are deferred)
+            if (pair && ws0 && ws1 && ((char*)ws0 + nb0 <= (char*)ws1 || (char*)ws1 + nb1 <= (char*)ws0)) {
+                TOP(e, st, OP_DENSE1_WGRAD, mi_gemm_wgrad_bias_pair_ws(st, d.dtype, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11), ws0, nb0,
+                                                                       e->at(W.act[4]), e->at(W.dheads), B, g.flat, 2 * d.z_dim, e->gptr(8), e->gptr(9), ws1, nb1));
+                dense_done = true; pair_used = true;
+            }
             if (!dense_done) {
                 if (!bias_fused) TOP(e, st, OP_DENSE1_BIAS, bias_grad(st, e->at(W.gdec[0]), B, g.flat, e->gptr(11)));
                 TOP(e, st, OP_DENSE1_WGRAD, dense_wgrad(st, e->at(W.z), e->at(W.gdec[0]), B, d.z_dim, g.flat, e->gptr(10), e->gptr(11)));
@@ -916,10 +928,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             e->fin.pending = 0;
             // Round 5: behind the filter-gradient queue's last reduce instead (it ends ~20 us before the caller's queue does: the one-block kernel and its boundary leave
             // the critical tail; everything it reads exists since the forward pass, what it writes -- the loss scalars, deconv4's bias gradient -- is read behind the join).
-            // MI355_FIN_SIDE=0: on the caller's stream as before.
+            // MI355_FIN_SIDE=0: on the caller's stream as before.  Round 6: with dense1's and the heads' filter gradients in ONE launch the caller's queue ends first again
+            // (its last slab sum ~10 us before the other queue's): the kernel is back on the caller's stream unless MI355_FIN_SIDE=1 (0.7468 -> 0.7446, 0.7818 -> 0.7792 ms on two boxes).
             static int fin_side = -1;
-            if (fin_side < 0) { const char* ev = getenv("MI355_FIN_SIDE"); fin_side = (ev && ev[0] == '0') ? 0 : 1; }
-            void* sf = (fork && fin_side && part == 0) ? sw : st;
+            if (fin_side < 0) { const char* ev = getenv("MI355_FIN_SIDE"); fin_side = !ev ? 2 : ev[0] == '0' ? 0 : 1; }      // 2: by the tail's shape
+            void* sf = (fork && (fin_side == 1 || (fin_side == 2 && !pair_used)) && part == 0) ? sw : st;
             TOP(e, sf, OP_FINALIZE, mi_vae_finalize_losses_flat(sf, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
                                            (float*)e->at(W.out2), e->fin.metrics3, e->fin.metric_weight, (const float*)e->at(W.bpart), e->fin.nblk, d.ct, e->fin.dbias));
         }

@@ -54,8 +54,9 @@ __device__ __forceinline__ u16x8 tr_fragment(const bf16_t* tile, int pitch, int 
 }
 
 // BKC: kc rows per block (64 | 128); 2x2 waves, each wave BKC/64 accumulators of 32(kc) x 32(n)
+// the block (bx, by, bz) of one launch: kc block, output block, pixel split (wgrad_kernel: the grid's own indices; wgrad_pair_kernel: two launches in one grid)
 template <typename T, typename TIn, int VA, int AALIGN, int BKC>
-__global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_block(const WgradParams& p, const int bx, const int by, const int bz) {
     constexpr int NT = GEMM_NT;
     constexpr int BP = WgradCfg<T>::BP;
     constexpr int BN = 64;
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lgrp = lane >> 5;
-    const int kc0 = blockIdx.x * BKC, n0 = blockIdx.y * BN;
-    const int mbeg = blockIdx.z * p.m_per_split;
+    const int kc0 = bx * BKC, n0 = by * BN;
+    const int mbeg = bz * p.m_per_split;
     const int mend = min(p.M, mbeg + p.m_per_split);
     const int nsteps = (mend - mbeg + BP - 1) / BP;
     const int tpix = tid / TPP, tsub = tid % TPP;
@@ -216,16 +217,34 @@ __global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
             const int kc = kc0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lgrp;
             const int n = n0 + wn * 32 + lrow;
             if (kc < p.Kc && n < p.N) {
-                if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                if (p.slabs) p.slabs[(long long)bz * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
                 else if (p.overwrite) p.out[(long long)kc * p.N + n] = acc[i][r];
                 else atomicAdd(&p.out[(long long)kc * p.N + n], acc[i][r]);
             } else if (p.ones_row && kc == p.Kc && n < p.N) {
-                if (p.slabs) p.slabs[(long long)blockIdx.z * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
+                if (p.slabs) p.slabs[(long long)bz * p.slab_stride + (long long)kc * p.N + n] = acc[i][r];
                 else if (p.overwrite) p.dbias[n] = acc[i][r];
                 else atomicAdd(&p.dbias[n], acc[i][r]);
             }
         }
     }
+}
+
+template <typename T, typename TIn, int VA, int AALIGN, int BKC>
+__global__ __launch_bounds__(GEMM_NT) void wgrad_kernel(const WgradParams p) {
+    wgrad_block<T, TIn, VA, AALIGN, BKC>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Two independent filter gradients of the same kernel configuration as ONE launch (round 6: dense1's and the heads' at the end of the ConvVAE's backward pass -- two ~190-block
+// grids of a latency-bound kernel, back to back on the caller's stream, became one grid of both): blocks [0, n0) are launch 0's grid in x-fastest order, the rest launch 1's.
+// Every block computes exactly what it would have in its own launch: bit-identical results.
+struct WgradPair { WgradParams p[2]; int n0; int gx[2], gy[2]; };
+template <typename T, typename TIn, int VA, int AALIGN, int BKC>
+__global__ __launch_bounds__(GEMM_NT) void wgrad_pair_kernel(const WgradPair q) {
+    const int sel = (int)blockIdx.x >= q.n0 ? 1 : 0;       // block-uniform
+    int b = (int)blockIdx.x - (sel ? q.n0 : 0);
+    const int gx = q.gx[sel], gy = q.gy[sel];
+    const int bx = b % gx; b /= gx;
+    wgrad_block<T, TIn, VA, AALIGN, BKC>(q.p[sel], bx, b % gy, b / gy);
 }
 
 }  // namespace mi

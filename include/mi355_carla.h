@@ -219,6 +219,11 @@ long long mi_gemm_wgrad_scratch_bytes(int dtype, int M, int K, int N);
 int mi_gemm_wgrad_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, void* scratch, long long scratch_bytes);
 /* same + the layer's BiasAddGrad in the same launch: dbias[n] += sum_m dy[m,n] (a column of ones appended to `a` inside the kernel's loader; dbias may be NULL) */
 int mi_gemm_wgrad_bias_ws(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes);
+/* round 6: TWO such gradients as ONE launch -- exactly what the two single calls compute (problem 0, then problem 1), bit for bit: the ConvVAE's backward pass ends with dense1's
+ * (vae/models.py:259) and the heads' (:97-98) filter + bias gradients, two ~190-block grids of a latency-bound kernel back to back on the caller's stream.  Pairs the one-launch form
+ * does not cover (other dtypes / shapes) run as the two single calls. */
+int mi_gemm_wgrad_bias_pair_ws(void* stream, int dtype, const void* a0, const void* dy0, int M0, int K0, int N0, float* dw0, float* dbias0, void* scratch0, long long scratch_bytes0,
+                               const void* a1, const void* dy1, int M1, int K1, int N1, float* dw1, float* dbias1, void* scratch1, long long scratch_bytes1);
 /* same; overwrite != 0: dw (and dbias) = the gradient instead of += (plain stores / the storing form of the ordered sum): the gradient buffer need not be zeroed and no
  * element is touched by an atomic.  Row splits then NEED the scratch (MI_ERR_ARG otherwise). */
 int mi_gemm_wgrad_bias_set(void* stream, int dtype, const void* a, const void* dy, int M, int K, int N, float* dw, float* dbias, void* scratch, long long scratch_bytes, int overwrite);

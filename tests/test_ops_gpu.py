@@ -1483,3 +1483,40 @@ def test_deconv3_forward_and_fused_encoder_head_read_fragment_ordered_weights(B)
     for a_, b_ in zip(res[0], res[1]):
         assert torch.equal(a_, b_)
     assert float(res[0][2].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("B", [48, 512])
+def test_two_dense_filter_gradients_in_one_launch_equal_the_two_launches(B):
+    """Round 6 (mi_gemm_wgrad_bias_pair_ws): dense1's ([B, 64]^T [B, 6144]) and the heads' ([B, 6144]^T [B, 128]) filter + bias gradients as ONE launch of the first-generation kernel --
+    every block computes what it would have in its own launch, the ordered slab sums are the same: BITWISE the two single calls; a pair the one-launch form does not cover (fp32)
+    runs as the two calls."""
+    L = milib.get()
+    for tag in ("bf16", "f32"):
+        code, td = DT[tag]
+        rng = np.random.RandomState(B)
+        z = rng.randn(B, 64).astype(np.float32); g1 = rng.randn(B, 6144).astype(np.float32)
+        a4 = np.maximum(rng.randn(B, 6144), 0).astype(np.float32); gh = rng.randn(B, 128).astype(np.float32)
+        zd, g1d, a4d, ghd = dev(z, td), dev(g1, td), dev(a4, td), dev(gh, td)
+        nb0, nb1 = L.mi_gemm_wgrad_scratch_bytes(code, B, 64, 6144), L.mi_gemm_wgrad_scratch_bytes(code, B, 6144, 128)
+        ws0 = torch.zeros(max(nb0, 16), device="cuda", dtype=torch.uint8); ws1 = torch.zeros(max(nb1, 16), device="cuda", dtype=torch.uint8)
+        res = []
+        for pair in (False, True):
+            dw0 = torch.zeros(64, 6144, device="cuda"); db0 = torch.zeros(6144, device="cuda"); dw1 = torch.zeros(6144, 128, device="cuda"); db1 = torch.zeros(128, device="cuda")
+            if pair:
+                rc = L.mi_gemm_wgrad_bias_pair_ws(stream(), code, zd.data_ptr(), g1d.data_ptr(), B, 64, 6144, dw0.data_ptr(), db0.data_ptr(), ws0.data_ptr(), nb0,
+                                                  a4d.data_ptr(), ghd.data_ptr(), B, 6144, 128, dw1.data_ptr(), db1.data_ptr(), ws1.data_ptr(), nb1)
+            else:
+                rc = L.mi_gemm_wgrad_bias_ws(stream(), code, zd.data_ptr(), g1d.data_ptr(), B, 64, 6144, dw0.data_ptr(), db0.data_ptr(), ws0.data_ptr(), nb0)
+                assert rc == 0
+                rc = L.mi_gemm_wgrad_bias_ws(stream(), code, a4d.data_ptr(), ghd.data_ptr(), B, 6144, 128, dw1.data_ptr(), db1.data_ptr(), ws1.data_ptr(), nb1)
+            assert rc == 0, L.mi_last_error()
+            torch.cuda.synchronize()
+            res.append([t.clone() for t in (dw0, db0, dw1, db1)])
+        if tag == "bf16" or nb0 > 0:                       # (fp32 with one row split adds by atomics: order-dependent last bits, compared by value below)
+            for x, y in zip(res[0], res[1]):
+                if tag == "bf16":
+                    assert torch.equal(x, y)
+        zb, g1b = zd.float(), g1d.float()
+        want = zb.t() @ g1b
+        assert float((res[1][0] - want).abs().max()) <= 2e-3 * float(want.abs().max()) + 1e-4
+        assert float((res[1][3] - ghd.float().sum(0)).abs().max()) <= 2e-3 * float(ghd.float().sum(0).abs().max()) + 1e-3
