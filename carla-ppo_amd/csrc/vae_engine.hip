@@ -899,6 +899,23 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
             // round 6: dense1's and the heads' filter + bias gradients as ONE launch when both are issued here on the caller's stream (a fused encoder head in front): the two
             // ~190-block grids of a latency-bound kernel ran back to back on the step's critical tail (MI355_DENSE_PAIR=0: two launches; per-op timing keeps them apart)
             const bool pair = !dense_done && bias_fused && enc_fused && heads_main && e->tm.mode != 1;
+            // ... and the one-block loss finalisation IN FRONT of that launch (MI355_FIN_EARLY=0: behind the slab sums): the pair's blocks wait for conv2's filter gradient to release
+            // the CUs anyway, so the 4 us kernel and its boundary leave the serial tail (slab sums -> Adam)
+            static int fin_early = -1;
+            if (fin_early < 0) { const char* ev = getenv("MI355_FIN_EARLY"); fin_early = (ev && ev[0] == '0') ? 0 : 1; }
+            // ... and the small slab sums that are READY (the fused encoder head's, the decoder tail's) as their own launch in front of both (MI355_TAIL_EARLY_FLUSH=1; default: one launch with the
+            // pair's at the very end -- measured 0.7360 against 0.7380 ms): it runs while the pair waits for compute units, and the launch between the pair and Adam sums the pair's slabs only
+            static int early_flush = -1;
+            if (early_flush < 0) { const char* ev = getenv("MI355_TAIL_EARLY_FLUSH"); early_flush = (ev && ev[0] == '1') ? 1 : 0; }
+            if (pair && early_flush && tail_defer) {
+                if (e->tail_nblk > 0) { CK(mi_deconv2d_tail_reduce(st, e->at(W.tail_slabs), e->tail_nblk, e->gptr(18))); e->tail_nblk = 0; }
+                CK(mi_small_reduce_flush(st));
+            }
+            if (pair && fin_early && e->fin.pending && part == 0) {
+                e->fin.pending = 0;
+                TOP(e, st, OP_FINALIZE, mi_vae_finalize_losses_flat(st, (const float*)e->at(W.partial), e->fin.nblk, (const float*)e->at(W.kl_row), e->fin.kl_floor, e->fin.B, e->fin.inv_batch,
+                                               (float*)e->at(W.out2), e->fin.metrics3, e->fin.metric_weight, (const float*)e->at(W.bpart), e->fin.nblk, d.ct, e->fin.dbias));
+            }
             long long nb0 = 0, nb1 = 0;
             void* ws0 = pair ? small_ws(st, mi_gemm_wgrad_scratch_bytes(d.dtype, B, d.z_dim, g.flat), &nb0) : nullptr;
             void* ws1 = pair ? small_ws(st, mi_gemm_wgrad_scratch_bytes(d.dtype, B, g.flat, 2 * d.z_dim), &nb1) : nullptr;
