@@ -73,6 +73,7 @@ NAMES_R04 = [("ares_conv_kernel<4, 1>", None, "conv4.fwd / deconv1.dgrad"), ("ar
 NAMES_R05 = [("reduce_fused_kernel", "1864x1x1", "slab reduce, decoder filter gradients (mid-pass, filter-gradient queue's idle gap)"),
              ("reduce_fused_kernel", "1568x1x1", "slab reduce, encoder filter gradients (end of pass)"),
              ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "1x96x2", "dense1.wgrad (+ bias row)"), ("wgrad_kernel<bf16, bf16, 8, 16, 128>", "49x2x2", "heads.wgrad (+ bias row)"),
+             ("wgrad_pair_kernel<bf16, bf16, 8, 16, 128>", "388x1x1", "dense1.wgrad + heads.wgrad (+ bias rows): ONE launch in the step (the two rows above: per-op timing keeps them apart)"),
              # the encoder head of the forward pass is one kernel (conv1's activation never leaves LDS on its way into conv2); the two kernels it replaces
              # still run twice in a profile (bench.py's isolated per-op table): not listed
              ("enc12_fwd_kernel<unsigned char, 0, 1, 1>", None, "conv1.fwd / conv2.fwd (encoder head of forward: one kernel)")] \
@@ -102,6 +103,7 @@ for kern, grid, op in NAMES:
     traffic[op] = {"kernel": kern, "grid": key[1], "us": us, "fetch_mb_corrected": fmb, "write_mb": wmb, "hbm_bytes_per_launch": (fmb + wmb) * 1e6, "mfma_util": util,
                    "valu_per_mfma": None if nmf <= 0 else vpm}
     mult = 2 if "averaged" in op else 1                   # (two layers of a step share kernel and grid: one averaged row, two launches per step)
+    if "ONE launch in the step" in op: mult = 0           # (its two problems are the two single-launch rows of the per-op timing pass: counted there)
     step_bytes += mult * (fmb + wmb) * 1e6; step_kernels += mult
 doc = """# %s
 
