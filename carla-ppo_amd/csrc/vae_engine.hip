@@ -135,6 +135,8 @@ struct VaeEngine {
     hipStream_t side;                   // filter-gradient stream of the backward pass (created on first use; host object only)
     hipEvent_t ev_ready, ev_done;
     int side_ok;
+    int dp_open_join, dp_side_ready;    // mi_vae_train_step_dp (round 6): a backward PART ends with the filter-gradient stream waiting for the caller's instead of the other way round; the bucket's
+                                        // all-reduce is then chained to the filter-gradient stream and the caller's stream goes straight on with the next part's input-gradient chain
     int ares_mid;                       // ... and the mid-layer copies (conv3's input gradient, deconv2 forward)
     int ares_ok;                        // the fragment-ordered weight copies exist (bf16 engine, the model's geometry): the four small-grid layers run on the activation-resident kernels
     int fwd_produced;                   // the last forward's final kernel (the fused decoder tail) carries ev_ready on its own dispatch packet (MI355_KEVENT; consumed by the backward pass's first hand-over)
@@ -721,6 +723,11 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     if (defer) mi_tapwgrad_defer(1);
     auto join = [&]() {
         if (defer) mi_tapwgrad_flush(sw);
+        if (fork && e->dp_open_join) {                      // (one-call data-parallel step, parts 1 and 3) everything of this part that ran on the caller's stream is complete on the other one
+            hipEventRecord(e->ev_done, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_done, 0);
+            e->dp_side_ready = 1;
+            return;
+        }
         if (fork) { hipEventRecord(e->ev_done, e->side); hipStreamWaitEvent((hipStream_t)st, e->ev_done, 0); }
     };
     struct DeferGuard { bool on; ~DeferGuard() { if (on) mi_tapwgrad_defer(0); } } guard{defer};
@@ -1055,10 +1062,19 @@ int mi_vae_train_step_dp(void* h, void* comm, void* stream, const void* src, con
     // A LOCAL failure between two buckets must not leave all-reduces queued with nothing joined behind them: whatever was queued is joined to `stream` before
     // the error is returned, so the caller's buffers are quiescent once `stream` drains.  The collective schedule of THIS rank is broken all the same -- its peers are
     // inside (or about to enter) collectives it will never issue: a non-OK return is FATAL for the job (the host mirror raises; the launcher tears every rank down).
+    // Round 6: the first two parts do NOT make the caller's stream wait for the filter-gradient stream (that join idled the input-gradient chain ~50 us per part: the
+    // data-parallel step without its collectives ran 0.863 ms against the single-rank step's 0.744).  Nothing the later parts issue on the caller's stream reads what the
+    // filter-gradient stream produces; the part's bucket is complete when THAT stream has also seen the caller's work of the part, so the all-reduce is chained to it.
+    // MI355_DP_OPEN_JOIN=0: the joins of round 5.
+    static int open_join = -1;
+    if (open_join < 0) { const char* ev = getenv("MI355_DP_OPEN_JOIN"); open_join = (ev && ev[0] == '0') ? 0 : 1; }
     int rc = MI_OK;
     for (int i = 0; i < 3 && rc == MI_OK; ++i) {
+        e->dp_open_join = (open_join && i < 2) ? 1 : 0; e->dp_side_ready = 0;
         rc = mi_vae_backward(h, stream, src, idx, eps, inv_batch, (int)bk[3 * i]);
-        if (rc == MI_OK) rc = mi_allreduce_sum_f32_async(comm, stream, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]);
+        void* producer = (e->dp_side_ready && e->side_ok == 1) ? (void*)e->side : stream;
+        e->dp_open_join = 0; e->dp_side_ready = 0;
+        if (rc == MI_OK) rc = mi_allreduce_sum_f32_async(comm, producer, e->grads + bk[3 * i + 1], bk[3 * i + 2] - bk[3 * i + 1]);
     }
     const int rcw = mi_comm_wait(comm, stream);
     if (rc != MI_OK) return rc;
