@@ -692,17 +692,24 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     if (tail_fuse_on < 0) { const char* ev = getenv("MI355_TAIL_FUSE"); tail_fuse_on = (ev && ev[0] == '0') ? 0 : 1; }
     bool tail_defer = false;
     long long tail_bump = 0;
-    struct SrGuard { bool* on; ~SrGuard() { if (*on) mi_small_reduce_defer(0); } } sr_guard{&tail_defer};
+    // A backward PART on two streams (the data-parallel step; round 6): the small slab sums of the part's filter-gradient stream -- the latent layer's filter + bias gradient, the bias
+    // rows of a lone raw-staged filter gradient -- are recorded the same way and issued as ONE launch in front of the part's join (they were two or three ~5 us launches per part on the
+    // stream that ends the data-parallel step); MI355_PART_FUSE=0: a launch each.  (tail_defer belongs to the full pass, part 0: the two never meet.)
+    static int part_fuse_on = -1;
+    if (part_fuse_on < 0) { const char* ev = getenv("MI355_PART_FUSE"); part_fuse_on = (ev && ev[0] == '0') ? 0 : 1; }
+    bool side_defer = false;
+    if (part_fuse_on && fork && part != 0 && W.scratch_tail_bytes > 0 && e->tm.mode != 1) { mi_small_reduce_defer(1); mi_small_reduce_bind(sw); side_defer = true; }
+    struct SrGuard { bool* on; bool* on2; ~SrGuard() { if (*on || *on2) mi_small_reduce_defer(0); } } sr_guard{&tail_defer, &side_defer};
     auto small_ws = [&](void* s_, long long need, long long* bytes) -> void* {
-        if (tail_defer && s_ == st) {
+        if ((tail_defer && s_ == st) || (side_defer && s_ == sw)) {
             need = (need + 255) / 256 * 256;
             if (need <= W.scratch_tail_bytes) {
-                if (tail_bump + need > W.scratch_tail_bytes) { mi_small_reduce_flush(st); tail_bump = 0; }      // (the jobs recorded so far read their slabs before anything below overwrites them: same stream)
+                if (tail_bump + need > W.scratch_tail_bytes) { mi_small_reduce_flush(s_); tail_bump = 0; }      // (the jobs recorded so far read their slabs before anything below overwrites them: same stream)
                 void* ptr = (char*)e->at(W.scratch_tail) + tail_bump;
                 tail_bump += need; *bytes = need;
                 return ptr;
             }
-            mi_small_reduce_flush(st);
+            mi_small_reduce_flush(s_);
         }
         if (fork && s_ == (void*)e->side) { *bytes = W.scratch_side_bytes; return e->at(W.scratch_side); }
         if (e->third_ok == 1 && s_ == (void*)e->third) { *bytes = W.scratch_third_bytes; return e->at(W.scratch_third); }
@@ -723,6 +730,7 @@ int mi_vae_backward(void* h, void* stream, const void* src, const int* idx, cons
     if (defer) mi_tapwgrad_defer(1);
     auto join = [&]() {
         if (defer) mi_tapwgrad_flush(sw);
+        if (side_defer) { mi_small_reduce_flush(sw); mi_small_reduce_defer(0); side_defer = false; }
         if (fork && e->dp_open_join) {                      // (one-call data-parallel step, parts 1 and 3) everything of this part that ran on the caller's stream is complete on the other one
             hipEventRecord(e->ev_done, (hipStream_t)st); hipStreamWaitEvent(e->side, e->ev_done, 0);
             e->dp_side_ready = 1;
