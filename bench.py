@@ -607,6 +607,7 @@ def main():
     ap.add_argument("--no-x3", action="store_true")
     ap.add_argument("--no-mlp", action="store_true")
     ap.add_argument("--no-replay", action="store_true")
+    ap.add_argument("--no-dp-form", action="store_true", help="skip the N = 1 timing of the data-parallel form of the step (recording communicator)")
     ap.add_argument("--replay-rows", type=int, default=1024)
     ap.add_argument("--condition-ms", type=float, default=300.0, help="untimed steps in FRONT of the counted warm-up until this much wall time has passed: the box reaches its "
                                                                     "sustained clocks / power state before anything is measured (0 = off)")
@@ -771,6 +772,37 @@ def main():
         long_leg = {"steps": args.long_steps, "ms_per_step": float(tl[0].item()) / args.long_steps * 1e3, "frames_per_s": B * world * args.long_steps / float(tl[0].item()),
                     "note": "the same step, %d more steps timed the same way right behind the counted region (not the headline: `value` is the counted K steps)" % args.long_steps}
 
+    # what the DATA-PARALLEL form of this very step costs one rank before any byte travels (round 6): at N = 1 the same C call the N > 1 run issues (mi_vae_train_step_dp: the three
+    # backward parts in bucket order, every bucket handed to the communicator, the join, Adam) on a RECORDING communicator -- the driver computes scaling efficiency from the N = 1
+    # line, and the part that is schedule, not transport, can be read here
+    dp_form = None
+    if world == 1 and args.precision == "bf16" and not args.no_dp_form and hasattr(dev, "train_step_dp"):
+        try:
+            import ctypes
+            from vae.models import adam_alpha, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON
+            hcomm = ctypes.c_void_p(); rec_log = np.zeros((64, 4), np.int64)
+            dev.L.mi_comm_init_recording(ctypes.addressof(hcomm), 0, 1, rec_log.ctypes.data, 64)
+            a_ = adam_alpha(1e-4, np.float32(0.9), np.float32(0.999))
+            f_dp = lambda i: dev.train_step_dp(hcomm, pool, pool, idx[i % n_idx], B, inv_b, None, a_, ADAM_BETA1, ADAM_BETA2, ADAM_EPSILON)
+            for i in range(20):
+                f_dp(i)
+            torch.cuda.synchronize(); td0 = time.perf_counter()
+            for i in range(100):
+                f_dp(i)
+            torch.cuda.synchronize(); t_dp = (time.perf_counter() - td0) / 100 * 1e3
+            for i in range(20):
+                step(i)
+            torch.cuda.synchronize(); td0 = time.perf_counter()
+            for i in range(100):
+                step(i)
+            torch.cuda.synchronize(); t_sg = (time.perf_counter() - td0) / 100 * 1e3
+            dev.L.mi_comm_destroy(hcomm)
+            dp_form = {"ms_per_step_dp_call_recording_comm": t_dp, "ms_per_step_single_rank_call": t_sg, "ratio": t_dp / t_sg, "steps": 100,
+                       "note": "mi_vae_train_step_dp on a recording communicator (no collective is issued) against mi_vae_train_step, 100 steps each, back to back in this run: "
+                               "what weak-scaling efficiency loses to the bucket-ordered schedule before transport"}
+        except Exception as e:
+            dp_form = {"error": repr(e)}
+
     # data parallel: what one rank spends per step, and how much of it is gradient all-reduce that nothing overlaps
     dp = None
     if world > 1:
@@ -817,6 +849,7 @@ def main():
             "per_op_ms": {k: round(v, 4) for k, v in sorted(per_op.items(), key=lambda kv: -kv[1])},
             "final_losses": {"reconstruction": float(losses[0]), "kl": float(losses[1])},
             "data_parallel": dp,
+            "data_parallel_form_at_one_rank": dp_form,
             "value_200": long_leg,
         }
         if roofline is not None and args.precision == "bf16":

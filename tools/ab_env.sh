@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 log=$1; rounds=$2; shift 2
 # STEPS / WARMUP / EXTRA: bench.py arguments of every run (default 200 / 10; EXTRA e.g. "--precision bf16x3" or "--condition-ms 0")
-X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-box --steps ${STEPS:-200} --warmup ${WARMUP:-10} ${EXTRA:-}"
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form --no-box --steps ${STEPS:-200} --warmup ${WARMUP:-10} ${EXTRA:-}"
 rm -f "$log"
 for r in $(seq 1 $rounds); do
   for cfg in "$@"; do

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 log=$1; pat=$2; shift 2
-X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-box --steps ${STEPS:-100} --warmup ${WARMUP:-10}"
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form --no-box --steps ${STEPS:-100} --warmup ${WARMUP:-10}"
 rm -f "$log"
 for cfg in "$@"; do
   env $cfg timeout 300 python bench.py $X 2>/dev/null | python -c "

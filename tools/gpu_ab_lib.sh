@@ -2,7 +2,7 @@
 # usage: tools/gpu_ab_lib.sh <libA.so> <libB.so> [reps]  -> interleaved bench runs of two builds of the library on the SAME box
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --steps 100"
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form --steps 100"
 for r in $(seq 1 ${3:-2}); do
 for tag in A B; do
   if [ $tag = A ]; then L="$1"; else L="$2"; fi

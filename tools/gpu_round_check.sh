@@ -21,7 +21,7 @@ r = d["roofline"]; print("roofline:", r["kernel"][:40], r["avg_launch_ms"], r["f
 for k in ("bf16x3", "fp32", "mlp_vae", "ppo"):
     print(k, json.dumps({kk: vv for kk, vv in (d.get(k) or {}).items() if kk in ("frames_per_s", "ms_per_step", "ms_per_update", "error")}))
 PY
-X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --gpus 1 --steps 20 --warmup 5"
+X="--no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form --gpus 1 --steps 20 --warmup 5"
 for r in 1 2; do
   for c in 0 300; do
     ms=$(timeout 300 python bench.py $X --condition-ms $c 2>/dev/null | python -c "import sys,json; print(round(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'],4))" 2>/dev/null)

@@ -108,7 +108,7 @@ for kern, grid, op in NAMES:
 doc = """# %s
 
 ConvVAE bf16 SGD step, batch 512 (BASELINE configs[1]), 1x MI355X.  ONE `gpurun` call = one box, one library (stamp and the box's own calibration: `config.library` / `box` in the bench line below).  Sources: `rocprofv3 --kernel-trace --stats` of
-`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
+`python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form` (rocpd database summarised by `tools/rocpd_summary.py`) and three separate
 `rocprofv3 --pmc` passes (`tools/pmc_pass.sh`: SQ/GRBM counters, FETCH_SIZE alone, WRITE_SIZE alone -- one TCC-derived counter per pass, no trace
 domains combined with --pmc).  Assembled by `tools/make_profile.py`.
 

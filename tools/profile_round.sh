@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout 400 python bench.py --steps 30 --warmup 5 > gpurun_out/bench_${tag}_full.json 2> gpurun_out/bench_${tag}_full.err
 cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-box > $R/gpurun_out/prof_$tag.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-ppo --no-fp32 --no-mlp --no-replay --no-x3 --no-dp-form --no-box > $R/gpurun_out/prof_$tag.log 2>&1
 cd $R
 python tools/rocpd_summary.py $(find gpurun_out/prof_$tag -name "*.db" | head -1) > gpurun_out/prof_$tag.md 2>> gpurun_out/prof_$tag.log
 rm -rf gpurun_out/prof_$tag
