@@ -5,7 +5,7 @@
 #   gpurun --timeout 1800 -- 'tools/gpu_call.sh r06x tests "tests/test_ops_gpu.py -k filter_gradient" -- ab 3 "MI355_TW_LDEC=0" "MI355_TW_LDEC=1" -- suite 2 -- driver -- profile'
 #
 # actions
-#   tests "<pytest arguments>"          targeted tests (-x -q), tail of the log
+#   tests "<pytest arguments>"          targeted tests (-x -q), tail of the log; quote -k expressions with escaped or single quotes inside: tests "tests/test_ops_gpu.py -k 'a or b'" 
 #   suite [n]                           the driver's GPU suite (pytest -m gpu) n times in a row (default 1)
 #   smoke                               __graft_entry__.smoke()
 #   ab <rounds> "<VAR=val ...>" ...     interleaved step-time A/B of environment-knob configurations (tools/ab_env.sh; STEPS / WARMUP / EXTRA pass through)
@@ -26,7 +26,7 @@ while [ $# -gt 0 ]; do
   k=$((k + 1))
   echo "=== [$tag] $act ${args[*]}"
   case $act in
-    tests) timeout 1500 python -m pytest ${args[0]} -x -q -p no:cacheprovider > gpurun_out/tests_${tag}_$k.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/tests_${tag}_$k.log ;;
+    tests) eval "timeout 1500 python -m pytest ${args[0]} -x -q -p no:cacheprovider" > gpurun_out/tests_${tag}_$k.log 2>&1; echo "rc=$?"; tail -6 gpurun_out/tests_${tag}_$k.log ;;      # (eval: quoted -k expressions inside the argument string survive)
     suite) for i in $(seq 1 ${args[0]:-1}); do timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/suite_${tag}_$i.log 2>&1; echo "run $i rc=$?"; grep -E "passed|failed|error" gpurun_out/suite_${tag}_$i.log | tail -2; done ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_$tag.log 2>&1; echo "rc=$?"; tail -2 gpurun_out/smoke_$tag.log ;;
     ab) r=${args[0]}; tools/ab_env.sh gpurun_out/ab_${tag}_$k.txt $r "${args[@]:1}" | tail -$(( ${#args[@]} - 1 )) ;;
